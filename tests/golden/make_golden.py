@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json from the read-only reference tree (run in the build container only;
+/root/reference does not exist on the GPU box, so tests consume the committed JSON, never this script).
+
+Sources (all in /root/reference):
+  * zokrates_field/src/bn128.rs:44-240,273-292      Fr known-answer tests (decimal literals)
+  * zokrates_proof_systems/src/scheme/groth16.rs:157 snark_scalar_field
+  * zokrates_proof_systems/src/solidity.rs:24-26,430-441  FIELD_MODULUS, TWISTBX/Y, P1(), P2()
+  * zokrates_book/src/toolbox/ir.md:15               curve id of bn128
+  * zokrates_cli/examples/book/mpc_tutorial/phase1radix2m2   BN254 points (bellman uncompressed BE)
+  * zokrates_ast/src/ir/witness.rs:99-156            witness binary layout (restated as a vector)
+"""
+import json
+import os
+import re
+import sys
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def must_contain(path, literal):
+    txt = open(os.path.join(REF, path)).read()
+    if literal not in txt:
+        sys.exit(f"literal {literal!r} not found in {path}")
+    return txt
+
+
+def field_kats():
+    p = "zokrates_field/src/bn128.rs"
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    kats = [
+        # (op, a, b, expected)  -- negative operands as written in the reference (From<i32>)
+        ("add", "65416358", "68135", "65484493"),
+        ("add", "5", "-2", "3"),
+        ("add", "65416358", "-68135", "65348223"),
+        ("sub", "65416358", "68135", "65348223"),
+        ("sub", "65416358", "-68135", "65484493"),
+        ("sub", "68135", "65416358",
+         "21888242871839275222246405745257275088548364400416034343698204186575743147394"),
+        ("mul", "32", "421", "13472"),
+        ("mul", "54", "-8912",
+         "21888242871839275222246405745257275088548364400416034343698204186575808014369"),
+        ("pow", "54", "12", "614787626176508399616"),
+        ("div", "-1", "2",
+         "10944121435919637611123202872628637544274182200208017171849102093287904247808"),
+    ]
+    for _, a, b, e in kats:
+        for lit in (a.lstrip("-"), b.lstrip("-"), e):
+            must_contain(p, lit)
+    must_contain("zokrates_proof_systems/src/scheme/groth16.rs", str(R))
+    return {"modulus": str(R), "source": p, "kats": kats}
+
+
+def curve_consts():
+    sol = open(os.path.join(REF, "zokrates_proof_systems/src/solidity.rs")).read()
+    q = int(re.search(r"FIELD_MODULUS = (0x[0-9a-f]+)", sol).group(1), 16)
+    tbx = int(re.search(r"TWISTBX = (0x[0-9a-f]+)", sol).group(1), 16)
+    tby = int(re.search(r"TWISTBY = (0x[0-9a-f]+)", sol).group(1), 16)
+    # P2(): the four literals inside function P2()
+    p2 = sol[sol.index("function P2()"):]
+    nums = [int(x) for x in re.findall(r"\b(\d{60,})\b", p2)[:4]]
+    ir = must_contain("zokrates_book/src/toolbox/ir.md", "0xb4f7b5bd")
+    return {
+        "bn254_q": str(q), "twist_b_c0": str(tbx), "twist_b_c1": str(tby),
+        # Solidity G2Point layout is X = [x.c1, x.c0], Y = [y.c1, y.c0] (solidity.rs:424 comment)
+        "p2_literals": [str(n) for n in nums],
+        "bn128_curve_id": "b4f7b5bd",
+    }
+
+
+def phase1_points():
+    raw = open(os.path.join(REF, "zokrates_cli/examples/book/mpc_tutorial/phase1radix2m2"), "rb").read()
+    assert len(raw) == 1728
+    o = 0
+
+    def g1():
+        nonlocal o
+        x = int.from_bytes(raw[o:o + 32], "big"); y = int.from_bytes(raw[o + 32:o + 64], "big"); o += 64
+        return [str(x), str(y)]
+
+    def g2():
+        nonlocal o
+        v = [int.from_bytes(raw[o + 32 * i:o + 32 * i + 32], "big") for i in range(4)]; o += 128
+        # bellman uncompressed: x.c1 | x.c0 | y.c1 | y.c0
+        return [[str(v[1]), str(v[0])], [str(v[3]), str(v[2])]]
+
+    d = {"alpha_g1": g1(), "beta_g1": g1(), "beta_g2": g2()}
+    d["coeffs_g1"] = [g1() for _ in range(4)]   # L_i(tau)*G1, Lagrange basis of the size-4 domain
+    d["coeffs_g2"] = [g2() for _ in range(4)]   # L_i(tau)*G2
+    d["alpha_coeffs_g1"] = [g1() for _ in range(4)]
+    d["beta_coeffs_g1"] = [g1() for _ in range(4)]
+    d["h_g1"] = [g1() for _ in range(3)]
+    assert o == 1728
+    return d
+
+
+def witness_vector():
+    # layout of Witness::write (witness.rs:44-53): usize LE count, then (isize LE id, 32-byte LE value)
+    # in BTreeMap order; ids: ~out_8 -> -9, ~one -> 0, _42 -> 43 (variable.rs:6-35)
+    must_contain("zokrates_ast/src/ir/witness.rs", '"~out_8": "8"')
+    import struct
+    entries = [(-9, 8), (0, 1), (43, 42)]
+    b = struct.pack("<Q", len(entries))
+    for vid, val in entries:
+        b += struct.pack("<q", vid) + val.to_bytes(32, "little")
+    return {"hex": b.hex(), "json": {"~out_8": "8", "~one": "1", "_42": "42"}}
+
+
+def main():
+    json.dump(field_kats(), open(os.path.join(OUT, "bn128_field_kats.json"), "w"), indent=1)
+    json.dump(curve_consts(), open(os.path.join(OUT, "bn254_consts.json"), "w"), indent=1)
+    json.dump(phase1_points(), open(os.path.join(OUT, "phase1radix2m2_points.json"), "w"), indent=1)
+    json.dump(witness_vector(), open(os.path.join(OUT, "witness_kat.json"), "w"), indent=1)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
