@@ -1,0 +1,155 @@
+/* zkhip.h — C ABI of libzkhip.so, the MI355X-native Groth16 proving backend.
+ *
+ * This is the drop-in boundary for ONE reference path: `Backend<T, G16>::generate_proof`
+ *   trait      /root/reference/zokrates_proof_systems/src/lib.rs:98-112
+ *   CPU impl   /root/reference/zokrates_ark/src/groth16.rs:20-53   (`impl Backend<T,G16> for Ark`)
+ *   call site  /root/reference/zokrates_cli/src/ops/generate_proof.rs:187
+ * A Rust crate `zokrates_hip` (source in INTEGRATION.md) implements that trait by calling the
+ * functions below; everything above the trait (CLI, JSON, Solidity export, verify) is untouched.
+ *
+ * Conventions
+ *  - Every function returns int32_t: 0 = ZKHIP_OK, < 0 = error class; text via zkhip_last_error().
+ *    The library never throws across the boundary and never aborts.  (The reference panics on any
+ *    failure — zokrates_ark/src/groth16.rs:41-44 `.unwrap()` — so the Rust shim turns non-zero
+ *    into `panic!`.)
+ *  - Field elements cross the boundary as canonical little-endian bytes (32 B for Fr; sz(Fq) =
+ *    32 B for bn128, 48 B for bls12_381): the bytes of ark `ToBytes` / `Field::write`
+ *    (/root/reference/zokrates_field/src/lib.rs:215-226).  Neither side needs the other's
+ *    Montgomery constant.
+ *  - Caller owns every input buffer for the duration of the call; the library copies what it
+ *    keeps; outputs go to caller-allocated buffers; long-lived objects are opaque handles with
+ *    paired create/free.  No callbacks.
+ *  - A context is bound to one GPU and is not re-entrant (one call at a time per context);
+ *    distinct contexts may be used from distinct threads.
+ *  - There is no CPU fallback: without a usable gfx950 device zkhip_ctx_create fails with
+ *    ZKHIP_ERR_DEVICE.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKHIP_OK 0
+#define ZKHIP_ERR_BAD_ARG (-1)      /* null pointer, size mismatch, unsupported curve/size        */
+#define ZKHIP_ERR_PARSE (-2)        /* malformed proving key / non-canonical field element         */
+#define ZKHIP_ERR_NOMEM (-3)        /* host or device allocation failed                            */
+#define ZKHIP_ERR_DEVICE (-4)       /* no GPU, HIP runtime error, kernel launch failure            */
+#define ZKHIP_ERR_UNSATISFIED (-5)  /* assignment does not satisfy the R1CS (only when checked)    */
+
+/* curve ids; names are zokrates_common::constants (/root/reference/zokrates_common/src/constants.rs:5-9) */
+#define ZKHIP_CURVE_BN128 0
+#define ZKHIP_CURVE_BLS12_381 1
+
+typedef struct zkhip_ctx zkhip_ctx;
+typedef struct zkhip_pk zkhip_pk;
+typedef struct zkhip_r1cs zkhip_r1cs;
+
+/* Per-proof phase timings in milliseconds (HIP events on the library's own streams).
+ * Replaces nothing in the reference (it has no prover timers) — added observability. */
+typedef struct zkhip_timings {
+    float h2d_ms;       /* assignment upload + Montgomery conversion                */
+    float matvec_ms;    /* K1: sparse A,B,C mat-vec                                  */
+    float ntt_ms;       /* K2-K4: 7 transforms + pointwise quotient                  */
+    float msm_h_ms;     /* K5: h_query MSM (scalar prep + buckets + reduce)          */
+    float msm_z_ms;     /* K6-K8: a/b_g1/l (G1) and b_g2 (G2) MSMs over z            */
+    float finish_ms;    /* K9: window combine, assembly, to-affine (host)            */
+    float total_ms;     /* wall clock of the whole call                              */
+    float kernel_msm_accum_g1_ms; /* sum of G1 bucket-accumulation kernel time       */
+    float kernel_msm_accum_g2_ms; /* G2 bucket-accumulation kernel time              */
+    float reserved[7];
+} zkhip_timings;
+
+/* ---- context ---- */
+/* Number of usable HIP devices (0 if none / no runtime). */
+int32_t zkhip_device_count(void);
+/* Create a context on HIP device `device`. */
+int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out);
+void zkhip_ctx_free(zkhip_ctx* ctx);
+/* Last error text of this context (or of the failed create when ctx == NULL). Never NULL. */
+const char* zkhip_last_error(const zkhip_ctx* ctx);
+
+/* ---- proving key ----
+ * Replaces `ProvingKey::<E>::deserialize_unchecked(proving_key)` at
+ * /root/reference/zokrates_ark/src/groth16.rs:40-42: `bytes` is exactly the `proving.key` file the
+ * reference's `setup` writes (zokrates_ark/src/groth16.rs:97-98, ark `serialize_unchecked`:
+ * vk{alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1[]}, beta_g1, delta_g1, a_query[],
+ * b_g1_query[], b_g2_query[], h_query[], l_query[]; Vec = u64 LE length + elements; affine points
+ * uncompressed, infinity = bit 6 of the last byte).  Points are uploaded, converted to Montgomery
+ * form and laid out for the MSM kernels; like the reference ("unchecked") no on-curve or subgroup
+ * check is made. */
+int32_t zkhip_pk_load_g16(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, zkhip_pk** out);
+void zkhip_pk_free(zkhip_pk* pk);
+/* Shape of a loaded key: out[0]=m (a_query len), out[1]=N-1 (h_query len), out[2]=w (l_query len),
+ * out[3]=l (gamma_abc len). */
+int32_t zkhip_pk_dims(const zkhip_pk* pk, uint64_t out[4]);
+
+/* ---- constraint system ----
+ * Replaces the `ConstraintSystem` that `Computation::generate_constraints`
+ * (/root/reference/zokrates_ark/src/lib.rs:80-129) builds on every call: the three R1CS matrices in
+ * CSR form, columns in ark variable order (column 0 = ONE, columns < l instance, then witness).
+ * n = constraints, l = num_instance, w = num_witness.  val* = nnz x 32 B canonical LE. */
+int32_t zkhip_r1cs_load(zkhip_ctx* ctx, int32_t curve, uint64_t n, uint64_t l, uint64_t w,
+                        const uint64_t* rowptr_a, const uint32_t* col_a, const uint8_t* val_a,
+                        const uint64_t* rowptr_b, const uint32_t* col_b, const uint8_t* val_b,
+                        const uint64_t* rowptr_c, const uint32_t* col_c, const uint8_t* val_c,
+                        zkhip_r1cs** out);
+void zkhip_r1cs_free(zkhip_r1cs* r1cs);
+
+/* ---- the hot path ----
+ * Replaces `Groth16::<E>::prove(&pk, computation, rng)` at /root/reference/zokrates_ark/src/groth16.rs:44
+ * ([UPSTREAM] ark_groth16::create_random_proof).
+ *   z        : m x 32 B, full assignment in ark order (z[0] must be 1)
+ *   r, s     : the two blinding scalars (32 B each).  They are inputs so that the Rust shim samples
+ *              them from the caller's RNG exactly as ark does (`Fr::rand(rng)` twice, r then s).
+ *   proof_out: 8 x sz(Fq) bytes  A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y  (canonical LE),
+ *              then 3 bytes: infinity flags of A, B, C  — the same bytes ark `ToBytes` gives
+ *              `parse_g1`/`parse_g2` (/root/reference/zokrates_ark/src/lib.rs:150-218).
+ *   timings  : optional. */
+int32_t zkhip_prove_g16(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z,
+                        const uint8_t* r, const uint8_t* s, uint8_t* proof_out, zkhip_timings* timings);
+
+/* Steady-state variant for proofs/sec: `count` assignments (each m x 32 B, contiguous), `count`
+ * (r, s) pairs (64 B each) and `count` proof slots (8*sz(Fq)+3 B each).  Same results as `count`
+ * calls of zkhip_prove_g16; the library pipelines upload / NTT / MSM of consecutive proofs. */
+int32_t zkhip_prove_g16_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count,
+                              const uint8_t* z, const uint8_t* rs, uint8_t* proofs_out, zkhip_timings* timings);
+
+/* ---- primitives (exported for parity tests and micro-benchmarks) ---- */
+/* [UPSTREAM] ark_poly::Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place (App. A.4).
+ * data: 2^log_n x 32 B canonical LE, natural order in and out, transformed in place.
+ * dir: 0 fft, 1 ifft, 2 coset_fft, 3 coset_ifft. */
+int32_t zkhip_ntt(zkhip_ctx* ctx, int32_t curve, uint32_t log_n, int32_t dir, uint8_t* data);
+/* LibsnarkReduction::witness_map (App. A.3): h coefficients (N x 32 B, natural order). */
+int32_t zkhip_witness_map(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* z, uint8_t* h_out);
+/* [UPSTREAM] ark_ec::msm::VariableBaseMSM::multi_scalar_mul (App. A.5).
+ * bases: n affine points in the ark uncompressed encoding (2 x sz(Fq) for G1, 4 x sz(Fq) for G2);
+ * scalars: n x 32 B canonical LE; out: affine coords canonical LE + 1 infinity-flag byte. */
+int32_t zkhip_msm_g1(zkhip_ctx* ctx, int32_t curve, uint64_t n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out);
+int32_t zkhip_msm_g2(zkhip_ctx* ctx, int32_t curve, uint64_t n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out);
+/* Element-wise Montgomery field ops on the device (parity tests): op 0 add, 1 sub, 2 mul;
+ * field 0 = Fr, 1 = Fq; a, b, out: count x sz(field) canonical LE. */
+int32_t zkhip_field_op(zkhip_ctx* ctx, int32_t curve, int32_t field, int32_t op, uint64_t count,
+                       const uint8_t* a, const uint8_t* b, uint8_t* out);
+
+/* ---- "next" row N3: setup ----
+ * Replaces `Groth16::<E>::circuit_specific_setup` at /root/reference/zokrates_ark/src/groth16.rs:95
+ * ([UPSTREAM] generate_random_parameters, App. A.6) with the randomness made explicit:
+ * toxic = alpha, beta, gamma, delta, tau (5 x 32 B); g1/g2 = group generators in ark uncompressed
+ * encoding (ark samples random ones; NULL = the standard generators).  Writes the ark
+ * `serialize_unchecked` proving key into pk_out (size from zkhip_setup_g16_size). */
+int32_t zkhip_setup_g16_size(const zkhip_r1cs* r1cs, uint64_t* pk_bytes);
+int32_t zkhip_setup_g16(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* toxic, const uint8_t* g1,
+                        const uint8_t* g2, uint8_t* pk_out, uint64_t pk_cap);
+
+/* Library / device description, NUL-terminated, for logs. */
+int32_t zkhip_describe(const zkhip_ctx* ctx, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

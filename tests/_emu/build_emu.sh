@@ -1,0 +1,13 @@
+#!/bin/sh
+# TEST-ONLY: builds the fibre-emulated copy of libzkhip (same kernel sources, g++, -DZK_EMU) so that
+# kernel indexing / LDS / barrier logic runs under `pytest -m "not gpu"`.  Never shipped, never a fallback.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+SRC="$HERE/../../zokrates_amd/csrc"
+FLAGS="-O2 -g -std=c++17 -fPIC -DZK_EMU -x c++ -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-unused-variable"
+mkdir -p "$HERE/obj"
+for f in curve_bn254 curve_bls381 zkhip_api; do
+  g++ $FLAGS -c "$SRC/$f.hip" -o "$HERE/obj/$f.o" &
+done
+wait
+g++ -shared -o "$HERE/libzkhip_emu.so" "$HERE/obj/curve_bn254.o" "$HERE/obj/curve_bls381.o" "$HERE/obj/zkhip_api.o"

@@ -1,0 +1,22 @@
+"""Loads the TEST-ONLY fibre-emulated build of libzkhip (tests/_emu).  Used only by `-m "not gpu"` tests to
+exercise kernel indexing / LDS / barrier logic on tiny inputs; the product library is never built this way."""
+import os
+import subprocess
+
+from zokrates_amd import native
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "_emu")
+EMU_LIB = os.path.join(EMU_DIR, "libzkhip_emu.so")
+CSRC = os.path.join(HERE, "..", "zokrates_amd", "csrc")
+_lib = None
+
+
+def emu_library():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "zkhip.h")]
+        if not os.path.exists(EMU_LIB) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):
+            subprocess.check_call([os.path.join(EMU_DIR, "build_emu.sh")])
+        _lib = native.Library(EMU_LIB)
+    return _lib

@@ -1,0 +1,171 @@
+"""Kernel-logic tests on the TEST-ONLY CPU emulator (tests/_emu): same kernel sources as libzkhip.so,
+checked bit-for-bit against the oracle on tiny inputs.  These do not replace the `-m gpu` parity tests."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cpu, formats
+from oracle import groth16 as g16
+from oracle.curves import groups
+from oracle.fields import BN254, BLS12_381
+from zokrates_amd import native
+
+from emu_util import emu_library
+
+CURVES = [BN254, BLS12_381]
+
+
+def le(vals, nb=32):
+    return np.frombuffer(b"".join(int(v).to_bytes(nb, "little") for v in vals), dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = native.Context(0, emu_library())
+    assert "EMULATOR" in c.describe()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_field_ops(ctx, curve):
+    rnd = random.Random(5)
+    for field, p, nb in ((0, curve.r, 32), (1, curve.q, curve.fq_bytes)):
+        a = [0, 1, p - 1, p - 1, 2, (1 << (8 * nb)) % p] + [rnd.randrange(p) for _ in range(70)]
+        b = [0, p - 1, p - 1, 1, p - 2, (1 << (8 * nb)) % p] + [rnd.randrange(p) for _ in range(70)]
+        for op, fn in (("add", lambda x, y: (x + y) % p), ("sub", lambda x, y: (x - y) % p), ("mul", lambda x, y: x * y % p)):
+            got = ctx.field_op(curve.curve_id, field, op, le(a, nb), le(b, nb))
+            assert got.tobytes() == le([fn(x, y) for x, y in zip(a, b)], nb).tobytes(), (field, op)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("single_max", [10, 1])
+def test_ntt(ctx, curve, single_max):
+    """single_max = 1 forces the two-pass (cols + rows, sigma-order) path on small domains."""
+    os.environ["ZKHIP_NTT_SINGLE_MAX_LOG"] = str(single_max)
+    c2 = native.Context(0, emu_library())   # fresh plan cache
+    rnd = random.Random(6)
+    try:
+        for logn in ((0, 1, 2, 5) if single_max == 10 else (2, 3, 5, 6)):
+            a = le([rnd.randrange(curve.r) for _ in range(1 << logn)])
+            for d in ("fft", "ifft", "coset_fft", "coset_ifft"):
+                assert c2.ntt(curve.curve_id, a, d).tobytes() == cpu.ntt(curve.curve_id, a, d).tobytes(), (logn, d)
+    finally:
+        os.environ.pop("ZKHIP_NTT_SINGLE_MAX_LOG")
+        c2.close()
+
+
+def _rand_points(curve, n, rnd, with_edge=True):
+    G1, G2 = groups(curve)
+    p1 = [G1.amul(G1.gen, rnd.randrange(1, curve.r)) for _ in range(n)]
+    p2 = [G2.amul(G2.gen, rnd.randrange(1, curve.r)) for _ in range(n)]
+    ks = [rnd.randrange(curve.r) for _ in range(n)]
+    if with_edge and n >= 8:
+        ks[0] = 0; ks[1] = 1; ks[2] = curve.r - 1
+        p1[3] = None; p2[4] = None
+        p1[5] = p1[6]; ks[5] = ks[6]                      # equal points in one bucket -> doubling branch
+        p2[5] = p2[6]
+        p1[7] = G1.aneg(p1[6]); ks[7] = ks[6]             # P + (-P) in one bucket -> infinity branch
+    b1 = np.frombuffer(b"".join(formats.ser_g1(curve, P) for P in p1), dtype=np.uint8)
+    b2 = np.frombuffer(b"".join(formats.ser_g2(curve, P) for P in p2), dtype=np.uint8)
+    return b1, b2, le(ks)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_msm(ctx, curve):
+    rnd = random.Random(7)
+    for n in (1, 3, 20, 70):
+        b1, b2, ks = _rand_points(curve, n, rnd)
+        assert ctx.msm(curve.curve_id, 1, b1, ks) == cpu.msm(curve.curve_id, 1, b1, ks), n
+        if n <= 20:
+            assert ctx.msm(curve.curve_id, 2, b2, ks) == cpu.msm(curve.curve_id, 2, b2, ks), n
+    # empty and all-zero
+    assert ctx.msm(curve.curve_id, 1, b1[:0], ks[:0])[-1] == 1
+    assert ctx.msm(curve.curve_id, 1, b1, np.zeros_like(ks))[-1] == 1
+
+
+def test_msm_window_sizes(ctx):
+    """Same answer for every window width (exercises digit recoding / carries / fold geometry)."""
+    rnd = random.Random(8)
+    b1, _, ks = _rand_points(BN254, 40, rnd)
+    want = cpu.msm(0, 1, b1, ks)
+    try:
+        for c in (2, 3, 5, 8, 13):
+            os.environ["ZKHIP_MSM_C"] = str(c)
+            assert ctx.msm(0, 1, b1, ks) == want, c
+    finally:
+        os.environ.pop("ZKHIP_MSM_C")
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("kind", ["dense", "sha"])
+def test_prove_matches_oracle(ctx, curve, kind):
+    n = 13 if kind == "dense" else 29
+    oc = cpu.Circuit.synth(curve.curve_id, n, 0x5EED0007, kind)
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    opk = cpu.ProvingKey.setup(oc, tox)
+    z = oc.assignment()
+    r_, s_ = 0x1234567 % curve.r, 0x89abcdef0123 % curve.r
+    want, _ = cpu.prove(oc, opk, z, r_, s_)
+    assert want == cpu.trapdoor(oc, tox, z, r_, s_)
+    cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, curve.curve_id, opk.serialize())
+    assert (pk.m, pk.hlen, pk.w, pk.l) == (oc.m, oc.N - 1, oc.w, oc.l)
+    assert cs.witness_map(z).tobytes() == cpu.witness_map(oc, z).tobytes()
+    got, tm = native.prove_g16(ctx, pk, cs, z, r_, s_, want_timings=True)
+    assert got == want
+    # r = 0 / s = 0 corner (ark skips B1 when r == 0; the result must not change)
+    assert native.prove_g16(ctx, pk, cs, z, 0, s_) == cpu.trapdoor(oc, tox, z, 0, s_)
+    assert native.prove_g16(ctx, pk, cs, z, r_, 0) == cpu.trapdoor(oc, tox, z, r_, 0)
+    # batch == singles
+    proofs, _ = native.prove_g16_batch(ctx, pk, cs, np.concatenate([z, z]), [(r_, s_), (5, 6)])
+    assert proofs[0] == want and proofs[1] == cpu.trapdoor(oc, tox, z, 5, 6)
+
+
+def test_two_pass_prove(ctx):
+    """Force the two-pass NTT (sigma order, permuted h_query) inside the full prover."""
+    os.environ["ZKHIP_NTT_SINGLE_MAX_LOG"] = "2"
+    c2 = native.Context(0, emu_library())
+    try:
+        curve = BN254
+        oc = cpu.Circuit.synth(0, 30, 0x5EED0008)   # N = 32 -> N1 = 4, N2 = 8
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        opk = cpu.ProvingKey.setup(oc, tox)
+        z = oc.assignment()
+        cs = native.ConstraintSystem(c2, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+        pk = native.ProvingKey(c2, 0, opk.serialize())
+        assert cs.witness_map(z).tobytes() == cpu.witness_map(oc, z).tobytes()
+        assert native.prove_g16(c2, pk, cs, z, 11, 13) == cpu.trapdoor(oc, tox, z, 11, 13)
+    finally:
+        os.environ.pop("ZKHIP_NTT_SINGLE_MAX_LOG")
+        c2.close()
+
+
+def test_error_paths(ctx):
+    curve = BN254
+    oc = cpu.Circuit.synth(0, 5, 1)
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    raw = cpu.ProvingKey.setup(oc, tox).serialize()
+    with pytest.raises(native.ZkhipError) as e:
+        native.ProvingKey(ctx, 0, raw[:-1])
+    assert e.value.code == -2
+    with pytest.raises(native.ZkhipError) as e:
+        native.ProvingKey(ctx, 7, raw)
+    assert e.value.code == -1
+    cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, 0, raw)
+    z = oc.assignment().copy()
+    z[0] = 2                                       # z[0] != 1
+    with pytest.raises(native.ZkhipError) as e:
+        native.prove_g16(ctx, pk, cs, z, 1, 2)
+    assert e.value.code == -1
+    oc2 = cpu.Circuit.synth(0, 9, 1)               # key / circuit mismatch
+    cs2 = native.ConstraintSystem(ctx, 0, oc2.n, oc2.l, oc2.w, [oc2.csr(k) for k in range(3)])
+    with pytest.raises(native.ZkhipError):
+        native.prove_g16(ctx, pk, cs2, oc2.assignment(), 1, 2)
+    with pytest.raises(native.ZkhipError):         # bad column index
+        rp, col, val = oc.csr(0)
+        col = col.copy(); col[0] = 10 ** 6
+        native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [(rp, col, val), oc.csr(1), oc.csr(2)])

@@ -1,0 +1,62 @@
+"""Builds libzkhip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m zokrates_amd.build            # incremental
+    python -m zokrates_amd.build --force
+
+The three translation units (two curves + the C ABI) compile in parallel; hipcc cross-compiles for
+gfx950 without a GPU.  The result `zokrates_amd/libzkhip.so` is git-ignored but travels to the GPU
+box with the repository snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "libzkhip.so")
+UNITS = ["curve_bn254", "curve_bls381", "zkhip_api"]
+HEADERS = ["core.cuh", "devrt.h", "ec.cuh", "field.cuh", "kernels_msm.cuh", "kernels_ntt.cuh"]
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(unit, force, verbose):
+    src = os.path.join(CSRC, unit + ".hip")
+    obj = os.path.join(OBJ, unit + ".o")
+    deps = [src, os.path.join(HERE, "..", "include", "zkhip.h")] + [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _newer(obj, deps):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj, True
+
+
+def build_lib(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 and link libzkhip.so.  Returns the library path."""
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+        results = list(ex.map(lambda u: _compile(u, force, verbose), UNITS))
+    objs = [o for o, _ in results]
+    if force or any(changed for _, changed in results) or _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,775 @@
+// core.cuh — host side of libzkhip.so: contexts, key/constraint-system residency and the Groth16 prover
+// schedule, templated on the curve.  Instantiated once per curve in curve_bn254.hip / curve_bls381.hip
+// (separate translation units so the two curves compile in parallel); the C ABI lives in zkhip_api.hip.
+//
+// Replaces `<Ark as Backend<T, G16>>::generate_proof` (/root/reference/zokrates_ark/src/groth16.rs:20-53)
+// from the point where the reference hands over to ark: `ProvingKey::deserialize_unchecked` (:40-42) and
+// `Groth16::prove` (:44).  SURVEY.md §8(a) rows a7, a8, K1-K9.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/zkhip.h"
+#include "devrt.h"
+#include "ec.cuh"
+#include "kernels_msm.cuh"
+#include "kernels_ntt.cuh"
+
+namespace zk {
+
+// ------------------------------------------------------------------ curves
+struct CurveBn254 {
+    static constexpr int ID = ZKHIP_CURVE_BN128;
+    typedef Fe<Bn254Fr> Fr;
+    typedef Fe<Bn254Fq> Fq;
+    typedef Fe2<Bn254Fq> Fq2;
+    static constexpr u64 GENERATOR = 5;       // Fr::GENERATOR, the coset shift g
+    static constexpr int TWO_ADICITY = 28;
+};
+struct CurveBls381 {
+    static constexpr int ID = ZKHIP_CURVE_BLS12_381;
+    typedef Fe<Bls381Fr> Fr;
+    typedef Fe<Bls381Fq> Fq;
+    typedef Fe2<Bls381Fq> Fq2;
+    static constexpr u64 GENERATOR = 7;
+    static constexpr int TWO_ADICITY = 32;
+};
+
+struct ApiError {
+    int32_t code;
+    std::string msg;
+};
+static inline void require(bool ok, int32_t code, const char* msg) {
+    if (!ok) throw ApiError{code, msg};
+}
+
+// ------------------------------------------------------------------ device buffers
+struct DBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DBuf() {}
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf() { dev_free(p); }
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        dev_free(p);
+        p = nullptr;
+        cap = 0;
+        p = dev_alloc(bytes);
+        cap = bytes;
+    }
+};
+template <class T> static inline T* ptr(const DBuf& b) { return (T*)b.p; }
+
+static inline unsigned blocks_for(u64 n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+static inline int ilog2_floor(u64 x) { int l = 0; while (x >>= 1) ++l; return l; }
+static inline int ilog2_ceil(u64 x) { int l = 0; while (((u64)1 << l) < x) ++l; return l; }
+
+}  // namespace zk
+
+using namespace zk;
+
+// ------------------------------------------------------------------ context
+struct NttPlanBase {
+    int curve, logN;
+    virtual ~NttPlanBase() {}
+};
+struct zkhip_ctx {
+    int device = 0;
+    Stream stream = 0;
+    std::string err;
+    std::string desc;
+    // MSM workspace (grow-only)
+    DBuf dig, sorted, cnt, off, cursor, chunk_sum, grand, buckets, partial;
+    // prover workspace
+    DBuf scalars, zmont, va, vb, vc, tmp, ws1, ws2;
+    std::vector<std::unique_ptr<NttPlanBase>> plans;
+    std::vector<Event> ev_pool;
+};
+
+namespace zk {
+
+// ------------------------------------------------------------------ NTT plan
+template <class C>
+struct NttPlan : NttPlanBase {
+    typedef typename C::Fr Fr;
+    int log1, log2;          // N = N1 * N2, cols pass over N1, rows pass over N2
+    u64 N;
+    u32 N1, N2, M;           // M = max(N1, N2): root tables hold w_M^j, j < M/2
+    DBuf roots_fwd, roots_inv, tw_fwd, tw_inv, s_coset, s_cosetinv_canon;
+    Fr omega, omega_inv, n_inv, g, g_inv, zinv;
+    int C_cols, R_rows, threads_cols, threads_rows;
+    size_t smem_cols, smem_rows;
+};
+
+template <class Fr>
+static Fr host_root_of_unity(int two_adicity, u64 generator, int logN) {
+    // GENERATOR^((r-1) >> S), then squared down to order 2^logN   (App. A.4)
+    u32 e[Fr::N];
+    u64 bw = 1;
+    for (int i = 0; i < Fr::N; ++i) {
+        u64 t = (u64)Fr::Params::mod(i) - bw;
+        e[i] = (u32)t;
+        bw = t >> 63;
+    }
+    for (int s = 0; s < two_adicity; ++s)
+        for (int i = 0; i < Fr::N; ++i) e[i] = (e[i] >> 1) | (i + 1 < Fr::N ? e[i + 1] << 31 : 0);
+    Fr root = fe_pow(fe_from_u64<typename Fr::Params>(generator), e, Fr::N);
+    for (int i = logN; i < two_adicity; ++i) root = fe_sqr(root);
+    return root;
+}
+
+static constexpr int NTT_MAX_SUBLOG = 11;   // 2^11 x 32 B = 64 KiB per staged sequence
+
+template <class C>
+static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
+    typedef typename C::Fr Fr;
+    for (auto& p : ctx->plans)
+        if (p->curve == C::ID && p->logN == logN) return (NttPlan<C>*)p.get();
+    require(logN >= 0 && logN <= 2 * NTT_MAX_SUBLOG && logN <= C::TWO_ADICITY, ZKHIP_ERR_BAD_ARG,
+            "domain size unsupported (log2 N must be <= 22)");
+    auto* pl = new NttPlan<C>();
+    ctx->plans.emplace_back(pl);
+    pl->curve = C::ID;
+    pl->logN = logN;
+    pl->N = (u64)1 << logN;
+    int single_max = 10;   // largest domain handled by one LDS-resident pass
+    if (const char* e = getenv("ZKHIP_NTT_SINGLE_MAX_LOG")) single_max = std::max(0, std::min(NTT_MAX_SUBLOG, atoi(e)));
+    pl->log1 = logN <= single_max ? 0 : logN / 2;
+    pl->log2 = logN - pl->log1;
+    pl->N1 = 1u << pl->log1;
+    pl->N2 = 1u << pl->log2;
+    pl->M = std::max(pl->N1, pl->N2);
+    pl->omega = host_root_of_unity<Fr>(C::TWO_ADICITY, C::GENERATOR, logN);
+    pl->omega_inv = fe_inv(pl->omega);
+    pl->n_inv = fe_inv(fe_from_u64<typename Fr::Params>(pl->N));
+    pl->g = fe_from_u64<typename Fr::Params>(C::GENERATOR);
+    pl->g_inv = fe_inv(pl->g);
+    pl->zinv = fe_inv(fe_sub(fe_pow_u64(pl->g, pl->N), Fr::one()));
+    Stream s = ctx->stream;
+    const unsigned T = 256;
+    // sub-NTT roots: w_M^j, j < M/2
+    const Fr wM = fe_pow_u64(pl->omega, pl->N / pl->M);
+    const u64 nroots = std::max<u64>(pl->M / 2, 1);
+    pl->roots_fwd.ensure(nroots * sizeof(Fr));
+    pl->roots_inv.ensure(nroots * sizeof(Fr));
+    ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(nroots, T)), dim3(T), 0, s, ptr<Fr>(pl->roots_fwd), wM, Fr::one(), nroots, 0u, 0u, 0);
+    ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(nroots, T)), dim3(T), 0, s, ptr<Fr>(pl->roots_inv), fe_inv(wM), Fr::one(), nroots, 0u, 0u, 0);
+    if (pl->log1 > 0) {
+        pl->tw_fwd.ensure(pl->N * sizeof(Fr));
+        pl->tw_inv.ensure(pl->N * sizeof(Fr));
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->tw_fwd), pl->omega, Fr::one(), pl->N, pl->N1, pl->N2, 1);
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->tw_inv), pl->omega_inv, Fr::one(), pl->N, pl->N1, pl->N2, 1);
+    }
+    pl->s_coset.ensure(pl->N * sizeof(Fr));
+    pl->s_cosetinv_canon.ensure(pl->N * sizeof(Fr));
+    ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->s_coset), pl->g, pl->n_inv, pl->N, pl->N1, pl->N2, 2);
+    ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->s_cosetinv_canon), pl->g_inv, fe_from_mont(pl->n_inv), pl->N,
+              pl->N1, pl->N2, 2);
+    // launch geometry: C columns (>= 128 B contiguous per row when N2 allows), R rows, <= 128 KiB of LDS
+    pl->C_cols = (int)std::min<u32>(pl->N2, pl->log1 >= 11 ? 2 : 4);
+    pl->smem_cols = (size_t)pl->C_cols * (pl->N1 + 1) * 32;
+    u32 R = std::max<u32>(1, std::min<u32>(pl->N1, 4096u / pl->N2));
+    if (pl->log1 == 0) R = 1;
+    pl->R_rows = (int)R;
+    pl->smem_rows = (size_t)R * (pl->N2 + 1) * 32;
+    auto pick_threads = [](u64 butterflies) { return (int)std::min<u64>(1024, std::max<u64>(64, (butterflies + 63) / 64 * 64)); };
+    pl->threads_cols = pick_threads((u64)pl->C_cols * pl->N1 / 2);
+    pl->threads_rows = pick_threads((u64)R * pl->N2 / 2);
+#ifndef ZK_EMU
+    // gfx950 has 160 KiB of LDS per CU; anything above the 64 KiB default must be opted into
+    ZK_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_cols<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_rows<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
+    stream_sync(s);
+    return pl;
+}
+
+template <class C>
+static void ntt_cols(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* pre, const typename C::Fr* post) {
+    typedef typename C::Fr Fr;
+    const Fr* roots = inverse ? ptr<Fr>(pl->roots_inv) : ptr<Fr>(pl->roots_fwd);
+    ZK_LAUNCH((k_ntt_cols<Fr>), dim3(pl->N2 / pl->C_cols), dim3(pl->threads_cols), pl->smem_cols, ctx->stream, data, pl->log1, pl->N2,
+              pl->C_cols, roots, (int)(pl->M / pl->N1), pre, post);
+}
+template <class C>
+static void ntt_rows(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* pre, const typename C::Fr* post) {
+    typedef typename C::Fr Fr;
+    const Fr* roots = inverse ? ptr<Fr>(pl->roots_inv) : ptr<Fr>(pl->roots_fwd);
+    ZK_LAUNCH((k_ntt_rows<Fr>), dim3(pl->N1 / pl->R_rows), dim3(pl->threads_rows), pl->smem_rows, ctx->stream, data, pl->log2, pl->R_rows,
+              roots, (int)(pl->M / pl->N2), pre, post);
+}
+// natural order in -> sigma order out
+template <class C>
+static void ntt_kind_a(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* final_post) {
+    typedef typename C::Fr Fr;
+    if (pl->log1 > 0) ntt_cols<C>(ctx, pl, data, inverse, nullptr, inverse ? ptr<Fr>(pl->tw_inv) : ptr<Fr>(pl->tw_fwd));
+    ntt_rows<C>(ctx, pl, data, inverse, nullptr, final_post);
+}
+// sigma order in -> natural order out
+template <class C>
+static void ntt_kind_b(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* final_post) {
+    typedef typename C::Fr Fr;
+    if (pl->log1 > 0) {
+        ntt_rows<C>(ctx, pl, data, inverse, nullptr, inverse ? ptr<Fr>(pl->tw_inv) : ptr<Fr>(pl->tw_fwd));
+        ntt_cols<C>(ctx, pl, data, inverse, nullptr, final_post);
+    } else {
+        ntt_rows<C>(ctx, pl, data, inverse, nullptr, final_post);
+    }
+}
+
+// ------------------------------------------------------------------ MSM driver
+struct MsmShape {
+    u64 n;
+    int c, W;
+    u32 K;          // buckets per window = 2^(c-1)
+    u64 nbuckets;   // W * K
+    int L;          // buckets per work-item in the fold
+    u32 fold_threads, fold_blocks;
+};
+static inline MsmShape msm_shape(u64 n, int scalar_bits) {
+    MsmShape s;
+    s.n = n;
+    int lg = ilog2_floor(std::max<u64>(n, 1));
+    s.c = std::max(2, std::min(16, lg - 3));
+    if (const char* e = getenv("ZKHIP_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 16) s.c = v; }
+    s.W = (scalar_bits + 1 + s.c - 1) / s.c;
+    s.K = 1u << (s.c - 1);
+    s.nbuckets = (u64)s.W * s.K;
+    s.L = s.K >= 2048 ? 8 : 1;
+    u64 items = (s.K + s.L - 1) / s.L;
+    s.fold_threads = (u32)std::min<u64>(256, std::max<u64>(64, (items + 63) / 64 * 64));
+    s.fold_blocks = (u32)((items + s.fold_threads - 1) / s.fold_threads);
+    return s;
+}
+
+// digits + counting sort; leaves ctx->off / ctx->sorted describing every bucket's point list
+static inline void msm_prepare(zkhip_ctx* ctx, const u32* d_scalars, const MsmShape& sh) {
+    Stream s = ctx->stream;
+    const u64 nb = sh.nbuckets;
+    ctx->dig.ensure(sh.n * sh.W * 4);
+    ctx->sorted.ensure(sh.n * sh.W * 4);
+    ctx->cnt.ensure(nb * 4);
+    ctx->off.ensure((nb + 1) * 4);
+    ctx->cursor.ensure(nb * 4);
+    const u32 nchunks = (u32)((nb + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    ctx->chunk_sum.ensure((size_t)nchunks * 4);
+    ctx->grand.ensure(4);
+    dev_memset(ctx->cnt.p, 0, nb * 4, s);
+    dev_memset(ctx->cursor.p, 0, nb * 4, s);
+    const unsigned T = 256;
+    ZK_LAUNCH(k_msm_digits, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, sh.c, sh.W, ptr<u32>(ctx->dig), ptr<u32>(ctx->cnt));
+    ZK_LAUNCH(k_scan_local, dim3(nchunks), dim3(SCAN_THREADS), 0, s, ptr<u32>(ctx->cnt), ptr<u32>(ctx->off), ptr<u32>(ctx->chunk_sum), nb);
+    ZK_LAUNCH(k_scan_chunks, dim3(1), dim3(SCAN_THREADS), 0, s, ptr<u32>(ctx->chunk_sum), nchunks, ptr<u32>(ctx->grand));
+    ZK_LAUNCH(k_scan_add, dim3(blocks_for(nb + 1, T)), dim3(T), 0, s, ptr<u32>(ctx->off), ptr<u32>(ctx->chunk_sum), nb, ptr<u32>(ctx->grand));
+    ZK_LAUNCH(k_msm_scatter, dim3(blocks_for(sh.n * sh.W, T)), dim3(T), 0, s, ptr<u32>(ctx->dig), sh.n, sh.c, sh.W, ptr<u32>(ctx->off),
+              ptr<u32>(ctx->cursor), ptr<u32>(ctx->sorted));
+}
+
+static inline Event pool_event(zkhip_ctx* ctx) {
+    Event e = event_create();
+    ctx->ev_pool.push_back(e);
+    return e;
+}
+
+// bucket accumulation + fold for one base set; window sums land in d_window_sums[0..W)
+template <class F>
+static void msm_run(zkhip_ctx* ctx, const Aff<F>* d_bases, const MsmShape& sh, Xyzz<F>* d_window_sums, Event* ev_begin, Event* ev_end) {
+    Stream s = ctx->stream;
+    ctx->buckets.ensure(sh.nbuckets * sizeof(Xyzz<F>));
+    ctx->partial.ensure((size_t)sh.W * sh.fold_blocks * sizeof(Xyzz<F>));
+    const unsigned T = 128;
+    if (ev_begin) { *ev_begin = pool_event(ctx); event_record(*ev_begin, s); }
+    ZK_LAUNCH((k_msm_accum<F>), dim3(blocks_for(sh.nbuckets, T)), dim3(T), 0, s, d_bases, ptr<u32>(ctx->off), ptr<u32>(ctx->sorted),
+              ptr<Xyzz<F>>(ctx->buckets), sh.nbuckets);
+    if (ev_end) { *ev_end = pool_event(ctx); event_record(*ev_end, s); }
+    const size_t smem = (size_t)sh.fold_threads * sizeof(Xyzz<F>);
+#ifndef ZK_EMU
+    static bool lds_opt_in = false;   // per point type (template instance)
+    if (!lds_opt_in) {
+        ZK_HIP_CHECK(hipFuncSetAttribute((const void*)k_msm_fold<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_opt_in = true;
+    }
+#endif
+    ZK_LAUNCH((k_msm_fold<F>), dim3(sh.fold_blocks, sh.W), dim3(sh.fold_threads), smem, s, ptr<Xyzz<F>>(ctx->buckets), sh.K, sh.L,
+              ptr<Xyzz<F>>(ctx->partial));
+    const unsigned TF = 64;
+    ZK_LAUNCH((k_msm_fold_final<F>), dim3(sh.W), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(ctx->partial), sh.fold_blocks, d_window_sums);
+}
+
+// host Horner over window sums: sum_j 2^(c j) S_j
+template <class F>
+static Xyzz<F> msm_combine(const Xyzz<F>* ws, const MsmShape& sh) {
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (int j = sh.W - 1; j >= 0; --j) {
+        for (int i = 0; i < sh.c; ++i) acc = xyzz_dbl(acc);
+        acc = xyzz_add(acc, ws[j]);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------ byte codecs (host)
+template <class F>
+static F fe_from_bytes_canon(const uint8_t* b) {   // canonical LE bytes -> canonical limbs (no Montgomery)
+    F x;
+    memcpy(x.v, b, F::BYTES);
+    return x;
+}
+template <class P>
+static bool canon_lt_mod(const Fe<P>& x) {
+    for (int i = P::N - 1; i >= 0; --i) {
+        if (x.v[i] != P::mod(i)) return x.v[i] < P::mod(i);
+    }
+    return false;
+}
+// ark uncompressed affine -> canonical coords with infinity as all-zero (the device sentinel)
+template <int FQ_BYTES, int NCOORD>
+static void decode_point(const uint8_t* src, uint8_t* dst) {
+    constexpr int SZ = FQ_BYTES * NCOORD;
+    const bool inf = src[SZ - 1] & 0x40;
+    if (inf) { memset(dst, 0, SZ); return; }
+    memcpy(dst, src, SZ);
+    dst[SZ - 1] &= 0x3f;
+}
+template <class F> static void write_fe(const F& mont, uint8_t* out) { F c = fe_from_mont(mont); memcpy(out, c.v, F::BYTES); }
+
+}  // namespace zk
+
+// ------------------------------------------------------------------ proving key
+struct zkhip_pk {
+    int curve;
+    zkhip_ctx* ctx;
+    u64 m, w, l, hlen, N;
+    int logN;
+    DBuf a_ext, b1_ext, l_ext, b2_ext, h_sigma;   // Montgomery affine, MSM-ready
+    std::vector<uint8_t> delta_g1_canon;          // for the -rs*delta_1 term of C (host)
+};
+
+struct zkhip_r1cs {
+    int curve;
+    zkhip_ctx* ctx;
+    u64 n, l, w, N;
+    int logN;
+    DBuf rp[3], col[3], val[3];
+    u64 nnz[3];
+    // host copy kept for setup (N3)
+    std::vector<u64> h_rp[3];
+    std::vector<u32> h_col[3];
+    std::vector<uint8_t> h_val[3];
+};
+
+namespace zk {
+
+template <class C>
+struct PkLoader {
+    typedef typename C::Fq Fq;
+    typedef typename C::Fq2 Fq2;
+    static constexpr int FQB = Fq::BYTES;
+    static constexpr int G1B = 2 * FQB, G2B = 4 * FQB;
+
+    struct Rd {
+        const uint8_t* p;
+        const uint8_t* e;
+        const uint8_t* take(size_t n) {
+            require((size_t)(e - p) >= n, ZKHIP_ERR_PARSE, "proving key truncated");
+            const uint8_t* r = p;
+            p += n;
+            return r;
+        }
+        u64 len(size_t elem) {
+            u64 n;
+            memcpy(&n, take(8), 8);
+            require(n <= (u64)(e - p) / elem, ZKHIP_ERR_PARSE, "proving key vector length exceeds file size");
+            return n;
+        }
+    };
+
+    // upload `count` decoded points (canonical) and convert every base-field coordinate to Montgomery form
+    static void upload_points(zkhip_ctx* ctx, DBuf& dst, const std::vector<uint8_t>& host, u64 ncoords) {
+        dst.ensure(host.size());
+        dev_h2d(dst.p, host.data(), host.size(), ctx->stream);
+        ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(ncoords, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(dst), ptr<Fq>(dst), ncoords);
+    }
+    // dev[idx] += P (host round trip of one point; P canonical ark encoding)
+    template <class F, int NC>
+    static void add_into(zkhip_ctx* ctx, DBuf& buf, u64 idx, const uint8_t* ark_point) {
+        uint8_t dec[G2B];
+        decode_point<FQB, NC>(ark_point, dec);
+        Aff<F> add;
+        memcpy(&add, dec, sizeof(add));
+        add = to_mont_point(add);
+        Aff<F> cur;
+        dev_d2h(&cur, ptr<Aff<F>>(buf) + idx, sizeof(cur), ctx->stream);
+        stream_sync(ctx->stream);
+        Aff<F> sum = xyzz_to_affine(xyzz_madd(Xyzz<F>::from_affine(cur), add));
+        dev_h2d(ptr<Aff<F>>(buf) + idx, &sum, sizeof(sum), ctx->stream);
+        stream_sync(ctx->stream);
+    }
+    static Aff<Fq> to_mont_point(const Aff<Fq>& p) { return {fe_to_mont(p.x), fe_to_mont(p.y)}; }
+    static Aff<Fq2> to_mont_point(const Aff<Fq2>& p) { return {fe_to_mont(p.x), fe_to_mont(p.y)}; }
+
+    static void load(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk* pk) {
+        Rd rd{bytes, bytes + len};
+        const uint8_t* alpha_g1 = rd.take(G1B);
+        const uint8_t* beta_g2 = rd.take(G2B);
+        rd.take(G2B);                                  // gamma_g2 (verifier only)
+        const uint8_t* delta_g2 = rd.take(G2B);
+        const u64 n_abc = rd.len(G1B);
+        rd.take(n_abc * G1B);                          // gamma_abc_g1 (verifier only)
+        const uint8_t* beta_g1 = rd.take(G1B);
+        const uint8_t* delta_g1 = rd.take(G1B);
+        const u64 m = rd.len(G1B);
+        const uint8_t* a_q = rd.take(m * G1B);
+        const u64 mb1 = rd.len(G1B);
+        const uint8_t* b1_q = rd.take(mb1 * G1B);
+        const u64 mb2 = rd.len(G2B);
+        const uint8_t* b2_q = rd.take(mb2 * G2B);
+        const u64 hl = rd.len(G1B);
+        const uint8_t* h_q = rd.take(hl * G1B);
+        const u64 w = rd.len(G1B);
+        const uint8_t* l_q = rd.take(w * G1B);
+        require(rd.p == rd.e, ZKHIP_ERR_PARSE, "trailing bytes after proving key");
+        require(m >= 1 && mb1 == m && mb2 == m && w <= m, ZKHIP_ERR_PARSE, "inconsistent query lengths in proving key");
+        const u64 l = m - w;
+        require(n_abc == l, ZKHIP_ERR_PARSE, "gamma_abc length != number of instance variables");
+        const u64 N = hl + 1;
+        require((N & (N - 1)) == 0, ZKHIP_ERR_PARSE, "h_query length + 1 is not a power of two");
+        require(m + 2 < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "too many variables");
+        pk->m = m; pk->w = w; pk->l = l; pk->hlen = hl; pk->N = N; pk->logN = ilog2_floor(N);
+        NttPlan<C>* plan = get_plan<C>(ctx, pk->logN);
+        pk->delta_g1_canon.assign(delta_g1, delta_g1 + G1B);
+
+        const u64 me = m + 2;   // extended by the (delta, r) and (delta, s) pairs — see prove()
+        std::vector<uint8_t> host;
+        // A_ext = [a_query..., delta_1, inf]          (+ alpha_1 folded into entry 0)
+        host.assign(me * G1B, 0);
+        for (u64 i = 0; i < m; ++i) decode_point<FQB, 2>(a_q + i * G1B, &host[i * G1B]);
+        decode_point<FQB, 2>(delta_g1, &host[m * G1B]);
+        upload_points(ctx, pk->a_ext, host, me * 2);
+        stream_sync(ctx->stream);
+        // B1_ext = [b_g1_query..., inf, delta_1]      (+ beta_1 folded into entry 0)
+        host.assign(me * G1B, 0);
+        for (u64 i = 0; i < m; ++i) decode_point<FQB, 2>(b1_q + i * G1B, &host[i * G1B]);
+        decode_point<FQB, 2>(delta_g1, &host[(m + 1) * G1B]);
+        upload_points(ctx, pk->b1_ext, host, me * 2);
+        stream_sync(ctx->stream);
+        // L_ext = [inf x l, l_query..., inf, inf]
+        host.assign(me * G1B, 0);
+        for (u64 j = 0; j < w; ++j) decode_point<FQB, 2>(l_q + j * G1B, &host[(l + j) * G1B]);
+        upload_points(ctx, pk->l_ext, host, me * 2);
+        stream_sync(ctx->stream);
+        // B2_ext = [b_g2_query..., inf, delta_2]      (+ beta_2 folded into entry 0)
+        host.assign(me * G2B, 0);
+        for (u64 i = 0; i < m; ++i) decode_point<FQB, 4>(b2_q + i * G2B, &host[i * G2B]);
+        decode_point<FQB, 4>(delta_g2, &host[(m + 1) * G2B]);
+        upload_points(ctx, pk->b2_ext, host, me * 4);
+        stream_sync(ctx->stream);
+        // h_query, permuted into the sigma order the NTT pipeline leaves h in, padded with infinity
+        host.assign(hl * G1B, 0);
+        for (u64 i = 0; i < hl; ++i) decode_point<FQB, 2>(h_q + i * G1B, &host[i * G1B]);
+        ctx->tmp.ensure(std::max<size_t>(host.size(), 16));
+        dev_h2d(ctx->tmp.p, host.data(), host.size(), ctx->stream);
+        ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(hl * 2, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(ctx->tmp), ptr<Fq>(ctx->tmp), hl * 2);
+        pk->h_sigma.ensure(N * G1B);
+        ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(N, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(ctx->tmp),
+                  ptr<Aff<Fq>>(pk->h_sigma), N, hl, plan->N1, plan->N2);
+        stream_sync(ctx->stream);
+        // constant terms: z_0 = 1, so alpha/beta ride on entry 0 of their query vectors
+        add_into<Fq, 2>(ctx, pk->a_ext, 0, alpha_g1);
+        add_into<Fq, 2>(ctx, pk->b1_ext, 0, beta_g1);
+        add_into<Fq2, 4>(ctx, pk->b2_ext, 0, beta_g2);
+    }
+};
+
+// ------------------------------------------------------------------ prover
+template <class C>
+struct Prover {
+    typedef typename C::Fr Fr;
+    typedef typename C::Fq Fq;
+    typedef typename C::Fq2 Fq2;
+    static constexpr int FQB = Fq::BYTES;
+
+    static CsrDev csr(const zkhip_r1cs* cs, int k) { return CsrDev{ptr<u64>(cs->rp[k]), ptr<u32>(cs->col[k]), cs->val[k].p}; }
+
+    // K1-K4 on the device: leaves h (canonical integers, sigma order) in ctx->va
+    static void witness_map(zkhip_ctx* ctx, const zkhip_r1cs* cs, NttPlan<C>* pl) {
+        Stream s = ctx->stream;
+        const u64 N = pl->N;
+        ctx->va.ensure(N * sizeof(Fr));
+        ctx->vb.ensure(N * sizeof(Fr));
+        ctx->vc.ensure(N * sizeof(Fr));
+        Fr *a = ptr<Fr>(ctx->va), *b = ptr<Fr>(ctx->vb), *c = ptr<Fr>(ctx->vc);
+        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256), 3), dim3(256), 0, s, csr(cs, 0), csr(cs, 1), csr(cs, 2), ptr<Fr>(ctx->zmont), a, b, c,
+                  cs->n, cs->l, N);
+        Fr* v[3] = {a, b, c};
+        for (int k = 0; k < 3; ++k) {
+            ntt_kind_a<C>(ctx, pl, v[k], true, ptr<Fr>(pl->s_coset));   // ifft, then * g^i   (coset shift)
+            ntt_kind_b<C>(ctx, pl, v[k], false, nullptr);                        // evaluations on g<w>
+        }
+        ZK_LAUNCH((k_quotient<Fr>), dim3(blocks_for(N, 256)), dim3(256), 0, s, a, b, c, pl->zinv, a, N);
+        ntt_kind_a<C>(ctx, pl, a, true, ptr<Fr>(pl->s_cosetinv_canon));   // coset_ifft, leaving Montgomery form
+    }
+
+    static void upload_assignment(zkhip_ctx* ctx, u64 m, const uint8_t* z, const uint8_t* r, const uint8_t* s_) {
+        Stream s = ctx->stream;
+        ctx->scalars.ensure((m + 2) * 32);
+        ctx->zmont.ensure(m * 32);
+        dev_h2d(ctx->scalars.p, z, m * 32, s);
+        dev_h2d(ptr<uint8_t>(ctx->scalars) + m * 32, r, 32, s);
+        dev_h2d(ptr<uint8_t>(ctx->scalars) + (m + 1) * 32, s_, 32, s);
+        ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, s, ptr<Fr>(ctx->scalars), ptr<Fr>(ctx->zmont), m);
+    }
+
+    static void prove(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z, const uint8_t* r, const uint8_t* s_,
+                      uint8_t* out, zkhip_timings* tm) {
+        const auto t_start = std::chrono::steady_clock::now();
+        require(pk->curve == C::ID && cs->curve == C::ID, ZKHIP_ERR_BAD_ARG, "curve mismatch between key and constraint system");
+        require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
+                "proving key does not match the constraint system (m, w or domain size)");
+        const u64 m = pk->m, N = pk->N;
+        Fr z0 = fe_from_bytes_canon<Fr>(z);
+        Fr one = Fr::zero(); one.v[0] = 1;
+        require(z0.equals(one), ZKHIP_ERR_BAD_ARG, "z[0] must be 1 (ark instance variable 0 is the constant ONE)");
+        Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
+        require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
+        NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
+        Stream st = ctx->stream;
+        for (Event e : ctx->ev_pool) event_destroy(e);
+        ctx->ev_pool.clear();
+        Event e0 = pool_event(ctx), e1 = pool_event(ctx), e2 = pool_event(ctx), e3 = pool_event(ctx), e4 = pool_event(ctx), e5 = pool_event(ctx);
+        event_record(e0, st);
+        upload_assignment(ctx, m, z, r, s_);
+        event_record(e1, st);
+
+        // ---- MSMs over S = [z_0..z_{m-1}, r, s]: A, B1, L in G1 and B2 in G2 share one digit/sort pass
+        const MsmShape shz = msm_shape(m + 2, Fr::Params::BITS);
+        const MsmShape shh = msm_shape(N, Fr::Params::BITS);
+        const int Wmax = std::max(shz.W, shh.W);
+        DBuf &d_ws1 = ctx->ws1, &d_ws2 = ctx->ws2;   // window sums: 4 G1 sets + 1 G2 set
+        d_ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
+        d_ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
+        Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(d_ws1);
+        Event ab[5], ae[5];
+        msm_prepare(ctx, ptr<u32>(ctx->scalars), shz);
+        msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->a_ext), shz, ws1 + 0 * Wmax, &ab[0], &ae[0]);
+        msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->b1_ext), shz, ws1 + 1 * Wmax, &ab[1], &ae[1]);
+        msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->l_ext), shz, ws1 + 2 * Wmax, &ab[2], &ae[2]);
+        msm_run<Fq2>(ctx, ptr<Aff<Fq2>>(pk->b2_ext), shz, ptr<Xyzz<Fq2>>(d_ws2), &ab[4], &ae[4]);
+        event_record(e2, st);
+
+        // ---- K1-K4
+        witness_map(ctx, cs, pl);
+        event_record(e3, st);
+
+        // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
+        msm_prepare(ctx, ptr<u32>(ctx->va), shh);
+        msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->h_sigma), shh, ws1 + 3 * Wmax, &ab[3], &ae[3]);
+        event_record(e4, st);
+
+        std::vector<Xyzz<Fq>> h_ws1((size_t)4 * Wmax);
+        std::vector<Xyzz<Fq2>> h_ws2(Wmax);
+        dev_d2h(h_ws1.data(), ws1, h_ws1.size() * sizeof(Xyzz<Fq>), st);
+        dev_d2h(h_ws2.data(), d_ws2.p, h_ws2.size() * sizeof(Xyzz<Fq2>), st);
+        event_record(e5, st);
+        stream_sync(st);
+
+        // ---- K9 on the host: Horner over window sums, then
+        //      C = s*A + r*B1 - rs*delta_1 + L + H   (App. A.3; alpha/beta/delta terms already inside A, B1, B2)
+        const auto t_fin = std::chrono::steady_clock::now();
+        Xyzz<Fq> gA = msm_combine(&h_ws1[0 * Wmax], shz);
+        Xyzz<Fq> gB1 = msm_combine(&h_ws1[1 * Wmax], shz);
+        Xyzz<Fq> gL = msm_combine(&h_ws1[2 * Wmax], shz);
+        Xyzz<Fq> gH = msm_combine(&h_ws1[3 * Wmax], shh);
+        Xyzz<Fq2> gB2 = msm_combine(h_ws2.data(), shz);
+        Fr rs = fe_from_mont(fe_mul(fe_to_mont(rr), fe_to_mont(ss)));
+        uint8_t dec[2 * FQB];
+        decode_point<FQB, 2>(pk->delta_g1_canon.data(), dec);
+        Aff<Fq> d1;
+        memcpy(&d1, dec, sizeof(d1));
+        d1 = PkLoader<C>::to_mont_point(d1);
+        Xyzz<Fq> gC = xyzz_mul_limbs(gA, ss.v, Fr::N);
+        gC = xyzz_add(gC, xyzz_mul_limbs(gB1, rr.v, Fr::N));
+        gC = xyzz_add(gC, xyzz_neg(xyzz_mul_limbs(Xyzz<Fq>::from_affine(d1), rs.v, Fr::N)));
+        gC = xyzz_add(gC, gL);
+        gC = xyzz_add(gC, gH);
+        Aff<Fq> pa = xyzz_to_affine(gA), pc = xyzz_to_affine(gC);
+        Aff<Fq2> pb = xyzz_to_affine(gB2);
+        memset(out, 0, 8 * FQB + 3);
+        if (!gA.is_inf()) { write_fe(pa.x, out); write_fe(pa.y, out + FQB); }
+        if (!gB2.is_inf()) {
+            write_fe(pb.x.c0, out + 2 * FQB); write_fe(pb.x.c1, out + 3 * FQB);
+            write_fe(pb.y.c0, out + 4 * FQB); write_fe(pb.y.c1, out + 5 * FQB);
+        }
+        if (!gC.is_inf()) { write_fe(pc.x, out + 6 * FQB); write_fe(pc.y, out + 7 * FQB); }
+        out[8 * FQB] = gA.is_inf(); out[8 * FQB + 1] = gB2.is_inf(); out[8 * FQB + 2] = gC.is_inf();
+        const auto t_end = std::chrono::steady_clock::now();
+        if (tm) {
+            memset(tm, 0, sizeof(*tm));
+            tm->h2d_ms = event_elapsed_ms(e0, e1);
+            tm->msm_z_ms = event_elapsed_ms(e1, e2);
+            tm->ntt_ms = event_elapsed_ms(e2, e3);   // matvec + 7 transforms + quotient
+            tm->msm_h_ms = event_elapsed_ms(e3, e4);
+            tm->finish_ms = std::chrono::duration<float, std::milli>(t_end - t_fin).count();
+            tm->total_ms = std::chrono::duration<float, std::milli>(t_end - t_start).count();
+            for (int k = 0; k < 4; ++k) tm->kernel_msm_accum_g1_ms += event_elapsed_ms(ab[k], ae[k]);
+            tm->kernel_msm_accum_g2_ms = event_elapsed_ms(ab[4], ae[4]);
+        }
+    }
+
+    // generic MSM primitive (bases in ark encoding)
+    template <class F, int NC>
+    static void msm_api(zkhip_ctx* ctx, u64 n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out) {
+        constexpr int PB = FQB * NC;
+        memset(out, 0, PB + 1);
+        if (n == 0) { out[PB] = 1; return; }
+        require(n < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "too many points");
+        Stream s = ctx->stream;
+        std::vector<uint8_t> host(n * PB);
+        for (u64 i = 0; i < n; ++i) decode_point<FQB, NC>(bases + i * PB, &host[i * PB]);
+        DBuf d_bases, d_ws;
+        d_bases.ensure(host.size());
+        dev_h2d(d_bases.p, host.data(), host.size(), s);
+        ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(n * NC, 256)), dim3(256), 0, s, ptr<Fq>(d_bases), ptr<Fq>(d_bases), n * NC);
+        ctx->scalars.ensure(n * 32);
+        dev_h2d(ctx->scalars.p, scalars, n * 32, s);
+        const MsmShape sh = msm_shape(n, Fr::Params::BITS);
+        d_ws.ensure((size_t)sh.W * sizeof(Xyzz<F>));
+        msm_prepare(ctx, ptr<u32>(ctx->scalars), sh);
+        msm_run<F>(ctx, ptr<Aff<F>>(d_bases), sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
+        std::vector<Xyzz<F>> ws(sh.W);
+        dev_d2h(ws.data(), d_ws.p, ws.size() * sizeof(Xyzz<F>), s);
+        stream_sync(s);
+        Xyzz<F> res = msm_combine(ws.data(), sh);
+        if (res.is_inf()) { out[PB] = 1; return; }
+        Aff<F> a = xyzz_to_affine(res);
+        uint8_t tmp[sizeof(Aff<F>)];
+        Aff<F> canon = from_mont_point(a);
+        memcpy(tmp, &canon, sizeof(canon));
+        memcpy(out, tmp, PB);
+    }
+    static Aff<Fq> from_mont_point(const Aff<Fq>& p) { return {fe_from_mont(p.x), fe_from_mont(p.y)}; }
+    static Aff<Fq2> from_mont_point(const Aff<Fq2>& p) { return {fe_from_mont(p.x), fe_from_mont(p.y)}; }
+
+    static void ntt_api(zkhip_ctx* ctx, u32 log_n, int dir, uint8_t* data) {
+        NttPlan<C>* pl = get_plan<C>(ctx, (int)log_n);
+        Stream s = ctx->stream;
+        const u64 N = pl->N;
+        const unsigned T = 256, B = blocks_for(N, T);
+        ctx->va.ensure(N * sizeof(Fr));
+        ctx->vb.ensure(N * sizeof(Fr));
+        ctx->vc.ensure(N * sizeof(Fr));
+        Fr *a = ptr<Fr>(ctx->va), *b = ptr<Fr>(ctx->vb), *t = ptr<Fr>(ctx->vc);
+        dev_h2d(a, data, N * 32, s);
+        ZK_LAUNCH((k_to_mont<Fr>), dim3(B), dim3(T), 0, s, a, a, N);
+        const bool inverse = dir == 1 || dir == 3;
+        if (dir == 2) {   // coset_fft: x_i * g^i first
+            ZK_LAUNCH((k_pow_table<Fr>), dim3(B), dim3(T), 0, s, t, pl->g, Fr::one(), N, 0u, 0u, 0);
+            ZK_LAUNCH((k_mul_table<Fr>), dim3(B), dim3(T), 0, s, a, t, a, N);
+        }
+        ntt_kind_a<C>(ctx, pl, a, inverse, nullptr);
+        ZK_LAUNCH((k_sigma_permute<Fr>), dim3(B), dim3(T), 0, s, a, b, N, pl->N1, pl->N2, 1);
+        if (inverse) {    // * 1/N (and g^-i for coset_ifft)
+            ZK_LAUNCH((k_pow_table<Fr>), dim3(B), dim3(T), 0, s, t, dir == 3 ? pl->g_inv : Fr::one(), pl->n_inv, N, 0u, 0u, 0);
+            ZK_LAUNCH((k_mul_table<Fr>), dim3(B), dim3(T), 0, s, b, t, b, N);
+        }
+        ZK_LAUNCH((k_from_mont<Fr>), dim3(B), dim3(T), 0, s, b, b, N);
+        dev_d2h(data, b, N * 32, s);
+        stream_sync(s);
+    }
+
+    static void witness_map_api(zkhip_ctx* ctx, const zkhip_r1cs* cs, const uint8_t* z, uint8_t* h_out) {
+        NttPlan<C>* pl = get_plan<C>(ctx, cs->logN);
+        const u64 m = cs->l + cs->w;
+        uint8_t zero[32] = {0};
+        upload_assignment(ctx, m, z, zero, zero);
+        witness_map(ctx, cs, pl);
+        ctx->vb.ensure(pl->N * sizeof(Fr));
+        ZK_LAUNCH((k_sigma_permute<Fr>), dim3(blocks_for(pl->N, 256)), dim3(256), 0, ctx->stream, ptr<Fr>(ctx->va), ptr<Fr>(ctx->vb), pl->N,
+                  pl->N1, pl->N2, 1);
+        dev_d2h(h_out, ctx->vb.p, pl->N * 32, ctx->stream);
+        stream_sync(ctx->stream);
+    }
+
+    template <class F>
+    static void field_op_api(zkhip_ctx* ctx, int op, u64 count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+        Stream s = ctx->stream;
+        const size_t bytes = count * sizeof(F);
+        ctx->va.ensure(bytes); ctx->vb.ensure(bytes);
+        dev_h2d(ctx->va.p, a, bytes, s);
+        dev_h2d(ctx->vb.p, b, bytes, s);
+        const unsigned T = 256, B = blocks_for(count, T);
+        ZK_LAUNCH((k_to_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->va), ptr<F>(ctx->va), count);
+        ZK_LAUNCH((k_to_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->vb), ptr<F>(ctx->vb), count);
+        ZK_LAUNCH((k_field_op<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->va), ptr<F>(ctx->vb), ptr<F>(ctx->va), count, op);
+        ZK_LAUNCH((k_from_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->va), ptr<F>(ctx->va), count);
+        dev_d2h(out, ctx->va.p, bytes, s);
+        stream_sync(s);
+    }
+
+    static void r1cs_load(zkhip_ctx* ctx, zkhip_r1cs* cs, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]) {
+        Stream s = ctx->stream;
+        for (int k = 0; k < 3; ++k) {
+            const u64 nnz = rp[k][cs->n];
+            require(rp[k][0] == 0, ZKHIP_ERR_BAD_ARG, "rowptr[0] must be 0");
+            for (u64 i = 0; i < cs->n; ++i) require(rp[k][i] <= rp[k][i + 1], ZKHIP_ERR_BAD_ARG, "rowptr not monotone");
+            for (u64 q = 0; q < nnz; ++q) require(col[k][q] < cs->l + cs->w, ZKHIP_ERR_BAD_ARG, "column index out of range");
+            cs->nnz[k] = nnz;
+            cs->rp[k].ensure((cs->n + 1) * 8);
+            cs->col[k].ensure(std::max<u64>(nnz, 1) * 4);
+            cs->val[k].ensure(std::max<u64>(nnz, 1) * 32);
+            dev_h2d(cs->rp[k].p, rp[k], (cs->n + 1) * 8, s);
+            if (nnz) {
+                dev_h2d(cs->col[k].p, col[k], nnz * 4, s);
+                dev_h2d(cs->val[k].p, val[k], nnz * 32, s);
+                ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(nnz, 256)), dim3(256), 0, s, ptr<Fr>(cs->val[k]), ptr<Fr>(cs->val[k]), nnz);
+            }
+            cs->h_rp[k].assign(rp[k], rp[k] + cs->n + 1);
+            cs->h_col[k].assign(col[k], col[k] + nnz);
+            cs->h_val[k].assign(val[k], val[k] + nnz * 32);
+        }
+        stream_sync(s);
+    }
+};
+
+}  // namespace zk
+
+
+// ------------------------------------------------------------------ per-curve entry points
+namespace zk {
+struct CurveOps {
+    void (*pk_load)(zkhip_ctx*, const uint8_t*, size_t, zkhip_pk*);
+    void (*r1cs_load)(zkhip_ctx*, zkhip_r1cs*, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]);
+    void (*prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
+    void (*ntt)(zkhip_ctx*, u32, int, uint8_t*);
+    void (*witness_map)(zkhip_ctx*, const zkhip_r1cs*, const uint8_t*, uint8_t*);
+    void (*msm_g1)(zkhip_ctx*, u64, const uint8_t*, const uint8_t*, uint8_t*);
+    void (*msm_g2)(zkhip_ctx*, u64, const uint8_t*, const uint8_t*, uint8_t*);
+    void (*field_op)(zkhip_ctx*, int field, int op, u64, const uint8_t*, const uint8_t*, uint8_t*);
+};
+template <class C>
+static void field_op_dispatch(zkhip_ctx* ctx, int field, int op, u64 count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    if (field == 0) Prover<C>::template field_op_api<typename C::Fr>(ctx, op, count, a, b, out);
+    else Prover<C>::template field_op_api<typename C::Fq>(ctx, op, count, a, b, out);
+}
+template <class C>
+static CurveOps make_curve_ops() {
+    CurveOps o;
+    o.pk_load = &PkLoader<C>::load;
+    o.r1cs_load = &Prover<C>::r1cs_load;
+    o.prove = &Prover<C>::prove;
+    o.ntt = &Prover<C>::ntt_api;
+    o.witness_map = &Prover<C>::witness_map_api;
+    o.msm_g1 = &Prover<C>::template msm_api<typename C::Fq, 2>;
+    o.msm_g2 = &Prover<C>::template msm_api<typename C::Fq2, 4>;
+    o.field_op = &field_op_dispatch<C>;
+    return o;
+}
+const CurveOps* curve_ops_bn254();
+const CurveOps* curve_ops_bls381();
+}  // namespace zk

@@ -1,0 +1,127 @@
+// devrt.h — the thin device-runtime layer under libzkhip.
+//
+// Product build (hipcc, gfx950): straight HIP — hipMalloc / hipMemcpyAsync / streams / events and
+// `hipLaunchKernelGGL`.  There is NO CPU fallback in the product: if no GPU is present every entry
+// point of libzkhip.so fails with ZKHIP_ERR_DEVICE.
+//
+// Test-only build (-DZK_EMU, g++): the same kernel sources run on a single-threaded fibre
+// emulator (emu.h) so that indexing / LDS / barrier logic can be exercised by `pytest -m "not gpu"`
+// in a container without a GPU.  That build produces tests/_emu/libzkhip_emu.so, never
+// libzkhip.so, and is loaded only by tests.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#ifdef ZK_EMU
+#include "emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+namespace zk {
+
+struct DevError {
+    std::string msg;
+};
+
+#ifndef ZK_EMU
+#define ZK_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            throw zk::DevError{std::string(#expr) + ": " + hipGetErrorString(e_)};                \
+    } while (0)
+
+typedef hipStream_t Stream;
+typedef hipEvent_t Event;
+
+inline int dev_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+inline void dev_set(int d) { ZK_HIP_CHECK(hipSetDevice(d)); }
+inline void* dev_alloc(size_t bytes) {
+    void* p = nullptr;
+    ZK_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    return p;
+}
+inline void dev_free(void* p) {
+    if (p) (void)hipFree(p);
+}
+inline void* host_alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    ZK_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault));
+    return p;
+}
+inline void host_free_pinned(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+inline void dev_h2d(void* d, const void* h, size_t n, Stream s) { ZK_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
+inline void dev_d2h(void* h, const void* d, size_t n, Stream s) { ZK_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
+inline void dev_d2d(void* d, const void* s_, size_t n, Stream s) { ZK_HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s)); }
+inline void dev_memset(void* d, int v, size_t n, Stream s) { ZK_HIP_CHECK(hipMemsetAsync(d, v, n, s)); }
+inline Stream stream_create() {
+    Stream s;
+    ZK_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+inline void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
+inline void stream_sync(Stream s) { ZK_HIP_CHECK(hipStreamSynchronize(s)); }
+inline Event event_create() {
+    Event e;
+    ZK_HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+inline void event_destroy(Event e) { (void)hipEventDestroy(e); }
+inline void event_record(Event e, Stream s) { ZK_HIP_CHECK(hipEventRecord(e, s)); }
+inline void event_sync(Event e) { ZK_HIP_CHECK(hipEventSynchronize(e)); }
+inline void stream_wait_event(Stream s, Event e) { ZK_HIP_CHECK(hipStreamWaitEvent(s, e, 0)); }
+inline float event_elapsed_ms(Event a, Event b) {
+    float ms = 0;
+    ZK_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+}
+inline void dev_check_last() { ZK_HIP_CHECK(hipGetLastError()); }
+
+#define ZK_LAUNCH(kernel, grid, block, smem, stream, ...)                                 \
+    do {                                                                                  \
+        hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);               \
+        zk::dev_check_last();                                                             \
+    } while (0)
+#define ZK_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+#else  // ---------------------------- emulator ----------------------------
+
+typedef int Stream;
+typedef double* Event;
+inline int dev_count() { return 1; }
+inline void dev_set(int) {}
+inline void* dev_alloc(size_t bytes) { return aligned_alloc(256, ((bytes ? bytes : 16) + 255) / 256 * 256); }
+inline void dev_free(void* p) { free(p); }
+inline void* host_alloc_pinned(size_t bytes) { return dev_alloc(bytes); }
+inline void host_free_pinned(void* p) { free(p); }
+inline void dev_h2d(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }
+inline void dev_d2h(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n); }
+inline void dev_d2d(void* d, const void* s_, size_t n, Stream) { memcpy(d, s_, n); }
+inline void dev_memset(void* d, int v, size_t n, Stream) { memset(d, v, n); }
+inline Stream stream_create() { return 0; }
+inline void stream_destroy(Stream) {}
+inline void stream_sync(Stream) {}
+inline Event event_create() { return new double(0); }
+inline void event_destroy(Event e) { delete e; }
+inline void event_record(Event e, Stream) { *e = emu::now_ms(); }
+inline void event_sync(Event) {}
+inline void stream_wait_event(Stream, Event) {}
+inline float event_elapsed_ms(Event a, Event b) { return (float)(*b - *a); }
+inline void dev_check_last() {}
+
+#define ZK_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu::launch(dim3(grid), dim3(block), (size_t)(smem), [&]() { kernel(__VA_ARGS__); })
+#define ZK_DYN_SMEM(name) unsigned char* name = emu::dyn_smem()
+
+#endif
+
+}  // namespace zk

@@ -1,0 +1,197 @@
+// zkhip_api.hip — the C ABI of include/zkhip.h: argument checking, error mapping, per-curve dispatch.
+// The drop-in boundary for `Backend<T, G16>::generate_proof` (/root/reference/zokrates_proof_systems/src/lib.rs:98-112).
+#include "core.cuh"
+
+// ------------------------------------------------------------------ C ABI
+static const CurveOps* ops_for(int curve) {
+    if (curve == ZKHIP_CURVE_BN128) return curve_ops_bn254();
+    if (curve == ZKHIP_CURVE_BLS12_381) return curve_ops_bls381();
+    throw ApiError{ZKHIP_ERR_BAD_ARG, "unknown curve id"};
+}
+static std::string g_create_err;
+
+template <class Fn>
+static int32_t guarded(zkhip_ctx* ctx, Fn&& fn) {
+    try {
+        if (ctx) dev_set(ctx->device);
+        fn();
+        return ZKHIP_OK;
+    } catch (const ApiError& e) {
+        (ctx ? ctx->err : g_create_err) = e.msg;
+        return e.code;
+    } catch (const DevError& e) {
+        (ctx ? ctx->err : g_create_err) = e.msg;
+        return ZKHIP_ERR_DEVICE;
+    } catch (const std::bad_alloc&) {
+        (ctx ? ctx->err : g_create_err) = "out of host memory";
+        return ZKHIP_ERR_NOMEM;
+    } catch (...) {
+        (ctx ? ctx->err : g_create_err) = "unexpected internal error";
+        return ZKHIP_ERR_DEVICE;
+    }
+}
+
+extern "C" {
+
+int32_t zkhip_device_count(void) { return dev_count(); }
+
+int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
+    if (!out) { g_create_err = "out is NULL"; return ZKHIP_ERR_BAD_ARG; }
+    *out = nullptr;
+    return guarded(nullptr, [&] {
+        const int n = dev_count();
+        require(n > 0, ZKHIP_ERR_DEVICE, "no HIP device available (libzkhip has no CPU fallback)");
+        require(device >= 0 && device < n, ZKHIP_ERR_BAD_ARG, "device index out of range");
+        dev_set(device);
+        std::unique_ptr<zkhip_ctx> ctx(new zkhip_ctx());
+        ctx->device = device;
+        ctx->stream = stream_create();
+#ifdef ZK_EMU
+        ctx->desc = "zkhip TEST EMULATOR (not a product build)";
+#else
+        hipDeviceProp_t prop;
+        ZK_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        char buf[256];
+        snprintf(buf, sizeof(buf), "zkhip on %s (%s), %d CUs, %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+                 prop.totalGlobalMem / 1073741824.0);
+        ctx->desc = buf;
+#endif
+        *out = ctx.release();
+    });
+}
+void zkhip_ctx_free(zkhip_ctx* ctx) {
+    if (!ctx) return;
+    for (Event e : ctx->ev_pool) event_destroy(e);
+    stream_destroy(ctx->stream);
+    delete ctx;
+}
+const char* zkhip_last_error(const zkhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int32_t zkhip_describe(const zkhip_ctx* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || !cap) return ZKHIP_ERR_BAD_ARG;
+    snprintf(buf, cap, "%s", ctx->desc.c_str());
+    return ZKHIP_OK;
+}
+
+int32_t zkhip_pk_load_g16(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, zkhip_pk** out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(bytes && out, ZKHIP_ERR_BAD_ARG, "null argument");
+        *out = nullptr;
+        std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
+        pk->curve = curve;
+        pk->ctx = ctx;
+        ops_for(curve)->pk_load(ctx, bytes, len, pk.get());
+        *out = pk.release();
+    });
+}
+void zkhip_pk_free(zkhip_pk* pk) { delete pk; }
+int32_t zkhip_pk_dims(const zkhip_pk* pk, uint64_t out[4]) {
+    if (!pk || !out) return ZKHIP_ERR_BAD_ARG;
+    out[0] = pk->m; out[1] = pk->hlen; out[2] = pk->w; out[3] = pk->l;
+    return ZKHIP_OK;
+}
+
+int32_t zkhip_r1cs_load(zkhip_ctx* ctx, int32_t curve, uint64_t n, uint64_t l, uint64_t w, const uint64_t* rowptr_a, const uint32_t* col_a,
+                        const uint8_t* val_a, const uint64_t* rowptr_b, const uint32_t* col_b, const uint8_t* val_b, const uint64_t* rowptr_c,
+                        const uint32_t* col_c, const uint8_t* val_c, zkhip_r1cs** out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(out && rowptr_a && rowptr_b && rowptr_c, ZKHIP_ERR_BAD_ARG, "null argument");
+        *out = nullptr;
+        require(l >= 1, ZKHIP_ERR_BAD_ARG, "num_instance must be >= 1 (the constant ONE)");
+        require(l + w + 2 < ((u64)1 << 31) && n < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "constraint system too large");
+        std::unique_ptr<zkhip_r1cs> cs(new zkhip_r1cs());
+        cs->curve = curve; cs->ctx = ctx; cs->n = n; cs->l = l; cs->w = w;
+        cs->logN = ilog2_ceil(n + l);
+        cs->N = (u64)1 << cs->logN;
+        const u64* rp[3] = {rowptr_a, rowptr_b, rowptr_c};
+        const u32* col[3] = {col_a, col_b, col_c};
+        const uint8_t* val[3] = {val_a, val_b, val_c};
+        ops_for(curve)->r1cs_load(ctx, cs.get(), rp, col, val);
+        *out = cs.release();
+    });
+}
+void zkhip_r1cs_free(zkhip_r1cs* cs) { delete cs; }
+
+int32_t zkhip_prove_g16(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z, const uint8_t* r, const uint8_t* s,
+                        uint8_t* proof_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && z && r && s && proof_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
+        ops_for(pk->curve)->prove(ctx, pk, r1cs, z, r, s, proof_out, timings);
+    });
+}
+
+int32_t zkhip_prove_g16_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count, const uint8_t* z, const uint8_t* rs,
+                              uint8_t* proofs_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && z && rs && proofs_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
+        const size_t fqb = pk->curve == ZKHIP_CURVE_BN128 ? 32 : 48;
+        zkhip_timings acc;
+        memset(&acc, 0, sizeof(acc));
+        for (uint32_t i = 0; i < count; ++i) {
+            zkhip_timings t;
+            ops_for(pk->curve)->prove(ctx, pk, r1cs, z + (size_t)i * pk->m * 32, rs + (size_t)i * 64, rs + (size_t)i * 64 + 32,
+                                      proofs_out + (size_t)i * (8 * fqb + 3), &t);
+            float* a = (float*)&acc; const float* b = (const float*)&t;
+            for (size_t k = 0; k < sizeof(acc) / sizeof(float); ++k) a[k] += b[k];
+        }
+        if (timings) *timings = acc;
+    });
+}
+
+int32_t zkhip_ntt(zkhip_ctx* ctx, int32_t curve, uint32_t log_n, int32_t dir, uint8_t* data) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(data && dir >= 0 && dir <= 3, ZKHIP_ERR_BAD_ARG, "bad argument");
+        ops_for(curve)->ntt(ctx, log_n, dir, data);
+    });
+}
+int32_t zkhip_witness_map(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* z, uint8_t* h_out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(r1cs && z && h_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        ops_for(r1cs->curve)->witness_map(ctx, r1cs, z, h_out);
+    });
+}
+int32_t zkhip_msm_g1(zkhip_ctx* ctx, int32_t curve, uint64_t n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(out && (n == 0 || (bases && scalars)), ZKHIP_ERR_BAD_ARG, "null argument");
+        ops_for(curve)->msm_g1(ctx, n, bases, scalars, out);
+    });
+}
+int32_t zkhip_msm_g2(zkhip_ctx* ctx, int32_t curve, uint64_t n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(out && (n == 0 || (bases && scalars)), ZKHIP_ERR_BAD_ARG, "null argument");
+        ops_for(curve)->msm_g2(ctx, n, bases, scalars, out);
+    });
+}
+int32_t zkhip_field_op(zkhip_ctx* ctx, int32_t curve, int32_t field, int32_t op, uint64_t count, const uint8_t* a, const uint8_t* b,
+                       uint8_t* out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(a && b && out && op >= 0 && op <= 2 && (field == 0 || field == 1), ZKHIP_ERR_BAD_ARG, "bad argument");
+        ops_for(curve)->field_op(ctx, field, op, count, a, b, out);
+    });
+}
+
+int32_t zkhip_setup_g16_size(const zkhip_r1cs* cs, uint64_t* pk_bytes) {
+    if (!cs || !pk_bytes) return ZKHIP_ERR_BAD_ARG;
+    const u64 fqb = cs->curve == ZKHIP_CURVE_BN128 ? 32 : 48;
+    const u64 g1 = 2 * fqb, g2 = 4 * fqb, m = cs->l + cs->w;
+    *pk_bytes = g1 + 3 * g2 + 8 + cs->l * g1 + 2 * g1 + 8 + m * g1 + 8 + m * g1 + 8 + m * g2 + 8 + (cs->N - 1) * g1 + 8 + cs->w * g1;
+    return ZKHIP_OK;
+}
+int32_t zkhip_setup_g16(zkhip_ctx* ctx, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, uint64_t) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    ctx->err = "zkhip_setup_g16: not implemented yet";
+    return ZKHIP_ERR_BAD_ARG;
+}
+
+}  // extern "C"

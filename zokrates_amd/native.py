@@ -1,0 +1,248 @@
+"""ctypes binding of libzkhip.so — the C ABI declared in include/zkhip.h.
+
+This is plumbing: it adds no arithmetic.  If the HIP library is missing or no GPU is usable, every
+entry point raises `ZkhipError`; there is no CPU path behind this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libzkhip.so")
+
+CURVE_IDS = {"bn128": 0, "bls12_381": 1}
+FQ_BYTES = {0: 32, 1: 48}
+
+ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "PARSE", -3: "NOMEM", -4: "DEVICE", -5: "UNSATISFIED"}
+
+
+class ZkhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zkhip error {code} ({ERR_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "h2d_ms", "matvec_ms", "ntt_ms", "msm_h_ms", "msm_z_ms", "finish_ms", "total_ms",
+        "kernel_msm_accum_g1_ms", "kernel_msm_accum_g2_ms")] + [("reserved", C.c_float * 7)]
+
+    def as_dict(self):
+        return {n: float(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(buf, n=None):
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+    if n is not None and a.size != n:
+        raise ValueError(f"buffer has {a.size} bytes, expected {n}")
+    return a
+
+
+class Library:
+    """One loaded copy of the C ABI."""
+
+    SYMBOLS = [
+        "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_free", "zkhip_last_error", "zkhip_pk_load_g16",
+        "zkhip_pk_free", "zkhip_pk_dims", "zkhip_r1cs_load", "zkhip_r1cs_free", "zkhip_prove_g16",
+        "zkhip_prove_g16_batch", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
+        "zkhip_field_op", "zkhip_setup_g16_size", "zkhip_setup_g16", "zkhip_describe",
+    ]
+
+    def __init__(self, path=None):
+        self.path = path or DEFAULT_LIB
+        if not os.path.exists(self.path):
+            raise ZkhipError(-4, f"{self.path} not found: build it with `python -m zokrates_amd.build` "
+                                 "(libzkhip has no CPU fallback)")
+        L = C.CDLL(self.path)
+        vp, u64, u32, i32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_size_t
+        pp = C.POINTER(C.c_void_p)
+        L.zkhip_device_count.restype = i32
+        L.zkhip_ctx_create.restype = i32; L.zkhip_ctx_create.argtypes = [i32, pp]
+        L.zkhip_ctx_free.restype = None; L.zkhip_ctx_free.argtypes = [vp]
+        L.zkhip_last_error.restype = C.c_char_p; L.zkhip_last_error.argtypes = [vp]
+        L.zkhip_pk_load_g16.restype = i32; L.zkhip_pk_load_g16.argtypes = [vp, i32, vp, sz, pp]
+        L.zkhip_pk_free.restype = None; L.zkhip_pk_free.argtypes = [vp]
+        L.zkhip_pk_dims.restype = i32; L.zkhip_pk_dims.argtypes = [vp, vp]
+        L.zkhip_r1cs_load.restype = i32; L.zkhip_r1cs_load.argtypes = [vp, i32, u64, u64, u64] + [vp] * 9 + [pp]
+        L.zkhip_r1cs_free.restype = None; L.zkhip_r1cs_free.argtypes = [vp]
+        L.zkhip_prove_g16.restype = i32; L.zkhip_prove_g16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        L.zkhip_prove_g16_batch.restype = i32; L.zkhip_prove_g16_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        L.zkhip_ntt.restype = i32; L.zkhip_ntt.argtypes = [vp, i32, u32, i32, vp]
+        L.zkhip_witness_map.restype = i32; L.zkhip_witness_map.argtypes = [vp, vp, vp, vp]
+        L.zkhip_msm_g1.restype = i32; L.zkhip_msm_g1.argtypes = [vp, i32, u64, vp, vp, vp]
+        L.zkhip_msm_g2.restype = i32; L.zkhip_msm_g2.argtypes = [vp, i32, u64, vp, vp, vp]
+        L.zkhip_field_op.restype = i32; L.zkhip_field_op.argtypes = [vp, i32, i32, i32, u64, vp, vp, vp]
+        L.zkhip_setup_g16_size.restype = i32; L.zkhip_setup_g16_size.argtypes = [vp, vp]
+        L.zkhip_setup_g16.restype = i32; L.zkhip_setup_g16.argtypes = [vp, vp, vp, vp, vp, vp, u64]
+        L.zkhip_describe.restype = i32; L.zkhip_describe.argtypes = [vp, vp, sz]
+        self.L = L
+
+    def device_count(self):
+        return int(self.L.zkhip_device_count())
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+class Context:
+    """`zkhip_ctx`: one GPU, not re-entrant."""
+
+    def __init__(self, device=0, library=None):
+        self.lib = library or default_library()
+        self.h = C.c_void_p()
+        rc = self.lib.L.zkhip_ctx_create(device, C.byref(self.h))
+        if rc != 0:
+            raise ZkhipError(rc, self.lib.L.zkhip_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ZkhipError(rc, self.lib.L.zkhip_last_error(self.h).decode())
+
+    def describe(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.L.zkhip_describe(self.h, buf, 256))
+        return buf.value.decode()
+
+    def close(self):
+        if self.h:
+            self.lib.L.zkhip_ctx_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- primitives ----
+    def ntt(self, curve_id, data, direction):
+        d = np.array(_u8(data), dtype=np.uint8, copy=True)
+        n = d.size // 32
+        logn = n.bit_length() - 1
+        if n == 0 or (1 << logn) != n:
+            raise ValueError("NTT size must be a power of two")
+        code = {"fft": 0, "ifft": 1, "coset_fft": 2, "coset_ifft": 3}[direction]
+        self._check(self.lib.L.zkhip_ntt(self.h, curve_id, logn, code, _ptr(d)))
+        return d
+
+    def msm(self, curve_id, group, bases, scalars):
+        nb = FQ_BYTES[curve_id]
+        pt = 2 * nb * group
+        scalars = _u8(scalars)
+        n = scalars.size // 32
+        bases = _u8(bases, n * pt)
+        out = np.zeros(pt + 1, dtype=np.uint8)
+        fn = self.lib.L.zkhip_msm_g1 if group == 1 else self.lib.L.zkhip_msm_g2
+        self._check(fn(self.h, curve_id, n, _ptr(bases), _ptr(scalars), _ptr(out)))
+        return out.tobytes()
+
+    def field_op(self, curve_id, field, op, a, b):
+        nb = 32 if field == 0 else FQ_BYTES[curve_id]
+        a = _u8(a); b = _u8(b, a.size)
+        out = np.zeros(a.size, dtype=np.uint8)
+        code = {"add": 0, "sub": 1, "mul": 2}[op]
+        self._check(self.lib.L.zkhip_field_op(self.h, curve_id, field, code, a.size // nb, _ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+
+class ProvingKey:
+    """`zkhip_pk`: an ark `proving.key` resident on the GPU in MSM-ready layout."""
+
+    def __init__(self, ctx, curve_id, data):
+        self.ctx = ctx
+        self.curve_id = curve_id
+        data = _u8(data)
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.L.zkhip_pk_load_g16(ctx.h, curve_id, _ptr(data), data.size, C.byref(self.h)))
+        d = np.zeros(4, dtype=np.uint64)
+        ctx._check(ctx.lib.L.zkhip_pk_dims(self.h, _ptr(d)))
+        self.m, self.hlen, self.w, self.l = (int(x) for x in d)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.L.zkhip_pk_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ConstraintSystem:
+    """`zkhip_r1cs`: CSR matrices in ark variable order, resident on the GPU."""
+
+    def __init__(self, ctx, curve_id, n, l, w, mats):
+        self.ctx = ctx
+        self.curve_id = curve_id
+        self.n, self.l, self.w = n, l, w
+        self.m = l + w
+        args, keep = [], []
+        for rp, col, val in mats:
+            rp = np.ascontiguousarray(rp, dtype=np.uint64)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            val = _u8(val)
+            if rp.size != n + 1 or val.size != col.size * 32:
+                raise ValueError("CSR shape mismatch")
+            keep += [rp, col, val]
+            args += [_ptr(rp), _ptr(col), _ptr(val)]
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.L.zkhip_r1cs_load(ctx.h, curve_id, n, l, w, *args, C.byref(self.h)))
+
+    def witness_map(self, z):
+        N = 1
+        while N < self.n + self.l:
+            N *= 2
+        z = _u8(z, self.m * 32)
+        out = np.zeros(N * 32, dtype=np.uint8)
+        self.ctx._check(self.ctx.lib.L.zkhip_witness_map(self.ctx.h, self.h, _ptr(z), _ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.L.zkhip_r1cs_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove_g16(ctx, pk, cs, z, r, s, want_timings=False):
+    """Raw proof bytes (8*sz(Fq)+3) for assignment z (m*32 B canonical LE) and blinding scalars r, s (ints)."""
+    nb = FQ_BYTES[pk.curve_id]
+    z = _u8(z, cs.m * 32)
+    rb = np.frombuffer(int(r).to_bytes(32, "little"), dtype=np.uint8)
+    sb = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8)
+    out = np.zeros(8 * nb + 3, dtype=np.uint8)
+    tm = Timings()
+    ctx._check(ctx.lib.L.zkhip_prove_g16(ctx.h, pk.h, cs.h, _ptr(z), _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm)))
+    return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+
+def prove_g16_batch(ctx, pk, cs, zs, rs):
+    """zs: uint8[count*m*32]; rs: list of (r, s) ints.  Returns (list of raw proofs, summed timings)."""
+    nb = FQ_BYTES[pk.curve_id]
+    count = len(rs)
+    zs = _u8(zs, count * pk.m * 32)
+    rsb = np.frombuffer(b"".join(int(r).to_bytes(32, "little") + int(s).to_bytes(32, "little") for r, s in rs), dtype=np.uint8)
+    out = np.zeros(count * (8 * nb + 3), dtype=np.uint8)
+    tm = Timings()
+    ctx._check(ctx.lib.L.zkhip_prove_g16_batch(ctx.h, pk.h, cs.h, count, _ptr(zs), _ptr(rsb), _ptr(out), C.byref(tm)))
+    step = 8 * nb + 3
+    return [out[i * step:(i + 1) * step].tobytes() for i in range(count)], tm.as_dict()
