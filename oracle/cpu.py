@@ -11,10 +11,30 @@ LIB_PATH = os.path.join(HERE, "c", "liboracle_g16.so")
 _lib = None
 
 
+def _cpu_tag():
+    """The library is compiled with -march=native: rebuild when the host CPU differs from the build host
+    (the .so travels to the GPU box with the repository snapshot)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    import hashlib
+                    return hashlib.sha1(line.encode()).hexdigest()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build(force=False):
     srcs = [os.path.join(HERE, "c", f) for f in ("oracle_g16.cpp", "ff.hpp", "ec.hpp")]
-    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-C", HERE, "-s"])
+    stamp = LIB_PATH + ".cpu"
+    tag = _cpu_tag()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if (force or have != tag or not os.path.exists(LIB_PATH)
+            or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)):
+        subprocess.check_call(["make", "-C", HERE, "-s", "-B"])
+        with open(stamp, "w") as f:
+            f.write(tag)
     return LIB_PATH
 
 

