@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — Groth16 proofs/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-domain 20] [--curve bn128] [--kind dense]
+
+A "step" is one Groth16 proof (`zkhip_prove_g16_resident`: sparse mat-vec, 7 NTTs, 5 MSMs, assembly) of the
+synthetic 2^20-constraint BN254 circuit of BASELINE.json configs[1].  The proving key, the
+constraint system and the assignments are resident in HBM when the timed region starts; every step uses a
+different (witness, r, s).  With N > 1 every rank proves its own K proofs on its own GPU with a full copy of
+the key (independent proofs: no data-path collective; "weak" scaling) and `value` is N*K / max-over-ranks time.
+
+Besides the contract fields the JSON line carries
+  roofline     — the dominant kernel's algorithmic bytes per launch / its HIP-event-measured duration vs 8 TB/s
+  cpu_baseline — the C++ restatement of zokrates_ark/ark-groth16 0.3.0 (oracle/, kind "port") timed on this
+                 box's host cores on the same circuit, key and witness (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from zokrates_amd import native, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def make_proving_key(ctx, cs, circ, curve_id):
+    """Groth16 setup for the synthetic circuit with fixed toxic waste, on the GPU (zkhip_setup_g16)."""
+    return native.setup_g16(ctx, cs, synth.toxic_waste(curve_id, 0xC0FFEE))
+
+
+def cpu_baseline(circ, pk_bytes, z, budget_s):
+    """Times the CPU port of the reference path on the host cores: same circuit, key, assignment."""
+    from oracle import cpu   # test infrastructure; used here only as the timed CPU baseline
+    threads = cpu.hw_threads()
+    oc = cpu.Circuit.from_csr(circ.curve_id, circ.n, circ.l, circ.w, circ.mats())
+    opk = cpu.ProvingKey.parse(circ.curve_id, pk_bytes)
+    t0 = time.time()
+    done, proofs = 0, []
+    while True:
+        raw, _ = cpu.prove(oc, opk, z, 1000 + done, 2000 + done, threads)
+        proofs.append(raw)
+        done += 1
+        el = time.time() - t0
+        if el >= budget_s or el + el / done > 2.5 * budget_s or done >= 64:
+            break
+    return {"value": done / el, "unit": "proofs/s", "cores": threads, "kind": "port",
+            "sample": f"{done} proof(s) of the same 2^{int(np.log2(circ.N))} circuit in {el:.1f} s, "
+                      f"C++ restatement of ark-groth16 0.3.0 (Pippenger c=0.69*log2(n)+2, radix-2 FFT), {threads} threads",
+            "ms_per_proof": 1000.0 * el / done}, proofs[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-domain", type=int, default=20)
+    ap.add_argument("--curve", default="bn128")
+    ap.add_argument("--kind", default="dense")
+    ap.add_argument("--witnesses", type=int, default=2, help="distinct assignments kept resident and cycled")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier_sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        # every libzkhip call returns only after its stream has drained, so there is no outstanding GPU work here
+
+    curve_id = synth.CURVE_IDS[args.curve]
+    ctx = native.Context(local_rank)
+    circ = synth.circuit(curve_id, args.log_domain, kind=args.kind)
+    cs = native.ConstraintSystem(ctx, curve_id, circ.n, circ.l, circ.w, circ.mats())
+    t0 = time.time()
+    pk_bytes = make_proving_key(ctx, cs, circ, curve_id)
+    t_setup = time.time() - t0
+    t0 = time.time()
+    pk = native.ProvingKey(ctx, curve_id, pk_bytes)
+    t_pkload = time.time() - t0
+    nw = max(1, min(args.witnesses, args.steps + args.warmup))
+    zs = [circ.assignment(0x5EED0000 + rank * 1000 + i) for i in range(nw)]
+    t0 = time.time()
+    resident = [native.Assignment(ctx, cs, z) for z in zs]
+    t_h2d = (time.time() - t0) / nw
+
+    def rs(i):
+        return 0x1111111111111111 * (i + 1) + rank, 0x2222222222222222 * (i + 3) + rank
+
+    proofs = []
+    for i in range(args.warmup):
+        proofs.append(native.prove_g16_resident(ctx, pk, cs, resident[i % nw], *rs(i)))
+    barrier_sync()
+    t_begin = time.perf_counter()
+    acc = None
+    for i in range(args.steps):
+        j = args.warmup + i
+        raw, tm = native.prove_g16_resident(ctx, pk, cs, resident[j % nw], *rs(j), want_timings=True)
+        acc = tm if acc is None else {k: acc[k] + v for k, v in tm.items()}
+    barrier_sync()
+    elapsed = time.perf_counter() - t_begin
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    avg = {k: v / args.steps for k, v in acc.items()}
+    # ---- roofline of the dominant kernel (HIP events on the library's stream, inside the timed region)
+    m, N = circ.m, circ.N
+    fq = native.FQ_BYTES[curve_id]
+    kernels = {
+        # algorithmic bytes per launch: bases read once + the 32-B scalars they pair with (SURVEY.md §8d (iv)+(v))
+        "msm_accumulate<G2> (b_g2_query)": (avg["kernel_msm_accum_g2_ms"], (m + 2) * (4 * fq + 32), 1),
+        "msm_accumulate<G1> (a/b_g1/l/h_query)": (avg["kernel_msm_accum_g1_ms"], (3 * (m + 2) + N) * (2 * fq + 32), 4),
+    }
+    name, (ms, bytes_all, launches) = max(kernels.items(), key=lambda kv: kv[1][0])
+    achieved = bytes_all / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": bytes_all / launches, "ms_per_launch": ms / launches, "launches_per_proof": launches,
+                "note": "bucket accumulation is integer-ALU bound (Montgomery multiplies), not HBM bound; see DESIGN.md"}
+    b_alg = proof_algorithmic_bytes(circ, fq)
+    out = {
+        "metric": "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints (QAP domain 2^{args.log_domain}), "
+                               f"{args.curve} Groth16, 7 NTTs + 5 MSMs per proof", "curve": args.curve, "constraints": circ.n,
+                   "variables": m, "domain": N, "parallelism": f"{world} independent prover(s), full key per GPU"},
+        "single_proof_ms": avg["total_ms"], "phases_ms": avg,
+        "whole_proof_hbm": {"algorithmic_bytes": b_alg, "achieved_GBs": b_alg / (elapsed / args.steps) / 1e9,
+                            "frac": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+        "roofline": roofline,
+        "host_ms": {"setup_gpu": 1000 * t_setup, "pk_load": 1000 * t_pkload, "assignment_h2d": 1000 * t_h2d},
+        "device": ctx.describe(),
+    }
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        base, cpu_proof = cpu_baseline(circ, pk_bytes, zs[0], args.cpu_seconds)
+        out["cpu_baseline"] = base
+        # same inputs -> byte-identical proof (the CPU leg doubles as a full-size parity check)
+        gpu_proof = native.prove_g16_resident(ctx, pk, cs, resident[0], 1000, 2000)
+        out["cpu_baseline"]["gpu_proof_identical"] = bool(gpu_proof == cpu_proof)
+        out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def proof_algorithmic_bytes(circ, fq):
+    """Compulsory HBM traffic of one proof: every input read once, every output written once per logical stage
+    (SURVEY.md §8d): mat-vec, 7 transforms, MSM bases, MSM scalars."""
+    F, n, m, N, w, l = 32, circ.n, circ.m, circ.N, circ.w, circ.l
+    nnz = sum(int(mat[0][-1]) for mat in circ.mats())
+    matvec = nnz * (F + 4) + 3 * (n + 1) * 8 + m * F + 3 * N * F
+    transforms = 7 * 2 * N * F
+    bases = (N - 1) * 2 * fq + w * 2 * fq + 2 * m * 2 * fq + m * 4 * fq
+    scalars = N * F + w * F + 3 * m * F
+    return matvec + transforms + bases + scalars
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,11 @@ def test_prove_matches_oracle(ctx, curve, kind):
     # r = 0 / s = 0 corner (ark skips B1 when r == 0; the result must not change)
     assert native.prove_g16(ctx, pk, cs, z, 0, s_) == cpu.trapdoor(oc, tox, z, 0, s_)
     assert native.prove_g16(ctx, pk, cs, z, r_, 0) == cpu.trapdoor(oc, tox, z, r_, 0)
+    # resident assignment == host assignment, reusable across (r, s)
+    za = native.Assignment(ctx, cs, z)
+    assert native.prove_g16_resident(ctx, pk, cs, za, r_, s_) == want
+    assert native.prove_g16_resident(ctx, pk, cs, za, 5, 6) == cpu.trapdoor(oc, tox, z, 5, 6)
+    za.close()
     # batch == singles
     proofs, _ = native.prove_g16_batch(ctx, pk, cs, np.concatenate([z, z]), [(r_, s_), (5, 6)])
     assert proofs[0] == want and proofs[1] == cpu.trapdoor(oc, tox, z, 5, 6)

@@ -127,6 +127,9 @@ def test_prove_matches_oracle(ctx, curve, logn, kind):
     got, tm = native.prove_g16(ctx, pk, cs, z, r_, s_, want_timings=True)
     assert got == want
     assert native.prove_g16(ctx, pk, cs, z, 0, 0) == cpu.trapdoor(oc, tox, z, 0, 0)
+    za = native.Assignment(ctx, cs, z)
+    assert native.prove_g16_resident(ctx, pk, cs, za, r_, s_) == want
+    assert native.prove_g16_resident(ctx, pk, cs, za, 3, 4) == cpu.trapdoor(oc, tox, z, 3, 4)
     # determinism: same (pk, z, r, s) -> same bytes (cf. zokrates_js/tests/tests.js:248-267)
     assert native.prove_g16(ctx, pk, cs, z, r_, s_) == got
 
@@ -162,3 +165,75 @@ def test_error_paths(ctx):
     with pytest.raises(native.ZkhipError) as e:
         native.prove_g16(ctx, pk, cs, z, 1, 2)
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("curve,logn,kind", [(BN254, 6, "dense"), (BN254, 12, "sha"), (BLS12_381, 9, "dense")],
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_setup_matches_oracle(ctx, curve, logn, kind):
+    """N3: zkhip_setup_g16 writes the same `proving.key` bytes as the oracle's restatement of
+    ark_groth16::generate_random_parameters (App. A.6) for the same toxic waste and generators; the key then
+    round-trips through zkhip_pk_load_g16 and proves."""
+    from zokrates_amd import synth
+    circ = synth.circuit(curve.curve_id, logn, kind=kind, seed=0x77 + logn)
+    cs = native.ConstraintSystem(ctx, curve.curve_id, circ.n, circ.l, circ.w, circ.mats())
+    tox = synth.toxic_waste(curve.curve_id, 0xBEEF)
+    raw = native.setup_g16(ctx, cs, tox)
+    oc = cpu.Circuit.from_csr(curve.curve_id, circ.n, circ.l, circ.w, circ.mats())
+    tb = b"".join(int(v).to_bytes(32, "little") for v in tox)
+    assert raw.tobytes() == cpu.ProvingKey.setup(oc, tb).serialize().tobytes()
+    z = circ.assignment(99)
+    pk = native.ProvingKey(ctx, curve.curve_id, raw)
+    assert native.prove_g16(ctx, pk, cs, z, 17, 19) == cpu.trapdoor(oc, tb, z, 17, 19)
+    # non-standard generators (ark samples random ones): 5*G1, 7*G2 from the oracle's MSM
+    g1, g2 = cpu.generators(curve.curve_id)
+    g1b = cpu.msm(curve.curve_id, 1, np.frombuffer(g1, dtype=np.uint8), le([5]))[:-1]
+    g2b = cpu.msm(curve.curve_id, 2, np.frombuffer(g2, dtype=np.uint8), le([7]))[:-1]
+    raw2 = native.setup_g16(ctx, cs, tox, np.frombuffer(g1b, dtype=np.uint8), np.frombuffer(g2b, dtype=np.uint8))
+    assert raw2.tobytes() != raw.tobytes()
+    pk2 = native.ProvingKey(ctx, curve.curve_id, raw2)
+    opk2 = cpu.ProvingKey.parse(curve.curve_id, raw2.tobytes())
+    want, _ = cpu.prove(oc, opk2, z, 17, 19)
+    assert native.prove_g16(ctx, pk2, cs, z, 17, 19) == want
+
+
+def test_full_size_properties(ctx):
+    """BASELINE.json configs[1] (2^20 constraints, BN254) is too large for the Python oracle; check it through
+    size-independent properties: (1) the device proof for a key with known toxic waste equals the closed-form
+    trapdoor proof computed by the C++ oracle with pure Fr arithmetic + 3 scalar multiplications, (2) MSM
+    linearity: MSM(P, k) + MSM(P, k') = MSM(P, k + k') over 2^20 points, (3) NTT round trip on 2^20 points."""
+    from zokrates_amd import synth
+    lg = int(os.environ.get("ZKHIP_TEST_FULL_LOG", "20"))
+    circ = synth.circuit(0, lg)
+    cs = native.ConstraintSystem(ctx, 0, circ.n, circ.l, circ.w, circ.mats())
+    tox = synth.toxic_waste(0)
+    raw = native.setup_g16(ctx, cs, tox)
+    pk = native.ProvingKey(ctx, 0, raw)
+    z = circ.assignment(0x5EED0001)
+    oc = cpu.Circuit.from_csr(0, circ.n, circ.l, circ.w, circ.mats())
+    tb = b"".join(int(v).to_bytes(32, "little") for v in tox)
+    r_, s_ = 0xDEADBEEF12345678, 0xCAFEBABE87654321
+    assert native.prove_g16(ctx, pk, cs, z, r_, s_) == cpu.trapdoor(oc, tb, z, r_, s_)
+    # (2) linearity on the key's own a_query bases
+    nb = 32
+    off = 2 * nb + 3 * 4 * nb + 8 + circ.l * 2 * nb + 2 * 2 * nb + 8
+    g1 = raw[off:off + circ.m * 2 * nb]
+    rnd = np.random.default_rng(5)
+    k1 = rnd.integers(0, 256, size=circ.m * 32, dtype=np.uint8); k1.reshape(-1, 32)[:, 31] &= 0x07
+    k2 = rnd.integers(0, 256, size=circ.m * 32, dtype=np.uint8); k2.reshape(-1, 32)[:, 31] &= 0x07
+    a1 = k1.view(np.uint64).reshape(-1, 4); a2 = k2.view(np.uint64).reshape(-1, 4)
+    ks = np.zeros_like(a1)
+    carry = np.zeros(circ.m, dtype=np.uint64)
+    for i in range(4):                      # 252-bit + 252-bit < r: plain multi-limb addition
+        t = a1[:, i] + a2[:, i]
+        c1 = t < a1[:, i]
+        t2 = t + carry
+        c2 = t2 < t
+        ks[:, i] = t2
+        carry = (c1 | c2).astype(np.uint64)
+    p1, p2, p12 = (ctx.msm(0, 1, g1, k) for k in (k1, k2, ks.view(np.uint8).reshape(-1)))
+    two = np.concatenate([np.frombuffer(p1[:-1], dtype=np.uint8), np.frombuffer(p2[:-1], dtype=np.uint8)])
+    assert ctx.msm(0, 1, two, le([1, 1])) == p12
+    # (3) NTT round trip
+    a = z[: (1 << lg) * 32]
+    assert ctx.ntt(0, ctx.ntt(0, a, "coset_fft"), "coset_ifft").tobytes() == a.tobytes()
+    assert ctx.ntt(0, ctx.ntt(0, a, "fft"), "ifft").tobytes() == a.tobytes()

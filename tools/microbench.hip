@@ -143,6 +143,7 @@ template <class F> float time_it(F f, int reps = 3) {
     return best;
 }
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("device %s %s CUs=%d clock=%d kHz\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
     const int blocks = prop.multiProcessorCount * 8, threads = 256;
@@ -161,8 +162,8 @@ int main() {
     report("fma_f64", time_it([&] { hipLaunchKernelGGL(k_fma64, dim3(blocks), dim3(threads), 0, 0, out, 1.0000001, 1e-9); }), 8.0 * ITERS);
     report("fma_f32", time_it([&] { hipLaunchKernelGGL(k_fma32, dim3(blocks), dim3(threads), 0, 0, out, 1.0000001f, 1e-9f); }), 8.0 * ITERS);
     {
-        Fq *in, *o; CK(hipMalloc(&in, (lanes + 1) * sizeof(Fq))); CK(hipMalloc(&o, lanes * sizeof(Fq)));
-        std::vector<u32> h((size_t)(lanes + 1) * 8);
+        Fq *in, *o; CK(hipMalloc(&in, (size_t)(2 * lanes + 4) * sizeof(Fq))); CK(hipMalloc(&o, lanes * sizeof(Fq)));
+        std::vector<u32> h((size_t)(2 * lanes + 4) * 8);
         for (auto& v : h) v = rand() * 2654435761u; for (size_t i = 7; i < h.size(); i += 8) h[i] &= 0x1fffffff;
         CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         const int it = 512;

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libzkhip.so")
 UNITS = ["curve_bn254", "curve_bls381", "zkhip_api"]
-HEADERS = ["core.cuh", "devrt.h", "ec.cuh", "field.cuh", "kernels_msm.cuh", "kernels_ntt.cuh"]
+HEADERS = ["core.cuh", "devrt.h", "ec.cuh", "field.cuh", "kernels_msm.cuh", "kernels_ntt.cuh", "setup.cuh"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

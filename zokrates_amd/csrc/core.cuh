@@ -30,6 +30,10 @@ struct CurveBn254 {
     typedef Fe2<Bn254Fq> Fq2;
     static constexpr u64 GENERATOR = 5;       // Fr::GENERATOR, the coset shift g
     static constexpr int TWO_ADICITY = 28;
+    // standard generators, canonical limbs (G1: x, y; G2: x.c0, x.c1, y.c0, y.c1); BN254's are the ones pinned by
+    // /root/reference/zokrates_proof_systems/src/solidity.rs:430-441
+    static const u32* g1_gen() { static const u32 t[] = {0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000002u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u}; return t; }
+    static const u32* g2_gen() { static const u32 t[] = {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu, 0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u, 0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u, 0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u}; return t; }
 };
 struct CurveBls381 {
     static constexpr int ID = ZKHIP_CURVE_BLS12_381;
@@ -38,6 +42,10 @@ struct CurveBls381 {
     typedef Fe2<Bls381Fq> Fq2;
     static constexpr u64 GENERATOR = 7;
     static constexpr int TWO_ADICITY = 32;
+    // standard generators, canonical limbs (G1: x, y; G2: x.c0, x.c1, y.c0, y.c1); BN254's are the ones pinned by
+    // /root/reference/zokrates_proof_systems/src/solidity.rs:430-441
+    static const u32* g1_gen() { static const u32 t[] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu, 0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u, 0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu, 0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u}; return t; }
+    static const u32* g2_gen() { static const u32 t[] = {0xc121bdb8u, 0xd48056c8u, 0xa805bbefu, 0x0bac0326u, 0x7ae3d177u, 0xb4510b64u, 0xfa403b02u, 0xc6e47ad4u, 0x2dc51051u, 0x26080527u, 0xf08f0a91u, 0x024aa2b2u, 0x5d042b7eu, 0xe5ac7d05u, 0x13945d57u, 0x334cf112u, 0xdc7f5049u, 0xb5da61bbu, 0x9920b61au, 0x596bd0d0u, 0x88274f65u, 0x7dacd3a0u, 0x52719f60u, 0x13e02b60u, 0x08b82801u, 0xe1935486u, 0x3baca289u, 0x923ac9ccu, 0x5160d12cu, 0x6d429a69u, 0x8cbdd3a7u, 0xadfd9baau, 0xda2e351au, 0x8cc9cdc6u, 0x727d6e11u, 0x0ce5d527u, 0xf05f79beu, 0xaaa9075fu, 0x5cec1da1u, 0x3f370d27u, 0x572e99abu, 0x267492abu, 0x85a763afu, 0xcb3e287eu, 0x2bc28b99u, 0x32acd2b0u, 0x2ea734ccu, 0x0606c4a0u}; return t; }
 };
 
 struct ApiError {
@@ -364,6 +372,14 @@ struct zkhip_r1cs {
     std::vector<uint8_t> h_val[3];
 };
 
+// an assignment resident in HBM: (m + 2) x 32 B canonical integers; the two tail slots receive r and s
+struct zkhip_assignment {
+    int curve;
+    zkhip_ctx* ctx;
+    u64 m;
+    DBuf scalars;
+};
+
 namespace zk {
 
 template <class C>
@@ -516,26 +532,50 @@ struct Prover {
         ntt_kind_a<C>(ctx, pl, a, true, ptr<Fr>(pl->s_cosetinv_canon));   // coset_ifft, leaving Montgomery form
     }
 
-    static void upload_assignment(zkhip_ctx* ctx, u64 m, const uint8_t* z, const uint8_t* r, const uint8_t* s_) {
+    // z -> HBM (canonical integers; slots m, m+1 are reserved for r, s)
+    static void upload_z(zkhip_ctx* ctx, DBuf& dst, u64 m, const uint8_t* z) {
+        Fr z0 = fe_from_bytes_canon<Fr>(z);
+        Fr one = Fr::zero(); one.v[0] = 1;
+        require(z0.equals(one), ZKHIP_ERR_BAD_ARG, "z[0] must be 1 (ark instance variable 0 is the constant ONE)");
+        dst.ensure((m + 2) * 32);
+        dev_h2d(dst.p, z, m * 32, ctx->stream);
+    }
+    // r, s into the tail slots; Montgomery copy of z for the mat-vec
+    static void stage_scalars(zkhip_ctx* ctx, void* d_scalars, u64 m, const uint8_t* r, const uint8_t* s_) {
         Stream s = ctx->stream;
-        ctx->scalars.ensure((m + 2) * 32);
         ctx->zmont.ensure(m * 32);
-        dev_h2d(ctx->scalars.p, z, m * 32, s);
-        dev_h2d(ptr<uint8_t>(ctx->scalars) + m * 32, r, 32, s);
-        dev_h2d(ptr<uint8_t>(ctx->scalars) + (m + 1) * 32, s_, 32, s);
-        ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, s, ptr<Fr>(ctx->scalars), ptr<Fr>(ctx->zmont), m);
+        dev_h2d((uint8_t*)d_scalars + m * 32, r, 32, s);
+        dev_h2d((uint8_t*)d_scalars + (m + 1) * 32, s_, 32, s);
+        ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, s, (const Fr*)d_scalars, ptr<Fr>(ctx->zmont), m);
     }
 
-    static void prove(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z, const uint8_t* r, const uint8_t* s_,
+    static void prove_host(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z, const uint8_t* r, const uint8_t* s_,
+                           uint8_t* out, zkhip_timings* tm) {
+        const auto t0 = std::chrono::steady_clock::now();
+        Event e0 = event_create(), e1 = event_create();
+        event_record(e0, ctx->stream);
+        upload_z(ctx, ctx->scalars, pk->m, z);
+        event_record(e1, ctx->stream);
+        prove(ctx, pk, cs, ctx->scalars.p, r, s_, out, tm);
+        if (tm) {
+            tm->h2d_ms = event_elapsed_ms(e0, e1);
+            tm->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        event_destroy(e0); event_destroy(e1);
+    }
+    static void assignment_upload(zkhip_ctx* ctx, zkhip_assignment* a, const uint8_t* z) {
+        upload_z(ctx, a->scalars, a->m, z);
+        stream_sync(ctx->stream);
+    }
+
+    // the hot path proper: the assignment is already in HBM at d_scalars
+    static void prove(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, void* d_scalars, const uint8_t* r, const uint8_t* s_,
                       uint8_t* out, zkhip_timings* tm) {
         const auto t_start = std::chrono::steady_clock::now();
         require(pk->curve == C::ID && cs->curve == C::ID, ZKHIP_ERR_BAD_ARG, "curve mismatch between key and constraint system");
         require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
                 "proving key does not match the constraint system (m, w or domain size)");
         const u64 m = pk->m, N = pk->N;
-        Fr z0 = fe_from_bytes_canon<Fr>(z);
-        Fr one = Fr::zero(); one.v[0] = 1;
-        require(z0.equals(one), ZKHIP_ERR_BAD_ARG, "z[0] must be 1 (ark instance variable 0 is the constant ONE)");
         Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
@@ -544,7 +584,7 @@ struct Prover {
         ctx->ev_pool.clear();
         Event e0 = pool_event(ctx), e1 = pool_event(ctx), e2 = pool_event(ctx), e3 = pool_event(ctx), e4 = pool_event(ctx), e5 = pool_event(ctx);
         event_record(e0, st);
-        upload_assignment(ctx, m, z, r, s_);
+        stage_scalars(ctx, d_scalars, m, r, s_);
         event_record(e1, st);
 
         // ---- MSMs over S = [z_0..z_{m-1}, r, s]: A, B1, L in G1 and B2 in G2 share one digit/sort pass
@@ -556,7 +596,7 @@ struct Prover {
         d_ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(d_ws1);
         Event ab[5], ae[5];
-        msm_prepare(ctx, ptr<u32>(ctx->scalars), shz);
+        msm_prepare(ctx, (const u32*)d_scalars, shz);
         msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->a_ext), shz, ws1 + 0 * Wmax, &ab[0], &ae[0]);
         msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->b1_ext), shz, ws1 + 1 * Wmax, &ab[1], &ae[1]);
         msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->l_ext), shz, ws1 + 2 * Wmax, &ab[2], &ae[2]);
@@ -611,7 +651,7 @@ struct Prover {
         const auto t_end = std::chrono::steady_clock::now();
         if (tm) {
             memset(tm, 0, sizeof(*tm));
-            tm->h2d_ms = event_elapsed_ms(e0, e1);
+            tm->matvec_ms = event_elapsed_ms(e0, e1);   // staging r, s + Montgomery copy of z
             tm->msm_z_ms = event_elapsed_ms(e1, e2);
             tm->ntt_ms = event_elapsed_ms(e2, e3);   // matvec + 7 transforms + quotient
             tm->msm_h_ms = event_elapsed_ms(e3, e4);
@@ -687,7 +727,8 @@ struct Prover {
         NttPlan<C>* pl = get_plan<C>(ctx, cs->logN);
         const u64 m = cs->l + cs->w;
         uint8_t zero[32] = {0};
-        upload_assignment(ctx, m, z, zero, zero);
+        upload_z(ctx, ctx->scalars, m, z);
+        stage_scalars(ctx, ctx->scalars.p, m, zero, zero);
         witness_map(ctx, cs, pl);
         ctx->vb.ensure(pl->N * sizeof(Fr));
         ZK_LAUNCH((k_sigma_permute<Fr>), dim3(blocks_for(pl->N, 256)), dim3(256), 0, ctx->stream, ptr<Fr>(ctx->va), ptr<Fr>(ctx->vb), pl->N,
@@ -739,6 +780,7 @@ struct Prover {
 
 }  // namespace zk
 
+#include "setup.cuh"
 
 // ------------------------------------------------------------------ per-curve entry points
 namespace zk {
@@ -746,11 +788,14 @@ struct CurveOps {
     void (*pk_load)(zkhip_ctx*, const uint8_t*, size_t, zkhip_pk*);
     void (*r1cs_load)(zkhip_ctx*, zkhip_r1cs*, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]);
     void (*prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
+    void (*prove_resident)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, void*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
+    void (*assignment_upload)(zkhip_ctx*, zkhip_assignment*, const uint8_t*);
     void (*ntt)(zkhip_ctx*, u32, int, uint8_t*);
     void (*witness_map)(zkhip_ctx*, const zkhip_r1cs*, const uint8_t*, uint8_t*);
     void (*msm_g1)(zkhip_ctx*, u64, const uint8_t*, const uint8_t*, uint8_t*);
     void (*msm_g2)(zkhip_ctx*, u64, const uint8_t*, const uint8_t*, uint8_t*);
     void (*field_op)(zkhip_ctx*, int field, int op, u64, const uint8_t*, const uint8_t*, uint8_t*);
+    void (*setup)(zkhip_ctx*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, u64);
 };
 template <class C>
 static void field_op_dispatch(zkhip_ctx* ctx, int field, int op, u64 count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -762,12 +807,15 @@ static CurveOps make_curve_ops() {
     CurveOps o;
     o.pk_load = &PkLoader<C>::load;
     o.r1cs_load = &Prover<C>::r1cs_load;
-    o.prove = &Prover<C>::prove;
+    o.prove = &Prover<C>::prove_host;
+    o.prove_resident = &Prover<C>::prove;
+    o.assignment_upload = &Prover<C>::assignment_upload;
     o.ntt = &Prover<C>::ntt_api;
     o.witness_map = &Prover<C>::witness_map_api;
     o.msm_g1 = &Prover<C>::template msm_api<typename C::Fq, 2>;
     o.msm_g2 = &Prover<C>::template msm_api<typename C::Fq2, 4>;
     o.field_op = &field_op_dispatch<C>;
+    o.setup = &Setup<C>::run;
     return o;
 }
 const CurveOps* curve_ops_bn254();

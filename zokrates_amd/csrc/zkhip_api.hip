@@ -124,6 +124,31 @@ int32_t zkhip_prove_g16(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1
     });
 }
 
+int32_t zkhip_assignment_upload(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* z, zkhip_assignment** out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(r1cs && z && out, ZKHIP_ERR_BAD_ARG, "null argument");
+        *out = nullptr;
+        require(r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "constraint system belongs to another context");
+        std::unique_ptr<zkhip_assignment> a(new zkhip_assignment());
+        a->curve = r1cs->curve; a->ctx = ctx; a->m = r1cs->l + r1cs->w;
+        ops_for(r1cs->curve)->assignment_upload(ctx, a.get(), z);
+        *out = a.release();
+    });
+}
+void zkhip_assignment_free(zkhip_assignment* a) { delete a; }
+
+int32_t zkhip_prove_g16_resident(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, zkhip_assignment* z, const uint8_t* r,
+                                 const uint8_t* s, uint8_t* proof_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && z && r && s && proof_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx && z->ctx == ctx, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
+        require(z->curve == pk->curve && z->m == pk->m, ZKHIP_ERR_BAD_ARG, "assignment does not match the proving key");
+        ops_for(pk->curve)->prove_resident(ctx, pk, r1cs, z->scalars.p, r, s, proof_out, timings);
+    });
+}
+
 int32_t zkhip_prove_g16_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count, const uint8_t* z, const uint8_t* rs,
                               uint8_t* proofs_out, zkhip_timings* timings) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
@@ -188,10 +213,14 @@ int32_t zkhip_setup_g16_size(const zkhip_r1cs* cs, uint64_t* pk_bytes) {
     *pk_bytes = g1 + 3 * g2 + 8 + cs->l * g1 + 2 * g1 + 8 + m * g1 + 8 + m * g1 + 8 + m * g2 + 8 + (cs->N - 1) * g1 + 8 + cs->w * g1;
     return ZKHIP_OK;
 }
-int32_t zkhip_setup_g16(zkhip_ctx* ctx, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, uint64_t) {
+int32_t zkhip_setup_g16(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* toxic, const uint8_t* g1, const uint8_t* g2, uint8_t* pk_out,
+                        uint64_t pk_cap) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
-    ctx->err = "zkhip_setup_g16: not implemented yet";
-    return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(r1cs && toxic && pk_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "constraint system belongs to another context");
+        ops_for(r1cs->curve)->setup(ctx, r1cs, toxic, g1, g2, pk_out, pk_cap);
+    });
 }
 
 }  // extern "C"

@@ -49,7 +49,7 @@ class Library:
     SYMBOLS = [
         "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_free", "zkhip_last_error", "zkhip_pk_load_g16",
         "zkhip_pk_free", "zkhip_pk_dims", "zkhip_r1cs_load", "zkhip_r1cs_free", "zkhip_prove_g16",
-        "zkhip_prove_g16_batch", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
+        "zkhip_prove_g16_batch", "zkhip_assignment_upload", "zkhip_assignment_free", "zkhip_prove_g16_resident", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
         "zkhip_field_op", "zkhip_setup_g16_size", "zkhip_setup_g16", "zkhip_describe",
     ]
 
@@ -72,6 +72,9 @@ class Library:
         L.zkhip_r1cs_free.restype = None; L.zkhip_r1cs_free.argtypes = [vp]
         L.zkhip_prove_g16.restype = i32; L.zkhip_prove_g16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         L.zkhip_prove_g16_batch.restype = i32; L.zkhip_prove_g16_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        L.zkhip_assignment_upload.restype = i32; L.zkhip_assignment_upload.argtypes = [vp, vp, vp, pp]
+        L.zkhip_assignment_free.restype = None; L.zkhip_assignment_free.argtypes = [vp]
+        L.zkhip_prove_g16_resident.restype = i32; L.zkhip_prove_g16_resident.argtypes = [vp] * 8
         L.zkhip_ntt.restype = i32; L.zkhip_ntt.argtypes = [vp, i32, u32, i32, vp]
         L.zkhip_witness_map.restype = i32; L.zkhip_witness_map.argtypes = [vp, vp, vp, vp]
         L.zkhip_msm_g1.restype = i32; L.zkhip_msm_g1.argtypes = [vp, i32, u64, vp, vp, vp]
@@ -221,6 +224,50 @@ class ConstraintSystem:
             self.close()
         except Exception:
             pass
+
+
+class Assignment:
+    """`zkhip_assignment`: a full assignment z (m x 32 B canonical LE, z[0] = 1) resident in HBM."""
+
+    def __init__(self, ctx, cs, z):
+        self.ctx = ctx
+        z = _u8(z, cs.m * 32)
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.L.zkhip_assignment_upload(ctx.h, cs.h, _ptr(z), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.L.zkhip_assignment_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove_g16_resident(ctx, pk, cs, assignment, r, s, want_timings=False):
+    """Like prove_g16 with the assignment already on the GPU."""
+    nb = FQ_BYTES[pk.curve_id]
+    rb = np.frombuffer(int(r).to_bytes(32, "little"), dtype=np.uint8)
+    sb = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8)
+    out = np.zeros(8 * nb + 3, dtype=np.uint8)
+    tm = Timings()
+    ctx._check(ctx.lib.L.zkhip_prove_g16_resident(ctx.h, pk.h, cs.h, assignment.h, _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm)))
+    return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+
+def setup_g16(ctx, cs, toxic, g1=None, g2=None):
+    """Groth16 setup on the GPU: `toxic` = (alpha, beta, gamma, delta, tau) ints; returns the ark-format proving key bytes."""
+    size = C.c_uint64()
+    ctx._check(ctx.lib.L.zkhip_setup_g16_size(cs.h, C.byref(size)))
+    tb = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in toxic), dtype=np.uint8)
+    out = np.zeros(size.value, dtype=np.uint8)
+    g1p = _ptr(_u8(g1)) if g1 is not None else None
+    g2p = _ptr(_u8(g2)) if g2 is not None else None
+    ctx._check(ctx.lib.L.zkhip_setup_g16(ctx.h, cs.h, _ptr(tb), g1p, g2p, _ptr(out), size.value))
+    return out
 
 
 def prove_g16(ctx, pk, cs, z, r, s, want_timings=False):
