@@ -50,7 +50,9 @@ typedef struct zkhip_pk zkhip_pk;
 typedef struct zkhip_r1cs zkhip_r1cs;
 typedef struct zkhip_assignment zkhip_assignment;
 
-/* Per-proof phase timings in milliseconds (HIP events on the library's own streams).
+/* Per-proof phase timings in milliseconds (HIP events on the library's own streams).  The MSMs run on their own
+ * streams concurrently with each other and with the NTT pipeline, so the phase intervals overlap: they do not
+ * add up to total_ms.
  * Replaces nothing in the reference (it has no prover timers) — added observability. */
 typedef struct zkhip_timings {
     float h2d_ms;       /* assignment upload + Montgomery conversion                */

@@ -99,6 +99,35 @@ def test_msm_window_sizes(ctx):
         os.environ.pop("ZKHIP_MSM_C")
 
 
+def test_msm_skewed_scalars(ctx):
+    """Hot buckets: many scalars equal to 1 (the dedicated ones bucket), many copies of one full-width value
+    and of -1 (a bucket spread over more than MSM_HEAVY lanes -> workgroup reduction), zeros; several slice
+    lengths P so that buckets straddle lane boundaries in every way."""
+    curve = BN254
+    rnd = random.Random(9)
+    n = 150
+    G1, G2 = groups(curve)
+    p1 = [G1.amul(G1.gen, rnd.randrange(1, curve.r)) for _ in range(n)]
+    p2 = [G2.amul(G2.gen, rnd.randrange(1, curve.r)) for _ in range(24)]
+    hot = rnd.randrange(curve.r)
+    ks = [1] * 50 + [hot] * 40 + [curve.r - 1] * 30 + [0] * 10 + [rnd.randrange(curve.r) for _ in range(20)]
+    rnd.shuffle(ks)
+    b1 = np.frombuffer(b"".join(formats.ser_g1(curve, P) for P in p1), dtype=np.uint8)
+    b2 = np.frombuffer(b"".join(formats.ser_g2(curve, P) for P in p2), dtype=np.uint8)
+    want1 = cpu.msm(0, 1, b1, le(ks))
+    want2 = cpu.msm(0, 2, b2, le(ks[:24]))
+    try:
+        for P, c in ((1, 4), (2, 5), (3, 3), (7, 6), (32, 4)):
+            os.environ["ZKHIP_MSM_P"] = str(P)
+            os.environ["ZKHIP_MSM_C"] = str(c)
+            assert ctx.msm(0, 1, b1, le(ks)) == want1, (P, c)
+            if P in (2, 32):
+                assert ctx.msm(0, 2, b2, le(ks[:24])) == want2, (P, c)
+    finally:
+        os.environ.pop("ZKHIP_MSM_P")
+        os.environ.pop("ZKHIP_MSM_C")
+
+
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("kind", ["dense", "sha"])
 def test_prove_matches_oracle(ctx, curve, kind):

@@ -86,6 +86,33 @@ def test_msm(ctx, curve, n):
         assert ctx.msm(curve.curve_id, 2, g2, ks) == cpu.msm(curve.curve_id, 2, g2, ks)
 
 
+def test_msm_skewed_scalars(ctx):
+    """Hot buckets at a realistic size: 60 % ones, 10 % zeros, 10 % copies of one value, 5 % of -1 (the
+    'sha-like' wire statistics); exercises the ones bucket, the heavy-bucket workgroup reduction and buckets
+    straddling work-item boundaries for several slice lengths."""
+    curve = BN254
+    m, g1, g2 = _bases(curve, 30000, 4242)
+    rnd = np.random.default_rng(17)
+    ks = rnd.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x0f
+    cls = rnd.random(m)
+    one = np.zeros(32, dtype=np.uint8); one[0] = 1
+    ks[cls < 0.6] = one
+    ks[(cls >= 0.6) & (cls < 0.7)] = 0
+    ks[(cls >= 0.7) & (cls < 0.8)] = ks[-1]
+    ks[(cls >= 0.8) & (cls < 0.85)] = le([curve.r - 1])
+    ks = ks.reshape(-1)
+    want1 = cpu.msm(0, 1, g1, ks)
+    assert ctx.msm(0, 1, g1, ks) == want1
+    assert ctx.msm(0, 2, g2[:4000 * 128], ks[:4000 * 32]) == cpu.msm(0, 2, g2[:4000 * 128], ks[:4000 * 32])
+    try:
+        for P in (1, 5, 64, 1000):
+            os.environ["ZKHIP_MSM_P"] = str(P)
+            assert ctx.msm(0, 1, g1, ks) == want1, P
+    finally:
+        os.environ.pop("ZKHIP_MSM_P")
+
+
 def test_msm_edge_points(ctx):
     curve = BN254
     G1, G2 = groups(curve)

@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libzkhip.so")
-UNITS = ["curve_bn254", "curve_bls381", "zkhip_api"]
-HEADERS = ["core.cuh", "devrt.h", "ec.cuh", "field.cuh", "kernels_msm.cuh", "kernels_ntt.cuh", "setup.cuh"]
+UNITS = ["bls381_g2", "bls381_g1", "bn254_g2", "bn254_g1", "curve_bn254", "curve_bls381", "zkhip_api"]   # slowest first
+HEADERS = ["core.cuh", "devrt.h", "ec.cuh", "field.cuh", "kernels_msm.cuh", "kernels_ntt.cuh", "setup.cuh", "group.cuh"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -47,7 +47,7 @@ def _compile(unit, force, verbose):
 def build_lib(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link libzkhip.so.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 4)) as ex:
         results = list(ex.map(lambda u: _compile(u, force, verbose), UNITS))
     objs = [o for o, _ in results]
     if force or any(changed for _, changed in results) or _newer(LIB, objs):

@@ -1,0 +1,5 @@
+// bn254_g2.hip — the G2 kernels of BN254 (bucket accumulation, fold, fixed-base) in a translation unit of their own.
+#include "group.cuh"
+namespace zk {
+ZK_INSTANTIATE_GROUP(Fe2<Bn254Fq>)
+}  // namespace zk

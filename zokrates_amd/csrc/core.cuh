@@ -88,13 +88,28 @@ struct NttPlanBase {
     int curve, logN;
     virtual ~NttPlanBase() {}
 };
+// result of one classification / digit / counting-sort pass; shared (read-only) by every base set paired with those scalars
+struct MsmSort {
+    DBuf dig, sorted, cnt, off, cursor, chunk_sum, grand;
+    Event ready = nullptr;   // recorded on the main stream when the pass is complete
+};
+// workspace and stream of one MSM: the five MSMs of a proof are independent once their scalars are sorted, and the
+// fold stages are latency-bound (few, long dependent chains), so they run concurrently and fill each other's gaps
+struct MsmLane {
+    Stream stream = 0;
+    DBuf lane_key, heavy, partial, bucket, rows, cols;
+    Event done = nullptr;
+};
+static constexpr int ZK_NLANES = 5;   // A, B1, L (G1), B2 (G2) over z; H over h
 struct zkhip_ctx {
     int device = 0;
     Stream stream = 0;
+    bool serial = false;     // ZKHIP_SERIAL=1: every MSM on the main stream (debugging / per-kernel timing)
     std::string err;
     std::string desc;
-    // MSM workspace (grow-only)
-    DBuf dig, sorted, cnt, off, cursor, chunk_sum, grand, buckets, partial;
+    // MSM workspaces (grow-only)
+    MsmSort sorts[2];
+    MsmLane lanes[ZK_NLANES];
     // prover workspace
     DBuf scalars, zmont, va, vb, vc, tmp, ws1, ws2;
     std::vector<std::unique_ptr<NttPlanBase>> plans;
@@ -237,47 +252,66 @@ struct MsmShape {
     u64 n;
     int c, W;
     u32 K;          // buckets per window = 2^(c-1)
-    u64 nbuckets;   // W * K
-    int L;          // buckets per work-item in the fold
-    u32 fold_threads, fold_blocks;
+    u32 nkeys;      // W * K + 1: every (window, bucket) plus the "ones" bucket
+    u32 P_env;      // ZKHIP_MSM_P override of the sorted entries per accumulation work-item (0 = per point type)
+    u32 Lw, H;      // fold geometry: K = H rows of Lw buckets
 };
+static inline int env_int(const char* name, int lo, int hi, int dflt) {
+    if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
+    return dflt;
+}
 static inline MsmShape msm_shape(u64 n, int scalar_bits) {
     MsmShape s;
     s.n = n;
-    int lg = ilog2_floor(std::max<u64>(n, 1));
-    s.c = std::max(2, std::min(16, lg - 3));
-    if (const char* e = getenv("ZKHIP_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 16) s.c = v; }
+    // Window width: about log2(n) - 5 (measured optimum at 2^20: 15), but never one that leaves the top window
+    // with only a few significant bits — its handful of buckets would each receive a large share of all points
+    // (same-address atomics in the sort, one bucket spread over thousands of slices).
+    const int lg = ilog2_floor(std::max<u64>(n, 1));
+    const int want = std::max(2, std::min(16, lg - 5));
+    s.c = want;
+    for (int d = 0; d <= 14; ++d) {
+        bool found = false;
+        for (int cand : {want + d, want - d}) {
+            if (cand < 2 || cand > 16) continue;
+            const int W = (scalar_bits + 1 + cand - 1) / cand;
+            const int top_bits = scalar_bits + 1 - (W - 1) * cand;
+            if (top_bits >= std::min(cand, 8)) { s.c = cand; found = true; break; }
+        }
+        if (found) break;
+    }
+    s.c = env_int("ZKHIP_MSM_C", 2, 16, s.c);
     s.W = (scalar_bits + 1 + s.c - 1) / s.c;
     s.K = 1u << (s.c - 1);
-    s.nbuckets = (u64)s.W * s.K;
-    s.L = s.K >= 2048 ? 8 : 1;
-    u64 items = (s.K + s.L - 1) / s.L;
-    s.fold_threads = (u32)std::min<u64>(256, std::max<u64>(64, (items + 63) / 64 * 64));
-    s.fold_blocks = (u32)((items + s.fold_threads - 1) / s.fold_threads);
+    s.nkeys = (u32)s.W * s.K + 1;
+    s.P_env = (u32)env_int("ZKHIP_MSM_P", 1, 4096, 0);
+    s.Lw = std::min<u32>(s.K, 256);
+    s.H = s.K / s.Lw;
     return s;
 }
 
-// digits + counting sort; leaves ctx->off / ctx->sorted describing every bucket's point list
-static inline void msm_prepare(zkhip_ctx* ctx, const u32* d_scalars, const MsmShape& sh) {
+// classification + digits + counting sort on the main stream; leaves so.off / so.sorted describing every bucket's point list
+static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars, const MsmShape& sh) {
     Stream s = ctx->stream;
-    const u64 nb = sh.nbuckets;
-    ctx->dig.ensure(sh.n * sh.W * 4);
-    ctx->sorted.ensure(sh.n * sh.W * 4);
-    ctx->cnt.ensure(nb * 4);
-    ctx->off.ensure((nb + 1) * 4);
-    ctx->cursor.ensure(nb * 4);
-    const u32 nchunks = (u32)((nb + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    ctx->chunk_sum.ensure((size_t)nchunks * 4);
-    ctx->grand.ensure(4);
-    dev_memset(ctx->cnt.p, 0, nb * 4, s);
-    dev_memset(ctx->cursor.p, 0, nb * 4, s);
+    const u64 nk = sh.nkeys;
+    require(sh.n * (u64)sh.W < ((u64)1 << 32) - sh.nkeys, ZKHIP_ERR_BAD_ARG, "MSM too large for 32-bit sort offsets");
+    so.dig.ensure(sh.n * sh.W * 4);
+    so.sorted.ensure(sh.n * sh.W * 4);
+    so.cnt.ensure(nk * 4);
+    so.off.ensure((nk + 1) * 4);
+    so.cursor.ensure(nk * 4);
+    const u32 nchunks = (u32)((nk + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    so.chunk_sum.ensure((size_t)nchunks * 4);
+    so.grand.ensure(4);
+    dev_memset(so.cnt.p, 0, nk * 4, s);
+    dev_memset(so.cursor.p, 0, nk * 4, s);
     const unsigned T = 256;
-    ZK_LAUNCH(k_msm_digits, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, sh.c, sh.W, ptr<u32>(ctx->dig), ptr<u32>(ctx->cnt));
-    ZK_LAUNCH(k_scan_local, dim3(nchunks), dim3(SCAN_THREADS), 0, s, ptr<u32>(ctx->cnt), ptr<u32>(ctx->off), ptr<u32>(ctx->chunk_sum), nb);
-    ZK_LAUNCH(k_scan_chunks, dim3(1), dim3(SCAN_THREADS), 0, s, ptr<u32>(ctx->chunk_sum), nchunks, ptr<u32>(ctx->grand));
-    ZK_LAUNCH(k_scan_add, dim3(blocks_for(nb + 1, T)), dim3(T), 0, s, ptr<u32>(ctx->off), ptr<u32>(ctx->chunk_sum), nb, ptr<u32>(ctx->grand));
-    ZK_LAUNCH(k_msm_scatter, dim3(blocks_for(sh.n * sh.W, T)), dim3(T), 0, s, ptr<u32>(ctx->dig), sh.n, sh.c, sh.W, ptr<u32>(ctx->off),
-              ptr<u32>(ctx->cursor), ptr<u32>(ctx->sorted));
+    ZK_LAUNCH(k_msm_digits, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, sh.c, sh.W, ptr<u32>(so.dig), ptr<u32>(so.cnt));
+    ZK_LAUNCH(k_scan_local, dim3(nchunks), dim3(SCAN_THREADS), 0, s, ptr<u32>(so.cnt), ptr<u32>(so.off), ptr<u32>(so.chunk_sum), nk);
+    ZK_LAUNCH(k_scan_chunks, dim3(1), dim3(SCAN_THREADS), 0, s, ptr<u32>(so.chunk_sum), nchunks, ptr<u32>(so.grand));
+    ZK_LAUNCH(k_scan_add, dim3(blocks_for(nk + 1, T)), dim3(T), 0, s, ptr<u32>(so.off), ptr<u32>(so.chunk_sum), nk, ptr<u32>(so.grand));
+    ZK_LAUNCH(k_msm_scatter, dim3(blocks_for(sh.n * sh.W, T)), dim3(T), 0, s, ptr<u32>(so.dig), sh.n, sh.n * (u64)sh.W, sh.nkeys - 1,
+              ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
+    event_record(so.ready, s);
 }
 
 static inline Event pool_event(zkhip_ctx* ctx) {
@@ -286,32 +320,20 @@ static inline Event pool_event(zkhip_ctx* ctx) {
     return e;
 }
 
-// bucket accumulation + fold for one base set; window sums land in d_window_sums[0..W)
+// bucket accumulation + fold for one base set; window sums land in d_window_sums[0..W], entry W = the ones bucket.
+// Defined in group.cuh and instantiated once per (curve, group) in its own translation unit (bn254_g1.hip, ...):
+// the elliptic-curve kernels are by far the most expensive code to compile.
+// Runs on lane.stream after so.ready; lane.done is recorded behind the last kernel.
 template <class F>
-static void msm_run(zkhip_ctx* ctx, const Aff<F>* d_bases, const MsmShape& sh, Xyzz<F>* d_window_sums, Event* ev_begin, Event* ev_end) {
-    Stream s = ctx->stream;
-    ctx->buckets.ensure(sh.nbuckets * sizeof(Xyzz<F>));
-    ctx->partial.ensure((size_t)sh.W * sh.fold_blocks * sizeof(Xyzz<F>));
-    const unsigned T = 128;
-    if (ev_begin) { *ev_begin = pool_event(ctx); event_record(*ev_begin, s); }
-    ZK_LAUNCH((k_msm_accum<F>), dim3(blocks_for(sh.nbuckets, T)), dim3(T), 0, s, d_bases, ptr<u32>(ctx->off), ptr<u32>(ctx->sorted),
-              ptr<Xyzz<F>>(ctx->buckets), sh.nbuckets);
-    if (ev_end) { *ev_end = pool_event(ctx); event_record(*ev_end, s); }
-    const size_t smem = (size_t)sh.fold_threads * sizeof(Xyzz<F>);
-#ifndef ZK_EMU
-    static bool lds_opt_in = false;   // per point type (template instance)
-    if (!lds_opt_in) {
-        ZK_HIP_CHECK(hipFuncSetAttribute((const void*)k_msm_fold<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_opt_in = true;
-    }
-#endif
-    ZK_LAUNCH((k_msm_fold<F>), dim3(sh.fold_blocks, sh.W), dim3(sh.fold_threads), smem, s, ptr<Xyzz<F>>(ctx->buckets), sh.K, sh.L,
-              ptr<Xyzz<F>>(ctx->partial));
-    const unsigned TF = 64;
-    ZK_LAUNCH((k_msm_fold_final<F>), dim3(sh.W), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(ctx->partial), sh.fold_blocks, d_window_sums);
-}
+void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const Aff<F>* d_bases, const MsmShape& sh, Xyzz<F>* d_window_sums,
+             Event* ev_begin, Event* ev_end);
+// fixed-base tables / multiplications for setup (N3); also per-group code
+template <class F>
+void fixed_base_table(zkhip_ctx* ctx, const Aff<F>* h_pj, int nwin, DBuf& tbl);
+template <class F>
+void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scalars, u64 count, Aff<F>* d_out);
 
-// host Horner over window sums: sum_j 2^(c j) S_j
+// host Horner over window sums: sum_j 2^(c j) S_j, plus the ones bucket
 template <class F>
 static Xyzz<F> msm_combine(const Xyzz<F>* ws, const MsmShape& sh) {
     Xyzz<F> acc = Xyzz<F>::inf();
@@ -319,7 +341,7 @@ static Xyzz<F> msm_combine(const Xyzz<F>* ws, const MsmShape& sh) {
         for (int i = 0; i < sh.c; ++i) acc = xyzz_dbl(acc);
         acc = xyzz_add(acc, ws[j]);
     }
-    return acc;
+    return xyzz_add(acc, ws[sh.W]);
 }
 
 // ------------------------------------------------------------------ byte codecs (host)
@@ -590,17 +612,17 @@ struct Prover {
         // ---- MSMs over S = [z_0..z_{m-1}, r, s]: A, B1, L in G1 and B2 in G2 share one digit/sort pass
         const MsmShape shz = msm_shape(m + 2, Fr::Params::BITS);
         const MsmShape shh = msm_shape(N, Fr::Params::BITS);
-        const int Wmax = std::max(shz.W, shh.W);
+        const int Wmax = std::max(shz.W, shh.W) + 1;   // + the ones bucket
         DBuf &d_ws1 = ctx->ws1, &d_ws2 = ctx->ws2;   // window sums: 4 G1 sets + 1 G2 set
         d_ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         d_ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(d_ws1);
         Event ab[5], ae[5];
-        msm_prepare(ctx, (const u32*)d_scalars, shz);
-        msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->a_ext), shz, ws1 + 0 * Wmax, &ab[0], &ae[0]);
-        msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->b1_ext), shz, ws1 + 1 * Wmax, &ab[1], &ae[1]);
-        msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->l_ext), shz, ws1 + 2 * Wmax, &ab[2], &ae[2]);
-        msm_run<Fq2>(ctx, ptr<Aff<Fq2>>(pk->b2_ext), shz, ptr<Xyzz<Fq2>>(d_ws2), &ab[4], &ae[4]);
+        msm_prepare(ctx, ctx->sorts[0], (const u32*)d_scalars, shz);
+        msm_run<Fq2>(ctx, ctx->lanes[3], ctx->sorts[0], ptr<Aff<Fq2>>(pk->b2_ext), shz, ptr<Xyzz<Fq2>>(d_ws2), &ab[4], &ae[4]);   // longest first
+        msm_run<Fq>(ctx, ctx->lanes[0], ctx->sorts[0], ptr<Aff<Fq>>(pk->a_ext), shz, ws1 + 0 * Wmax, &ab[0], &ae[0]);
+        msm_run<Fq>(ctx, ctx->lanes[1], ctx->sorts[0], ptr<Aff<Fq>>(pk->b1_ext), shz, ws1 + 1 * Wmax, &ab[1], &ae[1]);
+        msm_run<Fq>(ctx, ctx->lanes[2], ctx->sorts[0], ptr<Aff<Fq>>(pk->l_ext), shz, ws1 + 2 * Wmax, &ab[2], &ae[2]);
         event_record(e2, st);
 
         // ---- K1-K4
@@ -608,8 +630,9 @@ struct Prover {
         event_record(e3, st);
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
-        msm_prepare(ctx, ptr<u32>(ctx->va), shh);
-        msm_run<Fq>(ctx, ptr<Aff<Fq>>(pk->h_sigma), shh, ws1 + 3 * Wmax, &ab[3], &ae[3]);
+        msm_prepare(ctx, ctx->sorts[1], ptr<u32>(ctx->va), shh);
+        msm_run<Fq>(ctx, ctx->lanes[4], ctx->sorts[1], ptr<Aff<Fq>>(pk->h_sigma), shh, ws1 + 3 * Wmax, &ab[3], &ae[3]);
+        for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(st, ctx->lanes[k].done);
         event_record(e4, st);
 
         std::vector<Xyzz<Fq>> h_ws1((size_t)4 * Wmax);
@@ -652,9 +675,11 @@ struct Prover {
         if (tm) {
             memset(tm, 0, sizeof(*tm));
             tm->matvec_ms = event_elapsed_ms(e0, e1);   // staging r, s + Montgomery copy of z
-            tm->msm_z_ms = event_elapsed_ms(e1, e2);
+            // the five MSMs run on their own streams, concurrently with each other and with the NTT pipeline:
+            // msm_z = staging done -> last of A/B1/L/B2 finished; msm_h = h ready -> H finished (overlapping intervals)
+            for (int k = 0; k < 4; ++k) tm->msm_z_ms = std::max(tm->msm_z_ms, event_elapsed_ms(e1, ctx->lanes[k].done));
             tm->ntt_ms = event_elapsed_ms(e2, e3);   // matvec + 7 transforms + quotient
-            tm->msm_h_ms = event_elapsed_ms(e3, e4);
+            tm->msm_h_ms = event_elapsed_ms(e3, ctx->lanes[4].done);
             tm->finish_ms = std::chrono::duration<float, std::milli>(t_end - t_fin).count();
             tm->total_ms = std::chrono::duration<float, std::milli>(t_end - t_start).count();
             for (int k = 0; k < 4; ++k) tm->kernel_msm_accum_g1_ms += event_elapsed_ms(ab[k], ae[k]);
@@ -679,10 +704,11 @@ struct Prover {
         ctx->scalars.ensure(n * 32);
         dev_h2d(ctx->scalars.p, scalars, n * 32, s);
         const MsmShape sh = msm_shape(n, Fr::Params::BITS);
-        d_ws.ensure((size_t)sh.W * sizeof(Xyzz<F>));
-        msm_prepare(ctx, ptr<u32>(ctx->scalars), sh);
-        msm_run<F>(ctx, ptr<Aff<F>>(d_bases), sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
-        std::vector<Xyzz<F>> ws(sh.W);
+        d_ws.ensure((size_t)(sh.W + 1) * sizeof(Xyzz<F>));
+        msm_prepare(ctx, ctx->sorts[0], ptr<u32>(ctx->scalars), sh);
+        msm_run<F>(ctx, ctx->lanes[0], ctx->sorts[0], ptr<Aff<F>>(d_bases), sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
+        stream_wait_event(s, ctx->lanes[0].done);
+        std::vector<Xyzz<F>> ws(sh.W + 1);
         dev_d2h(ws.data(), d_ws.p, ws.size() * sizeof(Xyzz<F>), s);
         stream_sync(s);
         Xyzz<F> res = msm_combine(ws.data(), sh);

@@ -11,6 +11,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -86,10 +88,20 @@ inline float event_elapsed_ms(Event a, Event b) {
 }
 inline void dev_check_last() { ZK_HIP_CHECK(hipGetLastError()); }
 
+// ZKHIP_TRACE=1 in the environment: synchronise after every launch and name it on stderr (debugging aid)
+inline bool trace_enabled() {
+    static const bool on = getenv("ZKHIP_TRACE") != nullptr;
+    return on;
+}
 #define ZK_LAUNCH(kernel, grid, block, smem, stream, ...)                                 \
     do {                                                                                  \
+        if (zk::trace_enabled()) fprintf(stderr, "[zkhip] launch %s ...", #kernel);       \
         hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);               \
         zk::dev_check_last();                                                             \
+        if (zk::trace_enabled()) {                                                        \
+            ZK_HIP_CHECK(hipStreamSynchronize(stream));                                   \
+            fprintf(stderr, " done\n");                                                   \
+        }                                                                                 \
     } while (0)
 #define ZK_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 

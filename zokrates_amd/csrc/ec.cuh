@@ -41,32 +41,40 @@ ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F>& p) {
 
 // 2*(x, y) for an affine point (mdbl-2008-s-1)
 template <class F>
-ZK_HD_CALL Xyzz<F> xyzz_dbl_affine(const Aff<F>& p) {
+ZK_HD Xyzz<F> xyzz_dbl_affine_inl(const Aff<F>& p) {
     if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
     F U = fe_dbl(p.y);
-    F V = fe_sqr(U);
-    F W = fe_mul(U, V);
-    F S = fe_mul(p.x, V);
-    F X2 = fe_sqr(p.x);
+    F V = ec_sqr(U);
+    F W = ec_mul(U, V);
+    F S = ec_mul(p.x, V);
+    F X2 = ec_sqr(p.x);
     F M = fe_add(fe_dbl(X2), X2);
-    F X3 = fe_sub(fe_sqr(M), fe_dbl(S));
-    F Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
+    F X3 = fe_sub(ec_sqr(M), fe_dbl(S));
+    F Y3 = fe_sub(ec_mul(M, fe_sub(S, X3)), ec_mul(W, p.y));
     return {X3, Y3, V, W};
+}
+template <class F>
+ZK_HD_CALL Xyzz<F> xyzz_dbl_affine(const Aff<F>& p) {
+    return xyzz_dbl_affine_inl(p);
 }
 
 // dbl-2008-s-1
 template <class F>
-ZK_HD_CALL Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
+ZK_HD Xyzz<F> xyzz_dbl_inl(const Xyzz<F>& p) {
     if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
     F U = fe_dbl(p.y);
-    F V = fe_sqr(U);
-    F W = fe_mul(U, V);
-    F S = fe_mul(p.x, V);
-    F X2 = fe_sqr(p.x);
+    F V = ec_sqr(U);
+    F W = ec_mul(U, V);
+    F S = ec_mul(p.x, V);
+    F X2 = ec_sqr(p.x);
     F M = fe_add(fe_dbl(X2), X2);
-    F X3 = fe_sub(fe_sqr(M), fe_dbl(S));
-    F Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
-    return {X3, Y3, fe_mul(V, p.zz), fe_mul(W, p.zzz)};
+    F X3 = fe_sub(ec_sqr(M), fe_dbl(S));
+    F Y3 = fe_sub(ec_mul(M, fe_sub(S, X3)), ec_mul(W, p.y));
+    return {X3, Y3, ec_mul(V, p.zz), ec_mul(W, p.zzz)};
+}
+template <class F>
+ZK_HD_CALL Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
+    return xyzz_dbl_inl(p);
 }
 
 // acc + affine (madd-2008-s) with the exceptional cases handled
@@ -74,20 +82,20 @@ template <class F>
 ZK_HD Xyzz<F> xyzz_madd(const Xyzz<F>& a, const Aff<F>& p) {
     if (p.is_inf()) return a;
     if (a.is_inf()) return {p.x, p.y, F::one(), F::one()};
-    F U2 = fe_mul(p.x, a.zz);
-    F S2 = fe_mul(p.y, a.zzz);
+    F U2 = ec_mul(p.x, a.zz);
+    F S2 = ec_mul(p.y, a.zzz);
     F Pp = fe_sub(U2, a.x);
     F R = fe_sub(S2, a.y);
     if (Pp.is_zero()) {
         if (R.is_zero()) return xyzz_dbl_affine(p);
         return Xyzz<F>::inf();
     }
-    F PP = fe_sqr(Pp);
-    F PPP = fe_mul(Pp, PP);
-    F Q = fe_mul(a.x, PP);
-    F X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    F Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(a.y, PPP));
-    return {X3, Y3, fe_mul(a.zz, PP), fe_mul(a.zzz, PPP)};
+    F PP = ec_sqr(Pp);
+    F PPP = ec_mul(Pp, PP);
+    F Q = ec_mul(a.x, PP);
+    F X3 = fe_sub(fe_sub(ec_sqr(R), PPP), fe_dbl(Q));
+    F Y3 = fe_sub(ec_mul(R, fe_sub(Q, X3)), ec_mul(a.y, PPP));
+    return {X3, Y3, ec_mul(a.zz, PP), ec_mul(a.zzz, PPP)};
 }
 
 // general add (add-2008-s)
@@ -95,22 +103,22 @@ template <class F>
 ZK_HD_CALL Xyzz<F> xyzz_add(const Xyzz<F>& a, const Xyzz<F>& b) {
     if (b.is_inf()) return a;
     if (a.is_inf()) return b;
-    F U1 = fe_mul(a.x, b.zz);
-    F U2 = fe_mul(b.x, a.zz);
-    F S1 = fe_mul(a.y, b.zzz);
-    F S2 = fe_mul(b.y, a.zzz);
+    F U1 = ec_mul(a.x, b.zz);
+    F U2 = ec_mul(b.x, a.zz);
+    F S1 = ec_mul(a.y, b.zzz);
+    F S2 = ec_mul(b.y, a.zzz);
     F Pp = fe_sub(U2, U1);
     F R = fe_sub(S2, S1);
     if (Pp.is_zero()) {
         if (R.is_zero()) return xyzz_dbl(a);
         return Xyzz<F>::inf();
     }
-    F PP = fe_sqr(Pp);
-    F PPP = fe_mul(Pp, PP);
-    F Q = fe_mul(U1, PP);
-    F X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    F Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(S1, PPP));
-    return {X3, Y3, fe_mul(fe_mul(a.zz, b.zz), PP), fe_mul(fe_mul(a.zzz, b.zzz), PPP)};
+    F PP = ec_sqr(Pp);
+    F PPP = ec_mul(Pp, PP);
+    F Q = ec_mul(U1, PP);
+    F X3 = fe_sub(fe_sub(ec_sqr(R), PPP), fe_dbl(Q));
+    F Y3 = fe_sub(ec_mul(R, fe_sub(Q, X3)), ec_mul(S1, PPP));
+    return {X3, Y3, ec_mul(ec_mul(a.zz, b.zz), PP), ec_mul(ec_mul(a.zzz, b.zzz), PPP)};
 }
 
 // k * p for a small unsigned k (left-to-right double-and-add)
@@ -139,8 +147,64 @@ ZK_HD_CALL Aff<F> xyzz_to_affine(const Xyzz<F>& p) {
     if (p.is_inf()) return Aff<F>::inf();
     // one inversion: i3 = 1/ZZZ; the invariant ZZ^3 = ZZZ^2 gives 1/ZZ = (ZZ/ZZZ)^2
     F i3 = fe_inv(p.zzz);
-    F i2 = fe_sqr(fe_mul(p.zz, i3));
-    return {fe_mul(p.x, i2), fe_mul(p.y, i3)};
+    F i2 = ec_sqr(ec_mul(p.zz, i3));
+    return {ec_mul(p.x, i2), ec_mul(p.y, i3)};
+}
+
+// ---- hot-loop variants for the MSM kernels ----
+// Everything is inlined, including the exceptional cases (equal or opposite x): an out-of-line call would
+// force the accumulator through scratch memory (its address escapes), which costs more than the few extra
+// instructions of a doubling that is almost never executed.
+template <class F>
+ZK_HD void xyzz_madd_acc(Xyzz<F>& a, const Aff<F>& p) {   // a += p, p affine and not infinity
+    if (a.is_inf()) {
+        a.x = p.x; a.y = p.y; a.zz = F::one(); a.zzz = F::one();
+        return;
+    }
+    F Pp = fe_sub(ec_mul(p.x, a.zz), a.x);
+    F R = fe_sub(ec_mul(p.y, a.zzz), a.y);
+    if (Pp.is_zero()) {
+        a = R.is_zero() ? xyzz_dbl_affine_inl(p) : Xyzz<F>::inf();
+        return;
+    }
+    F PP = ec_sqr(Pp);
+    F PPP = ec_mul(Pp, PP);
+    F Q = ec_mul(a.x, PP);
+    a.zz = ec_mul(a.zz, PP);
+    a.zzz = ec_mul(a.zzz, PPP);
+    F X3 = fe_sub(fe_sub(ec_sqr(R), PPP), fe_dbl(Q));
+    a.y = fe_sub(ec_mul(R, fe_sub(Q, X3)), ec_mul(a.y, PPP));
+    a.x = X3;
+}
+template <class F>
+ZK_HD void xyzz_add_acc(Xyzz<F>& a, const Xyzz<F>& b) {   // a += b, both XYZZ
+    if (b.is_inf()) return;
+    if (a.is_inf()) { a = b; return; }
+    F U1 = ec_mul(a.x, b.zz);
+    F S1 = ec_mul(a.y, b.zzz);
+    F Pp = fe_sub(ec_mul(b.x, a.zz), U1);
+    F R = fe_sub(ec_mul(b.y, a.zzz), S1);
+    if (Pp.is_zero()) {
+        a = R.is_zero() ? xyzz_dbl_inl(a) : Xyzz<F>::inf();
+        return;
+    }
+    F PP = ec_sqr(Pp);
+    F PPP = ec_mul(Pp, PP);
+    F Q = ec_mul(U1, PP);
+    a.zz = ec_mul(ec_mul(a.zz, b.zz), PP);
+    a.zzz = ec_mul(ec_mul(a.zzz, b.zzz), PPP);
+    F X3 = fe_sub(fe_sub(ec_sqr(R), PPP), fe_dbl(Q));
+    a.y = fe_sub(ec_mul(R, fe_sub(Q, X3)), ec_mul(S1, PPP));
+    a.x = X3;
+}
+
+// out-of-line a += b for the cold kernels (fold, heavy-bucket reduction): one copy of the addition per point
+// type keeps their code small; the accumulator then lives in scratch memory, which is fine off the hot path.
+// It deliberately wraps the out-of-line xyzz_add (whose doubling case is a further call): a single large
+// function with the doubling inlined hangs on gfx950 for Fq2 (ROCm 7.2 code generation; tools/fold_probe.hip).
+template <class F>
+ZK_HD_CALL void xyzz_add_to(Xyzz<F>* a, const Xyzz<F>* b) {
+    *a = xyzz_add(*a, *b);
 }
 
 }  // namespace zk

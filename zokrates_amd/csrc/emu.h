@@ -176,6 +176,20 @@ inline T wave_exchange(T v, int src_lane) {
     return out;
 }
 
+// wave ballot: every lane of the wave (none may have exited) must call it
+inline unsigned long long wave_ballot(bool pred) {
+    Global& g = G();
+    const unsigned flat = g.cur->flat, w = flat / 64;
+    const unsigned nt = g.blockDim.x * g.blockDim.y * g.blockDim.z;
+    g.xchg[w * 64 + (flat & 63)] = pred ? 1 : 0;
+    sync_wave();
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64 && w * 64 + l < nt; ++l)
+        if (g.xchg[w * 64 + l]) m |= (unsigned long long)1 << l;
+    sync_wave();
+    return m;
+}
+
 }  // namespace emu
 
 #define threadIdx (emu::G().threadIdx)

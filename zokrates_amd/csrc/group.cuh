@@ -1,0 +1,78 @@
+// group.cuh — host-side launchers of the elliptic-curve kernels, instantiated once per (curve, group) in a
+// translation unit of their own (bn254_g1.hip, bn254_g2.hip, bls381_g1.hip, bls381_g2.hip).
+#pragma once
+#include "core.cuh"
+
+namespace zk {
+
+template <class K>
+static void lds_opt_in(K kernel) {
+#ifndef ZK_EMU
+    ZK_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
+}
+
+template <class F>
+void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const Aff<F>* d_bases, const MsmShape& sh, Xyzz<F>* d_window_sums,
+             Event* ev_begin, Event* ev_end) {
+    Stream s = ctx->serial ? ctx->stream : lane.stream;
+    stream_wait_event(s, so.ready);
+    // slice length of the balanced accumulation, the first bucket of every slice, the buckets needing a workgroup
+    const u32 P = sh.P_env ? sh.P_env : MsmTuning<F>::SLICE;
+    lane.heavy.ensure(((size_t)sh.nkeys + 1) * 4);            // [0] = count, [1..] = keys
+    const u32 nlanes = (u32)((sh.n * (u64)sh.W + P - 1) / P);
+    lane.lane_key.ensure((size_t)nlanes * 4);
+    lane.partial.ensure(((size_t)sh.nkeys + nlanes) * sizeof(Xyzz<F>));
+    lane.bucket.ensure((size_t)sh.W * sh.K * sizeof(Xyzz<F>));
+    lane.rows.ensure((size_t)sh.W * sh.H * sizeof(Xyzz<F>));
+    lane.cols.ensure((size_t)sh.W * sh.Lw * sizeof(Xyzz<F>));
+    static bool once = false;   // per point type (template instance)
+    if (!once) {
+        lds_opt_in(k_msm_fold_rows<F>);
+        lds_opt_in(k_msm_fold_cols<F>);
+        lds_opt_in(k_msm_fold_final<F>);
+        lds_opt_in(k_msm_heavy_reduce<F>);
+        once = true;
+    }
+    const unsigned T = 256;
+    dev_memset(lane.heavy.p, 0, 4, s);
+    ZK_LAUNCH(k_msm_lane_keys, dim3(blocks_for(nlanes, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, P, nlanes, ptr<u32>(lane.lane_key));
+    ZK_LAUNCH(k_msm_find_heavy, dim3(blocks_for(sh.nkeys, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, P, ptr<u32>(lane.heavy) + 1,
+              ptr<u32>(lane.heavy));
+    if (ev_begin) { *ev_begin = pool_event(ctx); event_record(*ev_begin, s); }
+    ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE>), dim3(blocks_for(nlanes, T)), dim3(T), 0, s, d_bases, ptr<u32>(so.off), ptr<u32>(so.sorted),
+              ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), sh.nkeys, P, nlanes);
+    if (ev_end) { *ev_end = pool_event(ctx); event_record(*ev_end, s); }
+    ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(256), dim3(T), T * sizeof(Xyzz<F>), s, ptr<u32>(so.off), P, ptr<u32>(lane.heavy) + 1,
+              ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.partial));
+    ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.W), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial),
+              ptr<u32>(so.off), P, sh.K, sh.Lw, ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));
+    const u32 CW = std::min<u32>(sh.Lw, 32), HG = std::max<u32>(1, std::min<u32>(8, sh.H));   // 256 work-items for big windows
+    ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.W), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
+              sh.Lw, sh.H, ptr<Xyzz<F>>(lane.cols));
+    const unsigned TF = std::max<u32>(64, sh.Lw);
+    ZK_LAUNCH((k_msm_fold_final<F>), dim3(sh.W + 1), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
+              sh.H, ptr<Xyzz<F>>(lane.partial), ptr<u32>(so.off), P, (u32)sh.W, sh.nkeys - 1, d_window_sums);
+    event_record(lane.done, s);
+}
+
+template <class F>
+void fixed_base_table(zkhip_ctx* ctx, const Aff<F>* h_pj, int nwin, DBuf& tbl) {
+    DBuf d_pj;
+    d_pj.ensure((size_t)nwin * sizeof(Aff<F>));
+    dev_h2d(d_pj.p, h_pj, (size_t)nwin * sizeof(Aff<F>), ctx->stream);
+    tbl.ensure((size_t)nwin * 256 * sizeof(Aff<F>));
+    ZK_LAUNCH((k_fixed_base_table<F>), dim3(blocks_for(nwin * 256, 64)), dim3(64), 0, ctx->stream, ptr<Aff<F>>(d_pj), ptr<Aff<F>>(tbl), nwin);
+    stream_sync(ctx->stream);
+}
+template <class F>
+void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scalars, u64 count, Aff<F>* d_out) {
+    ZK_LAUNCH((k_fixed_base_mul<F>), dim3(blocks_for(count, 64)), dim3(64), 0, ctx->stream, d_scalars, count, ptr<Aff<F>>(tbl), nwin, d_out);
+}
+
+#define ZK_INSTANTIATE_GROUP(F)                                                                                         \
+    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const Aff<F>*, const MsmShape&, Xyzz<F>*, Event*, Event*);                     \
+    template void fixed_base_table<F>(zkhip_ctx*, const Aff<F>*, int, DBuf&);                                           \
+    template void fixed_base_mul<F>(zkhip_ctx*, const DBuf&, int, const u32*, u64, Aff<F>*);
+
+}  // namespace zk

@@ -4,36 +4,76 @@
 // App. A.5), the five calls of which dominate `Groth16::prove`
 // (/root/reference/zokrates_ark/src/groth16.rs:44).  Same mathematics (bucket method), different
 // schedule: instead of one CPU thread per window walking all scalars, the device
-//   1. recodes every scalar into W signed c-bit digits (half the buckets: 2^(c-1) per window),
+//   1. classifies every scalar — 0 is dropped, 1 goes to a dedicated "ones" bucket (ark special-cases
+//      both; real witnesses are mostly bits) — and recodes the rest into W signed c-bit digits
+//      (half the buckets: 2^(c-1) per window),
 //   2. counting-sorts the (window, bucket) keys so that every bucket's points are contiguous,
-//   3. accumulates each bucket with XYZZ mixed additions (one work-item per bucket, bases gathered
-//      as whole 64-B / 128-B affine points),
-//   4. folds each window's buckets with the running-sum trick, many work-items per window plus an
-//      LDS tree, leaving W window sums for the host's Horner step.
+//   3. accumulates with XYZZ mixed additions in a *load-balanced* way: every work-item owns P
+//      consecutive entries of the sorted list, whatever buckets they belong to, and emits one partial
+//      sum per bucket it touches (a segmented reduction; slot = key + lane is collision free),
+//   4. buckets that ended up spread over many lanes are reduced by a whole workgroup each,
+//   5. folds each window's buckets with the running-sum trick (partials are combined on the fly),
+//      many work-items per window plus an LDS tree, leaving W window sums (+ the ones bucket) for
+//      the host's Horner step.
 // One digit/sort pass is shared by every base set that uses the same scalars (a_query, b_g1_query,
 // b_g2_query and l_query all pair with z).  The result is the exact group element, so it is
-// independent of c, of the bucket order and of how ark itself schedules the sum.
+// independent of c, P, of the summation order and of how ark itself schedules the sum.
 #pragma once
 #include "devrt.h"
 #include "ec.cuh"
 
 namespace zk {
 
-static constexpr u32 MSM_NO_DIGIT = 0xffffffffu;
+// per point type tuning (measured on MI355X with tools/accum_bench.hip, 2^24 mixed additions: G1 2.04 ms at 3 waves per
+// SIMD / slices of 32; G2 8.05 ms at 2 waves per SIMD / slices of 16).  *_WPE = waves per SIMD the register allocator must
+// leave room for; SLICE = sorted entries per accumulation work-item.
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3; static constexpr u32 SLICE = 32; };
+template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; static constexpr u32 SLICE = 16; };
 
-// ---- 1. signed-digit recoding + bucket histogram ----
-// scalars: n x 8 u32 canonical.  dig[j*n + i] = bucket | sign<<31 (bucket = |d|-1) or MSM_NO_DIGIT.
-// cnt[j*K + bucket] += 1.
+static constexpr u32 MSM_NO_DIGIT = 0xffffffffu;
+static constexpr u32 MSM_HEAVY = 32;  // a bucket spread over more slices than this is reduced by a whole workgroup
+
+// ---- wave-level helpers (64-wide wavefronts) ----
+#ifdef ZK_EMU
+static inline unsigned long long wave_ballot(bool p) { return emu::wave_ballot(p); }
+static inline int wave_lane() { return (int)(emu::G().cur->flat & 63); }
+#else
+static __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
+static __device__ __forceinline__ int wave_lane() { return (int)__lane_id(); }
+#endif
+static __device__ __forceinline__ int first_lane(unsigned long long m) { return m ? __builtin_ctzll(m) : 0; }
+static __device__ __forceinline__ u32 lanes_below(unsigned long long m, int lane) {
+    return (u32)__builtin_popcountll(m & (((unsigned long long)1 << lane) - 1));
+}
+
+// ---- 1. classification, signed-digit recoding, bucket histogram ----
+// scalars: n x 8 u32 canonical.  dig[j*n + i] = key | sign<<31 with key = j*K + (|d|-1), or MSM_NO_DIGIT.
+// Scalars equal to 1 get the single entry key = W*K (the "ones" bucket) in window 0.  cnt[key] += 1.
+// No early exit before the ballot: every lane of a wave takes part in it.
 static __global__ void k_msm_digits(const u32* __restrict__ scalars, u64 n, int c, int W, u32* __restrict__ dig, u32* __restrict__ cnt) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
     u32 k[9];
-    const uint4* sp = (const uint4*)(scalars + i * 8);
-    uint4 lo = sp[0], hi = sp[1];
-    k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w;
-    k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
-    k[8] = 0;
+    for (int q = 0; q < 9; ++q) k[q] = 0;
+    if (live) {
+        const uint4* sp = (const uint4*)(scalars + i * 8);
+        uint4 lo = sp[0], hi = sp[1];
+        k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w;
+        k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+    }
     const u32 K = 1u << (c - 1);
+    const u32 ones_key = (u32)W * K;
+    const u32 rest = k[1] | k[2] | k[3] | k[4] | k[5] | k[6] | k[7];
+    const bool is_one = live && rest == 0 && k[0] == 1;
+    const bool is_zero = live && rest == 0 && k[0] == 0;
+    const unsigned long long ones = wave_ballot(is_one);
+    if (is_one && wave_lane() == first_lane(ones)) atomicAdd(&cnt[ones_key], (u32)__builtin_popcountll(ones));
+    if (!live) return;
+    if (is_one || is_zero) {
+        for (int j = 0; j < W; ++j) dig[(u64)j * n + i] = MSM_NO_DIGIT;
+        if (is_one) dig[i] = ones_key;
+        return;
+    }
     const u32 mask = (1u << c) - 1;
     u32 carry = 0;
     for (int j = 0; j < W; ++j) {
@@ -46,19 +86,19 @@ static __global__ void k_msm_digits(const u32* __restrict__ scalars, u64 n, int 
         raw += carry;
         u32 out = MSM_NO_DIGIT;
         if (raw > K) {            // digit = raw - 2^c (negative), borrow one from the next window
-            u32 mag = (1u << c) - raw;
-            out = (mag - 1) | 0x80000000u;
+            u32 mag = (1u << c) - raw;   // raw == 2^c (all-ones digit + carry) is digit 0 with a borrow
+            if (mag) out = ((u32)j * K + mag - 1) | 0x80000000u;
             carry = 1;
         } else {
             carry = 0;
-            if (raw) out = raw - 1;
+            if (raw) out = (u32)j * K + raw - 1;
         }
         dig[(u64)j * n + i] = out;
-        if (out != MSM_NO_DIGIT) atomicAdd(&cnt[(u64)j * K + (out & 0x7fffffffu)], 1u);
+        if (out != MSM_NO_DIGIT) atomicAdd(&cnt[out & 0x7fffffffu], 1u);
     }
 }
 
-// ---- 2a. exclusive scan of the W*K counters: one workgroup per chunk of SCAN_CHUNK counters ----
+// ---- 2a. exclusive scan of the counters: one workgroup per chunk of SCAN_CHUNK counters ----
 static constexpr int SCAN_THREADS = 256;
 static constexpr int SCAN_PER_THREAD = 16;
 static constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_PER_THREAD;
@@ -117,84 +157,216 @@ static __global__ void k_scan_add(u32* __restrict__ off, const u32* __restrict__
 }
 
 // ---- 2b. scatter point indices into bucket order ----
-static __global__ void k_msm_scatter(const u32* __restrict__ dig, u64 n, int c, int W, const u32* __restrict__ off, u32* __restrict__ cursor,
-                              u32* __restrict__ sorted) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * (u64)W) return;
-    const u32 d = dig[t];
-    if (d == MSM_NO_DIGIT) return;
-    const u64 j = t / n, i = t - j * n;
-    const u32 K = 1u << (c - 1);
-    const u64 key = j * K + (d & 0x7fffffffu);
-    const u32 pos = atomicAdd(&cursor[key], 1u);
-    sorted[off[key] + pos] = (u32)i | (d & 0x80000000u);
+// Entries of the ones bucket reserve their slots with one atomic per wave (they all hit the same counter).
+static __global__ void k_msm_scatter(const u32* __restrict__ dig, u64 n, u64 total, u32 ones_key, const u32* __restrict__ off,
+                                     u32* __restrict__ cursor, u32* __restrict__ sorted) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 d = t < total ? dig[t] : MSM_NO_DIGIT;
+    const bool valid = d != MSM_NO_DIGIT;
+    const u32 key = d & 0x7fffffffu;
+    const bool agg = valid && key == ones_key;
+    const unsigned long long m = wave_ballot(agg);
+    const int leader = first_lane(m), lane = wave_lane();
+    u32 base = 0;
+    if (agg && lane == leader) base = atomicAdd(&cursor[key], (u32)__builtin_popcountll(m));
+    base = __shfl(base, leader);
+    if (!valid) return;
+    const u32 pos = agg ? base + lanes_below(m, lane) : atomicAdd(&cursor[key], 1u);
+    sorted[off[key] + pos] = (u32)(t % n) | (d & 0x80000000u);
 }
 
-// ---- 3. bucket accumulation: one work-item per (window, bucket) ----
-template <class F>
-__global__ void k_msm_accum(const Aff<F>* __restrict__ bases, const u32* __restrict__ off, const u32* __restrict__ sorted,
-                            Xyzz<F>* __restrict__ buckets, u64 nbuckets) {
-    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
-    const u32 beg = off[b], end = off[b + 1];
-    Xyzz<F> acc = Xyzz<F>::inf();
-    for (u32 k = beg; k < end; ++k) {
-        const u32 e = sorted[k];
-        Aff<F> p = bases[e & 0x7fffffffu];
-        if (e & 0x80000000u) p = aff_neg(p);
-        acc = xyzz_madd(acc, p);
+// ---- 3a. first key of every lane's slice of the sorted list (upper bound over the offsets) ----
+static __global__ void k_msm_lane_keys(const u32* __restrict__ off, u32 nkeys, u32 P, u32 nlanes, u32* __restrict__ lane_key) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nlanes) return;
+    const u64 pos = (u64)g * P;
+    if (pos >= off[nkeys]) { lane_key[g] = nkeys; return; }
+    u32 lo = 0, hi = nkeys;          // invariant: off[lo] <= pos < off[hi]
+    while (hi - lo > 1) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (off[mid] <= pos) lo = mid; else hi = mid;
     }
-    buckets[b] = acc;
+    lane_key[g] = lo;
+}
+// buckets whose entries span more than MSM_HEAVY lanes
+static __global__ void k_msm_find_heavy(const u32* __restrict__ off, u32 nkeys, u32 P, u32* __restrict__ heavy_list, u32* __restrict__ heavy_count) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nkeys) return;
+    const u32 b = off[k], e = off[k + 1];
+    if (e > b && (e - 1) / P - b / P + 1 > MSM_HEAVY) heavy_list[atomicAdd(heavy_count, 1u)] = k;
 }
 
-// ---- 4. window fold: sum_{b} (b+1) * B_b ----
-// Work-item t of window j owns buckets [t*L, (t+1)*L): running-sum over them gives
-// sum (b - tL + 1) B_b and the plain sum S; the missing tL * S is a short double-and-add.  The
-// workgroup then tree-adds its contributions in LDS and writes one partial per workgroup.
-template <class F>
-__global__ void k_msm_fold(const Xyzz<F>* __restrict__ buckets, u32 K, int L, Xyzz<F>* __restrict__ partial) {
-    ZK_DYN_SMEM(smem);
-    Xyzz<F>* sh = (Xyzz<F>*)smem;
-    const u32 j = blockIdx.y;
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    Xyzz<F> contrib = Xyzz<F>::inf();
-    if ((u64)t * L < K) {
-        const Xyzz<F>* B = buckets + (u64)j * K + (u64)t * L;
-        Xyzz<F> run = Xyzz<F>::inf(), acc = Xyzz<F>::inf();
-        for (int q = L - 1; q >= 0; --q) {
-            if ((u64)t * L + q < K) run = xyzz_add(run, B[q]);
-            acc = xyzz_add(acc, run);
+// ---- 3b. balanced bucket accumulation ----
+// Lane g owns sorted entries [g*P, (g+1)*P).  Whenever the walk crosses into another bucket the running sum is
+// written to partial[key + g]: along the sorted list (lane, key) only ever increase, so key + lane is unique,
+// and bucket `key` finds its partials at the contiguous slots key + g for the lanes g its range overlaps.
+template <class F, int WPE>
+__global__ void __launch_bounds__(256, WPE) k_msm_accum(const Aff<F>* __restrict__ bases, const u32* __restrict__ off, const u32* __restrict__ sorted,
+                                                    const u32* __restrict__ lane_key, Xyzz<F>* __restrict__ partial, u32 nkeys, u32 P,
+                                                    u32 nlanes) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nlanes) return;
+    u32 cur = lane_key[g];
+    if (cur >= nkeys) return;
+    const u32 total = off[nkeys];
+    const u32 p0 = g * P;
+    const u32 p1 = p0 + P < total ? p0 + P : total;
+    u32 end = off[cur + 1];
+    Xyzz<F> acc = Xyzz<F>::inf();
+    u32 e = sorted[p0];
+    Aff<F> pt = bases[e & 0x7fffffffu];
+    for (u32 pos = p0; pos < p1; ++pos) {
+        u32 e_next = e;
+        Aff<F> pt_next = pt;
+        if (pos + 1 < p1) {            // fetch the next base while this one is being added
+            e_next = sorted[pos + 1];
+            pt_next = bases[e_next & 0x7fffffffu];
         }
-        contrib = xyzz_add(acc, xyzz_mul_u32(run, t * (u32)L));
+        if (pos == end) {
+            partial[(u64)cur + g] = acc;
+            acc = Xyzz<F>::inf();
+            do { ++cur; end = off[cur + 1]; } while (end <= pos);
+        }
+        if (e & 0x80000000u) pt.y = fe_neg(pt.y);
+        if (!pt.is_inf()) xyzz_madd_acc(acc, pt);
+        e = e_next;
+        pt = pt_next;
     }
-    sh[threadIdx.x] = contrib;
+    partial[(u64)cur + g] = acc;
+}
+
+// sum of one bucket's partials (after the heavy pass the first slot of a heavy bucket holds its total)
+template <class F>
+__device__ __forceinline__ Xyzz<F> msm_bucket_sum(const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 key, u32 P) {
+    const u32 b = off[key], e = off[key + 1];
+    if (e <= b) return Xyzz<F>::inf();
+    const u32 g0 = b / P, g1 = (e - 1) / P;
+    Xyzz<F> s = partial[(u64)key + g0];
+    if (g1 - g0 + 1 <= MSM_HEAVY)
+        for (u32 g = g0 + 1; g <= g1; ++g) xyzz_add_acc(s, partial[(u64)key + g]);
+    return s;
+}
+
+// workgroup tree sum over sh[0 .. blockDim.x) (blockDim.x a power of two); result in sh[0]
+template <class F>
+__device__ __forceinline__ void block_tree_sum(Xyzz<F>* sh) {
     __syncthreads();
-    for (unsigned s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    for (unsigned st = blockDim.x >> 1; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            Xyzz<F> a = sh[threadIdx.x];
+            xyzz_add_acc(a, sh[threadIdx.x + st]);
+            sh[threadIdx.x] = a;
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[(u64)j * gridDim.x + blockIdx.x] = sh[0];
 }
-// one workgroup per window: sum its `nparts` partials
+
+// ---- 4. heavy buckets: one workgroup each, result into the bucket's first slot ----
 template <class F>
-__global__ void k_msm_fold_final(const Xyzz<F>* __restrict__ partial, u32 nparts, Xyzz<F>* __restrict__ window_sum) {
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_heavy_reduce(const u32* __restrict__ off, u32 P, const u32* __restrict__ heavy_list,
+                                                           const u32* __restrict__ heavy_count, Xyzz<F>* __restrict__ partial) {
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
-    const u32 j = blockIdx.x;
-    Xyzz<F> acc = Xyzz<F>::inf();
-    for (u32 q = threadIdx.x; q < nparts; q += blockDim.x) acc = xyzz_add(acc, partial[(u64)j * nparts + q]);
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (unsigned s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    const u32 nh = *heavy_count;
+    for (u32 h = blockIdx.x; h < nh; h += gridDim.x) {
+        const u32 key = heavy_list[h];
+        const u32 g0 = off[key] / P, g1 = (off[key + 1] - 1) / P;
+        Xyzz<F> s = Xyzz<F>::inf();
+        for (u32 g = g0 + threadIdx.x; g <= g1; g += blockDim.x) xyzz_add_acc(s, partial[(u64)key + g]);
+        sh[threadIdx.x] = s;
+        block_tree_sum<F>(sh);
+        if (threadIdx.x == 0) partial[(u64)key + g0] = sh[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0) window_sum[j] = sh[0];
+}
+
+// k * p for a small unsigned k (left-to-right double-and-add over the significant bits only)
+template <class F>
+__device__ __forceinline__ Xyzz<F> xyzz_mul_small(const Xyzz<F>& p, u32 k) {
+    Xyzz<F> r = Xyzz<F>::inf();
+    if (k == 0 || p.is_inf()) return r;
+    for (int i = 31 - __clz(k); i >= 0; --i) {
+        r = xyzz_dbl_inl(r);
+        if ((k >> i) & 1) xyzz_add_acc(r, p);
+    }
+    return r;
+}
+
+// ---- 5. window fold: sum_{b < K} (b+1) * B_b, two-digit form ----
+// Bucket index b = hi * Lw + lo (Lw = min(K, 256) buckets per row, H = K / Lw rows):
+//     sum (b+1) B_b = sum_lo (lo+1) * C_lo  +  Lw * sum_hi hi * R_hi,      R_hi = row sums, C_lo = column sums.
+// Both digit sums are plain (unweighted) reductions over all buckets — wide and shallow — and only the Lw + H
+// row/column totals per window need a (short) double-and-add.
+//
+// 5a. one workgroup per (row, window): combine each bucket's partials, keep the bucket value for the column pass,
+//     tree-sum the row.
+template <class F>
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 P, u32 K, u32 Lw,
+                                                        Xyzz<F>* __restrict__ bucket, Xyzz<F>* __restrict__ rows) {
+    ZK_DYN_SMEM(smem);
+    Xyzz<F>* sh = (Xyzz<F>*)smem;
+    const u32 j = blockIdx.y, hi = blockIdx.x, lo = threadIdx.x;
+    const u32 key = j * K + hi * Lw + lo;
+    Xyzz<F> v = msm_bucket_sum<F>(partial, off, key, P);
+    bucket[key] = v;
+    sh[lo] = v;
+    block_tree_sum<F>(sh);
+    if (lo == 0) rows[(u64)j * gridDim.x + hi] = sh[0];
+}
+// 5b. column sums: work-item (lo, hg) adds its share of the rows serially, then the HG shares are tree-added.
+//     blockDim = (CW, HG); grid = (Lw / CW, W).
+template <class F>
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(const Xyzz<F>* __restrict__ bucket, u32 K, u32 Lw, u32 H, Xyzz<F>* __restrict__ cols) {
+    ZK_DYN_SMEM(smem);
+    Xyzz<F>* sh = (Xyzz<F>*)smem;
+    const u32 j = blockIdx.y, lo = blockIdx.x * blockDim.x + threadIdx.x, hg = threadIdx.y, HG = blockDim.y;
+    Xyzz<F> s = Xyzz<F>::inf();
+    for (u32 hi = hg; hi < H; hi += HG) xyzz_add_acc(s, bucket[(u64)j * K + (u64)hi * Lw + lo]);
+    sh[hg * blockDim.x + threadIdx.x] = s;
+    __syncthreads();
+    for (unsigned st = HG >> 1; st > 0; st >>= 1) {
+        if (hg < st) {
+            Xyzz<F> a = sh[hg * blockDim.x + threadIdx.x];
+            xyzz_add_acc(a, sh[(hg + st) * blockDim.x + threadIdx.x]);
+            sh[hg * blockDim.x + threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (hg == 0) cols[(u64)j * Lw + lo] = sh[threadIdx.x];
+}
+// 5c. one workgroup per window: the two weighted digit sums; workgroup W delivers the ones bucket.
+template <class F>
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
+                                                         const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 P, u32 W,
+                                                         u32 ones_key, Xyzz<F>* __restrict__ window_sum) {
+    ZK_DYN_SMEM(smem);
+    Xyzz<F>* sh = (Xyzz<F>*)smem;
+    const u32 j = blockIdx.x, t = threadIdx.x;
+    if (j >= W) {
+        if (t == 0) window_sum[j] = msm_bucket_sum<F>(partial, off, ones_key, P);
+        return;
+    }
+    // sum_hi hi * R_hi, then times Lw (a power of two: log2 doublings)
+    Xyzz<F> term = Xyzz<F>::inf();
+    for (u32 hi = t; hi < H; hi += blockDim.x) xyzz_add_acc(term, xyzz_mul_small(rows[(u64)j * H + hi], hi));
+    sh[t] = term;
+    block_tree_sum<F>(sh);
+    Xyzz<F> hi_sum = sh[0];
+    __syncthreads();
+    // sum_lo (lo + 1) * C_lo
+    term = Xyzz<F>::inf();
+    for (u32 lo = t; lo < Lw; lo += blockDim.x) xyzz_add_acc(term, xyzz_mul_small(cols[(u64)j * Lw + lo], lo + 1));
+    sh[t] = term;
+    block_tree_sum<F>(sh);
+    if (t == 0) {
+        for (u32 q = Lw; q > 1; q >>= 1) hi_sum = xyzz_dbl_inl(hi_sum);
+        Xyzz<F> r = sh[0];
+        xyzz_add_acc(r, hi_sum);
+        window_sum[j] = r;
+    }
 }
 
 // ---- key preparation ----
-// canonical affine coordinates (+ host-decoded infinity as all-zero) -> Montgomery form; for Fq2 points the
-// coordinate array is simply twice as long, so this is an element-wise conversion over base-field elements.
 // out[p] = (idx < n_src) ? in[idx] : infinity, idx = natural index of sigma position p (h_query layout)
 template <class PT>
 __global__ void k_sigma_gather_points(const PT* __restrict__ in, PT* __restrict__ out, u64 n, u64 n_src, u32 n1, u32 n2) {
@@ -206,17 +378,26 @@ __global__ void k_sigma_gather_points(const PT* __restrict__ in, PT* __restrict_
 
 // fixed-base multiplication for setup (N3): out[i] = k_i * G with tbl[j*256 + d] = d * 2^(8j) * G (affine)
 template <class F>
-__global__ void k_fixed_base_mul(const u32* __restrict__ scalars, u64 n, const Aff<F>* __restrict__ tbl, int nwin,
-                                 Aff<F>* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_fixed_base_mul(const u32* __restrict__ scalars, u64 n, const Aff<F>* __restrict__ tbl, int nwin,
+                                                        Aff<F>* __restrict__ out) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32* k = scalars + i * 8;
     Xyzz<F> acc = Xyzz<F>::inf();
     for (int j = 0; j < nwin; ++j) {
         const u32 d = (k[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-        if (d) acc = xyzz_madd(acc, tbl[(size_t)j * 256 + d]);
+        if (d) xyzz_madd_acc(acc, tbl[(size_t)j * 256 + d]);
     }
     out[i] = xyzz_to_affine(acc);
+}
+
+// tbl[j*256 + d] = d * P_j (affine), P_j = 2^(8j) G given in pj[]
+template <class F>
+__global__ void __launch_bounds__(64) k_fixed_base_table(const Aff<F>* __restrict__ pj, Aff<F>* __restrict__ tbl, int nwin) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nwin * 256) return;
+    const int j = t >> 8, d = t & 255;
+    tbl[t] = xyzz_to_affine(xyzz_mul_u32(Xyzz<F>::from_affine(pj[j]), (u32)d));
 }
 
 }  // namespace zk

@@ -33,15 +33,6 @@ __global__ void k_lc_coeff(const F* __restrict__ a, const F* __restrict__ b, con
     F t = fe_add(fe_add(fe_mul(beta, a[i]), fe_mul(alpha, b[i])), c[i]);
     out[i] = fe_mul(t, i < l ? ginv : dinv);
 }
-// tbl[j*256 + d] = d * P_j (affine), P_j = 2^(8j) G given in pj[]
-template <class F>
-__global__ void k_fixed_base_table(const Aff<F>* __restrict__ pj, Aff<F>* __restrict__ tbl, int nwin) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nwin * 256) return;
-    const int j = t >> 8, d = t & 255;
-    tbl[t] = xyzz_to_affine(xyzz_mul_u32(Xyzz<F>::from_affine(pj[j]), (u32)d));
-}
-
 template <class C>
 struct Setup {
     typedef typename C::Fr Fr;
@@ -80,12 +71,7 @@ struct Setup {
             pj[j] = xyzz_to_affine(cur);
             for (int b = 0; b < 8; ++b) cur = xyzz_dbl(cur);
         }
-        DBuf d_pj;
-        d_pj.ensure(pj.size() * sizeof(Aff<F>));
-        dev_h2d(d_pj.p, pj.data(), pj.size() * sizeof(Aff<F>), ctx->stream);
-        tbl.ensure((size_t)NWIN * 256 * sizeof(Aff<F>));
-        ZK_LAUNCH((k_fixed_base_table<F>), dim3(blocks_for(NWIN * 256, 64)), dim3(64), 0, ctx->stream, ptr<Aff<F>>(d_pj), ptr<Aff<F>>(tbl), NWIN);
-        stream_sync(ctx->stream);
+        fixed_base_table<F>(ctx, pj.data(), NWIN, tbl);
     }
 
     // out (host, ark encoding) <- scalars[i] * G for i < count; d_scalars canonical on the device
@@ -96,8 +82,7 @@ struct Setup {
         constexpr int PB = FQB * NC;
         DBuf d_pts;
         d_pts.ensure(count * sizeof(Aff<F>));
-        ZK_LAUNCH((k_fixed_base_mul<F>), dim3(blocks_for(count, 64)), dim3(64), 0, s, (const u32*)d_scalars, count, ptr<Aff<F>>(tbl), NWIN,
-                  ptr<Aff<F>>(d_pts));
+        fixed_base_mul<F>(ctx, tbl, NWIN, (const u32*)d_scalars, count, ptr<Aff<F>>(d_pts));
         ZK_LAUNCH((k_from_mont<Fq>), dim3(blocks_for(count * NC, 256)), dim3(256), 0, s, ptr<Fq>(d_pts), ptr<Fq>(d_pts), count * NC);
         dev_d2h(out, d_pts.p, count * PB, s);
         stream_sync(s);

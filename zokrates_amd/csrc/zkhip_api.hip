@@ -46,6 +46,12 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         std::unique_ptr<zkhip_ctx> ctx(new zkhip_ctx());
         ctx->device = device;
         ctx->stream = stream_create();
+        ctx->serial = getenv("ZKHIP_SERIAL") != nullptr;
+        for (auto& so : ctx->sorts) so.ready = event_create();
+        for (auto& lane : ctx->lanes) {
+            lane.stream = stream_create();
+            lane.done = event_create();
+        }
 #ifdef ZK_EMU
         ctx->desc = "zkhip TEST EMULATOR (not a product build)";
 #else
@@ -62,6 +68,11 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
 void zkhip_ctx_free(zkhip_ctx* ctx) {
     if (!ctx) return;
     for (Event e : ctx->ev_pool) event_destroy(e);
+    for (auto& so : ctx->sorts) event_destroy(so.ready);
+    for (auto& lane : ctx->lanes) {
+        event_destroy(lane.done);
+        stream_destroy(lane.stream);
+    }
     stream_destroy(ctx->stream);
     delete ctx;
 }
