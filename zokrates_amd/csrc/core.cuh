@@ -275,7 +275,7 @@ static inline MsmShape msm_shape(u64 n, int scalar_bits) {
             if (cand < 2 || cand > 16) continue;
             const int W = (scalar_bits + 1 + cand - 1) / cand;
             const int top_bits = scalar_bits + 1 - (W - 1) * cand;
-            if (top_bits >= std::min(cand, 8)) { s.c = cand; found = true; break; }
+            if (top_bits >= cand || (n >> (top_bits - 1)) <= 4096) { s.c = cand; found = true; break; }   // <= 4096 points per top bucket
         }
         if (found) break;
     }
