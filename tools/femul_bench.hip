@@ -59,6 +59,51 @@ __device__ __forceinline__ void mac3(u64& acc, u32& ext, u32 a, u32 b) {
         : "+v"(acc), "=&s"(carry), "+v"(ext)
         : "v"(a), "v"(b));
 }
+template <int MODE>
+__device__ __forceinline__ void mac3m(u64& acc, u32& ext, u32 a, u32 b) {
+    if (MODE == 2) {          // two statements: the scheduler may separate the MAD from the carry add
+        u64 carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "v"(b));
+        asm("v_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(ext), "+s"(carry));
+    } else {                  // carry through VCC
+        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(ext) : "v"(a), "v"(b) : "vcc");
+    }
+}
+template <class PP, int MODE>
+__device__ __forceinline__ Fe<PP> mul_comba32m(const Fe<PP>& a, const Fe<PP>& b) {
+    constexpr int N = PP::N;
+    u32 m[N];
+    Fe<PP> r;
+    u64 acc = 0;
+    u32 ext = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+            mac3m<MODE>(acc, ext, a.v[i], b.v[k - i]);
+            mac3m<MODE>(acc, ext, m[i], PP::mod(k - i));
+        }
+        mac3m<MODE>(acc, ext, a.v[k], b.v[0]);
+        m[k] = (u32)acc * PP::INV;
+        mac3m<MODE>(acc, ext, m[k], PP::mod(0));
+        acc = (acc >> 32) | ((u64)ext << 32);
+        ext = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) {
+            mac3m<MODE>(acc, ext, a.v[i], b.v[k - i]);
+            mac3m<MODE>(acc, ext, m[i], PP::mod(k - i));
+        }
+        r.v[k - N] = (u32)acc;
+        acc = (acc >> 32) | ((u64)ext << 32);
+        ext = 0;
+    }
+    r.v[N - 1] = (u32)acc;
+    fe_reduce_once(r);
+    return r;
+}
 template <class PP>
 __device__ __forceinline__ Fe<PP> mul_comba32(const Fe<PP>& a, const Fe<PP>& b) {
     constexpr int N = PP::N;
@@ -113,6 +158,10 @@ __global__ void k_bench(Fq* out, const Fq* in, int iters) {
         for (int k = 0; k < iters; ++k) { x = fe_mul(x, y); y = fe_mul(y, x); }
     } else if (V == 2) {
         for (int k = 0; k < iters; ++k) { x = mul_comba32(x, y); y = mul_comba32(y, x); }
+    } else if (V == 3) {
+        for (int k = 0; k < iters; ++k) { x = mul_comba32m<P, 2>(x, y); y = mul_comba32m<P, 2>(y, x); }
+    } else if (V == 4) {
+        for (int k = 0; k < iters; ++k) { x = mul_comba32m<P, 3>(x, y); y = mul_comba32m<P, 3>(y, x); }
     }
     out[i] = fe_add(x, y);
 }
@@ -207,6 +256,21 @@ int main() {
     report("A  CIOS 8x32 (compiler)", time_it([&] { hipLaunchKernelGGL(k_bench<0>, dim3(blocks), dim3(threads), 0, 0, o0, in, it); }));
     report("B  Comba 9x29 lazy (compiler)", time_it([&] { hipLaunchKernelGGL(k_bench29, dim3(blocks), dim3(threads), 0, 0, o29, in29, it); }));
     report("C  Comba 8x32 + asm carry", time_it([&] { hipLaunchKernelGGL(k_bench<2>, dim3(blocks), dim3(threads), 0, 0, o2, in, it); }));
+    report("C2 Comba 8x32, split asm", time_it([&] { hipLaunchKernelGGL(k_bench<3>, dim3(blocks), dim3(threads), 0, 0, o2, in, it); }));
+    report("C3 Comba 8x32, carry in VCC", time_it([&] { hipLaunchKernelGGL(k_bench<4>, dim3(blocks), dim3(threads), 0, 0, o2, in, it); }));
+    {   // correctness of C2 / C3 against A on the benchmark's own output
+        std::vector<u32> ra(256 * 8), rc(256 * 8);
+        hipLaunchKernelGGL(k_bench<0>, dim3(1), dim3(256), 0, 0, o0, in, 3); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(ra.data(), o0, ra.size() * 4, hipMemcpyDeviceToHost));
+        for (int v = 3; v <= 4; ++v) {
+            if (v == 3) hipLaunchKernelGGL(k_bench<3>, dim3(1), dim3(256), 0, 0, o2, in, 3);
+            else hipLaunchKernelGGL(k_bench<4>, dim3(1), dim3(256), 0, 0, o2, in, 3);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(rc.data(), o2, rc.size() * 4, hipMemcpyDeviceToHost));
+            int bad = 0; for (size_t i = 0; i < ra.size(); ++i) bad += ra[i] != rc[i];
+            printf("C%d vs A mismatching words: %d\n", v - 1, bad);
+        }
+    }
     report("D  FP64 pattern 5x52 (rate only)", time_it([&] { hipLaunchKernelGGL(k_bench_fp, dim3(blocks), dim3(threads), 0, 0, fout, fin, it); }));
     // correctness dump
     hipLaunchKernelGGL(k_once, dim3(1), dim3(64), 0, 0, o0, o2, in, o29, in29);

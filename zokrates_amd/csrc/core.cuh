@@ -64,6 +64,7 @@ struct DBuf {
     DBuf(const DBuf&) = delete;
     DBuf& operator=(const DBuf&) = delete;
     ~DBuf() { dev_free(p); }
+    void swap(DBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
     void ensure(size_t bytes) {
         if (bytes <= cap) return;
         dev_free(p);
@@ -324,9 +325,15 @@ static inline Event pool_event(zkhip_ctx* ctx) {
 // Defined in group.cuh and instantiated once per (curve, group) in its own translation unit (bn254_g1.hip, ...):
 // the elliptic-curve kernels are by far the most expensive code to compile.
 // Runs on lane.stream after so.ready; lane.done is recorded behind the last kernel.
+// `d_bases_unsat` are affine points in the unsaturated working form (points_to_unsat); the window sums come back in the
+// saturated Montgomery form.
 template <class F>
-void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const Aff<F>* d_bases, const MsmShape& sh, Xyzz<F>* d_window_sums,
+void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bases_unsat, const MsmShape& sh, Xyzz<F>* d_window_sums,
              Event* ev_begin, Event* ev_end);
+// affine points, saturated Montgomery form -> unsaturated working form of the MSM kernels (fieldu.cuh); on ctx->stream
+template <class F>
+void points_to_unsat(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
+template <class F> static constexpr size_t unsat_point_bytes() { return sizeof(Aff<typename Unsat<F>::type>); }
 // fixed-base tables / multiplications for setup (N3); also per-group code
 template <class F>
 void fixed_base_table(zkhip_ctx* ctx, const Aff<F>* h_pj, int nwin, DBuf& tbl);
@@ -522,6 +529,20 @@ struct PkLoader {
         add_into<Fq, 2>(ctx, pk->a_ext, 0, alpha_g1);
         add_into<Fq, 2>(ctx, pk->b1_ext, 0, beta_g1);
         add_into<Fq2, 4>(ctx, pk->b2_ext, 0, beta_g2);
+        // the MSM kernels work on unsaturated limbs (fieldu.cuh): convert every base once, here
+        to_unsat<Fq>(ctx, pk->a_ext, me);
+        to_unsat<Fq>(ctx, pk->b1_ext, me);
+        to_unsat<Fq>(ctx, pk->l_ext, me);
+        to_unsat<Fq2>(ctx, pk->b2_ext, me);
+        to_unsat<Fq>(ctx, pk->h_sigma, N);
+    }
+    template <class F>
+    static void to_unsat(zkhip_ctx* ctx, DBuf& buf, u64 count) {
+        DBuf out;
+        out.ensure(count * unsat_point_bytes<F>());
+        points_to_unsat<F>(ctx, ptr<Aff<F>>(buf), out.p, count);
+        stream_sync(ctx->stream);
+        buf.swap(out);
     }
 };
 
@@ -619,10 +640,10 @@ struct Prover {
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(d_ws1);
         Event ab[5], ae[5];
         msm_prepare(ctx, ctx->sorts[0], (const u32*)d_scalars, shz);
-        msm_run<Fq2>(ctx, ctx->lanes[3], ctx->sorts[0], ptr<Aff<Fq2>>(pk->b2_ext), shz, ptr<Xyzz<Fq2>>(d_ws2), &ab[4], &ae[4]);   // longest first
-        msm_run<Fq>(ctx, ctx->lanes[0], ctx->sorts[0], ptr<Aff<Fq>>(pk->a_ext), shz, ws1 + 0 * Wmax, &ab[0], &ae[0]);
-        msm_run<Fq>(ctx, ctx->lanes[1], ctx->sorts[0], ptr<Aff<Fq>>(pk->b1_ext), shz, ws1 + 1 * Wmax, &ab[1], &ae[1]);
-        msm_run<Fq>(ctx, ctx->lanes[2], ctx->sorts[0], ptr<Aff<Fq>>(pk->l_ext), shz, ws1 + 2 * Wmax, &ab[2], &ae[2]);
+        msm_run<Fq2>(ctx, ctx->lanes[3], ctx->sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(d_ws2), &ab[4], &ae[4]);   // longest first
+        msm_run<Fq>(ctx, ctx->lanes[0], ctx->sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, &ab[0], &ae[0]);
+        msm_run<Fq>(ctx, ctx->lanes[1], ctx->sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, &ab[1], &ae[1]);
+        msm_run<Fq>(ctx, ctx->lanes[2], ctx->sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, &ab[2], &ae[2]);
         event_record(e2, st);
 
         // ---- K1-K4
@@ -631,7 +652,7 @@ struct Prover {
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
         msm_prepare(ctx, ctx->sorts[1], ptr<u32>(ctx->va), shh);
-        msm_run<Fq>(ctx, ctx->lanes[4], ctx->sorts[1], ptr<Aff<Fq>>(pk->h_sigma), shh, ws1 + 3 * Wmax, &ab[3], &ae[3]);
+        msm_run<Fq>(ctx, ctx->lanes[4], ctx->sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, &ab[3], &ae[3]);
         for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(st, ctx->lanes[k].done);
         event_record(e4, st);
 
@@ -706,7 +727,10 @@ struct Prover {
         const MsmShape sh = msm_shape(n, Fr::Params::BITS);
         d_ws.ensure((size_t)(sh.W + 1) * sizeof(Xyzz<F>));
         msm_prepare(ctx, ctx->sorts[0], ptr<u32>(ctx->scalars), sh);
-        msm_run<F>(ctx, ctx->lanes[0], ctx->sorts[0], ptr<Aff<F>>(d_bases), sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
+        DBuf d_unsat;
+        d_unsat.ensure(n * unsat_point_bytes<F>());
+        points_to_unsat<F>(ctx, ptr<Aff<F>>(d_bases), d_unsat.p, n);
+        msm_run<F>(ctx, ctx->lanes[0], ctx->sorts[0], d_unsat.p, sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
         stream_wait_event(s, ctx->lanes[0].done);
         std::vector<Xyzz<F>> ws(sh.W + 1);
         dev_d2h(ws.data(), d_ws.p, ws.size() * sizeof(Xyzz<F>), s);

@@ -8,7 +8,7 @@
 // Bases are affine in Montgomery form; the point at infinity is the sentinel (0, 0), which is on
 // neither curve family handled here (b != 0).
 #pragma once
-#include "field.cuh"
+#include "fieldu.cuh"
 
 namespace zk {
 
@@ -40,17 +40,20 @@ ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F>& p) {
 }
 
 // 2*(x, y) for an affine point (mdbl-2008-s-1)
+// Bounds for the unsaturated field (fieldu.cuh): products come out < 2p; the comments "< kp" track the integer values so
+// that every sub<K> has value(b) < K*p and every stored coordinate stays < 8p (X < 3p after fe_relax, Y < 4p, ZZ/ZZZ < 2p).
+// For the saturated field sub<K> is the plain modular subtraction and fe_relax the identity.
 template <class F>
 ZK_HD Xyzz<F> xyzz_dbl_affine_inl(const Aff<F>& p) {
-    if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
-    F U = fe_dbl(p.y);
+    if (p.is_inf() || fe_is_zero_modp(p.y)) return Xyzz<F>::inf();
+    F U = fe_dbl(p.y);                                   // < 2p (affine coordinates are canonical-sized)
     F V = ec_sqr(U);
     F W = ec_mul(U, V);
     F S = ec_mul(p.x, V);
     F X2 = ec_sqr(p.x);
-    F M = fe_add(fe_dbl(X2), X2);
-    F X3 = fe_sub(ec_sqr(M), fe_dbl(S));
-    F Y3 = fe_sub(ec_mul(M, fe_sub(S, X3)), ec_mul(W, p.y));
+    F M = fe_add(fe_dbl(X2), X2);                        // < 6p
+    F X3 = fe_relax(fe_sub_k<4>(ec_sqr(M), fe_dbl(S)));  // 2S < 4p
+    F Y3 = fe_sub_k<2>(ec_mul(M, fe_sub_k<4>(S, X3)), ec_mul(W, p.y));   // < 4p
     return {X3, Y3, V, W};
 }
 template <class F>
@@ -61,15 +64,15 @@ ZK_HD_CALL Xyzz<F> xyzz_dbl_affine(const Aff<F>& p) {
 // dbl-2008-s-1
 template <class F>
 ZK_HD Xyzz<F> xyzz_dbl_inl(const Xyzz<F>& p) {
-    if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
-    F U = fe_dbl(p.y);
+    if (p.is_inf() || fe_is_zero_modp(p.y)) return Xyzz<F>::inf();
+    F U = fe_dbl(p.y);                                   // < 8p
     F V = ec_sqr(U);
     F W = ec_mul(U, V);
     F S = ec_mul(p.x, V);
     F X2 = ec_sqr(p.x);
-    F M = fe_add(fe_dbl(X2), X2);
-    F X3 = fe_sub(ec_sqr(M), fe_dbl(S));
-    F Y3 = fe_sub(ec_mul(M, fe_sub(S, X3)), ec_mul(W, p.y));
+    F M = fe_add(fe_dbl(X2), X2);                        // < 6p
+    F X3 = fe_relax(fe_sub_k<4>(ec_sqr(M), fe_dbl(S)));
+    F Y3 = fe_sub_k<2>(ec_mul(M, fe_sub_k<4>(S, X3)), ec_mul(W, p.y));
     return {X3, Y3, ec_mul(V, p.zz), ec_mul(W, p.zzz)};
 }
 template <class F>
@@ -161,10 +164,10 @@ ZK_HD void xyzz_madd_acc(Xyzz<F>& a, const Aff<F>& p) {   // a += p, p affine an
         a.x = p.x; a.y = p.y; a.zz = F::one(); a.zzz = F::one();
         return;
     }
-    F Pp = fe_sub(ec_mul(p.x, a.zz), a.x);
-    F R = fe_sub(ec_mul(p.y, a.zzz), a.y);
-    if (Pp.is_zero()) {
-        a = R.is_zero() ? xyzz_dbl_affine_inl(p) : Xyzz<F>::inf();
+    F Pp = fe_sub_k<4>(ec_mul(p.x, a.zz), a.x);           // X1 < 3p;  Pp < 6p
+    F R = fe_sub_k<4>(ec_mul(p.y, a.zzz), a.y);           // Y1 < 4p;  R < 6p
+    if (fe_is_zero_modp(Pp)) {
+        a = fe_is_zero_modp(R) ? xyzz_dbl_affine_inl(p) : Xyzz<F>::inf();
         return;
     }
     F PP = ec_sqr(Pp);
@@ -172,8 +175,8 @@ ZK_HD void xyzz_madd_acc(Xyzz<F>& a, const Aff<F>& p) {   // a += p, p affine an
     F Q = ec_mul(a.x, PP);
     a.zz = ec_mul(a.zz, PP);
     a.zzz = ec_mul(a.zzz, PPP);
-    F X3 = fe_sub(fe_sub(ec_sqr(R), PPP), fe_dbl(Q));
-    a.y = fe_sub(ec_mul(R, fe_sub(Q, X3)), ec_mul(a.y, PPP));
+    F X3 = fe_relax(fe_sub_k<4>(fe_sub_k<2>(ec_sqr(R), PPP), fe_dbl(Q)));   // < 2 + 2 + 4 = 8p before, < 3p after
+    a.y = fe_sub_k<2>(ec_mul(R, fe_sub_k<4>(Q, X3)), ec_mul(a.y, PPP));       // < 4p
     a.x = X3;
 }
 template <class F>
@@ -182,10 +185,10 @@ ZK_HD void xyzz_add_acc(Xyzz<F>& a, const Xyzz<F>& b) {   // a += b, both XYZZ
     if (a.is_inf()) { a = b; return; }
     F U1 = ec_mul(a.x, b.zz);
     F S1 = ec_mul(a.y, b.zzz);
-    F Pp = fe_sub(ec_mul(b.x, a.zz), U1);
-    F R = fe_sub(ec_mul(b.y, a.zzz), S1);
-    if (Pp.is_zero()) {
-        a = R.is_zero() ? xyzz_dbl_inl(a) : Xyzz<F>::inf();
+    F Pp = fe_sub_k<2>(ec_mul(b.x, a.zz), U1);            // < 4p
+    F R = fe_sub_k<2>(ec_mul(b.y, a.zzz), S1);
+    if (fe_is_zero_modp(Pp)) {
+        a = fe_is_zero_modp(R) ? xyzz_dbl_inl(a) : Xyzz<F>::inf();
         return;
     }
     F PP = ec_sqr(Pp);
@@ -193,8 +196,8 @@ ZK_HD void xyzz_add_acc(Xyzz<F>& a, const Xyzz<F>& b) {   // a += b, both XYZZ
     F Q = ec_mul(U1, PP);
     a.zz = ec_mul(ec_mul(a.zz, b.zz), PP);
     a.zzz = ec_mul(ec_mul(a.zzz, b.zzz), PPP);
-    F X3 = fe_sub(fe_sub(ec_sqr(R), PPP), fe_dbl(Q));
-    a.y = fe_sub(ec_mul(R, fe_sub(Q, X3)), ec_mul(S1, PPP));
+    F X3 = fe_relax(fe_sub_k<4>(fe_sub_k<2>(ec_sqr(R), PPP), fe_dbl(Q)));
+    a.y = fe_sub_k<2>(ec_mul(R, fe_sub_k<4>(Q, X3)), ec_mul(S1, PPP));
     a.x = X3;
 }
 

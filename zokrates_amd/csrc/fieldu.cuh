@@ -1,0 +1,414 @@
+// fieldu.cuh — base-field arithmetic in UNSATURATED limbs for the MSM kernels (product code).
+//
+// gfx950 multiplies with v_mad_u64_u32 (32x32 + 64 -> 64).  With saturated 32-bit limbs every partial product needs
+// carry handling that costs more issue slots than the multiply itself (the CIOS code in field.cuh runs at 87 G mul/s).
+// With B-bit limbs, B < 32, the 64-bit column accumulators of a product-scanning (Comba) multiplication have enough
+// headroom to take every partial product of a column with NO carry at all:
+//     BN254 Fq:      9 limbs x 29 bits (R' = 2^261)  -> 166 G mul/s measured (tools/femul_bench.hip), 1.9x
+//     BLS12-381 Fq: 14 limbs x 28 bits (R' = 2^392)
+// Elements stay in Montgomery form w.r.t. R' and in a REDUNDANT representation: limbs may slightly exceed 2^B and
+// the integer value may be a small multiple of p above the canonical one.  Invariants (checked by the bounds notes in
+// ec.cuh and by the parity tests):
+//     TIGHT: every limb <= 2^B + 8 (the top limb carries the value's overflow); all stored elements are TIGHT;
+//     mul / mul2 accept TIGHT operands with values < 8p and return TIGHT results with value < 2p;
+//     add, dbl, sub<K> finish with one parallel carry round (no ripple): TIGHT out; sub<K>(a, b) = a + K*p - b needs b < K*p.
+// Only the curve kernels use this type; boundaries convert from/to the saturated Montgomery form of field.cuh
+// (fu_from_fe / fu_to_fe), so nothing outside the MSM sees it.  Results are exact group elements either way.
+#pragma once
+#include "field.cuh"
+
+namespace zk {
+
+template <class P> struct UCfg;
+template <> struct UCfg<Bn254Fq> { static constexpr int B = 29, N = 9; };
+template <> struct UCfg<Bls381Fq> { static constexpr int B = 28, N = 14; };
+
+// ---- compile-time constants: p, -p^-1, powers of two mod p and bias multiples of p, all in B-bit limbs ----
+template <class P>
+struct UConst {
+    static constexpr int B = UCfg<P>::B, N = UCfg<P>::N, W = P::N;   // W 32-bit words in the saturated form
+    static constexpr u32 M = (1u << B) - 1;
+    struct Words { u32 w[W + 1]; };
+    struct Limbs { u32 v[N]; };
+
+    static constexpr Words modulus() {
+        Words r{};
+        for (int i = 0; i < W; ++i) r.w[i] = P::mod(i);
+        r.w[W] = 0;
+        return r;
+    }
+    static constexpr bool geq(const Words& a, const Words& b) {
+        for (int i = W; i >= 0; --i)
+            if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
+        return true;
+    }
+    static constexpr Words sub(const Words& a, const Words& b) {
+        Words r{};
+        u64 bw = 0;
+        for (int i = 0; i <= W; ++i) {
+            u64 t = (u64)a.w[i] - b.w[i] - bw;
+            r.w[i] = (u32)t;
+            bw = (t >> 63) & 1;
+        }
+        return r;
+    }
+    static constexpr Words dbl_mod(const Words& a) {   // 2a mod p for a < p
+        Words r{};
+        u32 c = 0;
+        for (int i = 0; i <= W; ++i) {
+            r.w[i] = (a.w[i] << 1) | c;
+            c = a.w[i] >> 31;
+        }
+        const Words p = modulus();
+        return geq(r, p) ? sub(r, p) : r;
+    }
+    static constexpr Words pow2_mod(int k) {   // 2^k mod p
+        Words r{};
+        r.w[0] = 1;
+        for (int i = 0; i < k; ++i) r = dbl_mod(r);
+        return r;
+    }
+    static constexpr Words times_small(const Words& a, u32 k) {   // k * a as an integer (no reduction), k small
+        Words r{};
+        u64 c = 0;
+        for (int i = 0; i <= W; ++i) {
+            c += (u64)a.w[i] * k;
+            r.w[i] = (u32)c;
+            c >>= 32;
+        }
+        return r;
+    }
+    static constexpr Limbs split(const Words& a) {   // integer < 2^(B*N) -> B-bit limbs
+        Limbs l{};
+        for (int i = 0; i < N; ++i) {
+            const int bit = B * i, wi = bit >> 5, sh = bit & 31;
+            u64 two = wi <= W ? a.w[wi] : 0;
+            if (wi + 1 <= W) two |= (u64)a.w[wi + 1] << 32;
+            l.v[i] = (u32)(two >> sh) & M;
+        }
+        // the top limb keeps every remaining bit
+        {
+            const int bit = B * (N - 1), wi = bit >> 5, sh = bit & 31;
+            u64 two = wi <= W ? a.w[wi] : 0;
+            if (wi + 1 <= W) two |= (u64)a.w[wi + 1] << 32;
+            l.v[N - 1] = (u32)(two >> sh);
+        }
+        return l;
+    }
+    // K*p in "spread" limbs: same integer, every limb but the top one raised by 2^(B+2) (minus what the limb above
+    // gives back), so that a_i + bias_i - b_i never goes negative for b_i < 2^(B+2) - 4.
+    static constexpr Limbs bias(u32 k) {
+        Limbs c = split(times_small(modulus(), k));
+        Limbs r{};
+        for (int i = 0; i < N; ++i) {
+            if (i == 0) r.v[i] = c.v[i] + (1u << (B + 2));
+            else if (i < N - 1) r.v[i] = c.v[i] + (1u << (B + 2)) - 4;
+            else r.v[i] = c.v[i] - 4;
+        }
+        return r;
+    }
+    static constexpr u32 inv_low() {   // p^-1 mod 2^32 (Newton)
+        u32 p0 = P::mod(0), x = 1;
+        for (int i = 0; i < 6; ++i) x *= 2 - p0 * x;
+        return x;
+    }
+
+    ZK_HD static constexpr u32 p(int i) { constexpr Limbs t = split(modulus()); return t.v[i]; }
+    ZK_HD static constexpr u32 one(int i) { constexpr Limbs t = split(pow2_mod(B * N)); return t.v[i]; }            // R' mod p
+    ZK_HD static constexpr u32 from_fe(int i) { constexpr Limbs t = split(pow2_mod(2 * B * N - 32 * W)); return t.v[i]; }   // x*2^(32W) -> x*R'
+    ZK_HD static constexpr u32 bias2(int i) { constexpr Limbs t = bias(2); return t.v[i]; }
+    ZK_HD static constexpr u32 bias4(int i) { constexpr Limbs t = bias(4); return t.v[i]; }
+    ZK_HD static constexpr u32 bias8(int i) { constexpr Limbs t = bias(8); return t.v[i]; }
+    static constexpr u32 PINV = inv_low() & M;               //  p^-1 mod 2^B
+    static constexpr u32 NINV = (0u - inv_low()) & M;        // -p^-1 mod 2^B
+    static constexpr u32 P_TOP = split(modulus()).v[N - 1];
+    static constexpr u32 Q_MAGIC = (u32)(((u64)1 << 32) / ((u64)P_TOP + 1));   // floor(2^32 / (p_top + 1))
+};
+
+template <class P>
+struct Fu {
+    typedef P Params;
+    typedef UConst<P> C;
+    static constexpr int N = C::N, B = C::B;
+    static constexpr u32 M = C::M;
+    u32 v[N];
+
+    ZK_HD static Fu zero() {
+        Fu r;
+        ZK_UNROLL for (int i = 0; i < N; ++i) r.v[i] = 0;
+        return r;
+    }
+    ZK_HD static Fu one() {
+        Fu r;
+        ZK_UNROLL for (int i = 0; i < N; ++i) r.v[i] = C::one(i);
+        return r;
+    }
+    // all limbs zero: the representation of the affine-infinity sentinel and of an empty accumulator (NOT "== 0 mod p")
+    ZK_HD bool is_zero() const {
+        u32 a = 0;
+        ZK_UNROLL for (int i = 0; i < N; ++i) a |= v[i];
+        return a == 0;
+    }
+};
+
+// one parallel carry round: limb i keeps its low B bits and receives the overflow of limb i-1
+template <class P>
+ZK_HD Fu<P> fu_norm(const u32* t) {
+    constexpr int N = Fu<P>::N, B = Fu<P>::B;
+    Fu<P> r;
+    r.v[0] = t[0] & Fu<P>::M;
+    ZK_UNROLL for (int i = 1; i < N - 1; ++i) r.v[i] = (t[i] & Fu<P>::M) + (t[i - 1] >> B);
+    r.v[N - 1] = t[N - 1] + (t[N - 2] >> B);
+    return r;
+}
+template <class P>
+ZK_HD Fu<P> fe_add(const Fu<P>& a, const Fu<P>& b) {
+    u32 t[Fu<P>::N];
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) t[i] = a.v[i] + b.v[i];
+    return fu_norm<P>(t);
+}
+template <class P>
+ZK_HD Fu<P> fe_dbl(const Fu<P>& a) {
+    u32 t[Fu<P>::N];
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) t[i] = a.v[i] << 1;
+    return fu_norm<P>(t);
+}
+// a + K*p - b for K in {2, 4, 8}; needs value(b) < K*p
+template <int K, class P>
+ZK_HD Fu<P> fe_sub_k(const Fu<P>& a, const Fu<P>& b) {
+    typedef UConst<P> C;
+    u32 t[Fu<P>::N];
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) t[i] = a.v[i] + (K == 2 ? C::bias2(i) : K == 4 ? C::bias4(i) : C::bias8(i)) - b.v[i];
+    return fu_norm<P>(t);
+}
+template <class P> ZK_HD Fu<P> fe_sub(const Fu<P>& a, const Fu<P>& b) { return fe_sub_k<4>(a, b); }
+// negation of an AFFINE coordinate (value < 2p, as produced by fu_from_fe): the result is again < 2p, so a negated base
+// obeys the same bounds as any other; the all-zero sentinel of the point at infinity stays all-zero
+template <class P> ZK_HD Fu<P> fe_neg(const Fu<P>& a) { return a.is_zero() ? a : fe_sub_k<2>(Fu<P>::zero(), a); }
+
+// Montgomery product a*b/R' (product scanning; the column accumulator never overflows for TIGHT operands)
+template <class P>
+ZK_HD Fu<P> fu_mul_inl(const Fu<P>& a, const Fu<P>& b) {
+    typedef UConst<P> C;
+    constexpr int N = Fu<P>::N, B = Fu<P>::B;
+    constexpr u32 M = Fu<P>::M;
+    u32 m[N];
+    Fu<P> r;
+    u64 acc = 0;
+    ZK_UNROLL for (int k = 0; k < N; ++k) {
+        ZK_UNROLL for (int i = 0; i < k; ++i) {
+            acc += (u64)a.v[i] * b.v[k - i];
+            acc += (u64)m[i] * C::p(k - i);
+        }
+        acc += (u64)a.v[k] * b.v[0];
+        m[k] = ((u32)acc * C::NINV) & M;
+        acc += (u64)m[k] * C::p(0);
+        acc >>= B;
+    }
+    ZK_UNROLL for (int k = N; k < 2 * N - 1; ++k) {
+        ZK_UNROLL for (int i = k - N + 1; i < N; ++i) {
+            acc += (u64)a.v[i] * b.v[k - i];
+            acc += (u64)m[i] * C::p(k - i);
+        }
+        r.v[k - N] = (u32)acc & M;
+        acc >>= B;
+    }
+    r.v[N - 1] = (u32)acc;
+    return r;
+}
+// (a*b + c*d)/R' with one reduction — the building block of the Fq2 product
+template <class P>
+ZK_HD Fu<P> fu_mul2_inl(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d) {
+    typedef UConst<P> C;
+    constexpr int N = Fu<P>::N, B = Fu<P>::B;
+    constexpr u32 M = Fu<P>::M;
+    u32 m[N];
+    Fu<P> r;
+    u64 acc = 0;
+    ZK_UNROLL for (int k = 0; k < N; ++k) {
+        ZK_UNROLL for (int i = 0; i < k; ++i) {
+            acc += (u64)a.v[i] * b.v[k - i];
+            acc += (u64)c.v[i] * d.v[k - i];
+            acc += (u64)m[i] * C::p(k - i);
+        }
+        acc += (u64)a.v[k] * b.v[0];
+        acc += (u64)c.v[k] * d.v[0];
+        m[k] = ((u32)acc * C::NINV) & M;
+        acc += (u64)m[k] * C::p(0);
+        acc >>= B;
+    }
+    ZK_UNROLL for (int k = N; k < 2 * N - 1; ++k) {
+        ZK_UNROLL for (int i = k - N + 1; i < N; ++i) {
+            acc += (u64)a.v[i] * b.v[k - i];
+            acc += (u64)c.v[i] * d.v[k - i];
+            acc += (u64)m[i] * C::p(k - i);
+        }
+        r.v[k - N] = (u32)acc & M;
+        acc >>= B;
+    }
+    r.v[N - 1] = (u32)acc;
+    return r;
+}
+// out-of-line forms (operands by value in VGPRs) — what the curve code calls; see fe_mul_nc in field.cuh
+template <class P> ZK_HD_CALL Fu<P> fu_mul(const Fu<P> a, const Fu<P> b) { return fu_mul_inl(a, b); }
+template <class P> ZK_HD_CALL Fu<P> fu_mul2(const Fu<P> a, const Fu<P> b, const Fu<P> c, const Fu<P> d) { return fu_mul2_inl(a, b, c, d); }
+// Inline or out-of-line?  Measured on MI355X (tools/accum_bench.hip, 2^24 mixed additions, ms):
+//                                   G1     G2
+//   saturated CIOS, calls          2.05   8.05
+//   unsaturated, calls             1.65  12.9     (a 36-byte Fu / 72-byte Fu2 argument is passed through scratch memory)
+//   unsaturated, everything inline 1.22   3.17    <- default: the Comba body is 240 instructions, a whole mixed
+//                                                    addition stays inside the 64 KB instruction cache
+#ifndef ZK_FU_MUL_INLINE
+#define ZK_FU_MUL_INLINE 1
+#endif
+#ifndef ZK_FU2_MODE
+#define ZK_FU2_MODE 2   // 0: Fq2 product = call, built from fu_mul2 calls; 1: call with the two mul2 inlined; 2: everything inline
+#endif
+template <class P> ZK_HD Fu<P> ec_mul(const Fu<P>& a, const Fu<P>& b) { return ZK_FU_MUL_INLINE ? fu_mul_inl(a, b) : fu_mul(a, b); }
+template <class P> ZK_HD Fu<P> ec_sqr(const Fu<P>& a) { return ZK_FU_MUL_INLINE ? fu_mul_inl(a, a) : fu_mul(a, a); }
+
+// weak reduction: TIGHT x with value < 32p -> TIGHT, value < 3p.  The quotient estimate q = floor(x_top / (p_top+1))
+// never overshoots, so x - q*p >= 0; the subtraction runs through a signed ripple (it is off the multiplier's path:
+// one call per point operation).
+template <class P>
+ZK_HD Fu<P> fe_relax(const Fu<P>& x) {
+    typedef UConst<P> C;
+    constexpr int N = Fu<P>::N, B = Fu<P>::B;
+    const u32 q = (u32)(((u64)x.v[N - 1] * C::Q_MAGIC) >> 32);
+    Fu<P> r;
+    long long carry = 0;
+    ZK_UNROLL for (int i = 0; i < N; ++i) {
+        long long t = (long long)x.v[i] - (long long)((u64)q * C::p(i)) + carry;
+        if (i < N - 1) {
+            r.v[i] = (u32)t & Fu<P>::M;
+            carry = t >> B;
+        } else {
+            r.v[i] = (u32)t;
+        }
+    }
+    return r;
+}
+
+// x == 0 (mod p) for a TIGHT x with value < 16p.  The low limb of a multiple j*p is j*p0 mod 2^B, so
+// j = x0 * p0^-1 mod 2^B must be tiny: everything else (all but 2^-25 of the calls) is rejected by one multiply.
+template <class P>
+ZK_HD_CALL bool fu_is_zero_modp_slow(const Fu<P> x, u32 j) {
+    typedef UConst<P> C;
+    constexpr int N = Fu<P>::N, B = Fu<P>::B;
+    u32 a[N], b[N];
+    u32 c = 0;
+    for (int i = 0; i < N; ++i) {          // full carry propagation of x
+        u32 t = x.v[i] + c;
+        if (i < N - 1) { a[i] = t & Fu<P>::M; c = t >> B; } else a[i] = t;
+    }
+    u64 cc = 0;
+    for (int i = 0; i < N; ++i) {          // j * p, normalised
+        cc += (u64)j * C::p(i);
+        if (i < N - 1) { b[i] = (u32)cc & Fu<P>::M; cc >>= B; } else b[i] = (u32)cc;
+    }
+    u32 d = 0;
+    for (int i = 0; i < N; ++i) d |= a[i] ^ b[i];
+    return d == 0;
+}
+template <class P>
+ZK_HD bool fe_is_zero_modp(const Fu<P>& x) {
+    const u32 j = (x.v[0] * UConst<P>::PINV) & Fu<P>::M;   // x.v[0] < 2^B exactly: the low limb never receives a carry
+    if (j > 16) return false;
+    return fu_is_zero_modp_slow(x, j);
+}
+// the saturated field answers the same questions trivially (canonical representation)
+template <int K, class P> ZK_HD Fe<P> fe_sub_k(const Fe<P>& a, const Fe<P>& b) { return fe_sub(a, b); }
+template <class P> ZK_HD Fe<P> fe_relax(const Fe<P>& x) { return x; }
+template <class P> ZK_HD bool fe_is_zero_modp(const Fe<P>& x) { return x.is_zero(); }
+template <int K, class P> ZK_HD Fe2<P> fe_sub_k(const Fe2<P>& a, const Fe2<P>& b) { return fe_sub(a, b); }
+template <class P> ZK_HD Fe2<P> fe_relax(const Fe2<P>& x) { return x; }
+template <class P> ZK_HD bool fe_is_zero_modp(const Fe2<P>& x) { return x.is_zero(); }
+
+// ---- Fq2 = Fq[u]/(u^2+1) over unsaturated limbs ----
+template <class P>
+struct Fu2 {
+    typedef P Params;
+    Fu<P> c0, c1;
+    ZK_HD static Fu2 zero() { return {Fu<P>::zero(), Fu<P>::zero()}; }
+    ZK_HD static Fu2 one() { return {Fu<P>::one(), Fu<P>::zero()}; }
+    ZK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+};
+template <class P> ZK_HD Fu2<P> fe_add(const Fu2<P>& a, const Fu2<P>& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
+template <class P> ZK_HD Fu2<P> fe_dbl(const Fu2<P>& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
+template <int K, class P> ZK_HD Fu2<P> fe_sub_k(const Fu2<P>& a, const Fu2<P>& b) { return {fe_sub_k<K>(a.c0, b.c0), fe_sub_k<K>(a.c1, b.c1)}; }
+template <class P> ZK_HD Fu2<P> fe_sub(const Fu2<P>& a, const Fu2<P>& b) { return fe_sub_k<4>(a, b); }
+template <class P> ZK_HD Fu2<P> fe_neg(const Fu2<P>& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
+template <class P> ZK_HD Fu2<P> fe_relax(const Fu2<P>& a) { return {fe_relax(a.c0), fe_relax(a.c1)}; }
+template <class P> ZK_HD bool fe_is_zero_modp(const Fu2<P>& a) { return fe_is_zero_modp(a.c0) && fe_is_zero_modp(a.c1); }
+// (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: two sums of two products, each reduced once
+// (the same 4 x N^2 + 2 x N^2 multiply-adds as Karatsuba's three full products, but one negation instead of five
+// additions, and results that stay below 2p whatever the operands)
+#if ZK_FU2_MODE == 2
+#define ZK_FU2_ATTR ZK_HD
+#else
+#define ZK_FU2_ATTR ZK_HD_CALL
+#endif
+template <class P>
+ZK_FU2_ATTR Fu2<P> ec_mul(const Fu2<P> a, const Fu2<P> b) {
+    const Fu<P> nb1 = fe_sub_k<8>(Fu<P>::zero(), b.c1);
+    if (ZK_FU2_MODE == 0) return {fu_mul2(a.c0, b.c0, a.c1, nb1), fu_mul2(a.c0, b.c1, a.c1, b.c0)};
+    return {fu_mul2_inl(a.c0, b.c0, a.c1, nb1), fu_mul2_inl(a.c0, b.c1, a.c1, b.c0)};
+}
+template <class P>
+ZK_FU2_ATTR Fu2<P> ec_sqr(const Fu2<P> a) {
+    const Fu<P> na1 = fe_sub_k<8>(Fu<P>::zero(), a.c1);
+    if (ZK_FU2_MODE == 0) return {fu_mul2(a.c0, a.c0, a.c1, na1), fu_mul(fe_dbl(a.c0), a.c1)};
+    return {fu_mul2_inl(a.c0, a.c0, a.c1, na1), fu_mul_inl(fe_dbl(a.c0), a.c1)};
+}
+
+// ---- conversions at the MSM boundary ----
+// saturated Montgomery (x * 2^(32W) mod p, canonical) -> unsaturated Montgomery (x * R'), TIGHT, value < 2p
+template <class P>
+ZK_HD Fu<P> fu_from_fe(const Fe<P>& a) {
+    typedef UConst<P> C;
+    constexpr int N = Fu<P>::N, B = Fu<P>::B, W = P::N;
+    Fu<P> s, k;
+    ZK_UNROLL for (int i = 0; i < N; ++i) {
+        const int bit = B * i, wi = bit >> 5, sh = bit & 31;
+        u64 two = wi < W ? a.v[wi] : 0;
+        if (wi + 1 < W) two |= (u64)a.v[wi + 1] << 32;
+        s.v[i] = (u32)(two >> sh) & Fu<P>::M;
+        k.v[i] = C::from_fe(i);
+    }
+    return fu_mul_inl(s, k);
+}
+// unsaturated Montgomery, TIGHT, value < 8p -> saturated Montgomery, canonical
+template <class P>
+ZK_HD Fe<P> fu_to_fe(const Fu<P>& a) {
+    typedef UConst<P> C;
+    constexpr int N = Fu<P>::N, B = Fu<P>::B, W = P::N;
+    Fu<P> unit = Fu<P>::zero();
+    unit.v[0] = 1;
+    const Fu<P> x = fu_mul_inl(a, unit);          // x = value / R' = the plain integer (mod p), < 2p
+    u32 l[N];
+    u32 c = 0;
+    ZK_UNROLL for (int i = 0; i < N; ++i) {       // full carry propagation
+        u32 t = x.v[i] + c;
+        if (i < N - 1) { l[i] = t & Fu<P>::M; c = t >> B; } else l[i] = t;
+    }
+    Fe<P> r;
+    ZK_UNROLL for (int w = 0; w < W; ++w) {       // pack into 32-bit words
+        const int bit = 32 * w, li = bit / B, sh = bit % B;
+        u64 acc = (u64)l[li] >> sh;
+        int have = B - sh;
+        ZK_UNROLL for (int q = 1; q < 3; ++q)
+            if (li + q < N && have < 32) { acc |= (u64)l[li + q] << have; have += B; }
+        r.v[w] = (u32)acc;
+    }
+    fe_reduce_once(r);                            // < 2p -> canonical
+    return fe_to_mont(r);
+}
+template <class P> ZK_HD Fu2<P> fu_from_fe(const Fe2<P>& a) { return {fu_from_fe(a.c0), fu_from_fe(a.c1)}; }
+template <class P> ZK_HD Fe2<P> fu_to_fe(const Fu2<P>& a) { return {fu_to_fe(a.c0), fu_to_fe(a.c1)}; }
+
+// type map: saturated field of a group -> its unsaturated working type
+template <class F> struct Unsat;
+template <class P> struct Unsat<Fe<P>> { typedef Fu<P> type; };
+template <class P> struct Unsat<Fe2<P>> { typedef Fu2<P> type; };
+
+}  // namespace zk

@@ -12,9 +12,17 @@ static void lds_opt_in(K kernel) {
 #endif
 }
 
-template <class F>
-void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const Aff<F>* d_bases, const MsmShape& sh, Xyzz<F>* d_window_sums,
+template <class FS>
+void points_to_unsat(zkhip_ctx* ctx, const Aff<FS>* d_in, void* d_out, u64 n) {
+    typedef typename Unsat<FS>::type U;
+    ZK_LAUNCH((k_points_to_unsat<FS, U>), dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_in, (Aff<U>*)d_out, n);
+}
+
+template <class FS>
+void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bases_unsat, const MsmShape& sh, Xyzz<FS>* d_window_sums,
              Event* ev_begin, Event* ev_end) {
+    typedef typename Unsat<FS>::type F;   // the kernels run on the unsaturated field
+    const Aff<F>* d_bases = (const Aff<F>*)d_bases_unsat;
     Stream s = ctx->serial ? ctx->stream : lane.stream;
     stream_wait_event(s, so.ready);
     // slice length of the balanced accumulation, the first bucket of every slice, the buckets needing a workgroup
@@ -30,7 +38,7 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const Aff<F>* d_b
     if (!once) {
         lds_opt_in(k_msm_fold_rows<F>);
         lds_opt_in(k_msm_fold_cols<F>);
-        lds_opt_in(k_msm_fold_final<F>);
+        lds_opt_in(k_msm_fold_final<F, FS>);
         lds_opt_in(k_msm_heavy_reduce<F>);
         once = true;
     }
@@ -51,7 +59,7 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const Aff<F>* d_b
     ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.W), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
               sh.Lw, sh.H, ptr<Xyzz<F>>(lane.cols));
     const unsigned TF = std::max<u32>(64, sh.Lw);
-    ZK_LAUNCH((k_msm_fold_final<F>), dim3(sh.W + 1), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
+    ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.W + 1), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
               sh.H, ptr<Xyzz<F>>(lane.partial), ptr<u32>(so.off), P, (u32)sh.W, sh.nkeys - 1, d_window_sums);
     event_record(lane.done, s);
 }
@@ -71,7 +79,8 @@ void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scal
 }
 
 #define ZK_INSTANTIATE_GROUP(F)                                                                                         \
-    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const Aff<F>*, const MsmShape&, Xyzz<F>*, Event*, Event*);                     \
+    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event*, Event*);          \
+    template void points_to_unsat<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                     \
     template void fixed_base_table<F>(zkhip_ctx*, const Aff<F>*, int, DBuf&);                                           \
     template void fixed_base_mul<F>(zkhip_ctx*, const DBuf&, int, const u32*, u64, Aff<F>*);
 

@@ -24,11 +24,34 @@
 
 namespace zk {
 
-// per point type tuning (measured on MI355X with tools/accum_bench.hip, 2^24 mixed additions: G1 2.04 ms at 3 waves per
-// SIMD / slices of 32; G2 8.05 ms at 2 waves per SIMD / slices of 16).  *_WPE = waves per SIMD the register allocator must
+// per point type tuning (measured on MI355X with tools/accum_bench.hip, 2^24 mixed additions on the unsaturated field:
+// G1 1.22 ms at 3 waves per SIMD / slices of 32; G2 3.17 ms at 2 waves per SIMD / slices of 32).  *_WPE = waves per SIMD the register allocator must
 // leave room for; SLICE = sorted entries per accumulation work-item.
 template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3; static constexpr u32 SLICE = 32; };
 template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; static constexpr u32 SLICE = 16; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; static constexpr u32 SLICE = 32; };
+
+// The kernels below work on points over the UNSATURATED field types of fieldu.cuh (Fu / Fu2); only the window sums
+// leaving k_msm_fold_final go back to the saturated Montgomery form the host code uses.
+template <class P_> ZK_HD Fe<P_> to_sat(const Fu<P_>& a) { return fu_to_fe(a); }
+template <class P_> ZK_HD Fe2<P_> to_sat(const Fu2<P_>& a) { return fu_to_fe(a); }
+template <class P_> ZK_HD Fe<P_> to_sat(const Fe<P_>& a) { return a; }
+template <class P_> ZK_HD Fe2<P_> to_sat(const Fe2<P_>& a) { return a; }
+template <class FS, class U>
+ZK_HD Xyzz<FS> xyzz_to_sat(const Xyzz<U>& p) {
+    if (p.is_inf()) return Xyzz<FS>::inf();
+    return {to_sat(p.x), to_sat(p.y), to_sat(p.zz), to_sat(p.zzz)};
+}
+// affine points: saturated Montgomery -> unsaturated working form (key load)
+template <class FS, class U>
+__global__ void k_points_to_unsat(const Aff<FS>* __restrict__ in, Aff<U>* __restrict__ out, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff<FS> p = in[i];
+    Aff<U> q = Aff<U>::inf();
+    if (!p.is_inf()) { q.x = fu_from_fe(p.x); q.y = fu_from_fe(p.y); }
+    out[i] = q;
+}
 
 static constexpr u32 MSM_NO_DIGIT = 0xffffffffu;
 static constexpr u32 MSM_HEAVY = 32;  // a bucket spread over more slices than this is reduced by a whole workgroup
@@ -335,15 +358,15 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(c
     if (hg == 0) cols[(u64)j * Lw + lo] = sh[threadIdx.x];
 }
 // 5c. one workgroup per window: the two weighted digit sums; workgroup W delivers the ones bucket.
-template <class F>
+template <class F, class FS>
 __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
                                                          const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 P, u32 W,
-                                                         u32 ones_key, Xyzz<F>* __restrict__ window_sum) {
+                                                         u32 ones_key, Xyzz<FS>* __restrict__ window_sum) {
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x;
     if (j >= W) {
-        if (t == 0) window_sum[j] = msm_bucket_sum<F>(partial, off, ones_key, P);
+        if (t == 0) window_sum[j] = xyzz_to_sat<FS>(msm_bucket_sum<F>(partial, off, ones_key, P));
         return;
     }
     // sum_hi hi * R_hi, then times Lw (a power of two: log2 doublings)
@@ -362,7 +385,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(
         for (u32 q = Lw; q > 1; q >>= 1) hi_sum = xyzz_dbl_inl(hi_sum);
         Xyzz<F> r = sh[0];
         xyzz_add_acc(r, hi_sum);
-        window_sum[j] = r;
+        window_sum[j] = xyzz_to_sat<FS>(r);
     }
 }
 
