@@ -3,10 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log-domain 20] [--curve bn128] [--kind dense]
 
-A "step" is one Groth16 proof (`zkhip_prove_g16_resident`: sparse mat-vec, 7 NTTs, 5 MSMs, assembly) of the
-synthetic 2^20-constraint BN254 circuit of BASELINE.json configs[1].  The proving key, the
-constraint system and the assignments are resident in HBM when the timed region starts; every step uses a
-different (witness, r, s).  With N > 1 every rank proves its own K proofs on its own GPU with a full copy of
+A "step" is one Groth16 proof (sparse mat-vec, 7 NTTs, 5 MSMs, assembly) of the synthetic 2^20-constraint BN254
+circuit of BASELINE.json configs[1].  The proving key, the constraint system and the assignments are
+resident in HBM when the timed region starts; every step uses a different (witness, r, s).  The timed region is ONE
+call of `zkhip_prove_g16_resident_batch` over the K steps — the library keeps two proofs in flight (steady-state
+proofs/sec, the headline metric); `single_proof_ms` is the latency of an isolated `zkhip_prove_g16_resident` call.  With N > 1 every rank proves its own K proofs on its own GPU with a full copy of
 the key (independent proofs: no data-path collective; "weak" scaling) and `value` is N*K / max-over-ranks time.
 
 Besides the contract fields the JSON line carries
@@ -104,16 +105,16 @@ def main():
     def rs(i):
         return 0x1111111111111111 * (i + 1) + rank, 0x2222222222222222 * (i + 3) + rank
 
-    proofs = []
+    single = []
     for i in range(args.warmup):
-        proofs.append(native.prove_g16_resident(ctx, pk, cs, resident[i % nw], *rs(i)))
+        _, tm1 = native.prove_g16_resident(ctx, pk, cs, resident[i % nw], *rs(i), want_timings=True)
+        single.append(tm1["total_ms"])
+    if args.warmup:   # warm the pipelined path too (second slot's workspaces)
+        native.prove_g16_resident_batch(ctx, pk, cs, [resident[i % nw] for i in range(2)], [rs(100 + i) for i in range(2)])
+    steps = [args.warmup + i for i in range(args.steps)]
     barrier_sync()
     t_begin = time.perf_counter()
-    acc = None
-    for i in range(args.steps):
-        j = args.warmup + i
-        raw, tm = native.prove_g16_resident(ctx, pk, cs, resident[j % nw], *rs(j), want_timings=True)
-        acc = tm if acc is None else {k: acc[k] + v for k, v in tm.items()}
+    proofs, acc = native.prove_g16_resident_batch(ctx, pk, cs, [resident[j % nw] for j in steps], [rs(j) for j in steps])
     barrier_sync()
     elapsed = time.perf_counter() - t_begin
     if dist is not None:
@@ -121,6 +122,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # isolated single-proof latency (not part of the timed region)
+    for i in range(3):
+        _, tm1 = native.prove_g16_resident(ctx, pk, cs, resident[i % nw], *rs(200 + i), want_timings=True)
+        single.append(tm1["total_ms"])
+    single_ms = min(single)
 
     avg = {k: v / args.steps for k, v in acc.items()}
     # ---- roofline of the dominant kernel (HIP events on the library's stream, inside the timed region)
@@ -145,7 +151,7 @@ def main():
         "config": {"workload": f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints (QAP domain 2^{args.log_domain}), "
                                f"{args.curve} Groth16, 7 NTTs + 5 MSMs per proof", "curve": args.curve, "constraints": circ.n,
                    "variables": m, "domain": N, "parallelism": f"{world} independent prover(s), full key per GPU"},
-        "single_proof_ms": avg["total_ms"], "phases_ms": avg,
+        "single_proof_ms": single_ms, "phases_ms": avg,
         "whole_proof_hbm": {"algorithmic_bytes": b_alg, "achieved_GBs": b_alg / (elapsed / args.steps) / 1e9,
                             "frac": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         "roofline": roofline,
@@ -157,7 +163,8 @@ def main():
         out["cpu_baseline"] = base
         # same inputs -> byte-identical proof (the CPU leg doubles as a full-size parity check)
         gpu_proof = native.prove_g16_resident(ctx, pk, cs, resident[0], 1000, 2000)
-        out["cpu_baseline"]["gpu_proof_identical"] = bool(gpu_proof == cpu_proof)
+        batch_proof = native.prove_g16_resident_batch(ctx, pk, cs, [resident[0]] * 3, [(1000, 2000)] * 3)[0]
+        out["cpu_baseline"]["gpu_proof_identical"] = bool(gpu_proof == cpu_proof and all(p == cpu_proof for p in batch_proof))
         out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
     elif rank == 0:
         out["cpu_baseline"] = None

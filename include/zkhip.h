@@ -126,9 +126,14 @@ int32_t zkhip_prove_g16_resident(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip
 
 /* Steady-state variant for proofs/sec: `count` assignments (each m x 32 B, contiguous), `count`
  * (r, s) pairs (64 B each) and `count` proof slots (8*sz(Fq)+3 B each).  Same results as `count`
- * calls of zkhip_prove_g16; the library pipelines upload / NTT / MSM of consecutive proofs. */
+ * calls of zkhip_prove_g16; two proofs are kept in flight, so the latency-bound tail of one proof
+ * overlaps the MSMs of the next (timings: per-phase sums over the batch, total_ms = wall clock). */
 int32_t zkhip_prove_g16_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count,
                               const uint8_t* z, const uint8_t* rs, uint8_t* proofs_out, zkhip_timings* timings);
+/* The same over assignments already resident in HBM (zs[i] may repeat). */
+int32_t zkhip_prove_g16_resident_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count,
+                                       zkhip_assignment* const* zs, const uint8_t* rs, uint8_t* proofs_out,
+                                       zkhip_timings* timings);
 
 /* ---- primitives (exported for parity tests and micro-benchmarks) ---- */
 /* [UPSTREAM] ark_poly::Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place (App. A.4).

@@ -153,9 +153,14 @@ def test_prove_matches_oracle(ctx, curve, kind):
     assert native.prove_g16_resident(ctx, pk, cs, za, r_, s_) == want
     assert native.prove_g16_resident(ctx, pk, cs, za, 5, 6) == cpu.trapdoor(oc, tox, z, 5, 6)
     za.close()
-    # batch == singles
-    proofs, _ = native.prove_g16_batch(ctx, pk, cs, np.concatenate([z, z]), [(r_, s_), (5, 6)])
-    assert proofs[0] == want and proofs[1] == cpu.trapdoor(oc, tox, z, 5, 6)
+    # batch (two proofs in flight) == singles; resident batch with a repeated assignment
+    proofs, _ = native.prove_g16_batch(ctx, pk, cs, np.concatenate([z, z, z]), [(r_, s_), (5, 6), (7, 8)])
+    assert proofs[0] == want and proofs[1] == cpu.trapdoor(oc, tox, z, 5, 6) and proofs[2] == cpu.trapdoor(oc, tox, z, 7, 8)
+    za = native.Assignment(ctx, cs, z)
+    proofs, _ = native.prove_g16_resident_batch(ctx, pk, cs, [za] * 4, [(r_, s_), (5, 6), (7, 8), (0, 0)])
+    assert proofs[0] == want and proofs[1] == cpu.trapdoor(oc, tox, z, 5, 6) and proofs[3] == cpu.trapdoor(oc, tox, z, 0, 0)
+    proofs, _ = native.prove_g16_resident_batch(ctx, pk, cs, [za], [(r_, s_)])
+    assert proofs == [want]
 
 
 def test_two_pass_prove(ctx):

@@ -157,6 +157,14 @@ def test_prove_matches_oracle(ctx, curve, logn, kind):
     za = native.Assignment(ctx, cs, z)
     assert native.prove_g16_resident(ctx, pk, cs, za, r_, s_) == want
     assert native.prove_g16_resident(ctx, pk, cs, za, 3, 4) == cpu.trapdoor(oc, tox, z, 3, 4)
+    # pipelined batch (two proofs in flight): distinct witnesses and blinding factors, each equal to its single proof
+    rs = [(r_, s_), (3, 4), (0, 9), (r_ ^ 5, s_ ^ 7), (1, 1)]
+    proofs, _ = native.prove_g16_resident_batch(ctx, pk, cs, [za] * len(rs), rs)
+    assert proofs[0] == want
+    for (a, b), pr in zip(rs, proofs):
+        assert pr == cpu.trapdoor(oc, tox, z, a, b)
+    proofs, _ = native.prove_g16_batch(ctx, pk, cs, np.concatenate([z, z, z]), rs[:3])
+    assert proofs == [cpu.trapdoor(oc, tox, z, a, b) for a, b in rs[:3]]
     # determinism: same (pk, z, r, s) -> same bytes (cf. zokrates_js/tests/tests.js:248-267)
     assert native.prove_g16(ctx, pk, cs, z, r_, s_) == got
 

@@ -10,6 +10,7 @@ box with the repository snapshot.
 import os
 import subprocess
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -40,7 +41,10 @@ def _compile(unit, force, verbose):
     cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
+    t0 = time.time()
     subprocess.check_call(cmd)
+    if verbose:
+        print("  %s: %.0f s" % (unit, time.time() - t0), flush=True)
     return obj, True
 
 

@@ -102,19 +102,32 @@ struct MsmLane {
     Event done = nullptr;
 };
 static constexpr int ZK_NLANES = 5;   // A, B1, L (G1), B2 (G2) over z; H over h
-struct zkhip_ctx {
-    int device = 0;
-    Stream stream = 0;
-    bool serial = false;     // ZKHIP_SERIAL=1: every MSM on the main stream (debugging / per-kernel timing)
-    std::string err;
-    std::string desc;
-    // MSM workspaces (grow-only)
+static constexpr int ZK_NSLOTS = 2;   // proofs in flight (zkhip_prove_g16*_batch pipelines consecutive proofs)
+// everything one proof in flight owns: its scalars, NTT vectors, sort results, MSM workspaces, window sums and events
+struct ProofSlot {
+    DBuf scalars, zmont, va, vb, vc, ws1, ws2;
     MsmSort sorts[2];
     MsmLane lanes[ZK_NLANES];
-    // prover workspace
-    DBuf scalars, zmont, va, vb, vc, tmp, ws1, ws2;
+    void* h_ws = nullptr;      // pinned host copy of the window sums
+    size_t h_ws_cap = 0;
+    Event ev[4] = {nullptr, nullptr, nullptr, nullptr};   // staged, MSMs over z issued, h ready, all done (copied out)
+    Event acc_b[ZK_NLANES] = {}, acc_e[ZK_NLANES] = {};   // around each accumulation kernel
+    // the proof currently in flight in this slot
+    bool busy = false;
+    uint8_t r[32], s[32];
+    std::chrono::steady_clock::time_point t_start;
+};
+struct zkhip_ctx {
+    int device = 0;
+    Stream stream = 0;        // main stream: staging, sort, mat-vec, NTTs (high priority: short kernels the H MSM waits for)
+    Stream out_stream = 0;    // copies the window sums out once every MSM of a proof is done
+    bool serial = false;      // ZKHIP_SERIAL=1: every MSM on the main stream (debugging / per-kernel timing)
+    std::string err;
+    std::string desc;
+    ProofSlot slots[ZK_NSLOTS];
+    ProofSlot* cur = &slots[0];   // the slot the primitives (ntt, msm, ...) and the next enqueue work in
+    DBuf tmp;
     std::vector<std::unique_ptr<NttPlanBase>> plans;
-    std::vector<Event> ev_pool;
 };
 
 namespace zk {
@@ -315,12 +328,6 @@ static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars
     event_record(so.ready, s);
 }
 
-static inline Event pool_event(zkhip_ctx* ctx) {
-    Event e = event_create();
-    ctx->ev_pool.push_back(e);
-    return e;
-}
-
 // bucket accumulation + fold for one base set; window sums land in d_window_sums[0..W], entry W = the ones bucket.
 // Defined in group.cuh and instantiated once per (curve, group) in its own translation unit (bn254_g1.hip, ...):
 // the elliptic-curve kernels are by far the most expensive code to compile.
@@ -329,7 +336,7 @@ static inline Event pool_event(zkhip_ctx* ctx) {
 // saturated Montgomery form.
 template <class F>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bases_unsat, const MsmShape& sh, Xyzz<F>* d_window_sums,
-             Event* ev_begin, Event* ev_end);
+             Event ev_begin, Event ev_end);
 // affine points, saturated Montgomery form -> unsaturated working form of the MSM kernels (fieldu.cuh); on ctx->stream
 template <class F>
 void points_to_unsat(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
@@ -556,15 +563,15 @@ struct Prover {
 
     static CsrDev csr(const zkhip_r1cs* cs, int k) { return CsrDev{ptr<u64>(cs->rp[k]), ptr<u32>(cs->col[k]), cs->val[k].p}; }
 
-    // K1-K4 on the device: leaves h (canonical integers, sigma order) in ctx->va
+    // K1-K4 on the device: leaves h (canonical integers, sigma order) in ctx->cur->va
     static void witness_map(zkhip_ctx* ctx, const zkhip_r1cs* cs, NttPlan<C>* pl) {
         Stream s = ctx->stream;
         const u64 N = pl->N;
-        ctx->va.ensure(N * sizeof(Fr));
-        ctx->vb.ensure(N * sizeof(Fr));
-        ctx->vc.ensure(N * sizeof(Fr));
-        Fr *a = ptr<Fr>(ctx->va), *b = ptr<Fr>(ctx->vb), *c = ptr<Fr>(ctx->vc);
-        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256), 3), dim3(256), 0, s, csr(cs, 0), csr(cs, 1), csr(cs, 2), ptr<Fr>(ctx->zmont), a, b, c,
+        ctx->cur->va.ensure(N * sizeof(Fr));
+        ctx->cur->vb.ensure(N * sizeof(Fr));
+        ctx->cur->vc.ensure(N * sizeof(Fr));
+        Fr *a = ptr<Fr>(ctx->cur->va), *b = ptr<Fr>(ctx->cur->vb), *c = ptr<Fr>(ctx->cur->vc);
+        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256), 3), dim3(256), 0, s, csr(cs, 0), csr(cs, 1), csr(cs, 2), ptr<Fr>(ctx->cur->zmont), a, b, c,
                   cs->n, cs->l, N);
         Fr* v[3] = {a, b, c};
         for (int k = 0; k < 3; ++k) {
@@ -586,91 +593,95 @@ struct Prover {
     // r, s into the tail slots; Montgomery copy of z for the mat-vec
     static void stage_scalars(zkhip_ctx* ctx, void* d_scalars, u64 m, const uint8_t* r, const uint8_t* s_) {
         Stream s = ctx->stream;
-        ctx->zmont.ensure(m * 32);
+        ctx->cur->zmont.ensure(m * 32);
         dev_h2d((uint8_t*)d_scalars + m * 32, r, 32, s);
         dev_h2d((uint8_t*)d_scalars + (m + 1) * 32, s_, 32, s);
-        ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, s, (const Fr*)d_scalars, ptr<Fr>(ctx->zmont), m);
+        ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, s, (const Fr*)d_scalars, ptr<Fr>(ctx->cur->zmont), m);
     }
 
-    static void prove_host(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z, const uint8_t* r, const uint8_t* s_,
-                           uint8_t* out, zkhip_timings* tm) {
-        const auto t0 = std::chrono::steady_clock::now();
-        Event e0 = event_create(), e1 = event_create();
-        event_record(e0, ctx->stream);
-        upload_z(ctx, ctx->scalars, pk->m, z);
-        event_record(e1, ctx->stream);
-        prove(ctx, pk, cs, ctx->scalars.p, r, s_, out, tm);
-        if (tm) {
-            tm->h2d_ms = event_elapsed_ms(e0, e1);
-            tm->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        }
-        event_destroy(e0); event_destroy(e1);
-    }
-    static void assignment_upload(zkhip_ctx* ctx, zkhip_assignment* a, const uint8_t* z) {
-        upload_z(ctx, a->scalars, a->m, z);
-        stream_sync(ctx->stream);
-    }
-
-    // the hot path proper: the assignment is already in HBM at d_scalars
-    static void prove(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, void* d_scalars, const uint8_t* r, const uint8_t* s_,
-                      uint8_t* out, zkhip_timings* tm) {
-        const auto t_start = std::chrono::steady_clock::now();
+    // ---- enqueue: every kernel and copy of one proof, no host synchronisation
+    // src_dev != nullptr: the assignment is already in HBM (copied device-to-device into the slot); else z is a host buffer
+    static void enqueue(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* src_dev,
+                        const uint8_t* r, const uint8_t* s_) {
         require(pk->curve == C::ID && cs->curve == C::ID, ZKHIP_ERR_BAD_ARG, "curve mismatch between key and constraint system");
         require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
                 "proving key does not match the constraint system (m, w or domain size)");
+        require(!sl.busy, ZKHIP_ERR_DEVICE, "internal: proof slot still in flight");
         const u64 m = pk->m, N = pk->N;
         Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
+        sl.t_start = std::chrono::steady_clock::now();
+        memcpy(sl.r, r, 32);
+        memcpy(sl.s, s_, 32);
+        ctx->cur = &sl;
         Stream st = ctx->stream;
-        for (Event e : ctx->ev_pool) event_destroy(e);
-        ctx->ev_pool.clear();
-        Event e0 = pool_event(ctx), e1 = pool_event(ctx), e2 = pool_event(ctx), e3 = pool_event(ctx), e4 = pool_event(ctx), e5 = pool_event(ctx);
-        event_record(e0, st);
+        if (z_host) {
+            upload_z(ctx, sl.scalars, m, z_host);
+        } else {
+            sl.scalars.ensure((m + 2) * 32);
+            dev_d2d(sl.scalars.p, src_dev, m * 32, st);
+        }
+        void* d_scalars = sl.scalars.p;
         stage_scalars(ctx, d_scalars, m, r, s_);
-        event_record(e1, st);
+        event_record(sl.ev[0], st);
 
         // ---- MSMs over S = [z_0..z_{m-1}, r, s]: A, B1, L in G1 and B2 in G2 share one digit/sort pass
         const MsmShape shz = msm_shape(m + 2, Fr::Params::BITS);
         const MsmShape shh = msm_shape(N, Fr::Params::BITS);
         const int Wmax = std::max(shz.W, shh.W) + 1;   // + the ones bucket
-        DBuf &d_ws1 = ctx->ws1, &d_ws2 = ctx->ws2;   // window sums: 4 G1 sets + 1 G2 set
-        d_ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
-        d_ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
-        Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(d_ws1);
-        Event ab[5], ae[5];
-        msm_prepare(ctx, ctx->sorts[0], (const u32*)d_scalars, shz);
-        msm_run<Fq2>(ctx, ctx->lanes[3], ctx->sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(d_ws2), &ab[4], &ae[4]);   // longest first
-        msm_run<Fq>(ctx, ctx->lanes[0], ctx->sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, &ab[0], &ae[0]);
-        msm_run<Fq>(ctx, ctx->lanes[1], ctx->sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, &ab[1], &ae[1]);
-        msm_run<Fq>(ctx, ctx->lanes[2], ctx->sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, &ab[2], &ae[2]);
-        event_record(e2, st);
+        sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // window sums: 4 G1 sets + 1 G2 set
+        sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
+        Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
+        msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars, shz);
+        msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
+        msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
+        msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
+        msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2]);
+        event_record(sl.ev[1], st);
 
         // ---- K1-K4
         witness_map(ctx, cs, pl);
-        event_record(e3, st);
+        event_record(sl.ev[2], st);
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
-        msm_prepare(ctx, ctx->sorts[1], ptr<u32>(ctx->va), shh);
-        msm_run<Fq>(ctx, ctx->lanes[4], ctx->sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, &ab[3], &ae[3]);
-        for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(st, ctx->lanes[k].done);
-        event_record(e4, st);
+        msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va), shh);
+        msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
 
-        std::vector<Xyzz<Fq>> h_ws1((size_t)4 * Wmax);
-        std::vector<Xyzz<Fq2>> h_ws2(Wmax);
-        dev_d2h(h_ws1.data(), ws1, h_ws1.size() * sizeof(Xyzz<Fq>), st);
-        dev_d2h(h_ws2.data(), d_ws2.p, h_ws2.size() * sizeof(Xyzz<Fq2>), st);
-        event_record(e5, st);
-        stream_sync(st);
+        // ---- window sums to the host, on a stream of their own so that the main stream can start the next proof
+        Stream so = ctx->serial ? st : ctx->out_stream;
+        for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(so, sl.lanes[k].done);
+        const size_t b1 = (size_t)4 * Wmax * sizeof(Xyzz<Fq>), b2 = (size_t)Wmax * sizeof(Xyzz<Fq2>);
+        if (sl.h_ws_cap < b1 + b2) {
+            host_free_pinned(sl.h_ws);
+            sl.h_ws = nullptr; sl.h_ws_cap = 0;
+            sl.h_ws = host_alloc_pinned(b1 + b2);
+            sl.h_ws_cap = b1 + b2;
+        }
+        dev_d2h(sl.h_ws, ws1, b1, so);
+        dev_d2h((uint8_t*)sl.h_ws + b1, sl.ws2.p, b2, so);
+        event_record(sl.ev[3], so);
+        sl.busy = true;
+    }
 
-        // ---- K9 on the host: Horner over window sums, then
-        //      C = s*A + r*B1 - rs*delta_1 + L + H   (App. A.3; alpha/beta/delta terms already inside A, B1, B2)
+    // ---- finish: wait for the slot's proof, K9 on the host: Horner over window sums, then
+    //      C = s*A + r*B1 - rs*delta_1 + L + H   (App. A.3; alpha/beta/delta terms already inside A, B1, B2)
+    static void finish(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, uint8_t* out, zkhip_timings* tm) {
+        require(sl.busy, ZKHIP_ERR_DEVICE, "internal: no proof in flight in this slot");
+        event_sync(sl.ev[3]);
+        sl.busy = false;
         const auto t_fin = std::chrono::steady_clock::now();
+        const MsmShape shz = msm_shape(pk->m + 2, Fr::Params::BITS);
+        const MsmShape shh = msm_shape(pk->N, Fr::Params::BITS);
+        const int Wmax = std::max(shz.W, shh.W) + 1;
+        const Xyzz<Fq>* h_ws1 = (const Xyzz<Fq>*)sl.h_ws;
+        const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
+        Fr rr = fe_from_bytes_canon<Fr>(sl.r), ss = fe_from_bytes_canon<Fr>(sl.s);
         Xyzz<Fq> gA = msm_combine(&h_ws1[0 * Wmax], shz);
         Xyzz<Fq> gB1 = msm_combine(&h_ws1[1 * Wmax], shz);
         Xyzz<Fq> gL = msm_combine(&h_ws1[2 * Wmax], shz);
         Xyzz<Fq> gH = msm_combine(&h_ws1[3 * Wmax], shh);
-        Xyzz<Fq2> gB2 = msm_combine(h_ws2.data(), shz);
+        Xyzz<Fq2> gB2 = msm_combine(h_ws2, shz);
         Fr rs = fe_from_mont(fe_mul(fe_to_mont(rr), fe_to_mont(ss)));
         uint8_t dec[2 * FQB];
         decode_point<FQB, 2>(pk->delta_g1_canon.data(), dec);
@@ -695,17 +706,63 @@ struct Prover {
         const auto t_end = std::chrono::steady_clock::now();
         if (tm) {
             memset(tm, 0, sizeof(*tm));
-            tm->matvec_ms = event_elapsed_ms(e0, e1);   // staging r, s + Montgomery copy of z
             // the five MSMs run on their own streams, concurrently with each other and with the NTT pipeline:
             // msm_z = staging done -> last of A/B1/L/B2 finished; msm_h = h ready -> H finished (overlapping intervals)
-            for (int k = 0; k < 4; ++k) tm->msm_z_ms = std::max(tm->msm_z_ms, event_elapsed_ms(e1, ctx->lanes[k].done));
-            tm->ntt_ms = event_elapsed_ms(e2, e3);   // matvec + 7 transforms + quotient
-            tm->msm_h_ms = event_elapsed_ms(e3, ctx->lanes[4].done);
+            for (int k = 0; k < 4; ++k) tm->msm_z_ms = std::max(tm->msm_z_ms, event_elapsed_ms(sl.ev[0], sl.lanes[k].done));
+            tm->ntt_ms = event_elapsed_ms(sl.ev[1], sl.ev[2]);   // matvec + 7 transforms + quotient
+            tm->msm_h_ms = event_elapsed_ms(sl.ev[2], sl.lanes[4].done);
             tm->finish_ms = std::chrono::duration<float, std::milli>(t_end - t_fin).count();
-            tm->total_ms = std::chrono::duration<float, std::milli>(t_end - t_start).count();
-            for (int k = 0; k < 4; ++k) tm->kernel_msm_accum_g1_ms += event_elapsed_ms(ab[k], ae[k]);
-            tm->kernel_msm_accum_g2_ms = event_elapsed_ms(ab[4], ae[4]);
+            tm->total_ms = std::chrono::duration<float, std::milli>(t_end - sl.t_start).count();
+            for (int k = 0; k < 4; ++k) tm->kernel_msm_accum_g1_ms += event_elapsed_ms(sl.acc_b[k], sl.acc_e[k]);
+            tm->kernel_msm_accum_g2_ms = event_elapsed_ms(sl.acc_b[4], sl.acc_e[4]);
         }
+    }
+
+    // one proof from a host assignment / from an assignment resident in HBM
+    static void prove_host(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z, const uint8_t* r, const uint8_t* s_,
+                           uint8_t* out, zkhip_timings* tm) {
+        enqueue(ctx, ctx->slots[0], pk, cs, z, nullptr, r, s_);
+        finish(ctx, ctx->slots[0], pk, out, tm);
+    }
+    static void prove_resident(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, void* d_scalars, const uint8_t* r, const uint8_t* s_,
+                               uint8_t* out, zkhip_timings* tm) {
+        enqueue(ctx, ctx->slots[0], pk, cs, nullptr, d_scalars, r, s_);
+        finish(ctx, ctx->slots[0], pk, out, tm);
+    }
+    // `count` proofs, two in flight: while the GPU works on proof i the host finishes proof i-1 and enqueues proof i+1,
+    // so the latency-bound tail of one proof (the H fold) overlaps the MSMs of the next.
+    // z_host: count x m x 32 B, or nullptr with z_dev[i] = device pointers of resident assignments.
+    static void prove_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, u32 count, const uint8_t* z_host, void* const* z_dev,
+                            const uint8_t* rs, uint8_t* proofs_out, zkhip_timings* tm) {
+        const size_t proof_bytes = 8 * FQB + 3;
+        zkhip_timings acc, one;
+        memset(&acc, 0, sizeof(acc));
+        const auto t0 = std::chrono::steady_clock::now();
+        try {
+            for (u32 i = 0; i <= count; ++i) {
+                if (i < count)
+                    enqueue(ctx, ctx->slots[i % ZK_NSLOTS], pk, cs, z_host ? z_host + (size_t)i * pk->m * 32 : nullptr, z_host ? nullptr : z_dev[i],
+                            rs + (size_t)i * 64, rs + (size_t)i * 64 + 32);
+                if (i >= ZK_NSLOTS - 1 && i - (ZK_NSLOTS - 1) < count) {
+                    const u32 j = i - (ZK_NSLOTS - 1);
+                    finish(ctx, ctx->slots[j % ZK_NSLOTS], pk, proofs_out + (size_t)j * proof_bytes, &one);
+                    float* a = (float*)&acc; const float* b = (const float*)&one;
+                    for (size_t k = 0; k < sizeof(acc) / sizeof(float); ++k) a[k] += b[k];
+                }
+            }
+        } catch (...) {
+            for (auto& sl : ctx->slots) sl.busy = false;   // let the queues drain; the context stays usable
+            dev_sync_all();
+            throw;
+        }
+        if (tm) {
+            *tm = acc;
+            tm->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+    static void assignment_upload(zkhip_ctx* ctx, zkhip_assignment* a, const uint8_t* z) {
+        upload_z(ctx, a->scalars, a->m, z);
+        stream_sync(ctx->stream);
     }
 
     // generic MSM primitive (bases in ark encoding)
@@ -722,16 +779,16 @@ struct Prover {
         d_bases.ensure(host.size());
         dev_h2d(d_bases.p, host.data(), host.size(), s);
         ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(n * NC, 256)), dim3(256), 0, s, ptr<Fq>(d_bases), ptr<Fq>(d_bases), n * NC);
-        ctx->scalars.ensure(n * 32);
-        dev_h2d(ctx->scalars.p, scalars, n * 32, s);
+        ctx->cur->scalars.ensure(n * 32);
+        dev_h2d(ctx->cur->scalars.p, scalars, n * 32, s);
         const MsmShape sh = msm_shape(n, Fr::Params::BITS);
         d_ws.ensure((size_t)(sh.W + 1) * sizeof(Xyzz<F>));
-        msm_prepare(ctx, ctx->sorts[0], ptr<u32>(ctx->scalars), sh);
+        msm_prepare(ctx, ctx->cur->sorts[0], ptr<u32>(ctx->cur->scalars), sh);
         DBuf d_unsat;
         d_unsat.ensure(n * unsat_point_bytes<F>());
         points_to_unsat<F>(ctx, ptr<Aff<F>>(d_bases), d_unsat.p, n);
-        msm_run<F>(ctx, ctx->lanes[0], ctx->sorts[0], d_unsat.p, sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
-        stream_wait_event(s, ctx->lanes[0].done);
+        msm_run<F>(ctx, ctx->cur->lanes[0], ctx->cur->sorts[0], d_unsat.p, sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
+        stream_wait_event(s, ctx->cur->lanes[0].done);
         std::vector<Xyzz<F>> ws(sh.W + 1);
         dev_d2h(ws.data(), d_ws.p, ws.size() * sizeof(Xyzz<F>), s);
         stream_sync(s);
@@ -751,10 +808,10 @@ struct Prover {
         Stream s = ctx->stream;
         const u64 N = pl->N;
         const unsigned T = 256, B = blocks_for(N, T);
-        ctx->va.ensure(N * sizeof(Fr));
-        ctx->vb.ensure(N * sizeof(Fr));
-        ctx->vc.ensure(N * sizeof(Fr));
-        Fr *a = ptr<Fr>(ctx->va), *b = ptr<Fr>(ctx->vb), *t = ptr<Fr>(ctx->vc);
+        ctx->cur->va.ensure(N * sizeof(Fr));
+        ctx->cur->vb.ensure(N * sizeof(Fr));
+        ctx->cur->vc.ensure(N * sizeof(Fr));
+        Fr *a = ptr<Fr>(ctx->cur->va), *b = ptr<Fr>(ctx->cur->vb), *t = ptr<Fr>(ctx->cur->vc);
         dev_h2d(a, data, N * 32, s);
         ZK_LAUNCH((k_to_mont<Fr>), dim3(B), dim3(T), 0, s, a, a, N);
         const bool inverse = dir == 1 || dir == 3;
@@ -777,13 +834,13 @@ struct Prover {
         NttPlan<C>* pl = get_plan<C>(ctx, cs->logN);
         const u64 m = cs->l + cs->w;
         uint8_t zero[32] = {0};
-        upload_z(ctx, ctx->scalars, m, z);
-        stage_scalars(ctx, ctx->scalars.p, m, zero, zero);
+        upload_z(ctx, ctx->cur->scalars, m, z);
+        stage_scalars(ctx, ctx->cur->scalars.p, m, zero, zero);
         witness_map(ctx, cs, pl);
-        ctx->vb.ensure(pl->N * sizeof(Fr));
-        ZK_LAUNCH((k_sigma_permute<Fr>), dim3(blocks_for(pl->N, 256)), dim3(256), 0, ctx->stream, ptr<Fr>(ctx->va), ptr<Fr>(ctx->vb), pl->N,
+        ctx->cur->vb.ensure(pl->N * sizeof(Fr));
+        ZK_LAUNCH((k_sigma_permute<Fr>), dim3(blocks_for(pl->N, 256)), dim3(256), 0, ctx->stream, ptr<Fr>(ctx->cur->va), ptr<Fr>(ctx->cur->vb), pl->N,
                   pl->N1, pl->N2, 1);
-        dev_d2h(h_out, ctx->vb.p, pl->N * 32, ctx->stream);
+        dev_d2h(h_out, ctx->cur->vb.p, pl->N * 32, ctx->stream);
         stream_sync(ctx->stream);
     }
 
@@ -791,15 +848,15 @@ struct Prover {
     static void field_op_api(zkhip_ctx* ctx, int op, u64 count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
         Stream s = ctx->stream;
         const size_t bytes = count * sizeof(F);
-        ctx->va.ensure(bytes); ctx->vb.ensure(bytes);
-        dev_h2d(ctx->va.p, a, bytes, s);
-        dev_h2d(ctx->vb.p, b, bytes, s);
+        ctx->cur->va.ensure(bytes); ctx->cur->vb.ensure(bytes);
+        dev_h2d(ctx->cur->va.p, a, bytes, s);
+        dev_h2d(ctx->cur->vb.p, b, bytes, s);
         const unsigned T = 256, B = blocks_for(count, T);
-        ZK_LAUNCH((k_to_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->va), ptr<F>(ctx->va), count);
-        ZK_LAUNCH((k_to_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->vb), ptr<F>(ctx->vb), count);
-        ZK_LAUNCH((k_field_op<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->va), ptr<F>(ctx->vb), ptr<F>(ctx->va), count, op);
-        ZK_LAUNCH((k_from_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->va), ptr<F>(ctx->va), count);
-        dev_d2h(out, ctx->va.p, bytes, s);
+        ZK_LAUNCH((k_to_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->cur->va), ptr<F>(ctx->cur->va), count);
+        ZK_LAUNCH((k_to_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->cur->vb), ptr<F>(ctx->cur->vb), count);
+        ZK_LAUNCH((k_field_op<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->cur->va), ptr<F>(ctx->cur->vb), ptr<F>(ctx->cur->va), count, op);
+        ZK_LAUNCH((k_from_mont<F>), dim3(B), dim3(T), 0, s, ptr<F>(ctx->cur->va), ptr<F>(ctx->cur->va), count);
+        dev_d2h(out, ctx->cur->va.p, bytes, s);
         stream_sync(s);
     }
 
@@ -839,6 +896,7 @@ struct CurveOps {
     void (*r1cs_load)(zkhip_ctx*, zkhip_r1cs*, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]);
     void (*prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*prove_resident)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, void*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
+    void (*prove_batch)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, u32, const uint8_t*, void* const*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*assignment_upload)(zkhip_ctx*, zkhip_assignment*, const uint8_t*);
     void (*ntt)(zkhip_ctx*, u32, int, uint8_t*);
     void (*witness_map)(zkhip_ctx*, const zkhip_r1cs*, const uint8_t*, uint8_t*);
@@ -858,7 +916,8 @@ static CurveOps make_curve_ops() {
     o.pk_load = &PkLoader<C>::load;
     o.r1cs_load = &Prover<C>::r1cs_load;
     o.prove = &Prover<C>::prove_host;
-    o.prove_resident = &Prover<C>::prove;
+    o.prove_resident = &Prover<C>::prove_resident;
+    o.prove_batch = &Prover<C>::prove_batch;
     o.assignment_upload = &Prover<C>::assignment_upload;
     o.ntt = &Prover<C>::ntt_api;
     o.witness_map = &Prover<C>::witness_map_api;

@@ -70,8 +70,18 @@ inline Stream stream_create() {
     ZK_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
 }
+// highest scheduling priority the device offers (used for the short NTT pipeline, which otherwise queues behind the
+// MSM streams' long kernels and delays the H MSM that depends on it)
+inline Stream stream_create_high_priority() {
+    int lo = 0, hi = 0;
+    ZK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    Stream s;
+    ZK_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+    return s;
+}
 inline void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
 inline void stream_sync(Stream s) { ZK_HIP_CHECK(hipStreamSynchronize(s)); }
+inline void dev_sync_all() { (void)hipDeviceSynchronize(); }
 inline Event event_create() {
     Event e;
     ZK_HIP_CHECK(hipEventCreate(&e));
@@ -120,8 +130,10 @@ inline void dev_d2h(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n);
 inline void dev_d2d(void* d, const void* s_, size_t n, Stream) { memcpy(d, s_, n); }
 inline void dev_memset(void* d, int v, size_t n, Stream) { memset(d, v, n); }
 inline Stream stream_create() { return 0; }
+inline Stream stream_create_high_priority() { return 0; }
 inline void stream_destroy(Stream) {}
 inline void stream_sync(Stream) {}
+inline void dev_sync_all() {}
 inline Event event_create() { return new double(0); }
 inline void event_destroy(Event e) { delete e; }
 inline void event_record(Event e, Stream) { *e = emu::now_ms(); }

@@ -20,8 +20,10 @@
 namespace zk {
 
 template <class P> struct UCfg;
-template <> struct UCfg<Bn254Fq> { static constexpr int B = 29, N = 9; };
-template <> struct UCfg<Bls381Fq> { static constexpr int B = 28, N = 14; };
+// FQ2_INLINE: whether the Fq2 product is inlined into the curve formulas (see the measurements next to ZK_FU_MUL_INLINE;
+// with 14 limbs an inlined G2 mixed addition is > 100 KB of code, so BLS12-381 keeps it as a call)
+template <> struct UCfg<Bn254Fq> { static constexpr int B = 29, N = 9; static constexpr bool FQ2_INLINE = true; };
+template <> struct UCfg<Bls381Fq> { static constexpr int B = 28, N = 14; static constexpr bool FQ2_INLINE = false; };
 
 // ---- compile-time constants: p, -p^-1, powers of two mod p and bias multiples of p, all in B-bit limbs ----
 template <class P>
@@ -261,9 +263,6 @@ template <class P> ZK_HD_CALL Fu<P> fu_mul2(const Fu<P> a, const Fu<P> b, const 
 #ifndef ZK_FU_MUL_INLINE
 #define ZK_FU_MUL_INLINE 1
 #endif
-#ifndef ZK_FU2_MODE
-#define ZK_FU2_MODE 2   // 0: Fq2 product = call, built from fu_mul2 calls; 1: call with the two mul2 inlined; 2: everything inline
-#endif
 template <class P> ZK_HD Fu<P> ec_mul(const Fu<P>& a, const Fu<P>& b) { return ZK_FU_MUL_INLINE ? fu_mul_inl(a, b) : fu_mul(a, b); }
 template <class P> ZK_HD Fu<P> ec_sqr(const Fu<P>& a) { return ZK_FU_MUL_INLINE ? fu_mul_inl(a, a) : fu_mul(a, a); }
 
@@ -343,23 +342,20 @@ template <class P> ZK_HD bool fe_is_zero_modp(const Fu2<P>& a) { return fe_is_ze
 // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: two sums of two products, each reduced once
 // (the same 4 x N^2 + 2 x N^2 multiply-adds as Karatsuba's three full products, but one negation instead of five
 // additions, and results that stay below 2p whatever the operands)
-#if ZK_FU2_MODE == 2
-#define ZK_FU2_ATTR ZK_HD
-#else
-#define ZK_FU2_ATTR ZK_HD_CALL
-#endif
 template <class P>
-ZK_FU2_ATTR Fu2<P> ec_mul(const Fu2<P> a, const Fu2<P> b) {
+ZK_HD Fu2<P> fu2_mul_inl(const Fu2<P>& a, const Fu2<P>& b) {
     const Fu<P> nb1 = fe_sub_k<8>(Fu<P>::zero(), b.c1);
-    if (ZK_FU2_MODE == 0) return {fu_mul2(a.c0, b.c0, a.c1, nb1), fu_mul2(a.c0, b.c1, a.c1, b.c0)};
     return {fu_mul2_inl(a.c0, b.c0, a.c1, nb1), fu_mul2_inl(a.c0, b.c1, a.c1, b.c0)};
 }
 template <class P>
-ZK_FU2_ATTR Fu2<P> ec_sqr(const Fu2<P> a) {
+ZK_HD Fu2<P> fu2_sqr_inl(const Fu2<P>& a) {
     const Fu<P> na1 = fe_sub_k<8>(Fu<P>::zero(), a.c1);
-    if (ZK_FU2_MODE == 0) return {fu_mul2(a.c0, a.c0, a.c1, na1), fu_mul(fe_dbl(a.c0), a.c1)};
     return {fu_mul2_inl(a.c0, a.c0, a.c1, na1), fu_mul_inl(fe_dbl(a.c0), a.c1)};
 }
+template <class P> ZK_HD_CALL Fu2<P> fu2_mul_call(const Fu2<P> a, const Fu2<P> b) { return fu2_mul_inl(a, b); }
+template <class P> ZK_HD_CALL Fu2<P> fu2_sqr_call(const Fu2<P> a) { return fu2_sqr_inl(a); }
+template <class P> ZK_HD Fu2<P> ec_mul(const Fu2<P>& a, const Fu2<P>& b) { return UCfg<P>::FQ2_INLINE ? fu2_mul_inl(a, b) : fu2_mul_call(a, b); }
+template <class P> ZK_HD Fu2<P> ec_sqr(const Fu2<P>& a) { return UCfg<P>::FQ2_INLINE ? fu2_sqr_inl(a) : fu2_sqr_call(a); }
 
 // ---- conversions at the MSM boundary ----
 // saturated Montgomery (x * 2^(32W) mod p, canonical) -> unsaturated Montgomery (x * R'), TIGHT, value < 2p

@@ -20,7 +20,7 @@ void points_to_unsat(zkhip_ctx* ctx, const Aff<FS>* d_in, void* d_out, u64 n) {
 
 template <class FS>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bases_unsat, const MsmShape& sh, Xyzz<FS>* d_window_sums,
-             Event* ev_begin, Event* ev_end) {
+             Event ev_begin, Event ev_end) {
     typedef typename Unsat<FS>::type F;   // the kernels run on the unsaturated field
     const Aff<F>* d_bases = (const Aff<F>*)d_bases_unsat;
     Stream s = ctx->serial ? ctx->stream : lane.stream;
@@ -47,10 +47,10 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bas
     ZK_LAUNCH(k_msm_lane_keys, dim3(blocks_for(nlanes, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, P, nlanes, ptr<u32>(lane.lane_key));
     ZK_LAUNCH(k_msm_find_heavy, dim3(blocks_for(sh.nkeys, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, P, ptr<u32>(lane.heavy) + 1,
               ptr<u32>(lane.heavy));
-    if (ev_begin) { *ev_begin = pool_event(ctx); event_record(*ev_begin, s); }
+    if (ev_begin) event_record(ev_begin, s);
     ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE>), dim3(blocks_for(nlanes, T)), dim3(T), 0, s, d_bases, ptr<u32>(so.off), ptr<u32>(so.sorted),
               ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), sh.nkeys, P, nlanes);
-    if (ev_end) { *ev_end = pool_event(ctx); event_record(*ev_end, s); }
+    if (ev_end) event_record(ev_end, s);
     ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(256), dim3(T), T * sizeof(Xyzz<F>), s, ptr<u32>(so.off), P, ptr<u32>(lane.heavy) + 1,
               ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.partial));
     ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.W), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial),
@@ -79,7 +79,7 @@ void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scal
 }
 
 #define ZK_INSTANTIATE_GROUP(F)                                                                                         \
-    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event*, Event*);          \
+    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event);          \
     template void points_to_unsat<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                     \
     template void fixed_base_table<F>(zkhip_ctx*, const Aff<F>*, int, DBuf&);                                           \
     template void fixed_base_mul<F>(zkhip_ctx*, const DBuf&, int, const u32*, u64, Aff<F>*);

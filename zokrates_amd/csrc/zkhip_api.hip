@@ -45,12 +45,20 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         dev_set(device);
         std::unique_ptr<zkhip_ctx> ctx(new zkhip_ctx());
         ctx->device = device;
-        ctx->stream = stream_create();
+        ctx->stream = stream_create_high_priority();
+        ctx->out_stream = stream_create();
         ctx->serial = getenv("ZKHIP_SERIAL") != nullptr;
-        for (auto& so : ctx->sorts) so.ready = event_create();
-        for (auto& lane : ctx->lanes) {
-            lane.stream = stream_create();
-            lane.done = event_create();
+        Stream lane_streams[ZK_NLANES];
+        for (auto& st : lane_streams) st = stream_create();
+        for (auto& sl : ctx->slots) {
+            for (auto& so : sl.sorts) so.ready = event_create();
+            for (int k = 0; k < ZK_NLANES; ++k) {
+                sl.lanes[k].stream = lane_streams[k];     // lane k of every slot shares one stream
+                sl.lanes[k].done = event_create();
+                sl.acc_b[k] = event_create();
+                sl.acc_e[k] = event_create();
+            }
+            for (auto& e : sl.ev) e = event_create();
         }
 #ifdef ZK_EMU
         ctx->desc = "zkhip TEST EMULATOR (not a product build)";
@@ -67,12 +75,19 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
 }
 void zkhip_ctx_free(zkhip_ctx* ctx) {
     if (!ctx) return;
-    for (Event e : ctx->ev_pool) event_destroy(e);
-    for (auto& so : ctx->sorts) event_destroy(so.ready);
-    for (auto& lane : ctx->lanes) {
-        event_destroy(lane.done);
-        stream_destroy(lane.stream);
+    dev_sync_all();
+    for (auto& sl : ctx->slots) {
+        for (auto& so : sl.sorts) event_destroy(so.ready);
+        for (int k = 0; k < ZK_NLANES; ++k) {
+            event_destroy(sl.lanes[k].done);
+            event_destroy(sl.acc_b[k]);
+            event_destroy(sl.acc_e[k]);
+        }
+        for (auto& e : sl.ev) event_destroy(e);
+        host_free_pinned(sl.h_ws);
     }
+    for (int k = 0; k < ZK_NLANES; ++k) stream_destroy(ctx->slots[0].lanes[k].stream);
+    stream_destroy(ctx->out_stream);
     stream_destroy(ctx->stream);
     delete ctx;
 }
@@ -164,19 +179,24 @@ int32_t zkhip_prove_g16_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1
                               uint8_t* proofs_out, zkhip_timings* timings) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
-        require(pk && r1cs && z && rs && proofs_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk && r1cs && rs && proofs_out && (z || count == 0), ZKHIP_ERR_BAD_ARG, "null argument");
         require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
-        const size_t fqb = pk->curve == ZKHIP_CURVE_BN128 ? 32 : 48;
-        zkhip_timings acc;
-        memset(&acc, 0, sizeof(acc));
+        ops_for(pk->curve)->prove_batch(ctx, pk, r1cs, count, z, nullptr, rs, proofs_out, timings);
+    });
+}
+int32_t zkhip_prove_g16_resident_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count, zkhip_assignment* const* zs,
+                                       const uint8_t* rs, uint8_t* proofs_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && rs && proofs_out && (zs || count == 0), ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
+        std::vector<void*> dev(count);
         for (uint32_t i = 0; i < count; ++i) {
-            zkhip_timings t;
-            ops_for(pk->curve)->prove(ctx, pk, r1cs, z + (size_t)i * pk->m * 32, rs + (size_t)i * 64, rs + (size_t)i * 64 + 32,
-                                      proofs_out + (size_t)i * (8 * fqb + 3), &t);
-            float* a = (float*)&acc; const float* b = (const float*)&t;
-            for (size_t k = 0; k < sizeof(acc) / sizeof(float); ++k) a[k] += b[k];
+            require(zs[i] && zs[i]->ctx == ctx && zs[i]->curve == pk->curve && zs[i]->m == pk->m, ZKHIP_ERR_BAD_ARG,
+                    "assignment does not match the proving key");
+            dev[i] = zs[i]->scalars.p;
         }
-        if (timings) *timings = acc;
+        ops_for(pk->curve)->prove_batch(ctx, pk, r1cs, count, nullptr, dev.data(), rs, proofs_out, timings);
     });
 }
 

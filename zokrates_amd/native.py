@@ -49,7 +49,7 @@ class Library:
     SYMBOLS = [
         "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_free", "zkhip_last_error", "zkhip_pk_load_g16",
         "zkhip_pk_free", "zkhip_pk_dims", "zkhip_r1cs_load", "zkhip_r1cs_free", "zkhip_prove_g16",
-        "zkhip_prove_g16_batch", "zkhip_assignment_upload", "zkhip_assignment_free", "zkhip_prove_g16_resident", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
+        "zkhip_prove_g16_batch", "zkhip_assignment_upload", "zkhip_assignment_free", "zkhip_prove_g16_resident", "zkhip_prove_g16_resident_batch", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
         "zkhip_field_op", "zkhip_setup_g16_size", "zkhip_setup_g16", "zkhip_describe",
     ]
 
@@ -75,6 +75,7 @@ class Library:
         L.zkhip_assignment_upload.restype = i32; L.zkhip_assignment_upload.argtypes = [vp, vp, vp, pp]
         L.zkhip_assignment_free.restype = None; L.zkhip_assignment_free.argtypes = [vp]
         L.zkhip_prove_g16_resident.restype = i32; L.zkhip_prove_g16_resident.argtypes = [vp] * 8
+        L.zkhip_prove_g16_resident_batch.restype = i32; L.zkhip_prove_g16_resident_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
         L.zkhip_ntt.restype = i32; L.zkhip_ntt.argtypes = [vp, i32, u32, i32, vp]
         L.zkhip_witness_map.restype = i32; L.zkhip_witness_map.argtypes = [vp, vp, vp, vp]
         L.zkhip_msm_g1.restype = i32; L.zkhip_msm_g1.argtypes = [vp, i32, u64, vp, vp, vp]
@@ -280,6 +281,20 @@ def prove_g16(ctx, pk, cs, z, r, s, want_timings=False):
     tm = Timings()
     ctx._check(ctx.lib.L.zkhip_prove_g16(ctx.h, pk.h, cs.h, _ptr(z), _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm)))
     return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+
+def prove_g16_resident_batch(ctx, pk, cs, assignments, rs):
+    """Pipelined proofs over resident assignments (may repeat); rs: list of (r, s) ints.  Returns (proofs, timings)."""
+    nb = FQ_BYTES[pk.curve_id]
+    count = len(rs)
+    assert len(assignments) == count
+    handles = (C.c_void_p * count)(*[a.h for a in assignments])
+    rsb = np.frombuffer(b"".join(int(r).to_bytes(32, "little") + int(s).to_bytes(32, "little") for r, s in rs), dtype=np.uint8)
+    out = np.zeros(count * (8 * nb + 3), dtype=np.uint8)
+    tm = Timings()
+    ctx._check(ctx.lib.L.zkhip_prove_g16_resident_batch(ctx.h, pk.h, cs.h, count, handles, _ptr(rsb), _ptr(out), C.byref(tm)))
+    step = 8 * nb + 3
+    return [out[i * step:(i + 1) * step].tobytes() for i in range(count)], tm.as_dict()
 
 
 def prove_g16_batch(ctx, pk, cs, zs, rs):
