@@ -26,7 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from zokrates_amd import native, synth  # noqa: E402
+from zokrates_amd import native, parallel, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
@@ -69,22 +69,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    def barrier_sync():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
-        # every libzkhip call returns only after its stream has drained, so there is no outstanding GPU work here
+    ranks = parallel.Ranks()          # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; nccl = RCCL
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    barrier_sync = ranks.barrier
 
     curve_id = synth.CURVE_IDS[args.curve]
     ctx = native.Context(local_rank)
@@ -97,7 +84,7 @@ def main():
     pk = native.ProvingKey(ctx, curve_id, pk_bytes)
     t_pkload = time.time() - t0
     nw = max(1, min(args.witnesses, args.steps + args.warmup))
-    zs = [circ.assignment(0x5EED0000 + rank * 1000 + i) for i in range(nw)]
+    zs = [circ.assignment(ranks.witness_seed(i)) for i in range(nw)]
     t0 = time.time()
     resident = [native.Assignment(ctx, cs, z) for z in zs]
     t_h2d = (time.time() - t0) / nw
@@ -117,11 +104,7 @@ def main():
     proofs, acc = native.prove_g16_resident_batch(ctx, pk, cs, [resident[j % nw] for j in steps], [rs(j) for j in steps])
     barrier_sync()
     elapsed = time.perf_counter() - t_begin
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ranks.max_over_ranks(elapsed)
     # isolated single-proof latency (not part of the timed region)
     for i in range(3):
         _, tm1 = native.prove_g16_resident(ctx, pk, cs, resident[i % nw], *rs(200 + i), want_timings=True)
@@ -170,8 +153,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 def proof_algorithmic_bytes(circ, fq):
