@@ -30,6 +30,8 @@ template <class P> int test(const char* name) {
         if (fe_is_zero_modp(fe_sub_k<4>(ua, ub)) != a.equals(b)) { if (bad++ < 3) printf("%s iszero mismatch\n", name); }
         if (!fe_is_zero_modp(fe_sub_k<4>(ua, ua))) { if (bad++ < 3) printf("%s iszero(a-a) mismatch\n", name); }
         if (!eq(fu_to_fe(fu_mul2_inl(ua, ub, ub, ua)), fe_dbl(fe_mul(a, b)))) { if (bad++ < 3) printf("%s mul2 mismatch\n", name); }
+        if (!eq(fu_to_fe(fu_sqr_inl(ua)), fe_mul(a, a))) { if (bad++ < 3) printf("%s sqr mismatch\n", name); }
+        if (!eq(fu_to_fe(fu_sqr_inl(fe_sub_k<4>(ua, ub))), fe_sqr(fe_sub(a, b)))) { if (bad++ < 3) printf("%s sqr(loose) mismatch\n", name); }
         // Fq2
         Fe2<P> A{a, b}, Bq{b, fe_add(a, a)};
         Fu2<P> uA = fu_from_fe(A), uB = fu_from_fe(Bq);

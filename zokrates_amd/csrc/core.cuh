@@ -91,7 +91,7 @@ struct NttPlanBase {
 };
 // result of one classification / digit / counting-sort pass; shared (read-only) by every base set paired with those scalars
 struct MsmSort {
-    DBuf dig, sorted, cnt, off, cursor, chunk_sum, grand;
+    DBuf wm, sorted, cnt, off, cursor, chunk_sum, grand;   // wm: the scalars in word-major order
     Event ready = nullptr;   // recorded on the main stream when the pass is complete
 };
 // workspace and stream of one MSM: the five MSMs of a proof are independent once their scalars are sorted, and the
@@ -270,6 +270,13 @@ struct MsmShape {
     u32 P_env;      // ZKHIP_MSM_P override of the sorted entries per accumulation work-item (0 = per point type)
     u32 Lw, H;      // fold geometry: K = H rows of Lw buckets
 };
+static inline void lds_opt_in_plain(const void* kernel) {
+#ifndef ZK_EMU
+    ZK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#else
+    (void)kernel;
+#endif
+}
 static inline int env_int(const char* name, int lo, int hi, int dflt) {
     if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
     return dflt;
@@ -308,7 +315,7 @@ static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars
     Stream s = ctx->stream;
     const u64 nk = sh.nkeys;
     require(sh.n * (u64)sh.W < ((u64)1 << 32) - sh.nkeys, ZKHIP_ERR_BAD_ARG, "MSM too large for 32-bit sort offsets");
-    so.dig.ensure(sh.n * sh.W * 4);
+    so.wm.ensure(sh.n * 32);
     so.sorted.ensure(sh.n * sh.W * 4);
     so.cnt.ensure(nk * 4);
     so.off.ensure((nk + 1) * 4);
@@ -319,12 +326,26 @@ static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars
     dev_memset(so.cnt.p, 0, nk * 4, s);
     dev_memset(so.cursor.p, 0, nk * 4, s);
     const unsigned T = 256;
-    ZK_LAUNCH(k_msm_digits, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, sh.c, sh.W, ptr<u32>(so.dig), ptr<u32>(so.cnt));
+    // one workgroup per (chunk of scalars, window): chunks several times larger than a window's bucket count keep the
+    // global atomics (one per touched bucket per workgroup) well below one per digit
+    static bool lds_once = false;
+    if (!lds_once) {
+        lds_opt_in_plain((const void*)k_msm_count);
+        lds_opt_in_plain((const void*)k_msm_place);
+        lds_once = true;
+    }
+    const u64 want_chunks = std::max<u64>(1, (256 + sh.W - 1) / sh.W);
+    const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)sh.K));
+    const u64 sort_chunks = std::min(want_chunks, max_chunks);
+    const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;
+    const size_t hist_bytes = ((size_t)sh.K + 1) * 4;
+    ZK_LAUNCH(k_scalars_to_word_major, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, ptr<u32>(so.wm));
+    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, ptr<u32>(so.cnt));
     ZK_LAUNCH(k_scan_local, dim3(nchunks), dim3(SCAN_THREADS), 0, s, ptr<u32>(so.cnt), ptr<u32>(so.off), ptr<u32>(so.chunk_sum), nk);
     ZK_LAUNCH(k_scan_chunks, dim3(1), dim3(SCAN_THREADS), 0, s, ptr<u32>(so.chunk_sum), nchunks, ptr<u32>(so.grand));
     ZK_LAUNCH(k_scan_add, dim3(blocks_for(nk + 1, T)), dim3(T), 0, s, ptr<u32>(so.off), ptr<u32>(so.chunk_sum), nk, ptr<u32>(so.grand));
-    ZK_LAUNCH(k_msm_scatter, dim3(blocks_for(sh.n * sh.W, T)), dim3(T), 0, s, ptr<u32>(so.dig), sh.n, sh.n * (u64)sh.W, sh.nkeys - 1,
-              ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
+    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, ptr<u32>(so.off),
+              ptr<u32>(so.cursor), ptr<u32>(so.sorted));
     event_record(so.ready, s);
 }
 

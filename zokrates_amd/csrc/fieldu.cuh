@@ -218,6 +218,38 @@ ZK_HD Fu<P> fu_mul_inl(const Fu<P>& a, const Fu<P>& b) {
     r.v[N - 1] = (u32)acc;
     return r;
 }
+// a*a/R': the cross terms a_i*a_j (i < j) are taken once against the doubled limb, N(N+1)/2 products instead of N^2
+template <class P>
+ZK_HD Fu<P> fu_sqr_inl(const Fu<P>& a) {
+    typedef UConst<P> C;
+    constexpr int N = Fu<P>::N, B = Fu<P>::B;
+    constexpr u32 M = Fu<P>::M;
+    u32 m[N], a2[N];
+    ZK_UNROLL for (int i = 0; i < N; ++i) a2[i] = a.v[i] << 1;
+    Fu<P> r;
+    u64 acc = 0;
+    ZK_UNROLL for (int k = 0; k < N; ++k) {
+        ZK_UNROLL for (int i = 0; i < k; ++i) {
+            if (2 * i < k) acc += (u64)a2[i] * a.v[k - i];
+            acc += (u64)m[i] * C::p(k - i);
+        }
+        if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+        m[k] = ((u32)acc * C::NINV) & M;
+        acc += (u64)m[k] * C::p(0);
+        acc >>= B;
+    }
+    ZK_UNROLL for (int k = N; k < 2 * N - 1; ++k) {
+        ZK_UNROLL for (int i = k - N + 1; i < N; ++i) {
+            if (2 * i < k) acc += (u64)a2[i] * a.v[k - i];
+            acc += (u64)m[i] * C::p(k - i);
+        }
+        if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+        r.v[k - N] = (u32)acc & M;
+        acc >>= B;
+    }
+    r.v[N - 1] = (u32)acc;
+    return r;
+}
 // (a*b + c*d)/R' with one reduction — the building block of the Fq2 product
 template <class P>
 ZK_HD Fu<P> fu_mul2_inl(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d) {
@@ -264,7 +296,7 @@ template <class P> ZK_HD_CALL Fu<P> fu_mul2(const Fu<P> a, const Fu<P> b, const 
 #define ZK_FU_MUL_INLINE 1
 #endif
 template <class P> ZK_HD Fu<P> ec_mul(const Fu<P>& a, const Fu<P>& b) { return ZK_FU_MUL_INLINE ? fu_mul_inl(a, b) : fu_mul(a, b); }
-template <class P> ZK_HD Fu<P> ec_sqr(const Fu<P>& a) { return ZK_FU_MUL_INLINE ? fu_mul_inl(a, a) : fu_mul(a, a); }
+template <class P> ZK_HD Fu<P> ec_sqr(const Fu<P>& a) { return ZK_FU_MUL_INLINE ? fu_sqr_inl(a) : fu_mul(a, a); }
 
 // weak reduction: TIGHT x with value < 32p -> TIGHT, value < 3p.  The quotient estimate q = floor(x_top / (p_top+1))
 // never overshoots, so x - q*p >= 0; the subtraction runs through a signed ripple (it is off the multiplier's path:
@@ -347,10 +379,11 @@ ZK_HD Fu2<P> fu2_mul_inl(const Fu2<P>& a, const Fu2<P>& b) {
     const Fu<P> nb1 = fe_sub_k<8>(Fu<P>::zero(), b.c1);
     return {fu_mul2_inl(a.c0, b.c0, a.c1, nb1), fu_mul2_inl(a.c0, b.c1, a.c1, b.c0)};
 }
+// (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u: two single products.  Operands < 6p keep (a0 + a1) < 12p and
+// (a0 + 8p - a1) < 14p, so the result stays below 12*14/169 + 1 < 2p.
 template <class P>
 ZK_HD Fu2<P> fu2_sqr_inl(const Fu2<P>& a) {
-    const Fu<P> na1 = fe_sub_k<8>(Fu<P>::zero(), a.c1);
-    return {fu_mul2_inl(a.c0, a.c0, a.c1, na1), fu_mul_inl(fe_dbl(a.c0), a.c1)};
+    return {fu_mul_inl(fe_add(a.c0, a.c1), fe_sub_k<8>(a.c0, a.c1)), fu_mul_inl(fe_dbl(a.c0), a.c1)};
 }
 template <class P> ZK_HD_CALL Fu2<P> fu2_mul_call(const Fu2<P> a, const Fu2<P> b) { return fu2_mul_inl(a, b); }
 template <class P> ZK_HD_CALL Fu2<P> fu2_sqr_call(const Fu2<P> a) { return fu2_sqr_inl(a); }

@@ -69,55 +69,104 @@ static __device__ __forceinline__ u32 lanes_below(unsigned long long m, int lane
     return (u32)__builtin_popcountll(m & (((unsigned long long)1 << lane) - 1));
 }
 
-// ---- 1. classification, signed-digit recoding, bucket histogram ----
-// scalars: n x 8 u32 canonical.  dig[j*n + i] = key | sign<<31 with key = j*K + (|d|-1), or MSM_NO_DIGIT.
-// Scalars equal to 1 get the single entry key = W*K (the "ones" bucket) in window 0.  cnt[key] += 1.
-// No early exit before the ballot: every lane of a wave takes part in it.
-static __global__ void k_msm_digits(const u32* __restrict__ scalars, u64 n, int c, int W, u32* __restrict__ dig, u32* __restrict__ cnt) {
+// ---- 1. classification, signed-digit recoding, counting sort — window-major, histograms in LDS ----
+// One scalar produces W digits that land in W different key ranges; doing that with one global atomic per digit makes the
+// sort atomic-bound (17.8 M atomics per pass at 2^20).  Here a workgroup owns ONE window of a chunk of scalars, so all its
+// keys fall into that window's K buckets: the histogram lives in LDS (K x 4 B <= 128 KB) and only one global atomic
+// per touched (workgroup, bucket) remains.  Scalars are first transposed to word-major order so that a window reads the
+// two 32-bit words it needs with unit stride.
+static __global__ void k_scalars_to_word_major(const u32* __restrict__ scalars, u64 n, u32* __restrict__ wm) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    u32 k[9];
-    for (int q = 0; q < 9; ++q) k[q] = 0;
-    if (live) {
-        const uint4* sp = (const uint4*)(scalars + i * 8);
-        uint4 lo = sp[0], hi = sp[1];
-        k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w;
-        k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+    if (i >= n) return;
+    const uint4* sp = (const uint4*)(scalars + i * 8);
+    const uint4 lo = sp[0], hi = sp[1];
+    wm[0 * n + i] = lo.x; wm[1 * n + i] = lo.y; wm[2 * n + i] = lo.z; wm[3 * n + i] = lo.w;
+    wm[4 * n + i] = hi.x; wm[5 * n + i] = hi.y; wm[6 * n + i] = hi.z; wm[7 * n + i] = hi.w;
+}
+// bits [bit, bit + c) of scalar i (zero beyond bit 255)
+static __device__ __forceinline__ u32 msm_window_raw(const u32* __restrict__ wm, u64 n, u64 i, int bit, int c) {
+    if (bit >= 256) return 0;
+    const int limb = bit >> 5, off = bit & 31;
+    u64 two = wm[(u64)limb * n + i];
+    if (off + c > 32 && limb + 1 < 8) two |= (u64)wm[(u64)(limb + 1) * n + i] << 32;
+    return (u32)(two >> off) & ((1u << c) - 1);
+}
+// Signed digit of window j: bucket (|d| - 1) | sign << 31, or MSM_NO_DIGIT.  digit = raw + carry_in, minus 2^c (and a
+// carry out) when that exceeds K = 2^(c-1).  The carry into window j is decided by window j-1 alone unless its raw
+// value is exactly K, in which case it inherits the carry from below.
+static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ wm, u64 n, u64 i, int j, int c, u32 K) {
+    u32 raw = msm_window_raw(wm, n, i, j * c, c);
+    for (int jj = j - 1; jj >= 0; --jj) {
+        const u32 r = msm_window_raw(wm, n, i, jj * c, c);
+        if (r > K) { raw += 1; break; }
+        if (r < K) break;
     }
+    if (raw > K) {
+        const u32 mag = (1u << c) - raw;   // raw == 2^c (all-ones digit + carry) is digit 0 with a borrow
+        return mag ? ((mag - 1) | 0x80000000u) : MSM_NO_DIGIT;
+    }
+    return raw ? raw - 1 : MSM_NO_DIGIT;
+}
+static __device__ __forceinline__ bool msm_scalar_is_one(const u32* __restrict__ wm, u64 n, u64 i) {
+    u32 rest = 0;
+    for (int w = 1; w < 8; ++w) rest |= wm[(u64)w * n + i];
+    return rest == 0 && wm[i] == 1;
+}
+// grid (nchunks, W); dynamic LDS (K + 1) x 4 B.  cnt[key] += number of digits with that key in this chunk;
+// scalars equal to 1 go to the dedicated key W*K instead of (window 0, bucket 0).
+static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32* __restrict__ cnt) {
+    ZK_DYN_SMEM(smem);
+    u32* hist = (u32*)smem;
     const u32 K = 1u << (c - 1);
-    const u32 ones_key = (u32)W * K;
-    const u32 rest = k[1] | k[2] | k[3] | k[4] | k[5] | k[6] | k[7];
-    const bool is_one = live && rest == 0 && k[0] == 1;
-    const bool is_zero = live && rest == 0 && k[0] == 0;
-    const unsigned long long ones = wave_ballot(is_one);
-    if (is_one && wave_lane() == first_lane(ones)) atomicAdd(&cnt[ones_key], (u32)__builtin_popcountll(ones));
-    if (!live) return;
-    if (is_one || is_zero) {
-        for (int j = 0; j < W; ++j) dig[(u64)j * n + i] = MSM_NO_DIGIT;
-        if (is_one) dig[i] = ones_key;
-        return;
+    const int j = blockIdx.y;
+    for (u32 b = threadIdx.x; b <= K; b += blockDim.x) hist[b] = 0;   // hist[K] counts the ones
+    __syncthreads();
+    const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const u32 d = msm_window_digit(wm, n, i, j, c, K);
+        if (d == MSM_NO_DIGIT) continue;
+        u32 slot = d & 0x7fffffffu;
+        if (j == 0 && d == 0 && msm_scalar_is_one(wm, n, i)) slot = K;
+        atomicAdd(&hist[slot], 1u);
     }
-    const u32 mask = (1u << c) - 1;
-    u32 carry = 0;
-    for (int j = 0; j < W; ++j) {
-        const int bit = j * c, limb = bit >> 5, off = bit & 31;
-        u32 raw = 0;
-        if (limb < 8) {
-            u64 two = (u64)k[limb] | ((u64)k[limb + 1] << 32);
-            raw = (u32)(two >> off) & mask;
-        }
-        raw += carry;
-        u32 out = MSM_NO_DIGIT;
-        if (raw > K) {            // digit = raw - 2^c (negative), borrow one from the next window
-            u32 mag = (1u << c) - raw;   // raw == 2^c (all-ones digit + carry) is digit 0 with a borrow
-            if (mag) out = ((u32)j * K + mag - 1) | 0x80000000u;
-            carry = 1;
-        } else {
-            carry = 0;
-            if (raw) out = (u32)j * K + raw - 1;
-        }
-        dig[(u64)j * n + i] = out;
-        if (out != MSM_NO_DIGIT) atomicAdd(&cnt[out & 0x7fffffffu], 1u);
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < K; b += blockDim.x)
+        if (hist[b]) atomicAdd(&cnt[(u64)j * K + b], hist[b]);
+    if (threadIdx.x == 0 && hist[K]) atomicAdd(&cnt[(u64)W * K], hist[K]);
+}
+// same geometry; after the scan: reserve this workgroup's run inside every bucket it touches (one global atomic per
+// bucket), then place the entries with LDS atomics.  sorted[pos] = point index | sign << 31.
+static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, const u32* __restrict__ off,
+                                                        u32* __restrict__ cursor, u32* __restrict__ sorted) {
+    ZK_DYN_SMEM(smem);
+    u32* hist = (u32*)smem;
+    const u32 K = 1u << (c - 1);
+    const int j = blockIdx.y;
+    for (u32 b = threadIdx.x; b <= K; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const u32 d = msm_window_digit(wm, n, i, j, c, K);
+        if (d == MSM_NO_DIGIT) continue;
+        u32 slot = d & 0x7fffffffu;
+        if (j == 0 && d == 0 && msm_scalar_is_one(wm, n, i)) slot = K;
+        atomicAdd(&hist[slot], 1u);
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b <= K; b += blockDim.x) {
+        const u32 have = hist[b];
+        if (!have) continue;
+        const u64 key = b < K ? (u64)j * K + b : (u64)W * K;
+        hist[b] = off[key] + atomicAdd(&cursor[key], have);   // global position of this workgroup's first entry
+    }
+    __syncthreads();
+    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const u32 d = msm_window_digit(wm, n, i, j, c, K);
+        if (d == MSM_NO_DIGIT) continue;
+        u32 slot = d & 0x7fffffffu;
+        if (j == 0 && d == 0 && msm_scalar_is_one(wm, n, i)) slot = K;
+        const u32 pos = atomicAdd(&hist[slot], 1u);
+        sorted[pos] = (u32)i | (d & 0x80000000u);
     }
 }
 
@@ -177,25 +226,6 @@ static __global__ void k_scan_add(u32* __restrict__ off, const u32* __restrict__
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) off[i] += chunk_sum[i / SCAN_CHUNK];
     if (i == total) off[total] = *grand_total;   // sentinel: off has total+1 entries
-}
-
-// ---- 2b. scatter point indices into bucket order ----
-// Entries of the ones bucket reserve their slots with one atomic per wave (they all hit the same counter).
-static __global__ void k_msm_scatter(const u32* __restrict__ dig, u64 n, u64 total, u32 ones_key, const u32* __restrict__ off,
-                                     u32* __restrict__ cursor, u32* __restrict__ sorted) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 d = t < total ? dig[t] : MSM_NO_DIGIT;
-    const bool valid = d != MSM_NO_DIGIT;
-    const u32 key = d & 0x7fffffffu;
-    const bool agg = valid && key == ones_key;
-    const unsigned long long m = wave_ballot(agg);
-    const int leader = first_lane(m), lane = wave_lane();
-    u32 base = 0;
-    if (agg && lane == leader) base = atomicAdd(&cursor[key], (u32)__builtin_popcountll(m));
-    base = __shfl(base, leader);
-    if (!valid) return;
-    const u32 pos = agg ? base + lanes_below(m, lane) : atomicAdd(&cursor[key], 1u);
-    sorted[off[key] + pos] = (u32)(t % n) | (d & 0x80000000u);
 }
 
 // ---- 3a. first key of every lane's slice of the sorted list (upper bound over the offsets) ----
