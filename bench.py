@@ -122,10 +122,28 @@ def main():
     }
     name, (ms, bytes_all, launches) = max(kernels.items(), key=lambda kv: kv[1][0])
     achieved = bytes_all / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — measured offline, same workload
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path) and args.log_domain == 20 and args.curve == "bn128" and args.kind == "dense":
+        with open(pmc_path) as f:
+            traffic = json.load(f).get("G2" if "G2" in name else "G1", {}).get("traffic_bytes_per_launch")
+    # the honest bound of this kernel: mixed additions per second against the multiplier-limited rate of the same
+    # kernel on synthetic data (tools/accum_bench.hip); W signed windows, one mixed addition per non-zero digit
+    shape_w = {20: 17}.get(args.log_domain)
+    compute = None
+    if shape_w and args.curve == "bn128":
+        madds = (((m + 2) if "G2" in name else (3 * (m + 2) + N)) * shape_w)
+        peak = 5.29e9 if "G2" in name else 13.75e9
+        compute = {"unit": "mixed additions/s", "achieved": madds / (ms * 1e-3), "peak": peak, "frac": madds / (ms * 1e-3) / peak,
+                   "peak_source": "tools/accum_bench.hip on MI355X (same kernel, synthetic sorted lists)"}
     roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": bytes_all / launches, "ms_per_launch": ms / launches, "launches_per_proof": launches,
-                "note": "bucket accumulation is integer-ALU bound (Montgomery multiplies), not HBM bound; see DESIGN.md"}
+                "compute_bound": compute,
+                "note": "bucket accumulation is bound by integer-multiply issue (Montgomery products), not by HBM; durations are "
+                        "HIP-event intervals on the MSM streams inside the timed region, where the five MSMs overlap"}
     b_alg = proof_algorithmic_bytes(circ, fq)
     out = {
         "metric": "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
