@@ -135,6 +135,24 @@ int32_t zkhip_prove_g16_resident_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const
                                        zkhip_assignment* const* zs, const uint8_t* rs, uint8_t* proofs_out,
                                        zkhip_timings* timings);
 
+/* ---- one proof across several GPUs ----
+ * Every MSM is a sum over independent (scalar, base) pairs, so rank k of `world` loads only its index range of
+ * a_query / b_g1_query / b_g2_query / l_query / h_query (zkhip_pk_load_g16_shard), computes the partial sums of the five
+ * MSMs over that range (zkhip_prove_g16_partial; the mat-vec / NTT stage is replicated on every rank, it is < 10 % of
+ * the work) and the ranks exchange ONE fixed-size record each (zkhip_partial_size bytes: five points in XYZZ
+ * coordinates) — an all-gather over RCCL in zokrates_amd/parallel.py.  zkhip_combine_g16 adds the records and
+ * assembles the proof; the result is bit-identical to zkhip_prove_g16 with the whole key. */
+int32_t zkhip_pk_load_g16_shard(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, uint32_t rank,
+                                uint32_t world, zkhip_pk** out);
+int32_t zkhip_partial_size(int32_t curve, uint64_t* bytes);
+/* z: host assignment (m x 32 B) or NULL to use the resident one */
+int32_t zkhip_prove_g16_partial(zkhip_ctx* ctx, const zkhip_pk* pk_shard, const zkhip_r1cs* r1cs, const uint8_t* z,
+                                zkhip_assignment* z_resident, const uint8_t* r, const uint8_t* s, uint8_t* partial_out,
+                                zkhip_timings* timings);
+/* partials: count x zkhip_partial_size bytes, one record per rank, any order; pk: any shard (or the whole key) */
+int32_t zkhip_combine_g16(zkhip_ctx* ctx, const zkhip_pk* pk, uint32_t count, const uint8_t* partials, const uint8_t* r,
+                          const uint8_t* s, uint8_t* proof_out);
+
 /* ---- primitives (exported for parity tests and micro-benchmarks) ---- */
 /* [UPSTREAM] ark_poly::Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place (App. A.4).
  * data: 2^log_n x 32 B canonical LE, natural order in and out, transformed in place.

@@ -163,6 +163,30 @@ def test_prove_matches_oracle(ctx, curve, kind):
     assert proofs == [want]
 
 
+@pytest.mark.parametrize("curve,world", [(BN254, 2), (BN254, 5), (BLS12_381, 3)], ids=lambda v: getattr(v, "name", str(v)))
+def test_sharded_proof_virtual_ranks(ctx, curve, world):
+    """One proof split over `world` ranks (here: one after the other on the same device): every rank loads its share of
+    the key, computes partial sums, the records are combined — bit-identical to the unsharded proof."""
+    oc = cpu.Circuit.synth(curve.curve_id, 21, 0x5EED0011)
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    raw = cpu.ProvingKey.setup(oc, tox).serialize()
+    z = oc.assignment()
+    r_, s_ = 0xabcdef12345 % curve.r, 0x13579bdf2468 % curve.r
+    want = cpu.trapdoor(oc, tox, z, r_, s_)
+    cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    shards = [native.ProvingKey(ctx, curve.curve_id, raw, rank=k, world=world) for k in range(world)]
+    parts = [native.prove_g16_partial(ctx, shards[k], cs, z, r_, s_) for k in range(world)]
+    assert native.combine_g16(ctx, shards[0], parts, r_, s_) == want
+    assert native.combine_g16(ctx, shards[-1], parts[::-1], r_, s_) == want          # order and combining rank do not matter
+    za = native.Assignment(ctx, cs, z)
+    parts = [native.prove_g16_partial(ctx, shards[k], cs, za, 0, s_) for k in range(world)]
+    assert native.combine_g16(ctx, shards[0], parts, 0, s_) == cpu.trapdoor(oc, tox, z, 0, s_)
+    with pytest.raises(native.ZkhipError):                                           # a shard cannot prove alone
+        native.prove_g16(ctx, shards[0], cs, z, r_, s_)
+    whole = native.ProvingKey(ctx, curve.curve_id, raw)
+    assert native.combine_g16(ctx, whole, [native.prove_g16_partial(ctx, whole, cs, z, r_, s_)], r_, s_) == want
+
+
 def test_two_pass_prove(ctx):
     """Force the two-pass NTT (sigma order, permuted h_query) inside the full prover."""
     os.environ["ZKHIP_NTT_SINGLE_MAX_LOG"] = "2"

@@ -272,3 +272,24 @@ def test_full_size_properties(ctx):
     a = z[: (1 << lg) * 32]
     assert ctx.ntt(0, ctx.ntt(0, a, "coset_fft"), "coset_ifft").tobytes() == a.tobytes()
     assert ctx.ntt(0, ctx.ntt(0, a, "fft"), "ifft").tobytes() == a.tobytes()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_proof_virtual_ranks(ctx, world):
+    """one 2^14 proof split over `world` ranks (virtual ranks: one after the other on this GPU) is
+    bit-identical to the unsharded proof and to the oracle."""
+    from zokrates_amd import synth
+    circ = synth.circuit(0, 14, seed=0x5A4D)
+    cs = native.ConstraintSystem(ctx, 0, circ.n, circ.l, circ.w, circ.mats())
+    tox = synth.toxic_waste(0, 0xFACE)
+    raw = native.setup_g16(ctx, cs, tox)
+    z = circ.assignment(77)
+    r_, s_ = 0x1234567890abcdef1234, 0xfedcba0987654321
+    whole = native.ProvingKey(ctx, 0, raw)
+    want = native.prove_g16(ctx, whole, cs, z, r_, s_)
+    oc = cpu.Circuit.from_csr(0, circ.n, circ.l, circ.w, circ.mats())
+    assert want == cpu.trapdoor(oc, b"".join(int(v).to_bytes(32, "little") for v in tox), z, r_, s_)
+    shards = [native.ProvingKey(ctx, 0, raw, rank=k, world=world) for k in range(world)]
+    za = native.Assignment(ctx, cs, z)
+    parts = [native.prove_g16_partial(ctx, shards[k], cs, za, r_, s_) for k in range(world)]
+    assert native.combine_g16(ctx, shards[0], parts, r_, s_) == want

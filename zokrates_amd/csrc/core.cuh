@@ -281,7 +281,7 @@ static inline int env_int(const char* name, int lo, int hi, int dflt) {
     if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
     return dflt;
 }
-static inline MsmShape msm_shape(u64 n, int scalar_bits) {
+static inline MsmShape msm_shape(u64 n, int scalar_bits, int force_c = 0) {
     MsmShape s;
     s.n = n;
     // Window width: about log2(n) - 5 (measured optimum at 2^20: 15), but never one that leaves the top window
@@ -301,6 +301,7 @@ static inline MsmShape msm_shape(u64 n, int scalar_bits) {
         if (found) break;
     }
     s.c = env_int("ZKHIP_MSM_C", 2, 16, s.c);
+    if (force_c) s.c = force_c;
     s.W = (scalar_bits + 1 + s.c - 1) / s.c;
     s.K = 1u << (s.c - 1);
     s.nkeys = (u32)s.W * s.K + 1;
@@ -414,6 +415,12 @@ struct zkhip_pk {
     int logN;
     DBuf a_ext, b1_ext, l_ext, b2_ext, h_sigma;   // Montgomery affine, MSM-ready
     std::vector<uint8_t> delta_g1_canon;          // for the -rs*delta_1 term of C (host)
+    // Multi-GPU sharding of ONE proof (zkhip_pk_load_g16_shard): this key holds the bases of the index ranges
+    // [z_lo, z_lo + z_n) of the extended variable range [0, m+2) and [h_lo, h_lo + h_n) of the sigma-ordered h range
+    // [0, N); every rank derives the same window widths from the nominal (largest) range length.
+    u32 rank = 0, world = 1;
+    u64 z_lo = 0, z_n = 0, h_lo = 0, h_n = 0;
+    int c_z = 0, c_h = 0;
 };
 
 struct zkhip_r1cs {
@@ -487,6 +494,11 @@ struct PkLoader {
     static Aff<Fq> to_mont_point(const Aff<Fq>& p) { return {fe_to_mont(p.x), fe_to_mont(p.y)}; }
     static Aff<Fq2> to_mont_point(const Aff<Fq2>& p) { return {fe_to_mont(p.x), fe_to_mont(p.y)}; }
 
+    static void range_of(u64 total, u32 rank, u32 world, u64& lo, u64& n, u64& nominal) {
+        nominal = (total + world - 1) / world;
+        lo = std::min<u64>((u64)rank * nominal, total);
+        n = std::min<u64>(nominal, total - lo);
+    }
     static void load(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk* pk) {
         Rd rd{bytes, bytes + len};
         const uint8_t* alpha_g1 = rd.take(G1B);
@@ -557,18 +569,24 @@ struct PkLoader {
         add_into<Fq, 2>(ctx, pk->a_ext, 0, alpha_g1);
         add_into<Fq, 2>(ctx, pk->b1_ext, 0, beta_g1);
         add_into<Fq2, 4>(ctx, pk->b2_ext, 0, beta_g2);
+        // this rank's share of the bases (everything for world = 1)
+        u64 nominal_z, nominal_h;
+        range_of(me, pk->rank, pk->world, pk->z_lo, pk->z_n, nominal_z);
+        range_of(N, pk->rank, pk->world, pk->h_lo, pk->h_n, nominal_h);
+        pk->c_z = msm_shape(nominal_z, C::Fr::Params::BITS).c;
+        pk->c_h = msm_shape(nominal_h, C::Fr::Params::BITS).c;
         // the MSM kernels work on unsaturated limbs (fieldu.cuh): convert every base once, here
-        to_unsat<Fq>(ctx, pk->a_ext, me);
-        to_unsat<Fq>(ctx, pk->b1_ext, me);
-        to_unsat<Fq>(ctx, pk->l_ext, me);
-        to_unsat<Fq2>(ctx, pk->b2_ext, me);
-        to_unsat<Fq>(ctx, pk->h_sigma, N);
+        to_unsat<Fq>(ctx, pk->a_ext, pk->z_lo, pk->z_n);
+        to_unsat<Fq>(ctx, pk->b1_ext, pk->z_lo, pk->z_n);
+        to_unsat<Fq>(ctx, pk->l_ext, pk->z_lo, pk->z_n);
+        to_unsat<Fq2>(ctx, pk->b2_ext, pk->z_lo, pk->z_n);
+        to_unsat<Fq>(ctx, pk->h_sigma, pk->h_lo, pk->h_n);
     }
     template <class F>
-    static void to_unsat(zkhip_ctx* ctx, DBuf& buf, u64 count) {
+    static void to_unsat(zkhip_ctx* ctx, DBuf& buf, u64 lo, u64 count) {
         DBuf out;
-        out.ensure(count * unsat_point_bytes<F>());
-        points_to_unsat<F>(ctx, ptr<Aff<F>>(buf), out.p, count);
+        out.ensure(std::max<u64>(count, 1) * unsat_point_bytes<F>());
+        if (count) points_to_unsat<F>(ctx, ptr<Aff<F>>(buf) + lo, out.p, count);
         stream_sync(ctx->stream);
         buf.swap(out);
     }
@@ -648,17 +666,22 @@ struct Prover {
         event_record(sl.ev[0], st);
 
         // ---- MSMs over S = [z_0..z_{m-1}, r, s]: A, B1, L in G1 and B2 in G2 share one digit/sort pass
-        const MsmShape shz = msm_shape(m + 2, Fr::Params::BITS);
-        const MsmShape shh = msm_shape(N, Fr::Params::BITS);
+        // (a sharded key covers only its index range of the bases, and pairs them with the same range of the scalars)
+        const MsmShape shz = msm_shape(pk->z_n, Fr::Params::BITS, pk->c_z);
+        const MsmShape shh = msm_shape(pk->h_n, Fr::Params::BITS, pk->c_h);
         const int Wmax = std::max(shz.W, shh.W) + 1;   // + the ones bucket
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // window sums: 4 G1 sets + 1 G2 set
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
-        msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars, shz);
-        msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
-        msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
-        msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
-        msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2]);
+        if (pk->z_n) {
+            msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz);
+            msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
+            msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
+            msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
+            msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2]);
+        } else {
+            empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
+        }
         event_record(sl.ev[1], st);
 
         // ---- K1-K4
@@ -666,8 +689,12 @@ struct Prover {
         event_record(sl.ev[2], st);
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
-        msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va), shh);
-        msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+        if (pk->h_n) {
+            msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh);
+            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+        } else {
+            empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
+        }
 
         // ---- window sums to the host, on a stream of their own so that the main stream can start the next proof
         Stream so = ctx->serial ? st : ctx->out_stream;
@@ -685,24 +712,48 @@ struct Prover {
         sl.busy = true;
     }
 
-    // ---- finish: wait for the slot's proof, K9 on the host: Horner over window sums, then
-    //      C = s*A + r*B1 - rs*delta_1 + L + H   (App. A.3; alpha/beta/delta terms already inside A, B1, B2)
-    static void finish(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, uint8_t* out, zkhip_timings* tm) {
+    // a rank whose range is empty (more ranks than points): all-infinity window sums, events recorded so that the
+    // bookkeeping of the slot stays uniform
+    static void empty_msm(zkhip_ctx* ctx, ProofSlot& sl, Xyzz<Fq>* ws1, size_t n1, Xyzz<Fq2>* ws2, size_t n2, int lane_from, int lane_to) {
+        Stream st = ctx->stream;
+        if (n1) dev_memset(ws1, 0, n1 * sizeof(Xyzz<Fq>), st);
+        if (n2) dev_memset(ws2, 0, n2 * sizeof(Xyzz<Fq2>), st);
+        for (int k = lane_from; k < lane_to; ++k) {
+            const int e = k == 3 ? 4 : k == 4 ? 3 : k;   // lane 3 (B2) times with event pair 4, lane 4 (H) with pair 3
+            event_record(sl.acc_b[e], st);
+            event_record(sl.acc_e[e], st);
+            event_record(sl.lanes[k].done, st);
+        }
+    }
+
+    // the five MSM results of a proof (or of one rank's share of it)
+    struct Sums {
+        Xyzz<Fq> a, b1, l, h;
+        Xyzz<Fq2> b2;
+    };
+    // ---- wait for the slot's proof; Horner over its window sums
+    static Sums collect(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk) {
         require(sl.busy, ZKHIP_ERR_DEVICE, "internal: no proof in flight in this slot");
         event_sync(sl.ev[3]);
         sl.busy = false;
-        const auto t_fin = std::chrono::steady_clock::now();
-        const MsmShape shz = msm_shape(pk->m + 2, Fr::Params::BITS);
-        const MsmShape shh = msm_shape(pk->N, Fr::Params::BITS);
+        const MsmShape shz = msm_shape(pk->z_n, Fr::Params::BITS, pk->c_z);
+        const MsmShape shh = msm_shape(pk->h_n, Fr::Params::BITS, pk->c_h);
         const int Wmax = std::max(shz.W, shh.W) + 1;
         const Xyzz<Fq>* h_ws1 = (const Xyzz<Fq>*)sl.h_ws;
         const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
-        Fr rr = fe_from_bytes_canon<Fr>(sl.r), ss = fe_from_bytes_canon<Fr>(sl.s);
-        Xyzz<Fq> gA = msm_combine(&h_ws1[0 * Wmax], shz);
-        Xyzz<Fq> gB1 = msm_combine(&h_ws1[1 * Wmax], shz);
-        Xyzz<Fq> gL = msm_combine(&h_ws1[2 * Wmax], shz);
-        Xyzz<Fq> gH = msm_combine(&h_ws1[3 * Wmax], shh);
-        Xyzz<Fq2> gB2 = msm_combine(h_ws2, shz);
+        Sums g;
+        g.a = msm_combine(&h_ws1[0 * Wmax], shz);
+        g.b1 = msm_combine(&h_ws1[1 * Wmax], shz);
+        g.l = msm_combine(&h_ws1[2 * Wmax], shz);
+        g.h = msm_combine(&h_ws1[3 * Wmax], shh);
+        g.b2 = msm_combine(h_ws2, shz);
+        return g;
+    }
+    // ---- K9: C = s*A + r*B1 - rs*delta_1 + L + H   (App. A.3; alpha/beta/delta terms already inside A, B1, B2)
+    static void assemble(const zkhip_pk* pk, const Sums& g, const uint8_t* r, const uint8_t* s_, uint8_t* out) {
+        const Xyzz<Fq>&gA = g.a, &gB1 = g.b1, &gL = g.l, &gH = g.h;
+        const Xyzz<Fq2>& gB2 = g.b2;
+        Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         Fr rs = fe_from_mont(fe_mul(fe_to_mont(rr), fe_to_mont(ss)));
         uint8_t dec[2 * FQB];
         decode_point<FQB, 2>(pk->delta_g1_canon.data(), dec);
@@ -724,6 +775,8 @@ struct Prover {
         }
         if (!gC.is_inf()) { write_fe(pc.x, out + 6 * FQB); write_fe(pc.y, out + 7 * FQB); }
         out[8 * FQB] = gA.is_inf(); out[8 * FQB + 1] = gB2.is_inf(); out[8 * FQB + 2] = gC.is_inf();
+    }
+    static void fill_timings(ProofSlot& sl, zkhip_timings* tm, std::chrono::steady_clock::time_point t_fin) {
         const auto t_end = std::chrono::steady_clock::now();
         if (tm) {
             memset(tm, 0, sizeof(*tm));
@@ -738,6 +791,38 @@ struct Prover {
             tm->kernel_msm_accum_g2_ms = event_elapsed_ms(sl.acc_b[4], sl.acc_e[4]);
         }
     }
+    static void finish(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, uint8_t* out, zkhip_timings* tm) {
+        require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "this proving key is one shard of a multi-GPU key: use zkhip_prove_g16_partial + zkhip_combine_g16");
+        const Sums g = collect(ctx, sl, pk);
+        const auto t_fin = std::chrono::steady_clock::now();
+        assemble(pk, g, sl.r, sl.s, out);
+        fill_timings(sl, tm, t_fin);
+    }
+    // one rank's share of a proof: the five partial sums, raw (XYZZ, saturated Montgomery limbs)
+    static void prove_partial(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* z_dev, const uint8_t* r,
+                              const uint8_t* s_, uint8_t* partial_out, zkhip_timings* tm) {
+        enqueue(ctx, ctx->slots[0], pk, cs, z_host, z_dev, r, s_);
+        const Sums g = collect(ctx, ctx->slots[0], pk);
+        const auto t_fin = std::chrono::steady_clock::now();
+        memcpy(partial_out, &g, sizeof(g));
+        fill_timings(ctx->slots[0], tm, t_fin);
+    }
+    // sum of the ranks' partial results, then the assembly
+    static void combine(const zkhip_pk* pk, u32 count, const uint8_t* partials, const uint8_t* r, const uint8_t* s_, uint8_t* out) {
+        Sums t;
+        t.a = t.b1 = t.l = t.h = Xyzz<Fq>::inf();
+        t.b2 = Xyzz<Fq2>::inf();
+        for (u32 i = 0; i < count; ++i) {
+            Sums g;
+            memcpy(&g, partials + (size_t)i * sizeof(Sums), sizeof(g));
+            t.a = xyzz_add(t.a, g.a); t.b1 = xyzz_add(t.b1, g.b1); t.l = xyzz_add(t.l, g.l); t.h = xyzz_add(t.h, g.h);
+            t.b2 = xyzz_add(t.b2, g.b2);
+        }
+        Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
+        require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
+        assemble(pk, t, r, s_, out);
+    }
+    static constexpr size_t PARTIAL_BYTES = sizeof(Sums);
 
     // one proof from a host assignment / from an assignment resident in HBM
     static void prove_host(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z, const uint8_t* r, const uint8_t* s_,
@@ -918,6 +1003,10 @@ struct CurveOps {
     void (*prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*prove_resident)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, void*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*prove_batch)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, u32, const uint8_t*, void* const*, const uint8_t*, uint8_t*, zkhip_timings*);
+    void (*prove_partial)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const void*, const uint8_t*, const uint8_t*, uint8_t*,
+                          zkhip_timings*);
+    void (*combine)(const zkhip_pk*, u32, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*);
+    size_t partial_bytes;
     void (*assignment_upload)(zkhip_ctx*, zkhip_assignment*, const uint8_t*);
     void (*ntt)(zkhip_ctx*, u32, int, uint8_t*);
     void (*witness_map)(zkhip_ctx*, const zkhip_r1cs*, const uint8_t*, uint8_t*);
@@ -939,6 +1028,9 @@ static CurveOps make_curve_ops() {
     o.prove = &Prover<C>::prove_host;
     o.prove_resident = &Prover<C>::prove_resident;
     o.prove_batch = &Prover<C>::prove_batch;
+    o.prove_partial = &Prover<C>::prove_partial;
+    o.combine = &Prover<C>::combine;
+    o.partial_bytes = Prover<C>::PARTIAL_BYTES;
     o.assignment_upload = &Prover<C>::assignment_upload;
     o.ntt = &Prover<C>::ntt_api;
     o.witness_map = &Prover<C>::witness_map_api;

@@ -10,6 +10,14 @@ static const CurveOps* ops_for(int curve) {
 }
 static std::string g_create_err;
 
+// after a failed call: let whatever was enqueued drain and mark the proof slots free, so the context stays usable
+static void release_slots(zkhip_ctx* ctx) {
+    bool any = false;
+    for (auto& sl : ctx->slots) any = any || sl.busy;
+    if (!any) return;
+    dev_sync_all();
+    for (auto& sl : ctx->slots) sl.busy = false;
+}
 template <class Fn>
 static int32_t guarded(zkhip_ctx* ctx, Fn&& fn) {
     try {
@@ -18,9 +26,11 @@ static int32_t guarded(zkhip_ctx* ctx, Fn&& fn) {
         return ZKHIP_OK;
     } catch (const ApiError& e) {
         (ctx ? ctx->err : g_create_err) = e.msg;
+        if (ctx) release_slots(ctx);
         return e.code;
     } catch (const DevError& e) {
         (ctx ? ctx->err : g_create_err) = e.msg;
+        if (ctx) release_slots(ctx);
         return ZKHIP_ERR_DEVICE;
     } catch (const std::bad_alloc&) {
         (ctx ? ctx->err : g_create_err) = "out of host memory";
@@ -111,6 +121,21 @@ int32_t zkhip_pk_load_g16(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, s
         *out = pk.release();
     });
 }
+int32_t zkhip_pk_load_g16_shard(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, uint32_t rank, uint32_t world, zkhip_pk** out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(bytes && out, ZKHIP_ERR_BAD_ARG, "null argument");
+        *out = nullptr;
+        require(world >= 1 && world <= 64 && rank < world, ZKHIP_ERR_BAD_ARG, "rank / world out of range (1 <= world <= 64)");
+        std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
+        pk->curve = curve;
+        pk->ctx = ctx;
+        pk->rank = rank;
+        pk->world = world;
+        ops_for(curve)->pk_load(ctx, bytes, len, pk.get());
+        *out = pk.release();
+    });
+}
 void zkhip_pk_free(zkhip_pk* pk) { delete pk; }
 int32_t zkhip_pk_dims(const zkhip_pk* pk, uint64_t out[4]) {
     if (!pk || !out) return ZKHIP_ERR_BAD_ARG;
@@ -145,6 +170,7 @@ int32_t zkhip_prove_g16(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
         require(pk && r1cs && z && r && s && proof_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "this proving key is one shard of a multi-GPU key: use zkhip_prove_g16_partial + zkhip_combine_g16");
         require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
         ops_for(pk->curve)->prove(ctx, pk, r1cs, z, r, s, proof_out, timings);
     });
@@ -169,9 +195,39 @@ int32_t zkhip_prove_g16_resident(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
         require(pk && r1cs && z && r && s && proof_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "this proving key is one shard of a multi-GPU key: use zkhip_prove_g16_partial + zkhip_combine_g16");
         require(pk->ctx == ctx && r1cs->ctx == ctx && z->ctx == ctx, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
         require(z->curve == pk->curve && z->m == pk->m, ZKHIP_ERR_BAD_ARG, "assignment does not match the proving key");
         ops_for(pk->curve)->prove_resident(ctx, pk, r1cs, z->scalars.p, r, s, proof_out, timings);
+    });
+}
+
+int32_t zkhip_partial_size(int32_t curve, uint64_t* bytes) {
+    if (!bytes) return ZKHIP_ERR_BAD_ARG;
+    try {
+        *bytes = ops_for(curve)->partial_bytes;
+    } catch (...) {
+        return ZKHIP_ERR_BAD_ARG;
+    }
+    return ZKHIP_OK;
+}
+int32_t zkhip_prove_g16_partial(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z, zkhip_assignment* z_resident,
+                                const uint8_t* r, const uint8_t* s, uint8_t* partial_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && (z || z_resident) && r && s && partial_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
+        if (!z) require(z_resident->ctx == ctx && z_resident->curve == pk->curve && z_resident->m == pk->m, ZKHIP_ERR_BAD_ARG,
+                        "assignment does not match the proving key");
+        ops_for(pk->curve)->prove_partial(ctx, pk, r1cs, z, z ? nullptr : z_resident->scalars.p, r, s, partial_out, timings);
+    });
+}
+int32_t zkhip_combine_g16(zkhip_ctx* ctx, const zkhip_pk* pk, uint32_t count, const uint8_t* partials, const uint8_t* r, const uint8_t* s,
+                          uint8_t* proof_out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && partials && r && s && proof_out && count >= 1, ZKHIP_ERR_BAD_ARG, "null argument");
+        ops_for(pk->curve)->combine(pk, count, partials, r, s, proof_out);
     });
 }
 
@@ -180,6 +236,7 @@ int32_t zkhip_prove_g16_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
         require(pk && r1cs && rs && proofs_out && (z || count == 0), ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "this proving key is one shard of a multi-GPU key: use zkhip_prove_g16_partial + zkhip_combine_g16");
         require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
         ops_for(pk->curve)->prove_batch(ctx, pk, r1cs, count, z, nullptr, rs, proofs_out, timings);
     });
@@ -189,6 +246,7 @@ int32_t zkhip_prove_g16_resident_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
         require(pk && r1cs && rs && proofs_out && (zs || count == 0), ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "this proving key is one shard of a multi-GPU key: use zkhip_prove_g16_partial + zkhip_combine_g16");
         require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
         std::vector<void*> dev(count);
         for (uint32_t i = 0; i < count; ++i) {

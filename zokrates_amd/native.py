@@ -49,7 +49,8 @@ class Library:
     SYMBOLS = [
         "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_free", "zkhip_last_error", "zkhip_pk_load_g16",
         "zkhip_pk_free", "zkhip_pk_dims", "zkhip_r1cs_load", "zkhip_r1cs_free", "zkhip_prove_g16",
-        "zkhip_prove_g16_batch", "zkhip_assignment_upload", "zkhip_assignment_free", "zkhip_prove_g16_resident", "zkhip_prove_g16_resident_batch", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
+        "zkhip_prove_g16_batch", "zkhip_assignment_upload", "zkhip_assignment_free", "zkhip_prove_g16_resident", "zkhip_prove_g16_resident_batch",
+        "zkhip_pk_load_g16_shard", "zkhip_partial_size", "zkhip_prove_g16_partial", "zkhip_combine_g16", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
         "zkhip_field_op", "zkhip_setup_g16_size", "zkhip_setup_g16", "zkhip_describe",
     ]
 
@@ -76,6 +77,10 @@ class Library:
         L.zkhip_assignment_free.restype = None; L.zkhip_assignment_free.argtypes = [vp]
         L.zkhip_prove_g16_resident.restype = i32; L.zkhip_prove_g16_resident.argtypes = [vp] * 8
         L.zkhip_prove_g16_resident_batch.restype = i32; L.zkhip_prove_g16_resident_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        L.zkhip_pk_load_g16_shard.restype = i32; L.zkhip_pk_load_g16_shard.argtypes = [vp, i32, vp, sz, u32, u32, pp]
+        L.zkhip_partial_size.restype = i32; L.zkhip_partial_size.argtypes = [i32, vp]
+        L.zkhip_prove_g16_partial.restype = i32; L.zkhip_prove_g16_partial.argtypes = [vp] * 9
+        L.zkhip_combine_g16.restype = i32; L.zkhip_combine_g16.argtypes = [vp, vp, u32, vp, vp, vp, vp]
         L.zkhip_ntt.restype = i32; L.zkhip_ntt.argtypes = [vp, i32, u32, i32, vp]
         L.zkhip_witness_map.restype = i32; L.zkhip_witness_map.argtypes = [vp, vp, vp, vp]
         L.zkhip_msm_g1.restype = i32; L.zkhip_msm_g1.argtypes = [vp, i32, u64, vp, vp, vp]
@@ -164,12 +169,17 @@ class Context:
 class ProvingKey:
     """`zkhip_pk`: an ark `proving.key` resident on the GPU in MSM-ready layout."""
 
-    def __init__(self, ctx, curve_id, data):
+    def __init__(self, ctx, curve_id, data, rank=0, world=1):
+        """world > 1: load only rank's share of the bases (one proof sharded over several GPUs)."""
         self.ctx = ctx
         self.curve_id = curve_id
+        self.rank, self.world = rank, world
         data = _u8(data)
         self.h = C.c_void_p()
-        ctx._check(ctx.lib.L.zkhip_pk_load_g16(ctx.h, curve_id, _ptr(data), data.size, C.byref(self.h)))
+        if world == 1:
+            ctx._check(ctx.lib.L.zkhip_pk_load_g16(ctx.h, curve_id, _ptr(data), data.size, C.byref(self.h)))
+        else:
+            ctx._check(ctx.lib.L.zkhip_pk_load_g16_shard(ctx.h, curve_id, _ptr(data), data.size, rank, world, C.byref(self.h)))
         d = np.zeros(4, dtype=np.uint64)
         ctx._check(ctx.lib.L.zkhip_pk_dims(self.h, _ptr(d)))
         self.m, self.hlen, self.w, self.l = (int(x) for x in d)
@@ -257,6 +267,38 @@ def prove_g16_resident(ctx, pk, cs, assignment, r, s, want_timings=False):
     tm = Timings()
     ctx._check(ctx.lib.L.zkhip_prove_g16_resident(ctx.h, pk.h, cs.h, assignment.h, _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm)))
     return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+
+def partial_size(ctx, curve_id):
+    n = C.c_uint64()
+    ctx._check(ctx.lib.L.zkhip_partial_size(curve_id, C.byref(n)))
+    return int(n.value)
+
+
+def prove_g16_partial(ctx, pk_shard, cs, z, r, s, want_timings=False):
+    """One rank's share of a proof: z is a host assignment (uint8[m*32]) or an `Assignment`.  Returns the partial record."""
+    rb = np.frombuffer(int(r).to_bytes(32, "little"), dtype=np.uint8)
+    sb = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8)
+    out = np.zeros(partial_size(ctx, pk_shard.curve_id), dtype=np.uint8)
+    tm = Timings()
+    if isinstance(z, Assignment):
+        zp, za = None, z.h
+    else:
+        z = _u8(z, cs.m * 32)
+        zp, za = _ptr(z), None
+    ctx._check(ctx.lib.L.zkhip_prove_g16_partial(ctx.h, pk_shard.h, cs.h, zp, za, _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm)))
+    return (out, tm.as_dict()) if want_timings else out
+
+
+def combine_g16(ctx, pk, partials, r, s):
+    """Adds the ranks' partial records (list of uint8 arrays) and assembles the proof."""
+    nb = FQ_BYTES[pk.curve_id]
+    buf = np.ascontiguousarray(np.concatenate([_u8(p) for p in partials]))
+    rb = np.frombuffer(int(r).to_bytes(32, "little"), dtype=np.uint8)
+    sb = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8)
+    out = np.zeros(8 * nb + 3, dtype=np.uint8)
+    ctx._check(ctx.lib.L.zkhip_combine_g16(ctx.h, pk.h, len(partials), _ptr(buf), _ptr(rb), _ptr(sb), _ptr(out)))
+    return out.tobytes()
 
 
 def setup_g16(ctx, cs, toxic, g1=None, g2=None):

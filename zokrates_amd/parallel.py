@@ -1,7 +1,9 @@
 """One process per GPU: the rank plumbing of bench.py (and of a multi-GPU prover service).
 
-The Groth16 hot path shards by independent proofs: every rank holds the full proving key and proves its own witnesses,
-so there is no data-path collective — only a barrier around the timed region and a MAX reduction of the elapsed time.
+Throughput mode: the Groth16 hot path shards by independent proofs — every rank holds the full proving key and proves
+its own witnesses, no data-path collective, only a barrier around the timed region and a MAX reduction of the elapsed
+time.  Latency mode (`prove_sharded`): ONE proof over all ranks — every rank holds 1/world of the bases, computes the
+partial sums of the five MSMs, and the ranks all-gather one 768-byte record each.
 `backend="nccl"` (= RCCL on ROCm) on GPUs; `backend="gloo"` lets the same code run in CPU tests.
 """
 import os
@@ -19,7 +21,8 @@ class Ranks:
             import torch
             import torch.distributed as dist
             self._torch, self._dist = torch, dist
-            self.backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            # ZKHIP_DIST_BACKEND=gloo: test hook for boxes with fewer GPUs than ranks (RCCL wants one device per rank)
+            self.backend = backend or os.environ.get("ZKHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if self.backend == "nccl":
@@ -52,6 +55,20 @@ class Ranks:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return float(t.item())
 
+    def all_gather_bytes(self, record):
+        """Every rank contributes one fixed-size uint8 record; returns the list of all ranks' records (rank order).
+        On GPUs this is an RCCL all-gather of device tensors over xGMI; the records are a few hundred bytes."""
+        import numpy as np
+        record = np.ascontiguousarray(record, dtype=np.uint8)
+        if self._dist is None:
+            return [record]
+        torch = self._torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        mine = torch.from_numpy(record.copy()).to(dev)
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(out, mine)
+        return [t.cpu().numpy() for t in out]
+
     def witness_seed(self, step):
         """Distinct witnesses per (rank, step): ranks never prove the same statement twice."""
         return 0x5EED0000 + self.rank * 1000 + step
@@ -60,3 +77,12 @@ class Ranks:
         if self._dist is not None:
             self._dist.destroy_process_group()
             self._dist = None
+
+
+def prove_sharded(ranks, ctx, pk_shard, cs, z, r, s):
+    """One proof across all ranks.  `pk_shard` = native.ProvingKey(..., rank=ranks.rank, world=ranks.world); z, r, s are
+    the same on every rank.  Every rank returns the (identical) proof bytes."""
+    from . import native
+    part = native.prove_g16_partial(ctx, pk_shard, cs, z, r, s)
+    parts = ranks.all_gather_bytes(part)
+    return native.combine_g16(ctx, pk_shard, parts, r, s)
