@@ -26,7 +26,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from zokrates_amd import native, parallel, synth  # noqa: E402
+import importlib  # noqa: E402
+
+_pkg = os.environ.get("ZKHIP_PKG", "zokrates_amd")   # development hook: A/B two builds of the library on the same box
+native, parallel, synth = (importlib.import_module(_pkg + "." + m) for m in ("native", "parallel", "synth"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 

@@ -9,7 +9,10 @@
 // in a container without a GPU.  That build produces tests/_emu/libzkhip_emu.so, never
 // libzkhip.so, and is loaded only by tests.
 #pragma once
+#include <algorithm>
 #include <cstddef>
+#include <mutex>
+#include <unordered_map>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -45,17 +48,42 @@ inline int dev_count() {
     return n;
 }
 inline void dev_set(int d) { ZK_HIP_CHECK(hipSetDevice(d)); }
-// Device allocations are rounded up to whole 2 MiB pages: the runtime then backs every buffer with large pages whatever
-// the order and sizes of the other allocations (with odd sizes the latency-bound fold kernels ran up to 2x slower in
-// some builds — same device code, different allocation pattern).
+// Device allocations.  Two measured effects on MI355X, both on the latency-bound fold kernels (same device code, run times
+// differing by 2x between allocation patterns):
+//  * buffers whose sizes are not multiples of 2 MiB can end up on small pages -> every allocation is a whole number of
+//    2 MiB pages;
+//  * buffers that all START on a 2 MiB boundary alias each other in the caches / memory channels (the fold kernels walk
+//    five or six of them in lock step) -> each allocation is handed out at a different offset (a multiple of 4352 B =
+//    17 x 256 B) inside its first page.
+struct DevAllocTable {
+    std::mutex mu;
+    std::unordered_map<void*, void*> base_of;   // pointer handed out -> pointer hipMalloc returned
+    unsigned counter = 0;
+};
+inline DevAllocTable& dev_alloc_table() {
+    static DevAllocTable t;
+    return t;
+}
 inline void* dev_alloc(size_t bytes) {
-    void* p = nullptr;
-    const size_t page = (size_t)2 << 20;
-    ZK_HIP_CHECK(hipMalloc(&p, bytes <= 4096 ? 4096 : (bytes + page - 1) / page * page));
+    const size_t page = (size_t)2 << 20, slots = 61;
+    static const size_t step = getenv("ZKHIP_ALLOC_STEP") ? (size_t)atol(getenv("ZKHIP_ALLOC_STEP")) / 256 * 256 : 4352;
+    DevAllocTable& t = dev_alloc_table();
+    std::lock_guard<std::mutex> lock(t.mu);
+    const size_t offset = (size_t)(t.counter++ % slots) * step;
+    void* base = nullptr;
+    ZK_HIP_CHECK(hipMalloc(&base, (std::max<size_t>(bytes, 1) + offset + page - 1) / page * page));
+    void* p = (char*)base + offset;
+    t.base_of[p] = base;
     return p;
 }
 inline void dev_free(void* p) {
-    if (p) (void)hipFree(p);
+    if (!p) return;
+    DevAllocTable& t = dev_alloc_table();
+    std::lock_guard<std::mutex> lock(t.mu);
+    auto it = t.base_of.find(p);
+    if (it == t.base_of.end()) return;
+    (void)hipFree(it->second);
+    t.base_of.erase(it);
 }
 inline void* host_alloc_pinned(size_t bytes) {
     void* p = nullptr;
