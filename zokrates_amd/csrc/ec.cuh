@@ -40,20 +40,28 @@ ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F>& p) {
 }
 
 // 2*(x, y) for an affine point (mdbl-2008-s-1)
+// Product / square with a per-call-site inlining policy: HOT call sites (the accumulation kernel) always inline the Fq2
+// product; elsewhere the curve's default applies (UCfg::FQ2_INLINE — BLS12-381 keeps it out of line in the cold kernels,
+// whose fully inlined form takes minutes to compile).
+template <bool HOT, class F> ZK_HD F ecm(const F& a, const F& b) { return ec_mul(a, b); }
+template <bool HOT, class F> ZK_HD F ecs(const F& a) { return ec_sqr(a); }
+template <bool HOT, class P> ZK_HD Fu2<P> ecm(const Fu2<P>& a, const Fu2<P>& b) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_mul_inl(a, b) : fu2_mul_call(a, b); }
+template <bool HOT, class P> ZK_HD Fu2<P> ecs(const Fu2<P>& a) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_sqr_inl(a) : fu2_sqr_call(a); }
+
 // Bounds for the unsaturated field (fieldu.cuh): products come out < 2p; the comments "< kp" track the integer values so
 // that every sub<K> has value(b) < K*p and every stored coordinate stays < 8p (X < 3p after fe_relax, Y < 4p, ZZ/ZZZ < 2p).
 // For the saturated field sub<K> is the plain modular subtraction and fe_relax the identity.
-template <class F>
+template <bool HOT = false, class F>
 ZK_HD Xyzz<F> xyzz_dbl_affine_inl(const Aff<F>& p) {
     if (p.is_inf() || fe_is_zero_modp(p.y)) return Xyzz<F>::inf();
     F U = fe_dbl(p.y);                                   // < 2p (affine coordinates are canonical-sized)
-    F V = ec_sqr(U);
-    F W = ec_mul(U, V);
-    F S = ec_mul(p.x, V);
-    F X2 = ec_sqr(p.x);
+    F V = ecs<HOT>(U);
+    F W = ecm<HOT>(U, V);
+    F S = ecm<HOT>(p.x, V);
+    F X2 = ecs<HOT>(p.x);
     F M = fe_add(fe_dbl(X2), X2);                        // < 6p
-    F X3 = fe_relax(fe_sub_k<4>(ec_sqr(M), fe_dbl(S)));  // 2S < 4p
-    F Y3 = fe_sub_k<2>(ec_mul(M, fe_sub_k<4>(S, X3)), ec_mul(W, p.y));   // < 4p
+    F X3 = fe_relax(fe_sub_k<4>(ecs<HOT>(M), fe_dbl(S)));  // 2S < 4p
+    F Y3 = fe_sub_k<2>(ecm<HOT>(M, fe_sub_k<4>(S, X3)), ecm<HOT>(W, p.y));   // < 4p
     return {X3, Y3, V, W};
 }
 template <class F>
@@ -158,25 +166,25 @@ ZK_HD_CALL Aff<F> xyzz_to_affine(const Xyzz<F>& p) {
 // Everything is inlined, including the exceptional cases (equal or opposite x): an out-of-line call would
 // force the accumulator through scratch memory (its address escapes), which costs more than the few extra
 // instructions of a doubling that is almost never executed.
-template <class F>
+template <bool HOT = false, class F>
 ZK_HD void xyzz_madd_acc(Xyzz<F>& a, const Aff<F>& p) {   // a += p, p affine and not infinity
     if (a.is_inf()) {
         a.x = p.x; a.y = p.y; a.zz = F::one(); a.zzz = F::one();
         return;
     }
-    F Pp = fe_sub_k<4>(ec_mul(p.x, a.zz), a.x);           // X1 < 3p;  Pp < 6p
-    F R = fe_sub_k<4>(ec_mul(p.y, a.zzz), a.y);           // Y1 < 4p;  R < 6p
+    F Pp = fe_sub_k<4>(ecm<HOT>(p.x, a.zz), a.x);           // X1 < 3p;  Pp < 6p
+    F R = fe_sub_k<4>(ecm<HOT>(p.y, a.zzz), a.y);           // Y1 < 4p;  R < 6p
     if (fe_is_zero_modp(Pp)) {
-        a = fe_is_zero_modp(R) ? xyzz_dbl_affine_inl(p) : Xyzz<F>::inf();
+        a = fe_is_zero_modp(R) ? xyzz_dbl_affine_inl<HOT>(p) : Xyzz<F>::inf();
         return;
     }
-    F PP = ec_sqr(Pp);
-    F PPP = ec_mul(Pp, PP);
-    F Q = ec_mul(a.x, PP);
-    a.zz = ec_mul(a.zz, PP);
-    a.zzz = ec_mul(a.zzz, PPP);
-    F X3 = fe_relax(fe_sub_k<4>(fe_sub_k<2>(ec_sqr(R), PPP), fe_dbl(Q)));   // < 2 + 2 + 4 = 8p before, < 3p after
-    a.y = fe_sub_k<2>(ec_mul(R, fe_sub_k<4>(Q, X3)), ec_mul(a.y, PPP));       // < 4p
+    F PP = ecs<HOT>(Pp);
+    F PPP = ecm<HOT>(Pp, PP);
+    F Q = ecm<HOT>(a.x, PP);
+    a.zz = ecm<HOT>(a.zz, PP);
+    a.zzz = ecm<HOT>(a.zzz, PPP);
+    F X3 = fe_relax(fe_sub_k<4>(fe_sub_k<2>(ecs<HOT>(R), PPP), fe_dbl(Q)));   // < 2 + 2 + 4 = 8p before, < 3p after
+    a.y = fe_sub_k<2>(ecm<HOT>(R, fe_sub_k<4>(Q, X3)), ecm<HOT>(a.y, PPP));       // < 4p
     a.x = X3;
 }
 template <class F>

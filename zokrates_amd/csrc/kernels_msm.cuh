@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(const Aff<F>* __restrict
             do { ++cur; end = off[cur + 1]; } while (end <= pos);
         }
         if (e & 0x80000000u) pt.y = fe_neg(pt.y);
-        if (!pt.is_inf()) xyzz_madd_acc(acc, pt);
+        if (!pt.is_inf()) xyzz_madd_acc<true>(acc, pt);
         e = e_next;
         pt = pt_next;
     }
