@@ -30,6 +30,8 @@ namespace zk {
 template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3; static constexpr u32 SLICE = 32; };
 template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; static constexpr u32 SLICE = 16; };
 template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; static constexpr u32 SLICE = 32; };
+template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3; static constexpr u32 SLICE = 32; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2; static constexpr u32 SLICE = 32; };
 
 // The kernels below work on points over the UNSATURATED field types of fieldu.cuh (Fu / Fu2); only the window sums
 // leaving k_msm_fold_final go back to the saturated Montgomery form the host code uses.
