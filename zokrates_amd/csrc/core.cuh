@@ -845,7 +845,7 @@ struct Prover {
         memset(&acc, 0, sizeof(acc));
         const auto t0 = std::chrono::steady_clock::now();
         try {
-            for (u32 i = 0; i <= count; ++i) {
+            for (u32 i = 0; i < count + ZK_NSLOTS - 1; ++i) {
                 if (i < count)
                     enqueue(ctx, ctx->slots[i % ZK_NSLOTS], pk, cs, z_host ? z_host + (size_t)i * pk->m * 32 : nullptr, z_host ? nullptr : z_dev[i],
                             rs + (size_t)i * 64, rs + (size_t)i * 64 + 32);
