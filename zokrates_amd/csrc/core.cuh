@@ -12,6 +12,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/zkhip.h"
@@ -741,12 +742,14 @@ struct Prover {
         const int Wmax = std::max(shz.W, shh.W) + 1;
         const Xyzz<Fq>* h_ws1 = (const Xyzz<Fq>*)sl.h_ws;
         const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
+        // five independent Horner chains (W x c doublings each): one host thread per MSM, the G2 chain on this one
         Sums g;
-        g.a = msm_combine(&h_ws1[0 * Wmax], shz);
-        g.b1 = msm_combine(&h_ws1[1 * Wmax], shz);
-        g.l = msm_combine(&h_ws1[2 * Wmax], shz);
-        g.h = msm_combine(&h_ws1[3 * Wmax], shh);
+        std::thread ta([&] { g.a = msm_combine(&h_ws1[0 * Wmax], shz); });
+        std::thread tb([&] { g.b1 = msm_combine(&h_ws1[1 * Wmax], shz); });
+        std::thread tl([&] { g.l = msm_combine(&h_ws1[2 * Wmax], shz); });
+        std::thread th([&] { g.h = msm_combine(&h_ws1[3 * Wmax], shh); });
         g.b2 = msm_combine(h_ws2, shz);
+        ta.join(); tb.join(); tl.join(); th.join();
         return g;
     }
     // ---- K9: C = s*A + r*B1 - rs*delta_1 + L + H   (App. A.3; alpha/beta/delta terms already inside A, B1, B2)
@@ -760,9 +763,14 @@ struct Prover {
         Aff<Fq> d1;
         memcpy(&d1, dec, sizeof(d1));
         d1 = PkLoader<C>::to_mont_point(d1);
-        Xyzz<Fq> gC = xyzz_mul_limbs(gA, ss.v, Fr::N);
-        gC = xyzz_add(gC, xyzz_mul_limbs(gB1, rr.v, Fr::N));
-        gC = xyzz_add(gC, xyzz_neg(xyzz_mul_limbs(Xyzz<Fq>::from_affine(d1), rs.v, Fr::N)));
+        // three independent 254-bit scalar multiplications
+        Xyzz<Fq> sA, rB1, rsD;
+        std::thread t1([&] { sA = xyzz_mul_limbs(gA, ss.v, Fr::N); });
+        std::thread t2([&] { rB1 = xyzz_mul_limbs(gB1, rr.v, Fr::N); });
+        rsD = xyzz_mul_limbs(Xyzz<Fq>::from_affine(d1), rs.v, Fr::N);
+        t1.join(); t2.join();
+        Xyzz<Fq> gC = xyzz_add(sA, rB1);
+        gC = xyzz_add(gC, xyzz_neg(rsD));
         gC = xyzz_add(gC, gL);
         gC = xyzz_add(gC, gH);
         Aff<Fq> pa = xyzz_to_affine(gA), pc = xyzz_to_affine(gC);

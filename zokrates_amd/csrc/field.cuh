@@ -159,8 +159,51 @@ ZK_HD Fe<P> fe_dbl(const Fe<P>& a) {
 
 // Montgomery product a*b*R^{-1} mod p.  CIOS with the "spare top bit" simplification
 // (valid because 2p < 2^(32N) for all four moduli): per outer iteration 2N v_mad_u64_u32.
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device form: product scanning with a 96-bit column accumulator; the carry out of every v_mad_u64_u32 goes straight
+// into the third word (v_addc_co_u32) instead of through the compiler's 64-bit add sequences.  Same result as the
+// portable CIOS below (tools/femul_bench.hip: bit-identical, 125 vs 87 G mul/s on MI355X).
+__device__ __forceinline__ void fe_mac3(u64& acc, u32& ext, u32 a, u32 b) {
+    u64 carry;
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %0\n\tv_addc_co_u32_e64 %2, %1, 0, %2, %1" : "+v"(acc), "=&s"(carry), "+v"(ext) : "v"(a), "v"(b));
+}
+template <class P>
+__device__ __forceinline__ Fe<P> fe_mul_device(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int N = P::N;
+    u32 m[N];
+    Fe<P> r;
+    u64 acc = 0;
+    u32 ext = 0;
+    ZK_UNROLL for (int k = 0; k < N; ++k) {
+        ZK_UNROLL for (int i = 0; i < k; ++i) {
+            fe_mac3(acc, ext, a.v[i], b.v[k - i]);
+            fe_mac3(acc, ext, m[i], P::mod(k - i));
+        }
+        fe_mac3(acc, ext, a.v[k], b.v[0]);
+        m[k] = (u32)acc * P::INV;
+        fe_mac3(acc, ext, m[k], P::mod(0));
+        acc = (acc >> 32) | ((u64)ext << 32);
+        ext = 0;
+    }
+    ZK_UNROLL for (int k = N; k < 2 * N - 1; ++k) {
+        ZK_UNROLL for (int i = k - N + 1; i < N; ++i) {
+            fe_mac3(acc, ext, a.v[i], b.v[k - i]);
+            fe_mac3(acc, ext, m[i], P::mod(k - i));
+        }
+        r.v[k - N] = (u32)acc;
+        acc = (acc >> 32) | ((u64)ext << 32);
+        ext = 0;
+    }
+    r.v[N - 1] = (u32)acc;
+    fe_reduce_once(r);
+    return r;
+}
+#endif
 template <class P>
 ZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_mul_device(a, b);
+#else
     constexpr int N = P::N;
     u32 t[N];
     ZK_UNROLL for (int i = 0; i < N; ++i) t[i] = 0;
@@ -184,6 +227,7 @@ ZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
     ZK_UNROLL for (int i = 0; i < N; ++i) r.v[i] = t[i];
     fe_reduce_once(r);
     return r;
+#endif
 }
 template <class P>
 ZK_HD Fe<P> fe_sqr(const Fe<P>& a) {
