@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Groth16 proofs/sec on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-domain 20] [--curve bn128] [--kind dense]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-domain 20] [--curve bn128] [--kind dense] [--scheme g16]
 
 A "step" is one Groth16 proof (sparse mat-vec, 7 NTTs, 5 MSMs, assembly) of the synthetic 2^20-constraint BN254
 circuit of BASELINE.json configs[1].  The proving key, the constraint system and the assignments are
@@ -9,6 +9,9 @@ resident in HBM when the timed region starts; every step uses a different (witne
 call of `zkhip_prove_g16_resident_batch` over the K steps — the library keeps two proofs in flight (steady-state
 proofs/sec, the headline metric); `single_proof_ms` is the latency of an isolated `zkhip_prove_g16_resident` call.  With N > 1 every rank proves its own K proofs on its own GPU with a full copy of
 the key (independent proofs: no data-path collective; "weak" scaling) and `value` is N*K / max-over-ranks time.
+
+`--scheme gm17` runs BASELINE.json configs[4] instead (the same circuit through the GM17 prover: R1CS -> SAP on the
+device, 5 NTTs over the twice-larger domain, 5 MSMs over the extended assignment); the default line is Groth16.
 
 Besides the contract fields the JSON line carries
   roofline     — the dominant kernel's algorithmic bytes per launch / its HIP-event-measured duration vs 8 TB/s
@@ -34,9 +37,12 @@ native, parallel, synth = (importlib.import_module(_pkg + "." + m) for m in ("na
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def make_proving_key(ctx, cs, circ, curve_id):
-    """Groth16 setup for the synthetic circuit with fixed toxic waste, on the GPU (zkhip_setup_g16)."""
-    return native.setup_g16(ctx, cs, synth.toxic_waste(curve_id, 0xC0FFEE))
+def make_proving_key(ctx, cs, circ, curve_id, scheme="g16"):
+    """Setup for the synthetic circuit with fixed toxic waste, on the GPU (zkhip_setup_g16 / zkhip_setup_gm17)."""
+    tox = synth.toxic_waste(curve_id, 0xC0FFEE)
+    if scheme == "gm17":
+        return native.setup_gm17(ctx, cs, (tox[0], tox[1], tox[2], tox[4]))   # alpha, beta, gamma, t
+    return native.setup_g16(ctx, cs, tox)
 
 
 def cpu_baseline(circ, pk_bytes, z, budget_s):
@@ -68,6 +74,7 @@ def main():
     ap.add_argument("--log-domain", type=int, default=20)
     ap.add_argument("--curve", default="bn128")
     ap.add_argument("--kind", default="dense")
+    ap.add_argument("--scheme", default="g16", choices=["g16", "gm17"])
     ap.add_argument("--witnesses", type=int, default=2, help="distinct assignments kept resident and cycled")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
@@ -81,10 +88,11 @@ def main():
     circ = synth.circuit(curve_id, args.log_domain, kind=args.kind)
     cs = native.ConstraintSystem(ctx, curve_id, circ.n, circ.l, circ.w, circ.mats())
     t0 = time.time()
-    pk_bytes = make_proving_key(ctx, cs, circ, curve_id)
+    gm17 = args.scheme == "gm17"
+    pk_bytes = make_proving_key(ctx, cs, circ, curve_id, args.scheme)
     t_setup = time.time() - t0
     t0 = time.time()
-    pk = native.ProvingKey(ctx, curve_id, pk_bytes)
+    pk = native.ProvingKey(ctx, curve_id, pk_bytes, scheme=args.scheme)
     t_pkload = time.time() - t0
     nw = max(1, min(args.witnesses, args.steps + args.warmup))
     zs = [circ.assignment(ranks.witness_seed(i)) for i in range(nw)]
@@ -93,30 +101,40 @@ def main():
     t_h2d = (time.time() - t0) / nw
 
     def rs(i):
+        if gm17:   # d1, d2, r
+            return 0x1111111111111111 * (i + 1) + rank, 0x3333333333333333 * (i + 2) + rank, 0x2222222222222222 * (i + 3) + rank
         return 0x1111111111111111 * (i + 1) + rank, 0x2222222222222222 * (i + 3) + rank
 
+    if gm17:
+        prove_one = lambda a, rnd: native.prove_gm17(ctx, pk, cs, a, *rnd, want_timings=True)
+        prove_many = lambda aa, rnds: native.prove_gm17_resident_batch(ctx, pk, cs, aa, rnds)
+    else:
+        prove_one = lambda a, rnd: native.prove_g16_resident(ctx, pk, cs, a, *rnd, want_timings=True)
+        prove_many = lambda aa, rnds: native.prove_g16_resident_batch(ctx, pk, cs, aa, rnds)
     single = []
     for i in range(args.warmup):
-        _, tm1 = native.prove_g16_resident(ctx, pk, cs, resident[i % nw], *rs(i), want_timings=True)
+        _, tm1 = prove_one(resident[i % nw], rs(i))
         single.append(tm1["total_ms"])
     if args.warmup:   # warm the pipelined path too (second slot's workspaces)
-        native.prove_g16_resident_batch(ctx, pk, cs, [resident[i % nw] for i in range(2)], [rs(100 + i) for i in range(2)])
+        prove_many([resident[i % nw] for i in range(2)], [rs(100 + i) for i in range(2)])
     steps = [args.warmup + i for i in range(args.steps)]
     barrier_sync()
     t_begin = time.perf_counter()
-    proofs, acc = native.prove_g16_resident_batch(ctx, pk, cs, [resident[j % nw] for j in steps], [rs(j) for j in steps])
+    proofs, acc = prove_many([resident[j % nw] for j in steps], [rs(j) for j in steps])
     barrier_sync()
     elapsed = time.perf_counter() - t_begin
     elapsed = ranks.max_over_ranks(elapsed)
     # isolated single-proof latency (not part of the timed region)
     for i in range(3):
-        _, tm1 = native.prove_g16_resident(ctx, pk, cs, resident[i % nw], *rs(200 + i), want_timings=True)
+        _, tm1 = prove_one(resident[i % nw], rs(200 + i))
         single.append(tm1["total_ms"])
     single_ms = min(single)
 
     avg = {k: v / args.steps for k, v in acc.items()}
     # ---- roofline of the dominant kernel (HIP events on the library's stream, inside the timed region)
     m, N = circ.m, circ.N
+    if gm17:   # the MSMs run over the SAP variables and the SAP domain
+        m, N = pk.m, pk.hlen - 1
     fq = native.FQ_BYTES[curve_id]
     kernels = {
         # algorithmic bytes per launch: bases read once + the 32-B scalars they pair with (SURVEY.md §8d (iv)+(v))
@@ -129,12 +147,12 @@ def main():
     # separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — measured offline, same workload
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.log_domain == 20 and args.curve == "bn128" and args.kind == "dense":
+    if os.path.exists(pmc_path) and args.log_domain == 20 and args.curve == "bn128" and args.kind == "dense" and not gm17:
         with open(pmc_path) as f:
             traffic = json.load(f).get("G2" if "G2" in name else "G1", {}).get("traffic_bytes_per_launch")
     # the honest bound of this kernel: mixed additions per second against the multiplier-limited rate of the same
     # kernel on synthetic data (tools/accum_bench.hip); W signed windows, one mixed addition per non-zero digit
-    shape_w = {20: 17}.get(args.log_domain)
+    shape_w = {20: 16 if gm17 else 17}.get(args.log_domain)
     compute = None
     if shape_w and args.curve == "bn128":
         madds = (((m + 2) if "G2" in name else (3 * (m + 2) + N)) * shape_w)
@@ -147,13 +165,16 @@ def main():
                 "compute_bound": compute,
                 "note": "bucket accumulation is bound by integer-multiply issue (Montgomery products), not by HBM; durations are "
                         "HIP-event intervals on the MSM streams inside the timed region, where the five MSMs overlap"}
-    b_alg = proof_algorithmic_bytes(circ, fq)
+    b_alg = gm17_algorithmic_bytes(circ, fq, m, N) if gm17 else proof_algorithmic_bytes(circ, fq)
+    workload = (f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints, {args.curve} GM17 (SAP: {m} variables, domain {N}), "
+                f"5 NTTs + 5 MSMs per proof") if gm17 else (
+        f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints (QAP domain 2^{args.log_domain}), "
+        f"{args.curve} Groth16, 7 NTTs + 5 MSMs per proof")
     out = {
-        "metric": "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
+        "metric": "gm17_proofs_per_sec" if gm17 else "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints (QAP domain 2^{args.log_domain}), "
-                               f"{args.curve} Groth16, 7 NTTs + 5 MSMs per proof", "curve": args.curve, "constraints": circ.n,
+        "config": {"workload": workload, "curve": args.curve, "constraints": circ.n,
                    "variables": m, "domain": N, "parallelism": f"{world} independent prover(s), full key per GPU"},
         "single_proof_ms": single_ms, "phases_ms": avg,
         "whole_proof_hbm": {"algorithmic_bytes": b_alg, "achieved_GBs": b_alg / (elapsed / args.steps) / 1e9,
@@ -162,7 +183,7 @@ def main():
         "host_ms": {"setup_gpu": 1000 * t_setup, "pk_load": 1000 * t_pkload, "assignment_h2d": 1000 * t_h2d},
         "device": ctx.describe(),
     }
-    if world > 1:
+    if world > 1 and not gm17:
         # latency mode: ONE proof sharded over all ranks (1/world of the bases per GPU, RCCL all-gather of the partial
         # records); reported next to the throughput metric, never instead of it
         try:
@@ -180,7 +201,7 @@ def main():
                                            "exchange": "all-gather of one %d-byte record per rank" % native.partial_size(ctx, curve_id)}
         except Exception as e:  # the throughput line must survive a failure of the optional leg
             out["sharded_single_proof"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and not gm17:
         base, cpu_proof = cpu_baseline(circ, pk_bytes, zs[0], args.cpu_seconds)
         out["cpu_baseline"] = base
         # same inputs -> byte-identical proof (the CPU leg doubles as a full-size parity check)
@@ -189,7 +210,7 @@ def main():
         out["cpu_baseline"]["gpu_proof_identical"] = bool(gpu_proof == cpu_proof and all(p == cpu_proof for p in batch_proof))
         out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
     elif rank == 0:
-        out["cpu_baseline"] = None
+        out["cpu_baseline"] = None   # N > 1, --cpu-seconds 0, or GM17 (oracle/gm17.py is a python big-int checker, not a timed port)
     if rank == 0:
         print(json.dumps(out), flush=True)
     ranks.close()
@@ -205,6 +226,18 @@ def proof_algorithmic_bytes(circ, fq):
     bases = (N - 1) * 2 * fq + w * 2 * fq + 2 * m * 2 * fq + m * 4 * fq
     scalars = N * F + w * F + 3 * m * F
     return matvec + transforms + bases + scalars
+
+
+def gm17_algorithmic_bytes(circ, fq, M, D):
+    """The same accounting for GM17: SAP rows (matrices + z read, two D-vectors and the n + l - 1 extension written),
+    5 transforms over D, the five base sets (4 over the M SAP variables, one over D) and their scalars."""
+    F, n, m = 32, circ.n, circ.m
+    nnz = sum(int(mat[0][-1]) for mat in circ.mats())
+    rows = nnz * (F + 4) + 3 * (n + 1) * 8 + m * F + 2 * D * F + (M - m) * F
+    transforms = 5 * 2 * D * F
+    bases = 3 * M * 2 * fq + M * 4 * fq + D * 2 * fq
+    scalars = 4 * M * F + D * F
+    return rows + transforms + bases + scalars
 
 
 if __name__ == "__main__":

@@ -180,6 +180,33 @@ int32_t zkhip_setup_g16_size(const zkhip_r1cs* r1cs, uint64_t* pk_bytes);
 int32_t zkhip_setup_g16(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* toxic, const uint8_t* g1,
                         const uint8_t* g2, uint8_t* pk_out, uint64_t pk_cap);
 
+/* ---- GM17: the second proof system behind the same Backend trait (BASELINE.json config 5) ----
+ * Replaces `<Ark as Backend<T, GM17>>::generate_proof` (/root/reference/zokrates_ark/src/gm17.rs:43-78):
+ * zkhip_pk_load_gm17 stands for `ProvingKey::deserialize_unchecked` (:60-62) — `bytes` is the `proving.key` written by
+ * the reference's GM17 `setup` (:27-28; [UPSTREAM] ark_gm17::ProvingKey in `serialize_unchecked` layout: vk{h_g2,
+ * g_alpha_g1, h_beta_g2, g_gamma_g1, h_gamma_g2, query[]}, a_query[], b_query[] (G2), c_query_1[], c_query_2[],
+ * g_gamma_z, h_gamma_z (G2), g_ab_gamma_z, g_gamma2_z2, g_gamma2_z_t[]) — and zkhip_prove_gm17 for `GM17::prove`
+ * (:64; [UPSTREAM] ark_gm17::create_random_proof).  The constraint system is the same zkhip_r1cs (the R1CS -> SAP
+ * reduction happens on the device); the assignment is the same m x 32 B vector in ark order.
+ *   d1_d2_r  : the three blinding scalars (3 x 32 B) in the order ark samples them (`Fr::rand(rng)` x 3: d1, d2, r)
+ *   proof_out: as zkhip_prove_g16 (A | B | C canonical LE + 3 infinity flags); zkhip_pk_dims gives out[0] = SAP
+ *              variables (a_query len), out[1] = g_gamma2_z_t len, out[2] = c_query_1 len, out[3] = query len. */
+int32_t zkhip_pk_load_gm17(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, zkhip_pk** out);
+int32_t zkhip_prove_gm17(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z, const uint8_t* d1_d2_r,
+                         uint8_t* proof_out, zkhip_timings* timings);
+int32_t zkhip_prove_gm17_resident(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, zkhip_assignment* z,
+                                  const uint8_t* d1_d2_r, uint8_t* proof_out, zkhip_timings* timings);
+/* `count` proofs, two in flight (see zkhip_prove_g16_resident_batch); d1_d2_r: count x 96 B. */
+int32_t zkhip_prove_gm17_resident_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count,
+                                        zkhip_assignment* const* zs, const uint8_t* d1_d2_r, uint8_t* proofs_out,
+                                        zkhip_timings* timings);
+/* Replaces `GM17::circuit_specific_setup` at /root/reference/zokrates_ark/src/gm17.rs:25 ([UPSTREAM]
+ * ark_gm17::generate_parameters) with the randomness explicit: toxic = alpha, beta, gamma, t (4 x 32 B; ark's
+ * generate_random_parameters fixes gamma = 1); g1/g2 as in zkhip_setup_g16. */
+int32_t zkhip_setup_gm17_size(const zkhip_r1cs* r1cs, uint64_t* pk_bytes);
+int32_t zkhip_setup_gm17(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* toxic, const uint8_t* g1,
+                         const uint8_t* g2, uint8_t* pk_out, uint64_t pk_cap);
+
 /* Library / device description, NUL-terminated, for logs. */
 int32_t zkhip_describe(const zkhip_ctx* ctx, char* buf, size_t cap);
 

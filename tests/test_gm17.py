@@ -1,0 +1,229 @@
+"""GM17 (BASELINE.json config 5): oracle self-consistency (`-m "not gpu"`), the device path on the TEST-ONLY emulator,
+and — `-m gpu` — bit-exact parity of the HIP path through the C ABI.
+
+Reference: /root/reference/zokrates_ark/src/gm17.rs:19-78 (setup / generate_proof), verification equations
+/root/reference/zokrates_proof_systems/src/scheme/gm17.rs:168-184."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import formats, gm17
+from oracle import groth16 as g16
+from oracle.curves import groups
+from oracle.fields import BN254, BLS12_381
+from zokrates_amd import native
+
+CURVES = [BN254, BLS12_381]
+
+
+def le(vals, nb=32):
+    return np.frombuffer(b"".join(int(v).to_bytes(nb, "little") for v in vals), dtype=np.uint8)
+
+
+def csr_of(rows):
+    rp, col, val = [0], [], []
+    for row in rows:
+        for j, v in row:
+            col.append(j)
+            val.append(v)
+        rp.append(len(col))
+    return np.array(rp, dtype=np.uint64), np.array(col, dtype=np.uint32), le(val) if val else np.zeros(0, dtype=np.uint8)
+
+
+def circuit(curve, n, seed, kind="dense", extra_public=0):
+    """Synthetic chain; `extra_public` moves that many leading witness wires into the instance (l > 2) so that the
+    f_i rows of the SAP are exercised."""
+    cs, z = g16.synthetic_chain(curve, n, seed, kind)
+    if extra_public:
+        cs.l += extra_public
+        cs.w -= extra_public
+    return cs, z
+
+
+def proof_bytes(curve, proof):
+    return formats.proof_raw(curve, proof)
+
+
+# ------------------------------------------------------------------ oracle (CPU)
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_oracle_consistency(curve):
+    """O2 (ark's algorithm) == O1 (closed form), O3 accepts, a mutated proof is rejected, the proof depends on
+    (d1, d2, r) only through r + d1."""
+    cs, z = circuit(curve, 6, 21, extra_public=2)
+    assert cs.is_satisfied(z, curve.r)
+    M, D0, D = gm17.sap_shape(cs)
+    assert (M, D0, D) == (1 + 2 * 3 + cs.w + cs.n, 2 * 6 + 2 * 3 + 1, 32)
+    tox = gm17.Toxic.from_seed(curve)
+    pk, vk = gm17.setup(curve, cs, tox)
+    assert len(pk["a_query"]) == len(pk["b_query"]) == len(pk["c_query_2"]) == M
+    assert len(pk["c_query_1"]) == M - cs.l and len(pk["g_gamma2_z_t"]) == D + 1 and len(vk["query"]) == cs.l
+    rnd = random.Random(3)
+    d1, d2, r_ = (rnd.randrange(curve.r) for _ in range(3))
+    ext, h = gm17.witness_map(curve, cs, z, d1, d2)
+    assert len(ext) == M and len(h) == D + 1
+    proof = gm17.prove(curve, cs, pk, z, d1, d2, r_)
+    assert proof == gm17.trapdoor_prove(curve, cs, tox, z, d1, r_)
+    assert proof == gm17.prove(curve, cs, pk, z, (d1 + 9) % curve.r, 1, (r_ - 9) % curve.r)
+    assert gm17.verify(curve, vk, proof, z[1:cs.l])
+    G1, _ = groups(curve)
+    assert not gm17.verify(curve, vk, (proof[0], proof[1], G1.aadd(proof[2], G1.gen)), z[1:cs.l])
+    assert not gm17.verify(curve, vk, proof, [(z[1] + 1) % curve.r] + z[2:cs.l])
+
+
+def test_oracle_unsatisfied_assignment_fails_verification():
+    curve = BN254
+    cs, z = circuit(curve, 5, 22)
+    tox = gm17.Toxic.from_seed(curve)
+    pk, vk = gm17.setup(curve, cs, tox)
+    z = list(z)
+    z[-1] = (z[-1] + 1) % curve.r
+    assert not gm17.verify(curve, vk, gm17.prove(curve, cs, pk, z, 1, 2, 3), z[1:cs.l])
+
+
+# ------------------------------------------------------------------ device path (shared by emulator and GPU tests)
+def run_device_checks(ctx, curve, n, seed, kind="dense", extra_public=0):
+    cs, z = circuit(curve, n, seed, kind, extra_public)
+    tox = gm17.Toxic.from_seed(curve)
+    dcs = native.ConstraintSystem(ctx, curve.curve_id, cs.n, cs.l, cs.w, [csr_of(cs.A), csr_of(cs.B), csr_of(cs.C)])
+    raw = native.setup_gm17(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.t))
+    opk, ovk = gm17.setup(curve, cs, tox)
+    assert raw.tobytes() == gm17.pk_serialize(curve, opk)                     # setup: bit-identical key bytes
+    pk = native.ProvingKey(ctx, curve.curve_id, raw, scheme="gm17")
+    M, _, D = gm17.sap_shape(cs)
+    assert (pk.m, pk.hlen, pk.w, pk.l) == (M, D + 1, M - cs.l, cs.l)
+    zb = le(z)
+    rnd = random.Random(seed)
+    d1, d2, r_ = (rnd.randrange(curve.r) for _ in range(3))
+    want = proof_bytes(curve, gm17.trapdoor_prove(curve, cs, tox, z, d1, r_))
+    got, tm = native.prove_gm17(ctx, pk, dcs, zb, d1, d2, r_, want_timings=True)
+    assert got == want
+    assert got == proof_bytes(curve, gm17.prove(curve, cs, opk, z, d1, d2, r_))   # == ark's algorithm, term by term
+    assert gm17.verify(curve, ovk, formats.proof_from_raw(curve, got), z[1:cs.l])
+    # corner cases of the blinding: all zero; r + d1 == 0
+    assert native.prove_gm17(ctx, pk, dcs, zb, 0, 0, 0) == proof_bytes(curve, gm17.trapdoor_prove(curve, cs, tox, z, 0, 0))
+    assert native.prove_gm17(ctx, pk, dcs, zb, 5, 7, curve.r - 5) == proof_bytes(curve, gm17.trapdoor_prove(curve, cs, tox, z, 0, 0))
+    # resident assignment, batch with two proofs in flight
+    za = native.Assignment(ctx, dcs, zb)
+    assert native.prove_gm17(ctx, pk, dcs, za, d1, d2, r_) == want
+    proofs, _ = native.prove_gm17_resident_batch(ctx, pk, dcs, [za] * 3, [(d1, d2, r_), (1, 2, 3), (d1, 0, r_)])
+    assert proofs[0] == want and proofs[2] == want
+    assert proofs[1] == proof_bytes(curve, gm17.trapdoor_prove(curve, cs, tox, z, 1, 3))
+    za.close()
+    return cs, z, dcs, pk, raw
+
+
+def run_error_checks(ctx):
+    curve = BN254
+    cs, z, dcs, pk, raw = run_device_checks(ctx, curve, 5, 31)
+    with pytest.raises(native.ZkhipError) as e:
+        native.ProvingKey(ctx, 0, raw[:-1], scheme="gm17")
+    assert e.value.code == -2
+    with pytest.raises(native.ZkhipError) as e:                              # a GM17 key is not a Groth16 key
+        native.prove_g16(ctx, pk, dcs, le(z), 1, 2)
+    assert e.value.code == -1
+    with pytest.raises(native.ZkhipError) as e:                              # non-canonical blinding scalar
+        native.prove_gm17(ctx, pk, dcs, le(z), curve.r, 0, 1)
+    assert e.value.code == -1
+    zz = le(z).copy()
+    zz[0] = 2
+    with pytest.raises(native.ZkhipError) as e:
+        native.prove_gm17(ctx, pk, dcs, zz, 1, 2, 3)
+    assert e.value.code == -1
+    cs2, z2 = circuit(curve, 9, 32)                                           # key / circuit mismatch
+    dcs2 = native.ConstraintSystem(ctx, 0, cs2.n, cs2.l, cs2.w, [csr_of(cs2.A), csr_of(cs2.B), csr_of(cs2.C)])
+    with pytest.raises(native.ZkhipError) as e:
+        native.prove_gm17(ctx, pk, dcs2, le(z2), 1, 2, 3)
+    assert e.value.code == -1
+    assert native.prove_gm17(ctx, pk, dcs, le(z), 1, 2, 3)                   # the context stays usable
+
+
+# ------------------------------------------------------------------ emulator (CPU)
+@pytest.fixture(scope="module")
+def emu_ctx():
+    from emu_util import emu_library
+    c = native.Context(0, emu_library())
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_emu_gm17(emu_ctx, curve):
+    run_device_checks(emu_ctx, curve, 7, 41, extra_public=1)
+
+
+def test_emu_gm17_boolean_wires(emu_ctx):
+    run_device_checks(emu_ctx, BN254, 20, 42, kind="sha")
+
+
+def test_emu_gm17_two_pass_ntt():
+    """Force the two-pass NTT (sigma order, permuted g_gamma2_z_t) inside the GM17 prover."""
+    from emu_util import emu_library
+    os.environ["ZKHIP_NTT_SINGLE_MAX_LOG"] = "2"
+    c2 = native.Context(0, emu_library())
+    try:
+        run_device_checks(c2, BN254, 13, 43)          # D = 32 -> N1 = 4, N2 = 8
+    finally:
+        os.environ.pop("ZKHIP_NTT_SINGLE_MAX_LOG")
+        c2.close()
+
+
+def test_emu_gm17_errors(emu_ctx):
+    run_error_checks(emu_ctx)
+
+
+# ------------------------------------------------------------------ GPU parity
+@pytest.fixture(scope="module")
+def gpu_ctx():
+    c = native.Context(0)
+    assert "EMULATOR" not in c.describe()
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_gpu_gm17_small(gpu_ctx, curve):
+    run_device_checks(gpu_ctx, curve, 7, 41, extra_public=1)
+    run_device_checks(gpu_ctx, curve, 100, 44, kind="sha")
+
+
+@pytest.mark.gpu
+def test_gpu_gm17_two_pass(gpu_ctx):
+    run_device_checks(gpu_ctx, BN254, 700, 45)        # D = 2048: cols + rows passes
+
+
+@pytest.mark.gpu
+def test_gpu_gm17_errors(gpu_ctx):
+    run_error_checks(gpu_ctx)
+
+
+@pytest.mark.gpu
+def test_gpu_gm17_config5_full_size(gpu_ctx):
+    """BASELINE.json configs[4] at full size (2^20 - 2 constraints, BN254; SAP domain 2^21, ~2^21 variables) through
+    size-independent properties: the proof satisfies both verification equations under the key's own vk, it depends
+    on (d1, d2, r) only through r + d1, the pipelined batch equals isolated calls, and a different public input is rejected."""
+    from zokrates_amd import synth
+    curve = BN254
+    circ = synth.circuit(0, 20)
+    cs = native.ConstraintSystem(gpu_ctx, 0, circ.n, circ.l, circ.w, circ.mats())
+    tox = synth.toxic_waste(0)
+    raw = native.setup_gm17(gpu_ctx, cs, (tox[0], tox[1], tox[2], tox[4]))
+    pk = native.ProvingKey(gpu_ctx, 0, raw, scheme="gm17")
+    assert pk.hlen - 1 == 1 << 21 and pk.m == 1 + 2 + circ.w + circ.n
+    vk = gm17.vk_from_pk_bytes(curve, raw)
+    del raw
+    z = circ.assignment(0x5EED0001)
+    x = int.from_bytes(z[32:64].tobytes(), "little")
+    d1, d2, r_ = 0x123456789abcdef0123456789, 0xfedcba9876543210, 0x1111222233334444555566667777
+    p1 = native.prove_gm17(gpu_ctx, pk, cs, z, d1, d2, r_)
+    assert p1[-3:] == b"\0\0\0"
+    assert gm17.verify(curve, vk, formats.proof_from_raw(curve, p1), [x])
+    assert not gm17.verify(curve, vk, formats.proof_from_raw(curve, p1), [(x + 1) % curve.r])
+    assert native.prove_gm17(gpu_ctx, pk, cs, z, d1 + 77, 5, r_ - 77) == p1
+    za = native.Assignment(gpu_ctx, cs, z)
+    zb = native.Assignment(gpu_ctx, cs, circ.assignment(0x5EED0002))
+    proofs, _ = native.prove_gm17_resident_batch(gpu_ctx, pk, cs, [za, zb, za], [(d1, d2, r_), (1, 2, 3), (d1, 0, r_)])
+    assert proofs[0] == p1 and proofs[2] == p1 and proofs[1] == native.prove_gm17(gpu_ctx, pk, cs, zb, 1, 2, 3)
+    assert proofs[1] != p1

@@ -411,11 +411,13 @@ template <class F> static void write_fe(const F& mont, uint8_t* out) { F c = fe_
 // ------------------------------------------------------------------ proving key
 struct zkhip_pk {
     int curve;
+    int scheme = 0;                               // 0 = Groth16, 1 = GM17 (gm17.cuh: same five MSM lanes, other bases)
     zkhip_ctx* ctx;
     u64 m, w, l, hlen, N;
     int logN;
     DBuf a_ext, b1_ext, l_ext, b2_ext, h_sigma;   // Montgomery affine, MSM-ready
     std::vector<uint8_t> delta_g1_canon;          // for the -rs*delta_1 term of C (host)
+    std::vector<uint8_t> g_gamma2_z2_canon;       // GM17: for the rho^2 * g_gamma2_z2 term of C (host)
     // Multi-GPU sharding of ONE proof (zkhip_pk_load_g16_shard): this key holds the bases of the index ranges
     // [z_lo, z_lo + z_n) of the extended variable range [0, m+2) and [h_lo, h_lo + h_n) of the sigma-ordered h range
     // [0, N); every rank derives the same window widths from the nominal (largest) range length.
@@ -644,6 +646,7 @@ struct Prover {
     static void enqueue(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* src_dev,
                         const uint8_t* r, const uint8_t* s_) {
         require(pk->curve == C::ID && cs->curve == C::ID, ZKHIP_ERR_BAD_ARG, "curve mismatch between key and constraint system");
+        require(pk->scheme == 0, ZKHIP_ERR_BAD_ARG, "this is a GM17 proving key: use zkhip_prove_gm17");
         require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
                 "proving key does not match the constraint system (m, w or domain size)");
         require(!sl.busy, ZKHIP_ERR_DEVICE, "internal: proof slot still in flight");
@@ -697,7 +700,13 @@ struct Prover {
             empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
         }
 
-        // ---- window sums to the host, on a stream of their own so that the main stream can start the next proof
+        copy_out(ctx, sl, Wmax);
+    }
+
+    // ---- window sums to the host, on a stream of their own so that the main stream can start the next proof
+    static void copy_out(zkhip_ctx* ctx, ProofSlot& sl, int Wmax) {
+        Stream st = ctx->stream;
+        Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
         Stream so = ctx->serial ? st : ctx->out_stream;
         for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(so, sl.lanes[k].done);
         const size_t b1 = (size_t)4 * Wmax * sizeof(Xyzz<Fq>), b2 = (size_t)Wmax * sizeof(Xyzz<Fq2>);
@@ -1002,6 +1011,7 @@ struct Prover {
 }  // namespace zk
 
 #include "setup.cuh"
+#include "gm17.cuh"
 
 // ------------------------------------------------------------------ per-curve entry points
 namespace zk {
@@ -1022,6 +1032,13 @@ struct CurveOps {
     void (*msm_g2)(zkhip_ctx*, u64, const uint8_t*, const uint8_t*, uint8_t*);
     void (*field_op)(zkhip_ctx*, int field, int op, u64, const uint8_t*, const uint8_t*, uint8_t*);
     void (*setup)(zkhip_ctx*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, u64);
+    // GM17 (gm17.cuh)
+    void (*gm17_pk_load)(zkhip_ctx*, const uint8_t*, size_t, zkhip_pk*);
+    void (*gm17_prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const void*, const uint8_t*, uint8_t*, zkhip_timings*);
+    void (*gm17_prove_batch)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, u32, const uint8_t*, void* const*, const uint8_t*, uint8_t*,
+                             zkhip_timings*);
+    void (*gm17_setup)(zkhip_ctx*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, u64);
+    u64 (*gm17_key_bytes)(u64, u64, u64);
 };
 template <class C>
 static void field_op_dispatch(zkhip_ctx* ctx, int field, int op, u64 count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -1046,6 +1063,11 @@ static CurveOps make_curve_ops() {
     o.msm_g2 = &Prover<C>::template msm_api<typename C::Fq2, 4>;
     o.field_op = &field_op_dispatch<C>;
     o.setup = &Setup<C>::run;
+    o.gm17_pk_load = &Gm17<C>::load;
+    o.gm17_prove = &Gm17<C>::prove;
+    o.gm17_prove_batch = &Gm17<C>::prove_batch;
+    o.gm17_setup = &Gm17<C>::setup;
+    o.gm17_key_bytes = &Gm17<C>::key_bytes;
     return o;
 }
 const CurveOps* curve_ops_bn254();

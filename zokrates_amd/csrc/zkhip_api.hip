@@ -227,6 +227,7 @@ int32_t zkhip_combine_g16(zkhip_ctx* ctx, const zkhip_pk* pk, uint32_t count, co
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
         require(pk && partials && r && s && proof_out && count >= 1, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->scheme == 0, ZKHIP_ERR_BAD_ARG, "this is a GM17 proving key");
         ops_for(pk->curve)->combine(pk, count, partials, r, s, proof_out);
     });
 }
@@ -309,6 +310,72 @@ int32_t zkhip_setup_g16(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* t
         require(r1cs && toxic && pk_out, ZKHIP_ERR_BAD_ARG, "null argument");
         require(r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "constraint system belongs to another context");
         ops_for(r1cs->curve)->setup(ctx, r1cs, toxic, g1, g2, pk_out, pk_cap);
+    });
+}
+
+// ------------------------------------------------------------------ GM17 (config 5)
+int32_t zkhip_pk_load_gm17(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, zkhip_pk** out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(bytes && out, ZKHIP_ERR_BAD_ARG, "null argument");
+        *out = nullptr;
+        std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
+        pk->curve = curve;
+        pk->ctx = ctx;
+        ops_for(curve)->gm17_pk_load(ctx, bytes, len, pk.get());
+        *out = pk.release();
+    });
+}
+int32_t zkhip_prove_gm17(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z, const uint8_t* d1_d2_r,
+                         uint8_t* proof_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && z && d1_d2_r && proof_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
+        ops_for(pk->curve)->gm17_prove(ctx, pk, r1cs, z, nullptr, d1_d2_r, proof_out, timings);
+    });
+}
+int32_t zkhip_prove_gm17_resident(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, zkhip_assignment* z, const uint8_t* d1_d2_r,
+                                  uint8_t* proof_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && z && d1_d2_r && proof_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx && z->ctx == ctx, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
+        require(z->curve == pk->curve && z->m == r1cs->l + r1cs->w, ZKHIP_ERR_BAD_ARG, "assignment does not match the constraint system");
+        ops_for(pk->curve)->gm17_prove(ctx, pk, r1cs, nullptr, z->scalars.p, d1_d2_r, proof_out, timings);
+    });
+}
+int32_t zkhip_prove_gm17_resident_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count, zkhip_assignment* const* zs,
+                                        const uint8_t* d1_d2_r, uint8_t* proofs_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && d1_d2_r && proofs_out && (zs || count == 0), ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
+        std::vector<void*> dev(count);
+        for (uint32_t i = 0; i < count; ++i) {
+            require(zs[i] && zs[i]->ctx == ctx && zs[i]->curve == pk->curve && zs[i]->m == r1cs->l + r1cs->w, ZKHIP_ERR_BAD_ARG,
+                    "assignment does not match the constraint system");
+            dev[i] = zs[i]->scalars.p;
+        }
+        ops_for(pk->curve)->gm17_prove_batch(ctx, pk, r1cs, count, nullptr, dev.data(), d1_d2_r, proofs_out, timings);
+    });
+}
+int32_t zkhip_setup_gm17_size(const zkhip_r1cs* cs, uint64_t* pk_bytes) {
+    if (!cs || !pk_bytes) return ZKHIP_ERR_BAD_ARG;
+    try {
+        *pk_bytes = ops_for(cs->curve)->gm17_key_bytes(cs->n, cs->l, cs->w);
+    } catch (...) {
+        return ZKHIP_ERR_BAD_ARG;
+    }
+    return ZKHIP_OK;
+}
+int32_t zkhip_setup_gm17(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* toxic, const uint8_t* g1, const uint8_t* g2, uint8_t* pk_out,
+                         uint64_t pk_cap) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(r1cs && toxic && pk_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "constraint system belongs to another context");
+        ops_for(r1cs->curve)->gm17_setup(ctx, r1cs, toxic, g1, g2, pk_out, pk_cap);
     });
 }
 

@@ -52,6 +52,8 @@ class Library:
         "zkhip_prove_g16_batch", "zkhip_assignment_upload", "zkhip_assignment_free", "zkhip_prove_g16_resident", "zkhip_prove_g16_resident_batch",
         "zkhip_pk_load_g16_shard", "zkhip_partial_size", "zkhip_prove_g16_partial", "zkhip_combine_g16", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
         "zkhip_field_op", "zkhip_setup_g16_size", "zkhip_setup_g16", "zkhip_describe",
+        "zkhip_pk_load_gm17", "zkhip_prove_gm17", "zkhip_prove_gm17_resident", "zkhip_prove_gm17_resident_batch",
+        "zkhip_setup_gm17_size", "zkhip_setup_gm17",
     ]
 
     def __init__(self, path=None):
@@ -89,6 +91,12 @@ class Library:
         L.zkhip_setup_g16_size.restype = i32; L.zkhip_setup_g16_size.argtypes = [vp, vp]
         L.zkhip_setup_g16.restype = i32; L.zkhip_setup_g16.argtypes = [vp, vp, vp, vp, vp, vp, u64]
         L.zkhip_describe.restype = i32; L.zkhip_describe.argtypes = [vp, vp, sz]
+        L.zkhip_pk_load_gm17.restype = i32; L.zkhip_pk_load_gm17.argtypes = [vp, i32, vp, sz, pp]
+        L.zkhip_prove_gm17.restype = i32; L.zkhip_prove_gm17.argtypes = [vp] * 7
+        L.zkhip_prove_gm17_resident.restype = i32; L.zkhip_prove_gm17_resident.argtypes = [vp] * 7
+        L.zkhip_prove_gm17_resident_batch.restype = i32; L.zkhip_prove_gm17_resident_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        L.zkhip_setup_gm17_size.restype = i32; L.zkhip_setup_gm17_size.argtypes = [vp, vp]
+        L.zkhip_setup_gm17.restype = i32; L.zkhip_setup_gm17.argtypes = [vp, vp, vp, vp, vp, vp, u64]
         self.L = L
 
     def device_count(self):
@@ -169,14 +177,20 @@ class Context:
 class ProvingKey:
     """`zkhip_pk`: an ark `proving.key` resident on the GPU in MSM-ready layout."""
 
-    def __init__(self, ctx, curve_id, data, rank=0, world=1):
-        """world > 1: load only rank's share of the bases (one proof sharded over several GPUs)."""
+    def __init__(self, ctx, curve_id, data, rank=0, world=1, scheme="g16"):
+        """world > 1: load only rank's share of the bases (one proof sharded over several GPUs).
+        scheme = "gm17": an ark-gm17 proving key (zkhip_pk_load_gm17; m = SAP variables, hlen = len(g_gamma2_z_t))."""
         self.ctx = ctx
         self.curve_id = curve_id
         self.rank, self.world = rank, world
+        self.scheme = scheme
         data = _u8(data)
         self.h = C.c_void_p()
-        if world == 1:
+        if scheme == "gm17":
+            if world != 1:
+                raise ValueError("GM17 keys are not sharded")
+            ctx._check(ctx.lib.L.zkhip_pk_load_gm17(ctx.h, curve_id, _ptr(data), data.size, C.byref(self.h)))
+        elif world == 1:
             ctx._check(ctx.lib.L.zkhip_pk_load_g16(ctx.h, curve_id, _ptr(data), data.size, C.byref(self.h)))
         else:
             ctx._check(ctx.lib.L.zkhip_pk_load_g16_shard(ctx.h, curve_id, _ptr(data), data.size, rank, world, C.byref(self.h)))
@@ -348,5 +362,50 @@ def prove_g16_batch(ctx, pk, cs, zs, rs):
     out = np.zeros(count * (8 * nb + 3), dtype=np.uint8)
     tm = Timings()
     ctx._check(ctx.lib.L.zkhip_prove_g16_batch(ctx.h, pk.h, cs.h, count, _ptr(zs), _ptr(rsb), _ptr(out), C.byref(tm)))
+    step = 8 * nb + 3
+    return [out[i * step:(i + 1) * step].tobytes() for i in range(count)], tm.as_dict()
+
+
+# ---- GM17 (BASELINE.json config 5) ----
+def _rnd96(d1, d2, r):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in (d1, d2, r)), dtype=np.uint8)
+
+
+def setup_gm17(ctx, cs, toxic, g1=None, g2=None):
+    """GM17 setup on the GPU: `toxic` = (alpha, beta, gamma, t) ints; returns the ark-gm17-format proving key bytes."""
+    size = C.c_uint64()
+    ctx._check(ctx.lib.L.zkhip_setup_gm17_size(cs.h, C.byref(size)))
+    tb = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in toxic), dtype=np.uint8)
+    out = np.zeros(size.value, dtype=np.uint8)
+    g1p = _ptr(_u8(g1)) if g1 is not None else None
+    g2p = _ptr(_u8(g2)) if g2 is not None else None
+    ctx._check(ctx.lib.L.zkhip_setup_gm17(ctx.h, cs.h, _ptr(tb), g1p, g2p, _ptr(out), size.value))
+    return out
+
+
+def prove_gm17(ctx, pk, cs, z, d1, d2, r, want_timings=False):
+    """Raw proof bytes (8*sz(Fq)+3) for assignment z (host bytes or a resident `Assignment`) and blinding scalars d1, d2, r."""
+    nb = FQ_BYTES[pk.curve_id]
+    rnd = _rnd96(d1, d2, r)
+    out = np.zeros(8 * nb + 3, dtype=np.uint8)
+    tm = Timings()
+    if isinstance(z, Assignment):
+        ctx._check(ctx.lib.L.zkhip_prove_gm17_resident(ctx.h, pk.h, cs.h, z.h, _ptr(rnd), _ptr(out), C.byref(tm)))
+    else:
+        z = _u8(z, cs.m * 32)
+        ctx._check(ctx.lib.L.zkhip_prove_gm17(ctx.h, pk.h, cs.h, _ptr(z), _ptr(rnd), _ptr(out), C.byref(tm)))
+    return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+
+def prove_gm17_resident_batch(ctx, pk, cs, assignments, rnds):
+    """Pipelined GM17 proofs over resident assignments (may repeat); rnds: list of (d1, d2, r) ints."""
+    nb = FQ_BYTES[pk.curve_id]
+    count = len(rnds)
+    assert len(assignments) == count
+    handles = (C.c_void_p * count)(*[a.h for a in assignments])
+    rb = np.ascontiguousarray(np.concatenate([_rnd96(*t) for t in rnds])) if count else np.zeros(1, dtype=np.uint8)
+    out = np.zeros(max(count, 1) * (8 * nb + 3), dtype=np.uint8)
+    tm = Timings()
+    ctx._check(ctx.lib.L.zkhip_prove_gm17_resident_batch(ctx.h, pk.h, cs.h, count, handles, _ptr(rb), _ptr(out), C.byref(tm)))
     step = 8 * nb + 3
     return [out[i * step:(i + 1) * step].tobytes() for i in range(count)], tm.as_dict()
