@@ -207,6 +207,35 @@ int32_t zkhip_setup_gm17_size(const zkhip_r1cs* r1cs, uint64_t* pk_bytes);
 int32_t zkhip_setup_gm17(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* toxic, const uint8_t* g1,
                          const uint8_t* g2, uint8_t* pk_out, uint64_t pk_cap);
 
+/* ---- "next" row N1: ZoKrates' own input files (host only: no context, no device work) ----
+ * zkhip_prog_parse replaces `ProgEnum::deserialize` (/root/reference/zokrates_ast/src/ir/serialize.rs:306-390: header,
+ * sections, per-statement CBOR) followed by `Computation::generate_constraints`
+ * (/root/reference/zokrates_ark/src/lib.rs:80-129): `bytes` is the `out` file `zokrates compile` writes; the result is
+ * the R1CS in ark variable order — ONE, then instance variables (public arguments in argument order, `~out_k` as
+ * first seen), then witness variables (private arguments, then the others as first seen walking the A, B, C linear
+ * combinations of every constraint); duplicate variables in a combination are summed, zero coefficients dropped;
+ * directives and logs are ignored.  Errors are reported through zkhip_last_error(NULL).
+ *   zkhip_prog_dims: out[0] curve id, [1] n, [2] l, [3] w, [4] return count, [5] public arguments, [6] nnz(A)+nnz(B)+nnz(C)
+ *   zkhip_prog_matrix: CSR arrays of A (0), B (1), C (2), valid until zkhip_prog_free — the arguments of zkhip_r1cs_load
+ *   zkhip_prog_variable_order: the ZoKrates variable id of every column (0 = ~one, k > 0 = _{k-1}, -k = ~out_{k-1})
+ *   zkhip_prog_r1cs_load: zkhip_r1cs_load of those matrices
+ * zkhip_prog_assignment replaces `Witness::read` (/root/reference/zokrates_ast/src/ir/witness.rs:55-71) and the
+ * `witness.remove(..)` walk of generate_constraints: `witness` is the file `zokrates compute-witness` writes; z_out
+ * (m x 32 B, may be NULL) is the assignment in ark order — the `z` of zkhip_prove_g16 — and inputs_out (may be NULL;
+ * inputs_cap elements of 32 B) receives `public_inputs_values` (/root/reference/zokrates_ast/src/ir/mod.rs:278-288:
+ * public arguments in argument order, then ~out_0, ~out_1, ...: the `inputs` of proof.json); a variable without a value
+ * gives ZKHIP_ERR_UNSATISFIED (the reference panics with AssignmentMissing). */
+typedef struct zkhip_prog zkhip_prog;
+int32_t zkhip_prog_parse(const uint8_t* bytes, size_t len, zkhip_prog** out);
+void zkhip_prog_free(zkhip_prog* prog);
+int32_t zkhip_prog_dims(const zkhip_prog* prog, uint64_t out[8]);
+int32_t zkhip_prog_matrix(const zkhip_prog* prog, int32_t which, const uint64_t** rowptr, const uint32_t** col,
+                          const uint8_t** val);
+int32_t zkhip_prog_variable_order(const zkhip_prog* prog, const int64_t** ids);
+int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs** out);
+int32_t zkhip_prog_assignment(const zkhip_prog* prog, const uint8_t* witness, size_t len, uint8_t* z_out,
+                              uint8_t* inputs_out, uint64_t inputs_cap, uint64_t* n_inputs);
+
 /* Library / device description, NUL-terminated, for logs. */
 int32_t zkhip_describe(const zkhip_ctx* ctx, char* buf, size_t cap);
 

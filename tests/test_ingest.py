@@ -1,0 +1,274 @@
+"""`zkhip_prog_parse` / `zkhip_prog_assignment` (host-only C ABI, rows a2, a3, a5, a6 of SURVEY.md §8a) against the python
+restatement in oracle/ir.py: the `out` program file -> R1CS in ark variable order, the `witness` file -> z and the
+public inputs.  Runs on the TEST-ONLY emulator build for the CPU suite (the functions are pure host code, identical in
+libzkhip.so); the `-m gpu` test proves from the two files end to end.
+
+Reference: /root/reference/zokrates_ast/src/ir/serialize.rs:133-390, /root/reference/zokrates_ark/src/lib.rs:41-141,
+/root/reference/zokrates_ast/src/ir/witness.rs:44-71."""
+import random
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import formats, ir
+from oracle import groth16 as g16
+from oracle.fields import BN254, BLS12_381
+from zokrates_amd import native
+
+CURVES = [BN254, BLS12_381]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from emu_util import emu_library
+    return emu_library()
+
+
+def rows_of(mats, n):
+    out = []
+    for rp, col, val in mats:
+        rows = []
+        for i in range(n):
+            a, b = int(rp[i]), int(rp[i + 1])
+            cols = [int(c) for c in col[a:b]]
+            assert cols == sorted(cols) and len(set(cols)) == len(cols)          # ark keeps a row sorted, no duplicates
+            rows.append({c: int.from_bytes(val[32 * q:32 * q + 32].tobytes(), "little") for q, c in zip(range(a, b), cols)})
+        out.append(rows)
+    return tuple(out)
+
+
+def random_prog(curve, rnd, n, n_args=4, n_out=2, with_noise=True):
+    """A hand-built (non-canonical) program: duplicate variables inside a combination, zero coefficients, terms that
+    cancel, outputs first seen late and out of index order, private/public/unused arguments, directives and logs with
+    nested payloads between the constraints, spans and error annotations."""
+    r = curve.r
+    args = [ir.Parameter(id=k + 1, private=rnd.random() < 0.5) for k in range(n_args)]
+    pool = [0] + [p.id for p in args] + [-(k + 1) for k in reversed(range(n_out))] + list(range(n_args + 1, n_args + 1 + 2 * n))
+    coeff = lambda: rnd.choice([0, 1, r - 1, rnd.randrange(r), rnd.randrange(1 << 64)])
+
+    def lc():
+        t = [(rnd.choice(pool), coeff()) for _ in range(rnd.randrange(0, 5))]
+        if t and rnd.random() < 0.3:
+            v, c = t[0]
+            t.append((v, (r - c) % r))                                        # cancels -> zero after merging
+        if t and rnd.random() < 0.3:
+            t.append((t[-1][0], coeff()))                                     # duplicate variable
+        return t
+
+    stmts = []
+    for k in range(n):
+        if with_noise and rnd.random() < 0.4:
+            stmts.append(ir.Other("Directive", {"span": None, "inputs": [ir._lc(lc())], "outputs": [{"id": rnd.choice(pool)}],
+                                                "solver": {"Ref": {"index": k, "argument_count": 2}}}))
+        if with_noise and rnd.random() < 0.2:
+            stmts.append(ir.Other("Log", {"span": None, "format_string": {"parts": ["x = ", ""]}, "expressions": [["Int", [ir._lc(lc())]]]}))
+        span = (0x1234567890abcdef, (k + 1, 3), (k + 1, 300)) if rnd.random() < 0.5 else None
+        error = rnd.choice([None, "ArkConstraint", {"SourceAssertion": {"file": "main.zok", "position": {"line": 3, "col": 9}, "message": None}}])
+        stmts.append(ir.Constraint(lc(), lc(), lc(), span=span, error=error))
+    return ir.Prog(curve, args, stmts, return_count=n_out)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_parse_matches_ark_order(lib, curve):
+    rnd = random.Random(77)
+    for trial in range(12):
+        prog = random_prog(curve, rnd, n=rnd.randrange(0, 40), n_args=rnd.randrange(0, 6), n_out=rnd.randrange(0, 4))
+        p = native.Program(ir.serialize_prog(prog), lib)
+        l, w, order, rows = ir.ark_order(prog)
+        n = sum(isinstance(s, ir.Constraint) for s in prog.statements)
+        assert (p.curve_id, p.n, p.l, p.w, p.return_count) == (curve.curve_id, n, l, w, prog.return_count)
+        assert p.n_public_args == sum(not a.private for a in prog.arguments)
+        assert list(p.variable_order()) == order
+        assert rows_of(p.mats(), n) == rows
+        # witness file -> z in ark order + public_inputs_values
+        used = set(order) | {-(i + 1) for i in range(3)}
+        values = {v: (1 if v == 0 else rnd.randrange(curve.r)) for v in used}
+        z, inputs = p.assignment(ir.serialize_witness(values))
+        assert [int.from_bytes(z[32 * j:32 * j + 32].tobytes(), "little") for j in range(l + w)] == [1] + [values[v] for v in order[1:]]
+        want_inputs = ir.public_inputs_values(prog, values)
+        assert [int.from_bytes(inputs[32 * j:32 * j + 32].tobytes(), "little") for j in range(len(inputs) // 32)] == want_inputs
+        p.close()
+
+
+def test_compiler_shaped_program(lib):
+    """The shape the ZoKrates compiler emits: canonical combinations, outputs defined in index order — the instance
+    order [ONE, public args, ~out_0, ~out_1] then equals public_inputs_values (what makes a proof verify)."""
+    curve = BN254
+    r = curve.r
+    # def main(private field a, field b) -> (field, field): return a * b, a * b + b
+    prog = ir.Prog(curve, [ir.Parameter(1, True), ir.Parameter(2, False)], [
+        ir.Other("Directive", {"span": None, "inputs": [], "outputs": [{"id": 3}], "solver": "ConditionEq"}),
+        ir.Constraint([(1, 1)], [(2, 1)], [(3, 1)]),
+        ir.Constraint([(0, 1)], [(3, 1)], [(-1, 1)]),
+        ir.Constraint([(0, 1)], [(2, 1), (3, 1)], [(-2, 1)]),
+    ], return_count=2)
+    p = native.Program(ir.serialize_prog(prog), lib)
+    assert (p.n, p.l, p.w) == (3, 4, 2)
+    assert list(p.variable_order()) == [0, 2, -1, -2, 1, 3]
+    a, b = 7, 9
+    z, inputs = p.assignment(ir.serialize_witness({0: 1, 1: a, 2: b, 3: a * b, -1: a * b, -2: a * b + b}))
+    zi = [int.from_bytes(z[32 * j:32 * j + 32].tobytes(), "little") for j in range(6)]
+    assert zi == [1, b, a * b, a * b + b, a, a * b]
+    assert [int.from_bytes(inputs[32 * j:32 * j + 32].tobytes(), "little") for j in range(3)] == zi[1:4]
+    cs = g16.R1CS(l=p.l, w=p.w)
+    cs.A, cs.B, cs.C = ([list(row.items()) for row in m] for m in rows_of(p.mats(), p.n))
+    assert cs.is_satisfied(zi, r)
+
+
+def test_header_and_error_paths(lib):
+    curve = BN254
+    prog = random_prog(curve, random.Random(5), n=6, with_noise=False)
+    good = ir.serialize_prog(prog)
+    assert good[:4] == b"ZOK\0" and good[8:12] == bytes.fromhex("b4f7b5bd")     # zokrates_book/src/toolbox/ir.md:13-15
+    assert ir.curve_id_bytes(BLS12_381) == bytes.fromhex("40d8c1f9")
+
+    def err(data, code=-2):
+        with pytest.raises(native.ZkhipError) as e:
+            native.Program(data, lib)
+        assert e.value.code == code, e.value
+        return str(e.value)
+
+    assert "magic" in err(b"ZOL\0" + good[4:])
+    assert "version" in err(good[:4] + bytes([2, 0, 0, 0]) + good[8:])
+    assert "curve" in err(good[:8] + b"\x12\x34\x56\x78" + good[12:], code=-1)  # e.g. bls12_377 / bw6_761: other backends
+    err(good[:50])                                                               # truncated header
+    err(good[:130])                                  # sections point outside the file
+    bad = bytearray(good)
+    bad[12:16] = struct.pack("<I", 99)                                           # constraint count mismatch
+    assert "constraint count" in err(bytes(bad))
+    # a coefficient >= r
+    p2 = ir.Prog(curve, [], [ir.Constraint([(1, curve.r)], [(0, 1)], [(2, 1)])])
+    raw = ir.serialize_prog(p2).replace((curve.r % (1 << 256)).to_bytes(32, "little"), curve.r.to_bytes(32, "little"))
+    assert "canonical" in err(raw)
+    # witness errors
+    p = native.Program(good, lib)
+    order = list(p.variable_order())
+    values = {v: 3 for v in order}
+    p.assignment(ir.serialize_witness(values))
+    missing = dict(values)
+    del missing[order[-1]]
+    with pytest.raises(native.ZkhipError) as e:
+        p.assignment(ir.serialize_witness(missing))
+    assert e.value.code == -5 and "missing" in str(e.value)
+    with pytest.raises(native.ZkhipError) as e:
+        p.assignment(ir.serialize_witness(values)[:-1])
+    assert e.value.code == -2
+    with pytest.raises(native.ZkhipError) as e:
+        p.assignment(ir.serialize_witness({**values, order[1]: curve.r}))
+    assert e.value.code == -2
+
+
+def test_indefinite_length_cbor_is_accepted(lib):
+    """serde_cbor writes definite lengths, but a streaming producer may not: both decode to the same system."""
+    curve = BN254
+    prog = ir.Prog(curve, [ir.Parameter(1, False)], [ir.Constraint([(1, 2), (0, 5)], [(2, 1)], [(-1, 1)])], return_count=1)
+    good = ir.serialize_prog(prog)
+    st = ir.cbor(ir._statement(prog.statements[0]))
+    lcs = [ir.cbor(ir._lc(t)) for t in ([(1, 2), (0, 5)], [(2, 1)], [(-1, 1)])]
+    key = lambda s: ir.cbor(s)
+    indef_lc = lambda blob_terms: b"\xbf" + key("span") + b"\xf6" + key("value") + b"\x9f" + b"".join(
+        ir.cbor([{"id": v}, int(c).to_bytes(32, "little")]) for v, c in blob_terms) + b"\xff" + b"\xff"
+    st2 = (b"\xbf" + key("Constraint") + b"\xbf" + key("span") + b"\xf6" + key("quad") + b"\xbf" + key("span") + b"\xf6" + key("left")
+           + indef_lc([(1, 2), (0, 5)]) + key("right") + indef_lc([(2, 1)]) + b"\xff" + key("lin") + indef_lc([(-1, 1)]) + key("error") + b"\xf6"
+           + b"\xff" + b"\xff")
+    # the top-level statement map must announce one entry: keep it definite, make everything inside indefinite
+    st2 = b"\xa1" + st2[1:-1]
+    i = good.index(st)
+    raw = bytearray(good[:i] + st2 + good[i + len(st):])
+    delta = len(st2) - len(st)
+    # fix up section table: constraints length, solvers / modules offsets
+    off = 20
+    secs = [list(struct.unpack_from("<IQQ", raw, off + 20 * s)) for s in range(4)]
+    secs[1][2] += delta; secs[2][1] += delta; secs[3][1] += delta
+    for s in range(4):
+        struct.pack_into("<IQQ", raw, off + 20 * s, *secs[s])
+    a, b = native.Program(good, lib), native.Program(bytes(raw), lib)
+    assert rows_of(a.mats(), 1) == rows_of(b.mats(), 1) and list(a.variable_order()) == list(b.variable_order())
+
+
+@pytest.mark.gpu
+def test_gpu_prove_from_zokrates_files():
+    """`out` + `witness` + `proving.key` -> proof, all through the C ABI; equals the oracle's closed-form proof."""
+    from oracle import cpu
+    curve = BN254
+    ctx = native.Context(0)
+    cs_py, z = g16.synthetic_chain(curve, 200, 99)
+    # the same circuit as a ZoKrates program: x public, everything else private and discovered in first-use order
+    stmts = [ir.Constraint(list(a), list(b), list(c)) for a, b, c in zip(cs_py.A, cs_py.B, cs_py.C)]
+    # column j of the synthetic system <-> ZoKrates variable: 0 -> ~one, 1 -> _0 (public argument), j >= 2 -> _{j-1}
+    prog = ir.Prog(curve, [ir.Parameter(1, False)], stmts, return_count=0)
+    p = native.Program(ir.serialize_prog(prog))
+    assert (p.n, p.l, p.w) == (cs_py.n, cs_py.l, cs_py.w)
+    zz, inputs = p.assignment(ir.serialize_witness({j: v for j, v in enumerate(z)}))
+    order = list(p.variable_order())
+    z_ark = [z[v] for v in order]
+    dcs = p.constraint_system(ctx)
+    tox = g16.Toxic.from_seed(curve)
+    raw_pk = native.setup_g16(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau))
+    pk = native.ProvingKey(ctx, 0, raw_pk)
+    got = native.prove_g16(ctx, pk, dcs, zz, 11, 13)
+    # oracle on the ark-ordered system
+    l, w, _, rows = ir.ark_order(prog)
+    ocs = g16.R1CS(l=l, w=w)
+    ocs.A, ocs.B, ocs.C = ([list(row.items()) for row in m] for m in rows)
+    assert ocs.is_satisfied(z_ark, curve.r)
+    assert got == formats.proof_raw(curve, g16.trapdoor_prove(curve, ocs, tox, z_ark, 11, 13))
+    assert int.from_bytes(inputs.tobytes(), "little") == z[1]
+    ctx.close()
+
+
+# ------------------------------------------------------------------ the CLI shim over ZoKrates' own files
+def _cli_flow_zok(tmp_path, scheme):
+    """setup + generate-proof from `out` / `witness` (both schemes); the JSON artefacts pass the oracle's pairing check
+    with `inputs` = public arguments then outputs."""
+    import json
+    from oracle import gm17, pairing
+    from zokrates_amd import cli
+    curve = BN254
+    # def main(private field a, field b) -> (field, field): return a * b, a * b + b
+    prog = ir.Prog(curve, [ir.Parameter(1, True), ir.Parameter(2, False)], [
+        ir.Other("Directive", {"span": None, "inputs": [], "outputs": [{"id": 3}], "solver": "ConditionEq"}),
+        ir.Constraint([(1, 1)], [(2, 1)], [(3, 1)]),
+        ir.Constraint([(0, 1)], [(3, 1)], [(-1, 1)]),
+        ir.Constraint([(0, 1)], [(2, 1), (3, 1)], [(-2, 1)]),
+    ], return_count=2)
+    a, b = 1234567, 7654321
+    outp = tmp_path / "out"; wit = tmp_path / "witness"; pkp = tmp_path / "proving.key"; vkp = tmp_path / "verification.key"; pj = tmp_path / "proof.json"
+    outp.write_bytes(ir.serialize_prog(prog))
+    wit.write_bytes(ir.serialize_witness({0: 1, 1: a, 2: b, 3: a * b, -1: a * b, -2: a * b + b}))
+    cli.main(["setup", "-i", str(outp), "-p", str(pkp), "-v", str(vkp), "-s", scheme, "--entropy", "unit test"])
+    cli.main(["generate-proof", "-i", str(outp), "-w", str(wit), "-p", str(pkp), "-j", str(pj), "-s", scheme, "--entropy", "abc"])
+    proof = json.loads(pj.read_text())
+    vk = json.loads(vkp.read_text())
+    assert proof["scheme"] == vk["scheme"] == scheme and proof["curve"] == "bn128"
+    h = lambda s: int(s, 16)
+    g1 = lambda p: (h(p[0]), h(p[1]))
+    g2 = lambda p: ((h(p[0][0]), h(p[0][1])), (h(p[1][0]), h(p[1][1])))
+    pts = (g1(proof["proof"]["a"]), g2(proof["proof"]["b"]), g1(proof["proof"]["c"]))
+    inputs = [h(x) for x in proof["inputs"]]
+    assert inputs == [b, a * b, a * b + b]
+    if scheme == "g16":
+        ovk = dict(alpha_g1=g1(vk["alpha"]), beta_g2=g2(vk["beta"]), gamma_g2=g2(vk["gamma"]), delta_g2=g2(vk["delta"]),
+                   gamma_abc_g1=[g1(p) for p in vk["gamma_abc"]])
+        check = lambda inp: pairing.groth16_verify(curve, ovk, pts, inp)
+    else:
+        assert list(vk)[:2] == ["scheme", "curve"] and list(vk)[2:] == ["h", "g_alpha", "h_beta", "g_gamma", "h_gamma", "query"]
+        ovk = dict(h_g2=g2(vk["h"]), g_alpha_g1=g1(vk["g_alpha"]), h_beta_g2=g2(vk["h_beta"]), g_gamma_g1=g1(vk["g_gamma"]),
+                   h_gamma_g2=g2(vk["h_gamma"]), query=[g1(p) for p in vk["query"]])
+        check = lambda inp: gm17.verify(curve, ovk, pts, inp)
+    assert check(inputs)
+    assert not check([inputs[0], inputs[1], inputs[2] + 1])
+
+
+@pytest.mark.parametrize("scheme", ["g16", "gm17"])
+def test_cli_zokrates_files_on_emulator(tmp_path, monkeypatch, scheme):
+    from emu_util import emu_library
+    monkeypatch.setattr(native, "_default", emu_library())
+    _cli_flow_zok(tmp_path, scheme)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme", ["g16", "gm17"])
+def test_cli_zokrates_files_on_gpu(tmp_path, scheme):
+    _cli_flow_zok(tmp_path, scheme)

@@ -2,10 +2,14 @@
 /root/reference/zokrates_cli/src/ops/{setup,generate_proof}.rs over tool-neutral inputs (.r1cs / .wtns as written by
 `zokrates export-r1cs`-style tooling, zokrates_circom), producing ark-format `proving.key`, and `verification.key` /
 `proof.json` in ZoKrates' JSON.  Public inputs are listed in wire order (outputs, then public arguments), the order of
-the key's gamma_abc.  Needs a gfx950 GPU (there is no CPU fallback).
+the key's gamma_abc.  The inputs may also be ZoKrates' own files — the `out` program of `zokrates compile` and the
+`witness` of `zokrates compute-witness` (recognised by their magic bytes) — read by `zkhip_prog_parse` /
+`zkhip_prog_assignment` in ark variable order; `inputs` of proof.json is then `public_inputs_values` (public arguments,
+then outputs) as in /root/reference/zokrates_ark/src/groth16.rs:33-38.  `-s gm17` selects the GM17 scheme.
+Needs a gfx950 GPU (there is no CPU fallback).
 
-    python -m zokrates_amd.cli setup          -i circuit.r1cs -p proving.key -v verification.key [--entropy TEXT]
-    python -m zokrates_amd.cli generate-proof -i circuit.r1cs -w witness.wtns -p proving.key -j proof.json [--entropy TEXT]
+    python -m zokrates_amd.cli setup          -i circuit.r1cs|out -p proving.key -v verification.key [-s g16|gm17] [--entropy TEXT]
+    python -m zokrates_amd.cli generate-proof -i circuit.r1cs|out -w witness.wtns|witness -p proving.key -j proof.json [-s g16|gm17]
 """
 import argparse
 import hashlib
@@ -32,30 +36,54 @@ def _seed(entropy):
     return entropy.encode() if entropy is not None else os.urandom(32)
 
 
+def _load_system(ctx, path):
+    """(constraint system on the GPU, zkhip_prog or None) from an .r1cs file or a ZoKrates `out` file."""
+    data = open(path, "rb").read()
+    if data[:4] == b"ZOK\0":
+        prog = native.Program(data, ctx.lib)
+        return prog.constraint_system(ctx), prog
+    r1 = formats.read_r1cs(data)
+    return native.ConstraintSystem(ctx, r1.curve_id, r1.n, r1.l, r1.w, r1.mats), None
+
+
 def cmd_setup(args):
-    r1 = formats.read_r1cs(open(args.input, "rb").read())
     ctx = native.Context(args.device)
-    cs = native.ConstraintSystem(ctx, r1.curve_id, r1.n, r1.l, r1.w, r1.mats)
-    toxic = _field_elems(r1.curve_id, b"zkhip-setup" + _seed(args.entropy), 5)
-    pk = native.setup_g16(ctx, cs, toxic)
+    cs, _ = _load_system(ctx, args.input)
+    toxic = _field_elems(cs.curve_id, b"zkhip-setup" + _seed(args.entropy), 5)
+    if args.proving_scheme == "gm17":
+        toxic[2] = 1                                   # ark's generate_random_parameters: gamma = 1
+        pk = native.setup_gm17(ctx, cs, (toxic[0], toxic[1], toxic[2], toxic[4]))
+        vk = formats.verification_key_json_gm17(cs.curve_id, pk)
+    else:
+        pk = native.setup_g16(ctx, cs, toxic)
+        vk = formats.verification_key_json(cs.curve_id, pk)
     open(args.proving_key_path, "wb").write(pk.tobytes())
-    open(args.verification_key_path, "w").write(formats.verification_key_json(r1.curve_id, pk))
-    print(f"setup: {r1.n} constraints, {r1.n_wires} wires, {r1.l - 1} public; wrote {args.proving_key_path}, {args.verification_key_path}")
+    open(args.verification_key_path, "w").write(vk)
+    print(f"setup ({args.proving_scheme}): {cs.n} constraints, {cs.m} variables, {cs.l - 1} public; wrote {args.proving_key_path}, "
+          f"{args.verification_key_path}")
 
 
 def cmd_generate_proof(args):
-    r1 = formats.read_r1cs(open(args.input, "rb").read())
-    curve_w, z = formats.read_wtns(open(args.witness, "rb").read())
-    if curve_w != r1.curve_id or z.size != 32 * r1.n_wires:
-        sys.exit("witness does not match the constraint system")
     ctx = native.Context(args.device)
-    cs = native.ConstraintSystem(ctx, r1.curve_id, r1.n, r1.l, r1.w, r1.mats)
-    pk = native.ProvingKey(ctx, r1.curve_id, open(args.proving_key_path, "rb").read())
-    r, s = _field_elems(r1.curve_id, b"zkhip-prove" + _seed(args.entropy), 2)
-    raw = native.prove_g16(ctx, pk, cs, z, r, s)
-    inputs = [int.from_bytes(z[32 * i:32 * i + 32].tobytes(), "little") for i in range(1, r1.l)]
-    open(args.proof_path, "w").write(formats.proof_json(r1.curve_id, raw, inputs))
-    print(f"generate-proof: wrote {args.proof_path}")
+    cs, prog = _load_system(ctx, args.input)
+    wdata = open(args.witness, "rb").read()
+    if prog is not None:
+        z, inp = prog.assignment(wdata)                # ark order; inputs = public_inputs_values
+        inputs = [int.from_bytes(inp[32 * i:32 * i + 32].tobytes(), "little") for i in range(inp.size // 32)]
+    else:
+        curve_w, z = formats.read_wtns(wdata)
+        if curve_w != cs.curve_id or z.size != 32 * cs.m:
+            sys.exit("witness does not match the constraint system")
+        inputs = [int.from_bytes(z[32 * i:32 * i + 32].tobytes(), "little") for i in range(1, cs.l)]
+    pk = native.ProvingKey(ctx, cs.curve_id, open(args.proving_key_path, "rb").read(), scheme=args.proving_scheme)
+    if args.proving_scheme == "gm17":
+        d1, d2, r = _field_elems(cs.curve_id, b"zkhip-prove" + _seed(args.entropy), 3)
+        raw = native.prove_gm17(ctx, pk, cs, z, d1, d2, r)
+    else:
+        r, s = _field_elems(cs.curve_id, b"zkhip-prove" + _seed(args.entropy), 2)
+        raw = native.prove_g16(ctx, pk, cs, z, r, s)
+    open(args.proof_path, "w").write(formats.proof_json(cs.curve_id, raw, inputs, scheme=args.proving_scheme))
+    print(f"generate-proof ({args.proving_scheme}): wrote {args.proof_path}")
 
 
 def main(argv=None):
@@ -65,6 +93,7 @@ def main(argv=None):
     s.add_argument("-i", "--input", required=True)
     s.add_argument("-p", "--proving-key-path", default="proving.key")
     s.add_argument("-v", "--verification-key-path", default="verification.key")
+    s.add_argument("-s", "--proving-scheme", default="g16", choices=["g16", "gm17"])
     s.add_argument("--entropy")
     s.add_argument("--device", type=int, default=0)
     s.set_defaults(fn=cmd_setup)
@@ -73,6 +102,7 @@ def main(argv=None):
     g.add_argument("-w", "--witness", required=True)
     g.add_argument("-p", "--proving-key-path", default="proving.key")
     g.add_argument("-j", "--proof-path", default="proof.json")
+    g.add_argument("-s", "--proving-scheme", default="g16", choices=["g16", "gm17"])
     g.add_argument("--entropy")
     g.add_argument("--device", type=int, default=0)
     g.set_defaults(fn=cmd_generate_proof)

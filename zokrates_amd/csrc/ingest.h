@@ -1,0 +1,29 @@
+// ingest.h — host-side readers of ZoKrates' own input files ("next" row N1 of SURVEY.md §8f): the compiled program
+// `out` and the `witness` file, turned into the R1CS and the assignment in ark variable order.  Pure host code (no
+// device work); the C ABI wrappers are in zkhip_api.hip.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+struct zkhip_prog {
+    int curve = 0;
+    uint64_t n = 0, l = 0, w = 0, return_count = 0;
+    std::vector<uint64_t> rp[3];
+    std::vector<uint32_t> col[3];
+    std::vector<uint8_t> val[3];           // canonical LE, 32 B per entry
+    std::vector<int64_t> order;            // ZoKrates variable id (flat/variable.rs: 0 = ~one, k > 0 = _{k-1}, -k = ~out_{k-1}) of column j
+    std::vector<int64_t> public_args;      // ids of the public arguments, in argument order
+};
+
+namespace zk {
+struct IngestError {
+    int32_t code;
+    std::string msg;
+};
+// ProgEnum::deserialize + Computation::generate_constraints; throws IngestError
+void prog_parse(const uint8_t* bytes, size_t len, zkhip_prog* out);
+// Witness::read + the `witness.remove(..)` walk of generate_constraints (z, m x 32 B) + public_inputs_values
+// (inputs_out, up to cap elements; *n_inputs = how many there are); throws IngestError
+void prog_assignment(const zkhip_prog* prog, const uint8_t* wit, size_t len, uint8_t* z_out, uint8_t* inputs_out, uint64_t cap, uint64_t* n_inputs);
+}  // namespace zk

@@ -1,6 +1,7 @@
 // zkhip_api.hip — the C ABI of include/zkhip.h: argument checking, error mapping, per-curve dispatch.
 // The drop-in boundary for `Backend<T, G16>::generate_proof` (/root/reference/zokrates_proof_systems/src/lib.rs:98-112).
 #include "core.cuh"
+#include "ingest.h"
 
 // ------------------------------------------------------------------ C ABI
 static const CurveOps* ops_for(int curve) {
@@ -41,6 +42,22 @@ static int32_t guarded(zkhip_ctx* ctx, Fn&& fn) {
     }
 }
 
+template <class Fn>
+static int32_t guarded_host(Fn&& fn) {
+    try {
+        fn();
+        return ZKHIP_OK;
+    } catch (const IngestError& e) {
+        g_create_err = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_create_err = "out of host memory";
+        return ZKHIP_ERR_NOMEM;
+    } catch (...) {
+        g_create_err = "unexpected internal error";
+        return ZKHIP_ERR_PARSE;
+    }
+}
 extern "C" {
 
 int32_t zkhip_device_count(void) { return dev_count(); }
@@ -311,6 +328,47 @@ int32_t zkhip_setup_g16(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* t
         require(r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "constraint system belongs to another context");
         ops_for(r1cs->curve)->setup(ctx, r1cs, toxic, g1, g2, pk_out, pk_cap);
     });
+}
+
+// ------------------------------------------------------------------ ZoKrates' own files (N1): host only, no context
+int32_t zkhip_prog_parse(const uint8_t* bytes, size_t len, zkhip_prog** out) {
+    if (!bytes || !out) { g_create_err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
+    *out = nullptr;
+    return guarded_host([&] {
+        std::unique_ptr<zkhip_prog> p(new zkhip_prog());
+        prog_parse(bytes, len, p.get());
+        *out = p.release();
+    });
+}
+void zkhip_prog_free(zkhip_prog* prog) { delete prog; }
+int32_t zkhip_prog_dims(const zkhip_prog* prog, uint64_t out[8]) {
+    if (!prog || !out) return ZKHIP_ERR_BAD_ARG;
+    out[0] = (uint64_t)prog->curve; out[1] = prog->n; out[2] = prog->l; out[3] = prog->w; out[4] = prog->return_count;
+    out[5] = prog->public_args.size(); out[6] = prog->col[0].size() + prog->col[1].size() + prog->col[2].size(); out[7] = 0;
+    return ZKHIP_OK;
+}
+int32_t zkhip_prog_matrix(const zkhip_prog* prog, int32_t which, const uint64_t** rowptr, const uint32_t** col, const uint8_t** val) {
+    if (!prog || which < 0 || which > 2 || !rowptr || !col || !val) return ZKHIP_ERR_BAD_ARG;
+    *rowptr = prog->rp[which].data();
+    *col = prog->col[which].data();
+    *val = prog->val[which].data();
+    return ZKHIP_OK;
+}
+int32_t zkhip_prog_variable_order(const zkhip_prog* prog, const int64_t** ids) {
+    if (!prog || !ids) return ZKHIP_ERR_BAD_ARG;
+    *ids = prog->order.data();
+    return ZKHIP_OK;
+}
+int32_t zkhip_prog_assignment(const zkhip_prog* prog, const uint8_t* witness, size_t len, uint8_t* z_out, uint8_t* inputs_out, uint64_t inputs_cap,
+                              uint64_t* n_inputs) {
+    if (!prog || !witness) { g_create_err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
+    return guarded_host([&] { prog_assignment(prog, witness, len, z_out, inputs_out, inputs_cap, n_inputs); });
+}
+int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs** out) {
+    if (!ctx || !prog) return ZKHIP_ERR_BAD_ARG;
+    return zkhip_r1cs_load(ctx, prog->curve, prog->n, prog->l, prog->w, prog->rp[0].data(), prog->col[0].data(), prog->val[0].data(),
+                           prog->rp[1].data(), prog->col[1].data(), prog->val[1].data(), prog->rp[2].data(), prog->col[2].data(),
+                           prog->val[2].data(), out);
 }
 
 // ------------------------------------------------------------------ GM17 (config 5)

@@ -172,11 +172,12 @@ def _g2(buf, nb):
     return [[_hex_be(buf[:nb]), _hex_be(buf[nb:2 * nb])], [_hex_be(buf[2 * nb:3 * nb]), _hex_be(buf[3 * nb:4 * nb])]]
 
 
-def proof_json(curve_id, raw_proof, inputs):
-    """raw_proof: the 8*sz(Fq)+3 bytes of zkhip_prove_g16; inputs: public values (ints).  The text of `proof.json`."""
+def proof_json(curve_id, raw_proof, inputs, scheme="g16"):
+    """raw_proof: the 8*sz(Fq)+3 bytes of zkhip_prove_g16 / zkhip_prove_gm17; inputs: public values (ints).  The text of
+    `proof.json` (both schemes have proof points a (G1), b (G2), c (G1): scheme/groth16.rs:8-16, scheme/gm17.rs:12-17)."""
     nb = FQ_BYTES[curve_id]
     raw = bytes(raw_proof)
-    doc = {"scheme": "g16", "curve": CURVE_NAMES[curve_id],
+    doc = {"scheme": scheme, "curve": CURVE_NAMES[curve_id],
            "proof": {"a": _g1(raw[0:2 * nb], nb), "b": _g2(raw[2 * nb:6 * nb], nb), "c": _g1(raw[6 * nb:8 * nb], nb)},
            "inputs": ["0x" + int(v).to_bytes(32, "big").hex() for v in inputs]}
     return json.dumps(doc, indent=2)
@@ -199,4 +200,23 @@ def verification_key_json(curve_id, pk_bytes):
     abc = [pk[off + 8 + i * g1:off + 8 + (i + 1) * g1] for i in range(n_abc)]
     doc = {"scheme": "g16", "curve": CURVE_NAMES[curve_id], "alpha": _g1(_strip_flags(alpha), nb), "beta": _g2(_strip_flags(beta), nb),
            "gamma": _g2(_strip_flags(gamma), nb), "delta": _g2(_strip_flags(delta), nb), "gamma_abc": [_g1(_strip_flags(p), nb) for p in abc]}
+    return json.dumps(doc, indent=2)
+
+
+def verification_key_json_gm17(curve_id, pk_bytes):
+    """`verification.key` from the vk that leads an ark-gm17 proving key (h_g2, g_alpha_g1, h_beta_g2, g_gamma_g1,
+    h_gamma_g2, query[]) with the field names of /root/reference/zokrates_proof_systems/src/scheme/gm17.rs:19-27."""
+    nb = FQ_BYTES[curve_id]
+    g1, g2 = 2 * nb, 4 * nb
+    pk = bytes(pk_bytes[:3 * g2 + 2 * g1 + 8])
+    h, pos = pk[:g2], g2
+    g_alpha, pos = pk[pos:pos + g1], pos + g1
+    h_beta, pos = pk[pos:pos + g2], pos + g2
+    g_gamma, pos = pk[pos:pos + g1], pos + g1
+    h_gamma, pos = pk[pos:pos + g2], pos + g2
+    (nq,) = struct.unpack_from("<Q", pk, pos)
+    q = bytes(pk_bytes[pos + 8:pos + 8 + nq * g1])
+    doc = {"scheme": "gm17", "curve": CURVE_NAMES[curve_id], "h": _g2(_strip_flags(h), nb), "g_alpha": _g1(_strip_flags(g_alpha), nb),
+           "h_beta": _g2(_strip_flags(h_beta), nb), "g_gamma": _g1(_strip_flags(g_gamma), nb), "h_gamma": _g2(_strip_flags(h_gamma), nb),
+           "query": [_g1(_strip_flags(q[i * g1:(i + 1) * g1]), nb) for i in range(nq)]}
     return json.dumps(doc, indent=2)

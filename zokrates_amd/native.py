@@ -54,6 +54,8 @@ class Library:
         "zkhip_field_op", "zkhip_setup_g16_size", "zkhip_setup_g16", "zkhip_describe",
         "zkhip_pk_load_gm17", "zkhip_prove_gm17", "zkhip_prove_gm17_resident", "zkhip_prove_gm17_resident_batch",
         "zkhip_setup_gm17_size", "zkhip_setup_gm17",
+        "zkhip_prog_parse", "zkhip_prog_free", "zkhip_prog_dims", "zkhip_prog_matrix", "zkhip_prog_variable_order",
+        "zkhip_prog_r1cs_load", "zkhip_prog_assignment",
     ]
 
     def __init__(self, path=None):
@@ -97,6 +99,13 @@ class Library:
         L.zkhip_prove_gm17_resident_batch.restype = i32; L.zkhip_prove_gm17_resident_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
         L.zkhip_setup_gm17_size.restype = i32; L.zkhip_setup_gm17_size.argtypes = [vp, vp]
         L.zkhip_setup_gm17.restype = i32; L.zkhip_setup_gm17.argtypes = [vp, vp, vp, vp, vp, vp, u64]
+        L.zkhip_prog_parse.restype = i32; L.zkhip_prog_parse.argtypes = [vp, sz, pp]
+        L.zkhip_prog_free.restype = None; L.zkhip_prog_free.argtypes = [vp]
+        L.zkhip_prog_dims.restype = i32; L.zkhip_prog_dims.argtypes = [vp, vp]
+        L.zkhip_prog_matrix.restype = i32; L.zkhip_prog_matrix.argtypes = [vp, i32, pp, pp, pp]
+        L.zkhip_prog_variable_order.restype = i32; L.zkhip_prog_variable_order.argtypes = [vp, pp]
+        L.zkhip_prog_r1cs_load.restype = i32; L.zkhip_prog_r1cs_load.argtypes = [vp, vp, pp]
+        L.zkhip_prog_assignment.restype = i32; L.zkhip_prog_assignment.argtypes = [vp, vp, sz, vp, vp, u64, vp]
         self.L = L
 
     def device_count(self):
@@ -409,3 +418,72 @@ def prove_gm17_resident_batch(ctx, pk, cs, assignments, rnds):
     ctx._check(ctx.lib.L.zkhip_prove_gm17_resident_batch(ctx.h, pk.h, cs.h, count, handles, _ptr(rb), _ptr(out), C.byref(tm)))
     step = 8 * nb + 3
     return [out[i * step:(i + 1) * step].tobytes() for i in range(count)], tm.as_dict()
+
+
+# ---- ZoKrates' own files (N1): host only ----
+class Program:
+    """`zkhip_prog`: a ZoKrates `out` file parsed into the R1CS in ark variable order (no GPU involved)."""
+
+    def __init__(self, data, library=None):
+        self.lib = library or default_library()
+        data = _u8(data)
+        self.h = C.c_void_p()
+        rc = self.lib.L.zkhip_prog_parse(_ptr(data), data.size, C.byref(self.h))
+        if rc != 0:
+            raise ZkhipError(rc, self.lib.L.zkhip_last_error(None).decode())
+        d = np.zeros(8, dtype=np.uint64)
+        self.lib.L.zkhip_prog_dims(self.h, _ptr(d))
+        self.curve_id, self.n, self.l, self.w, self.return_count, self.n_public_args, self.nnz = (int(x) for x in d[:7])
+        self.m = self.l + self.w
+
+    def mats(self):
+        """[(rowptr u64[n+1], col u32[nnz], val u8[nnz*32])] for A, B, C — copies."""
+        out = []
+        for k in range(3):
+            rp, col, val = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            self.lib.L.zkhip_prog_matrix(self.h, k, C.byref(rp), C.byref(col), C.byref(val))
+            rpa = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint64)), (self.n + 1,)).copy()
+            nnz = int(rpa[-1])
+            if nnz:
+                cola = np.ctypeslib.as_array(C.cast(col, C.POINTER(C.c_uint32)), (nnz,)).copy()
+                vala = np.ctypeslib.as_array(C.cast(val, C.POINTER(C.c_uint8)), (nnz * 32,)).copy()
+            else:
+                cola, vala = np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8)
+            out.append((rpa, cola, vala))
+        return out
+
+    def variable_order(self):
+        ids = C.c_void_p()
+        self.lib.L.zkhip_prog_variable_order(self.h, C.byref(ids))
+        return np.ctypeslib.as_array(C.cast(ids, C.POINTER(C.c_int64)), (self.m,)).copy()
+
+    def constraint_system(self, ctx):
+        """Upload to the GPU (`zkhip_prog_r1cs_load`)."""
+        cs = ConstraintSystem.__new__(ConstraintSystem)
+        cs.ctx, cs.curve_id, cs.n, cs.l, cs.w, cs.m = ctx, self.curve_id, self.n, self.l, self.w, self.m
+        cs.h = C.c_void_p()
+        ctx._check(ctx.lib.L.zkhip_prog_r1cs_load(ctx.h, self.h, C.byref(cs.h)))
+        return cs
+
+    def assignment(self, witness_bytes):
+        """(z uint8[m*32] in ark order, inputs uint8[k*32] = public_inputs_values) from a ZoKrates `witness` file."""
+        wit = _u8(witness_bytes)
+        z = np.zeros(self.m * 32, dtype=np.uint8)
+        cap = self.n_public_args + wit.size // 40 + 1
+        inputs = np.zeros(cap * 32, dtype=np.uint8)
+        n_in = C.c_uint64()
+        rc = self.lib.L.zkhip_prog_assignment(self.h, _ptr(wit), wit.size, _ptr(z), _ptr(inputs), cap, C.byref(n_in))
+        if rc != 0:
+            raise ZkhipError(rc, self.lib.L.zkhip_last_error(None).decode())
+        return z, inputs[:32 * n_in.value].copy()
+
+    def close(self):
+        if self.h:
+            self.lib.L.zkhip_prog_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
