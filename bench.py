@@ -35,6 +35,7 @@ _pkg = os.environ.get("ZKHIP_PKG", "zokrates_amd")   # development hook: A/B two
 native, parallel, synth = (importlib.import_module(_pkg + "." + m) for m in ("native", "parallel", "synth"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+SHARDED_LEG_TIMEOUT_S = 120
 
 
 def make_proving_key(ctx, cs, circ, curve_id, scheme="g16"):
@@ -45,16 +46,19 @@ def make_proving_key(ctx, cs, circ, curve_id, scheme="g16"):
     return native.setup_g16(ctx, cs, tox)
 
 
-def cpu_baseline(circ, pk_bytes, z, budget_s):
+def cpu_baseline(circ, pk_bytes, z, budget_s, gm17=False):
     """Times the CPU port of the reference path on the host cores: same circuit, key, assignment."""
     from oracle import cpu   # test infrastructure; used here only as the timed CPU baseline
     threads = cpu.hw_threads()
     oc = cpu.Circuit.from_csr(circ.curve_id, circ.n, circ.l, circ.w, circ.mats())
-    opk = cpu.ProvingKey.parse(circ.curve_id, pk_bytes)
+    opk = (cpu.Gm17ProvingKey if gm17 else cpu.ProvingKey).parse(circ.curve_id, pk_bytes)
     t0 = time.time()
     done, proofs = 0, []
     while True:
-        raw, _ = cpu.prove(oc, opk, z, 1000 + done, 2000 + done, threads)
+        if gm17:
+            raw, _ = cpu.gm17_prove(oc, opk, z, 1000 + done, 3000 + done, 2000 + done, threads)
+        else:
+            raw, _ = cpu.prove(oc, opk, z, 1000 + done, 2000 + done, threads)
         proofs.append(raw)
         done += 1
         el = time.time() - t0
@@ -62,7 +66,8 @@ def cpu_baseline(circ, pk_bytes, z, budget_s):
             break
     return {"value": done / el, "unit": "proofs/s", "cores": threads, "kind": "port",
             "sample": f"{done} proof(s) of the same 2^{int(np.log2(circ.N))} circuit in {el:.1f} s, "
-                      f"C++ restatement of ark-groth16 0.3.0 (Pippenger c=0.69*log2(n)+2, radix-2 FFT), {threads} threads",
+                      f"C++ restatement of {'ark-gm17' if gm17 else 'ark-groth16'} 0.3.0 (Pippenger c=0.69*log2(n)+2, radix-2 FFT), "
+                      f"{threads} threads",
             "ms_per_proof": 1000.0 * el / done}, proofs[0]
 
 
@@ -185,7 +190,20 @@ def main():
     }
     if world > 1 and not gm17:
         # latency mode: ONE proof sharded over all ranks (1/world of the bases per GPU, RCCL all-gather of the partial
-        # records); reported next to the throughput metric, never instead of it
+        # records); reported next to the throughput metric, never instead of it.  A watchdog guarantees that the
+        # throughput line is printed even if this optional leg hangs in a collective (e.g. one rank failed asymmetrically).
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["sharded_single_proof"] = {"error": "timed out after %d s" % SHARDED_LEG_TIMEOUT_S}
+                out["cpu_baseline"] = None
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(SHARDED_LEG_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             shard = native.ProvingKey(ctx, curve_id, pk_bytes, rank=rank, world=world)
             z_common = native.Assignment(ctx, cs, circ.assignment(0x5EED7777))
@@ -201,16 +219,18 @@ def main():
                                            "exchange": "all-gather of one %d-byte record per rank" % native.partial_size(ctx, curve_id)}
         except Exception as e:  # the throughput line must survive a failure of the optional leg
             out["sharded_single_proof"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and args.cpu_seconds > 0 and not gm17:
-        base, cpu_proof = cpu_baseline(circ, pk_bytes, zs[0], args.cpu_seconds)
+        watchdog.cancel()
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        base, cpu_proof = cpu_baseline(circ, pk_bytes, zs[0], args.cpu_seconds, gm17)
         out["cpu_baseline"] = base
         # same inputs -> byte-identical proof (the CPU leg doubles as a full-size parity check)
-        gpu_proof = native.prove_g16_resident(ctx, pk, cs, resident[0], 1000, 2000)
-        batch_proof = native.prove_g16_resident_batch(ctx, pk, cs, [resident[0]] * 3, [(1000, 2000)] * 3)[0]
+        rnd0 = (1000, 3000, 2000) if gm17 else (1000, 2000)
+        gpu_proof = prove_one(resident[0], rnd0)[0]
+        batch_proof = prove_many([resident[0]] * 3, [rnd0] * 3)[0]
         out["cpu_baseline"]["gpu_proof_identical"] = bool(gpu_proof == cpu_proof and all(p == cpu_proof for p in batch_proof))
         out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
     elif rank == 0:
-        out["cpu_baseline"] = None   # N > 1, --cpu-seconds 0, or GM17 (oracle/gm17.py is a python big-int checker, not a timed port)
+        out["cpu_baseline"] = None   # N > 1 or --cpu-seconds 0
     if rank == 0:
         print(json.dumps(out), flush=True)
     ranks.close()

@@ -579,6 +579,8 @@ static ToxicT<C> toxic_from_bytes(const uint8_t* t) {
     return {Fr::from_bytes(t), Fr::from_bytes(t + 32), Fr::from_bytes(t + 64), Fr::from_bytes(t + 96), Fr::from_bytes(t + 128)};
 }
 
+#include "gm17.hpp"
+
 }  // namespace orc
 
 // =====================================================================================
@@ -761,5 +763,56 @@ int orc_field_op(int curve, int field, int op, const uint8_t* a, const uint8_t* 
 // generators, ark uncompressed
 void orc_generators(int curve, uint8_t* g1, uint8_t* g2) { DISPATCH(curve, { C::g1().to_bytes(g1); C::g2().to_bytes(g2); }); }
 int orc_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
+
+// ---------------- GM17 (oracle/c/gm17.hpp) ----------------
+void* orc_gm17_setup(void* h, const uint8_t* toxic /* alpha,beta,gamma,t: 4 x 32 B */, int threads) {
+    PkBase* pk = nullptr;
+    int curve = ((CircuitBase*)h)->curve;
+    DISPATCH(curve, {
+        ToxicGm17<C> tx{C::Fr::from_bytes(toxic), C::Fr::from_bytes(toxic + 32), C::Fr::from_bytes(toxic + 64), C::Fr::from_bytes(toxic + 96)};
+        pk = setup_gm17<C>(*(Circuit<C>*)h, tx, threads);
+    });
+    pk->curve = curve;
+    return pk;
+}
+void* orc_gm17_pk_parse(int curve, const uint8_t* data, uint64_t len) {
+    PkBase* out = nullptr;
+    DISPATCH(curve, {
+        auto* pk = new PkGm17<C>();
+        if (pk->parse(data, len)) out = pk; else delete pk;
+    });
+    if (out) out->curve = curve;
+    return out;
+}
+uint64_t orc_gm17_pk_size(void* h) { uint64_t s = 0; DISPATCH(((PkBase*)h)->curve, s = ((PkGm17<C>*)h)->byte_size()); return s; }
+void orc_gm17_pk_serialize(void* h, uint8_t* out) { DISPATCH(((PkBase*)h)->curve, ((PkGm17<C>*)h)->serialize(out)); }
+// timings: 8 doubles (-, witness map, G msm, C1+C2 msm, A msm, -, B msm, total) or NULL
+int orc_gm17_prove(void* ch, void* pkh, const uint8_t* z, const uint8_t* d1, const uint8_t* d2, const uint8_t* r, uint8_t* proof_raw, int threads,
+                   double* timings) {
+    int rc = -1;
+    DISPATCH(((CircuitBase*)ch)->curve, {
+        auto* c = (Circuit<C>*)ch;
+        std::vector<C::Fr> zz(c->m());
+        for (size_t i = 0; i < zz.size(); ++i) zz[i] = C::Fr::from_bytes(z + 32 * i);
+        ProofT<C> p;
+        Timings tm{};
+        rc = prove_gm17<C>(*c, *(PkGm17<C>*)pkh, zz, C::Fr::from_bytes(d1), C::Fr::from_bytes(d2), C::Fr::from_bytes(r), p, threads, &tm);
+        if (rc == 0) proof_to_raw<C>(p, proof_raw);
+        if (timings) memcpy(timings, &tm, sizeof(tm));
+    });
+    return rc;
+}
+int orc_gm17_trapdoor(void* ch, const uint8_t* toxic, const uint8_t* z, const uint8_t* d1, const uint8_t* r, uint8_t* proof_raw, int threads) {
+    DISPATCH(((CircuitBase*)ch)->curve, {
+        auto* c = (Circuit<C>*)ch;
+        std::vector<C::Fr> zz(c->m());
+        for (size_t i = 0; i < zz.size(); ++i) zz[i] = C::Fr::from_bytes(z + 32 * i);
+        ToxicGm17<C> tx{C::Fr::from_bytes(toxic), C::Fr::from_bytes(toxic + 32), C::Fr::from_bytes(toxic + 64), C::Fr::from_bytes(toxic + 96)};
+        ProofT<C> p;
+        trapdoor_gm17<C>(*c, tx, zz, C::Fr::from_bytes(d1), C::Fr::from_bytes(r), p, threads);
+        proof_to_raw<C>(p, proof_raw);
+    });
+    return 0;
+}
 
 }  // extern "C"

@@ -26,7 +26,7 @@ def _cpu_tag():
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, "c", f) for f in ("oracle_g16.cpp", "ff.hpp", "ec.hpp")]
+    srcs = [os.path.join(HERE, "c", f) for f in ("oracle_g16.cpp", "ff.hpp", "ec.hpp", "gm17.hpp")]
     stamp = LIB_PATH + ".cpu"
     tag = _cpu_tag()
     have = open(stamp).read().strip() if os.path.exists(stamp) else ""
@@ -62,6 +62,12 @@ def lib():
         L.orc_ntt.restype = i32; L.orc_ntt.argtypes = [i32, i32, i32, vp, i32]
         L.orc_msm.restype = i32; L.orc_msm.argtypes = [i32, i32, u64, vp, vp, vp, i32]
         L.orc_field_op.restype = i32; L.orc_field_op.argtypes = [i32, i32, i32, u8p, u8p, vp]
+        L.orc_gm17_setup.restype = vp; L.orc_gm17_setup.argtypes = [vp, u8p, i32]
+        L.orc_gm17_pk_parse.restype = vp; L.orc_gm17_pk_parse.argtypes = [i32, vp, u64]
+        L.orc_gm17_pk_size.restype = u64; L.orc_gm17_pk_size.argtypes = [vp]
+        L.orc_gm17_pk_serialize.argtypes = [vp, vp]
+        L.orc_gm17_prove.restype = i32; L.orc_gm17_prove.argtypes = [vp, vp, vp, u8p, u8p, u8p, vp, i32, vp]
+        L.orc_gm17_trapdoor.restype = i32; L.orc_gm17_trapdoor.argtypes = [vp, u8p, vp, u8p, u8p, vp, i32]
         L.orc_generators.argtypes = [i32, vp, vp]
         L.orc_hardware_threads.restype = i32
         _lib = L
@@ -225,3 +231,60 @@ def generators(curve_id):
     g2 = np.zeros(4 * nb, dtype=np.uint8)
     lib().orc_generators(curve_id, _ptr(g1), _ptr(g2))
     return g1.tobytes(), g2.tobytes()
+
+
+# ---------------- GM17 (oracle/c/gm17.hpp) ----------------
+def gm17_toxic_bytes(tox):
+    return b"".join(int(v).to_bytes(32, "little") for v in (tox.alpha, tox.beta, tox.gamma, tox.t))
+
+
+class Gm17ProvingKey:
+    def __init__(self, handle, curve_id):
+        self.h = handle
+        self.curve_id = curve_id
+
+    @staticmethod
+    def setup(circuit, toxic, threads=0):
+        return Gm17ProvingKey(lib().orc_gm17_setup(circuit.h, toxic, threads or hw_threads()), circuit.curve_id)
+
+    @staticmethod
+    def parse(curve_id, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        h = lib().orc_gm17_pk_parse(curve_id, _ptr(data), data.size)
+        if not h:
+            raise ValueError("malformed GM17 proving key")
+        return Gm17ProvingKey(h, curve_id)
+
+    def serialize(self):
+        n = lib().orc_gm17_pk_size(self.h)
+        out = np.zeros(n, dtype=np.uint8)
+        lib().orc_gm17_pk_serialize(self.h, _ptr(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pk_free(self.h)
+            self.h = None
+
+
+def gm17_prove(circuit, pk, z, d1, d2, r, threads=0):
+    """ark-gm17's create_proof, term by term.  Returns (proof_raw bytes, timings dict)."""
+    nb = FQ_BYTES[circuit.curve_id]
+    out = np.zeros(8 * nb + 3, dtype=np.uint8)
+    tm = np.zeros(8, dtype=np.float64)
+    z = np.ascontiguousarray(z, dtype=np.uint8)
+    b = lambda v: int(v).to_bytes(32, "little")
+    rc = lib().orc_gm17_prove(circuit.h, pk.h, _ptr(z), b(d1), b(d2), b(r), _ptr(out), threads or hw_threads(), _ptr(tm))
+    if rc != 0:
+        raise RuntimeError("oracle GM17 prove failed (shape mismatch)")
+    names = ("matvec", "witness_map", "msm_g", "msm_c", "msm_a", "msm_b1", "msm_b", "total")
+    return out.tobytes(), dict(zip(names, tm.tolist()))
+
+
+def gm17_trapdoor(circuit, toxic, z, d1, r, threads=0):
+    nb = FQ_BYTES[circuit.curve_id]
+    out = np.zeros(8 * nb + 3, dtype=np.uint8)
+    z = np.ascontiguousarray(z, dtype=np.uint8)
+    b = lambda v: int(v).to_bytes(32, "little")
+    lib().orc_gm17_trapdoor(circuit.h, toxic, _ptr(z), b(d1), b(r), _ptr(out), threads or hw_threads())
+    return out.tobytes()

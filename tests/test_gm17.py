@@ -227,3 +227,50 @@ def test_gpu_gm17_config5_full_size(gpu_ctx):
     proofs, _ = native.prove_gm17_resident_batch(gpu_ctx, pk, cs, [za, zb, za], [(d1, d2, r_), (1, 2, 3), (d1, 0, r_)])
     assert proofs[0] == p1 and proofs[2] == p1 and proofs[1] == native.prove_gm17(gpu_ctx, pk, cs, zb, 1, 2, 3)
     assert proofs[1] != p1
+
+
+# ------------------------------------------------------------------ C++ restatement (the timed CPU baseline) vs python
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_cpp_oracle_matches_python(curve):
+    """oracle/c/gm17.hpp (ark-gm17's setup / create_proof / closed form in C++) is pinned bit-for-bit against
+    oracle/gm17.py: key bytes, proof bytes, closed form — with extra public inputs so the f_i rows are exercised."""
+    from oracle import cpu
+    for n, extra, seed in ((9, 0, 51), (14, 2, 52)):
+        cs, z = circuit(curve, n, seed, extra_public=extra)
+        tox = gm17.Toxic.from_seed(curve, seed=seed)
+        oc = cpu.Circuit.from_csr(curve.curve_id, cs.n, cs.l, cs.w, [csr_of(cs.A), csr_of(cs.B), csr_of(cs.C)])
+        tb = cpu.gm17_toxic_bytes(tox)
+        cpk = cpu.Gm17ProvingKey.setup(oc, tb)
+        opk, ovk = gm17.setup(curve, cs, tox)
+        raw = cpk.serialize()
+        assert raw.tobytes() == gm17.pk_serialize(curve, opk)
+        assert cpu.Gm17ProvingKey.parse(curve.curve_id, raw).serialize().tobytes() == raw.tobytes()
+        rnd = random.Random(seed)
+        d1, d2, r_ = (rnd.randrange(curve.r) for _ in range(3))
+        got, _ = cpu.gm17_prove(oc, cpk, le(z), d1, d2, r_)
+        assert got == proof_bytes(curve, gm17.prove(curve, cs, opk, z, d1, d2, r_))
+        assert got == cpu.gm17_trapdoor(oc, tb, le(z), d1, r_)
+        assert cpu.gm17_trapdoor(oc, tb, le(z), 0, 0) == proof_bytes(curve, gm17.trapdoor_prove(curve, cs, tox, z, 0, 0))
+
+
+@pytest.mark.gpu
+def test_gpu_gm17_vs_cpp_oracle_mid_size(gpu_ctx):
+    """2^14 constraints (SAP domain 2^15, two-pass NTT, c = 10 windows): device key bytes and proof == C++ oracle."""
+    from oracle import cpu
+    from zokrates_amd import synth
+    for curve_id, lg in ((0, 14), (1, 12)):
+        circ = synth.circuit(curve_id, lg, seed=0x77 + lg)
+        z = circ.assignment(0x5EED0003)
+        cs = native.ConstraintSystem(gpu_ctx, curve_id, circ.n, circ.l, circ.w, circ.mats())
+        tox = synth.toxic_waste(curve_id)
+        t4 = (tox[0], tox[1], tox[2], tox[4])
+        raw = native.setup_gm17(gpu_ctx, cs, t4)
+        oc = cpu.Circuit.from_csr(curve_id, circ.n, circ.l, circ.w, circ.mats())
+        tb = b"".join(int(v).to_bytes(32, "little") for v in t4)
+        cpk = cpu.Gm17ProvingKey.setup(oc, tb)
+        assert cpk.serialize().tobytes() == raw.tobytes()
+        pk = native.ProvingKey(gpu_ctx, curve_id, raw, scheme="gm17")
+        d1, d2, r_ = 0x1234567890abcdef1234567890, 0xdeadbeef, 0x55556666777788889999
+        want, _ = cpu.gm17_prove(oc, cpk, z, d1, d2, r_)
+        assert want == cpu.gm17_trapdoor(oc, tb, z, d1, r_)
+        assert native.prove_gm17(gpu_ctx, pk, cs, z, d1, d2, r_) == want
