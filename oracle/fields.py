@@ -64,6 +64,17 @@ BLS12_381 = Curve(
 
 CURVES = {"bn128": BN254, "bls12_381": BLS12_381}
 
+# BLS12-377: not a curve libzkhip proves over — present only so that the oracle's GM17 verification equations can be
+# pinned on the reference's one golden (proof, vk, inputs) triple, which is over this curve
+# (/root/reference/zokrates_stdlib/tests/tests/snark/gm17.json; [UPSTREAM] ark-bls12-377 0.3.0 parameters).
+BLS12_377 = Curve(
+    name="bls12_377", curve_id=-1,
+    r=8444461749428370424248824938781546531375899335154063827935233455917409239041,
+    q=258664426012969094010652733694893533536393512754914660539884262666720468348340822774968888139573360124440321458177,
+    fr_generator=22, two_adicity=47, two_adic_root=0,
+    b1=1, b2=None, g1=None, g2=None, fq_bytes=48,
+)
+
 
 def inv(a, p):
     return pow(a, p - 2, p)

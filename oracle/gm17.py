@@ -288,3 +288,29 @@ def verify(curve, vk, proof, public_inputs):
     ])
     ok2 = ctx.pairing_product_is_one([(A, vk["h_gamma_g2"]), (G1.aneg(vk["g_gamma_g1"]), B)])
     return ok1 and ok2
+
+
+def verify_embedded(curve, vk, proof, public_inputs):
+    """The same two checks with every G2 operation carried out on E(Fq12) after the twist embedding — needs no Fq2
+    arithmetic for the curve, only its Fq12 tower (used for BLS12-377, whose Fq2 is Fq[u]/(u^2+5))."""
+    from .curves import Group
+    from .fields import FqOps
+    from .pairing import Fq12Ctx
+    G1 = Group(FqOps(curve.q), curve.b1, None)
+    ctx = Fq12Ctx(curve)
+    A, B, C = proof
+    q = vk["query"]
+    assert len(q) == len(public_inputs) + 1
+    acc = G1.to_jac(q[0])
+    for x, P in zip(public_inputs, q[1:]):
+        acc = G1.add(acc, G1.mul(G1.to_jac(P), x % curve.r))
+    vk_x = G1.to_affine(acc)
+    tw = ctx.twist
+    ok1 = ctx.pairing_product_is_one([
+        (vk["g_alpha_g1"], tw(vk["h_beta_g2"])),
+        (vk_x, tw(vk["h_gamma_g2"])),
+        (C, tw(vk["h_g2"])),
+        (G1.aneg(G1.aadd(A, vk["g_alpha_g1"])), ctx.padd(tw(B), tw(vk["h_beta_g2"]))),
+    ], embedded=True)
+    ok2 = ctx.pairing_product_is_one([(A, tw(vk["h_gamma_g2"])), (G1.aneg(vk["g_gamma_g1"]), tw(B))], embedded=True)
+    return ok1 and ok2

@@ -1,4 +1,4 @@
-"""Ate pairing check for BN254 and BLS12-381 in python big ints.  TEST ORACLE ONLY (O3).
+"""Ate pairing check for BN254, BLS12-381 and (pairing only, for the reference's GM17 golden triple) BLS12-377 in python big ints.  TEST ORACLE ONLY (O3).
 
 Implements the Groth16 verification equation of
 /root/reference/zokrates_proof_systems/src/scheme/groth16.rs:156-172
@@ -26,6 +26,12 @@ class Fq12Ctx:
             self.c6, self.c0, self.xi0 = 2, 2, 1       # w^12 = 2 w^6 - 2 ; u = w^6 - 1
             self.twist_d = False
             self.loop = 0xd201000000010000
+            self.bn = False
+        elif curve.name == "bls12_377":
+            # Fq2 = Fq[u]/(u^2 + 5), Fq6 = Fq2[v]/(v^3 - u), Fq12 = Fq6[w]/(w^2 - v)  =>  w^6 = u, w^12 = -5
+            self.c6, self.c0, self.xi0 = 0, 5, 0
+            self.twist_d = True
+            self.loop = 0x8508c00000000001
             self.bn = False
         else:
             raise ValueError("unsupported curve")
@@ -165,7 +171,10 @@ class Fq12Ctx:
 
     def miller(self, Q2, P1):
         """Miller loop f_{loop,Q}(P) with the BN Frobenius corrections; inputs affine, non-infinity."""
-        Q = self.twist(Q2)
+        return self.miller_embedded(self.twist(Q2), P1)
+
+    def miller_embedded(self, Q, P1):
+        """The same with Q already on E(Fq12) (the image of a G2 point under `twist`, or a sum of such images)."""
         P = self.cast_g1(P1)
         R = Q
         f = self.one()
@@ -187,13 +196,14 @@ class Fq12Ctx:
     def final_exp(self, f):
         return self.pow(f, (self.q ** 12 - 1) // self.r)
 
-    def pairing_product_is_one(self, pairs):
-        """pairs: [(P in G1 affine, Q in G2 affine)], None = infinity (skipped)."""
+    def pairing_product_is_one(self, pairs, embedded=False):
+        """pairs: [(P in G1 affine, Q in G2 affine)], None = infinity (skipped).  embedded=True: every Q is already a
+        point of E(Fq12) (see miller_embedded)."""
         f = self.one()
         for P, Q in pairs:
             if P is None or Q is None:
                 continue
-            f = self.mul(f, self.miller(Q, P))
+            f = self.mul(f, self.miller_embedded(Q, P) if embedded else self.miller(Q, P))
         return self.eq(self.final_exp(f), self.one())
 
 

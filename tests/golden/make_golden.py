@@ -9,6 +9,8 @@ Sources (all in /root/reference):
   * zokrates_book/src/toolbox/ir.md:15               curve id of bn128
   * zokrates_cli/examples/book/mpc_tutorial/phase1radix2m2   BN254 points (bellman uncompressed BE)
   * zokrates_ast/src/ir/witness.rs:99-156            witness binary layout (restated as a vector)
+  * zokrates_stdlib/tests/tests/snark/gm17.json      the reference's only golden (proof, vk, inputs) triple: GM17 over
+                                                     BLS12-377, expected to verify (`"Ok": {"value": true}`)
 """
 import json
 import os
@@ -107,7 +109,17 @@ def witness_vector():
     return {"hex": b.hex(), "json": {"~out_8": "8", "~one": "1", "_42": "42"}}
 
 
+def gm17_triple():
+    doc = json.load(open(os.path.join(REF, "zokrates_stdlib/tests/tests/snark/gm17.json")))
+    t = doc["tests"][0]
+    proof, vk = t["input"]["values"]
+    assert t["output"] == {"Ok": {"value": True}}
+    return {"source": "zokrates_stdlib/tests/tests/snark/gm17.json", "curve": "bls12_377", "expected": True,
+            "proof": proof["proof"], "inputs": proof["inputs"], "vk": vk}
+
+
 def main():
+    json.dump(gm17_triple(), open(os.path.join(OUT, "gm17_bls12_377_triple.json"), "w"), indent=1)
     json.dump(field_kats(), open(os.path.join(OUT, "bn128_field_kats.json"), "w"), indent=1)
     json.dump(curve_consts(), open(os.path.join(OUT, "bn254_consts.json"), "w"), indent=1)
     json.dump(phase1_points(), open(os.path.join(OUT, "phase1radix2m2_points.json"), "w"), indent=1)

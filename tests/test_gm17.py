@@ -274,3 +274,46 @@ def test_gpu_gm17_vs_cpp_oracle_mid_size(gpu_ctx):
         want, _ = cpu.gm17_prove(oc, cpk, z, d1, d2, r_)
         assert want == cpu.gm17_trapdoor(oc, tb, z, d1, r_)
         assert native.prove_gm17(gpu_ctx, pk, cs, z, d1, d2, r_) == want
+
+
+# ------------------------------------------------------------------ the reference's own golden vector
+def _golden_triple():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gm17_bls12_377_triple.json")
+    d = json.load(open(path))
+    h = lambda s: int(s, 16)
+    g1 = lambda p: (h(p[0]), h(p[1]))
+    g2 = lambda p: ((h(p[0][0]), h(p[0][1])), (h(p[1][0]), h(p[1][1])))
+    vk = d["vk"]
+    ovk = dict(h_g2=g2(vk["h"]), g_alpha_g1=g1(vk["g_alpha"]), h_beta_g2=g2(vk["h_beta"]), g_gamma_g1=g1(vk["g_gamma"]),
+               h_gamma_g2=g2(vk["h_gamma"]), query=[g1(p) for p in vk["query"]])
+    proof = (g1(d["proof"]["a"]), g2(d["proof"]["b"]), g1(d["proof"]["c"]))
+    return d, ovk, proof, [h(v) for v in d["inputs"]]
+
+
+def test_reference_golden_triple_verifies():
+    """The only (proof, verification key, inputs) triple the reference holds for a pairing-based scheme
+    (/root/reference/zokrates_stdlib/tests/tests/snark/gm17.json, produced by the reference's own ark GM17 backend over
+    BLS12-377, expected `true`) satisfies the oracle's restatement of the two GM17 verification equations — this pins
+    `gm17.verify` (equation shape, G2 JSON layout [[x.c0, x.c1], [y.c0, y.c1]], big-endian hex, query[0] + sum x_i
+    query[i]) on a reference artefact; any perturbation is rejected."""
+    from oracle.fields import BLS12_377
+    d, vk, proof, inputs = _golden_triple()
+    assert d["expected"] is True and len(vk["query"]) == len(inputs) + 1
+    assert vk["h_g2"] == vk["h_gamma_g2"]                      # gamma = 1: ark's generate_random_parameters
+    assert gm17.verify_embedded(BLS12_377, vk, proof, inputs)
+    assert not gm17.verify_embedded(BLS12_377, vk, proof, [inputs[0], inputs[1], inputs[2] + 1])
+    swapped = (proof[0], (proof[1][0][::-1], proof[1][1][::-1]), proof[2])      # [c1, c0] is not the encoding
+    with pytest.raises(Exception):
+        assert gm17.verify_embedded(BLS12_377, vk, swapped, inputs)
+
+
+def test_embedded_and_native_verification_agree():
+    curve = BN254
+    cs, z = circuit(curve, 5, 23)
+    tox = gm17.Toxic.from_seed(curve)
+    pk, vk = gm17.setup(curve, cs, tox)
+    proof = gm17.prove(curve, cs, pk, z, 4, 5, 6)
+    assert gm17.verify(curve, vk, proof, z[1:cs.l]) and gm17.verify_embedded(curve, vk, proof, z[1:cs.l])
+    bad = (proof[0], proof[1], pk["g_gamma_z"])
+    assert not gm17.verify(curve, vk, bad, z[1:cs.l]) and not gm17.verify_embedded(curve, vk, bad, z[1:cs.l])
