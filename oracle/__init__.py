@@ -20,4 +20,9 @@ reference cannot be run here.  What pins this oracle instead:
   O3 the pairing check implementing the verification equation of
   ``zokrates_proof_systems/src/scheme/groth16.rs:156-172``;
 * uniqueness of a Groth16 proof for fixed (pk, z, r, s).
+
+GM17 (``gm17.py``, ``c/gm17.hpp``) has the same layers plus one reference artefact: the in-tree golden
+(proof, verification key, inputs) triple ``zokrates_stdlib/tests/tests/snark/gm17.json`` (BLS12-377) verifies under the
+restated equations.  ``ir.py`` restates the ``out`` program format and ark's variable allocation order (no in-tree
+fixture exists for either: it is an independent reading of the same source files as the C++ reader).
 """
