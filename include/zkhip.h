@@ -207,6 +207,19 @@ int32_t zkhip_setup_gm17_size(const zkhip_r1cs* r1cs, uint64_t* pk_bytes);
 int32_t zkhip_setup_gm17(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* toxic, const uint8_t* g1,
                          const uint8_t* g2, uint8_t* pk_out, uint64_t pk_cap);
 
+/* ---- "next" row N2: proving-key cache ----
+ * zkhip_pk_export writes the *resident* form of a loaded key (Groth16 or GM17, whole or one shard): Montgomery /
+ * unsaturated limbs, MSM-ready order, the extended base vectors — the bytes the GPU holds, plus a small header.
+ * zkhip_pk_import brings such an image back with five host-to-device copies and no parsing or conversion, taking
+ * `ProvingKey::deserialize_unchecked` (/root/reference/zokrates_ark/src/groth16.rs:40-42; one Fq multiplication per
+ * coordinate and a single-threaded read in the reference) off the per-invocation path.  The library does no file I/O:
+ * the caller stores the image wherever it likes, keyed e.g. by the SHA-256 of the `proving.key` it came from
+ * (`python -m zokrates_amd.cli generate-proof --key-cache DIR` does exactly that).  An image is tied to the library
+ * build that wrote it (magic + layout version); a foreign image is rejected with ZKHIP_ERR_PARSE. */
+int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes);
+int32_t zkhip_pk_export(const zkhip_pk* pk, uint8_t* out, uint64_t cap);
+int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk** out);
+
 /* ---- "next" row N1: ZoKrates' own input files (host only: no context, no device work) ----
  * zkhip_prog_parse replaces `ProgEnum::deserialize` (/root/reference/zokrates_ast/src/ir/serialize.rs:306-390: header,
  * sections, per-statement CBOR) followed by `Computation::generate_constraints`

@@ -272,3 +272,70 @@ def test_cli_zokrates_files_on_emulator(tmp_path, monkeypatch, scheme):
 @pytest.mark.parametrize("scheme", ["g16", "gm17"])
 def test_cli_zokrates_files_on_gpu(tmp_path, scheme):
     _cli_flow_zok(tmp_path, scheme)
+
+
+# ------------------------------------------------------------------ N2: device-layout key images
+def _key_image_checks(ctx):
+    from oracle import cpu, gm17
+    curve = BN254
+    cs_py, z = g16.synthetic_chain(curve, 12, 7)
+    from test_gm17 import csr_of, le
+    dcs = native.ConstraintSystem(ctx, 0, cs_py.n, cs_py.l, cs_py.w, [csr_of(cs_py.A), csr_of(cs_py.B), csr_of(cs_py.C)])
+    tox = g16.Toxic.from_seed(curve)
+    for scheme, raw in (("g16", native.setup_g16(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau))),
+                        ("gm17", native.setup_gm17(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.tau)))):
+        pk = native.ProvingKey(ctx, 0, raw, scheme=scheme)
+        image = pk.export_image()
+        pk2 = native.ProvingKey.from_image(ctx, 0, image, scheme=scheme)
+        assert (pk2.m, pk2.hlen, pk2.w, pk2.l) == (pk.m, pk.hlen, pk.w, pk.l)
+        assert pk2.export_image().tobytes() == image.tobytes()
+        if scheme == "g16":
+            assert native.prove_g16(ctx, pk2, dcs, le(z), 3, 4) == native.prove_g16(ctx, pk, dcs, le(z), 3, 4)
+            with pytest.raises(native.ZkhipError):                       # the scheme travels with the image
+                native.prove_gm17(ctx, pk2, dcs, le(z), 1, 2, 3)
+        else:
+            assert native.prove_gm17(ctx, pk2, dcs, le(z), 1, 2, 3) == native.prove_gm17(ctx, pk, dcs, le(z), 1, 2, 3)
+        for bad in (image[:-1], image[:40], np.concatenate([image, image[:1]]), np.concatenate([np.frombuffer(b"ZKHIPPK0", dtype=np.uint8), image[8:]])):
+            with pytest.raises(native.ZkhipError) as e:
+                native.ProvingKey.from_image(ctx, 0, bad, scheme=scheme)
+            assert e.value.code == -2
+    # a shard keeps its index range
+    shard = native.ProvingKey(ctx, 0, native.setup_g16(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau)), rank=1, world=3)
+    sh2 = native.ProvingKey.from_image(ctx, 0, shard.export_image())
+    assert native.prove_g16_partial(ctx, sh2, dcs, le(z), 5, 6).tobytes() == native.prove_g16_partial(ctx, shard, dcs, le(z), 5, 6).tobytes()
+
+
+def test_key_image_on_emulator(lib):
+    ctx = native.Context(0, lib)
+    _key_image_checks(ctx)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_key_image_on_gpu():
+    ctx = native.Context(0)
+    _key_image_checks(ctx)
+    ctx.close()
+
+
+def test_cli_key_cache_on_emulator(tmp_path, monkeypatch):
+    from emu_util import emu_library
+    from zokrates_amd import cli
+    monkeypatch.setattr(native, "_default", emu_library())
+    curve = BN254
+    prog = ir.Prog(curve, [ir.Parameter(1, True), ir.Parameter(2, False)], [ir.Constraint([(1, 1)], [(2, 1)], [(-1, 1)])], return_count=1)
+    outp = tmp_path / "out"; wit = tmp_path / "witness"; pkp = tmp_path / "proving.key"; vkp = tmp_path / "verification.key"
+    outp.write_bytes(ir.serialize_prog(prog))
+    wit.write_bytes(ir.serialize_witness({0: 1, 1: 6, 2: 7, -1: 42}))
+    cli.main(["setup", "-i", str(outp), "-p", str(pkp), "-v", str(vkp), "--entropy", "k"])
+    cache = tmp_path / "cache"
+    proofs = []
+    for run in range(3):                                   # first run parses and writes the image, later runs import it
+        pj = tmp_path / f"proof{run}.json"
+        cli.main(["generate-proof", "-i", str(outp), "-w", str(wit), "-p", str(pkp), "-j", str(pj), "--entropy", "e", "--key-cache", str(cache)])
+        proofs.append(pj.read_text())
+        assert len(list(cache.iterdir())) == 1
+    assert proofs[0] == proofs[1] == proofs[2]
+    pj = tmp_path / "proof_nocache.json"
+    cli.main(["generate-proof", "-i", str(outp), "-w", str(wit), "-p", str(pkp), "-j", str(pj), "--entropy", "e"])
+    assert pj.read_text() == proofs[0]

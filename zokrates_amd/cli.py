@@ -46,6 +46,29 @@ def _load_system(ctx, path):
     return native.ConstraintSystem(ctx, r1.curve_id, r1.n, r1.l, r1.w, r1.mats), None
 
 
+def _load_key(ctx, curve_id, path, scheme, cache_dir):
+    """`proving.key` -> resident key.  With --key-cache DIR the device-layout image (`zkhip_pk_export`) is kept next to
+    it, named after (path, size, mtime, scheme) — hashing a 400 MB key would cost more than parsing it — and later runs
+    import the image (`zkhip_pk_import`: no parsing, no Montgomery conversion)."""
+    if cache_dir:
+        st = os.stat(path)
+        tag = hashlib.sha256(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}|{scheme}|{curve_id}".encode()).hexdigest()[:32]
+        image_path = os.path.join(cache_dir, tag + ".zkhippk")
+        if os.path.exists(image_path):
+            try:
+                return native.ProvingKey.from_image(ctx, curve_id, open(image_path, "rb").read(), scheme=scheme)
+            except native.ZkhipError:
+                pass                                   # stale image of another library build: fall through and rewrite it
+    pk = native.ProvingKey(ctx, curve_id, open(path, "rb").read(), scheme=scheme)
+    if cache_dir:
+        os.makedirs(cache_dir, exist_ok=True)
+        tmp = image_path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(pk.export_image().tobytes())
+        os.replace(tmp, image_path)
+    return pk
+
+
 def cmd_setup(args):
     ctx = native.Context(args.device)
     cs, _ = _load_system(ctx, args.input)
@@ -75,7 +98,7 @@ def cmd_generate_proof(args):
         if curve_w != cs.curve_id or z.size != 32 * cs.m:
             sys.exit("witness does not match the constraint system")
         inputs = [int.from_bytes(z[32 * i:32 * i + 32].tobytes(), "little") for i in range(1, cs.l)]
-    pk = native.ProvingKey(ctx, cs.curve_id, open(args.proving_key_path, "rb").read(), scheme=args.proving_scheme)
+    pk = _load_key(ctx, cs.curve_id, args.proving_key_path, args.proving_scheme, args.key_cache)
     if args.proving_scheme == "gm17":
         d1, d2, r = _field_elems(cs.curve_id, b"zkhip-prove" + _seed(args.entropy), 3)
         raw = native.prove_gm17(ctx, pk, cs, z, d1, d2, r)
@@ -103,6 +126,7 @@ def main(argv=None):
     g.add_argument("-p", "--proving-key-path", default="proving.key")
     g.add_argument("-j", "--proof-path", default="proof.json")
     g.add_argument("-s", "--proving-scheme", default="g16", choices=["g16", "gm17"])
+    g.add_argument("--key-cache", help="directory for device-layout key images (zkhip_pk_export / zkhip_pk_import)")
     g.add_argument("--entropy")
     g.add_argument("--device", type=int, default=0)
     g.set_defaults(fn=cmd_generate_proof)

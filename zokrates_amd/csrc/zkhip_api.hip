@@ -371,6 +371,98 @@ int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs*
                            prog->val[2].data(), out);
 }
 
+// ------------------------------------------------------------------ N2: device-layout image of a loaded key
+// "ZKHIPPK" + layout version; bump the version whenever the resident layout (unsaturated limbs, sigma order, the
+// extended base vectors) changes: an image is only meaningful to the library build that wrote it
+static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '1'};
+struct PkImageHeader {
+    char magic[8];
+    int32_t curve, scheme;
+    uint64_t m, w, l, hlen, N;
+    int32_t logN, c_z, c_h, reserved;
+    uint32_t rank, world;
+    uint64_t z_lo, z_n, h_lo, h_n;
+    uint64_t len_delta, len_g2z2, len_buf[5];
+};
+static DBuf* pk_bufs(zkhip_pk* pk, int k) { DBuf* b[5] = {&pk->a_ext, &pk->b1_ext, &pk->l_ext, &pk->b2_ext, &pk->h_sigma}; return b[k]; }
+int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes) {
+    if (!pk || !bytes) return ZKHIP_ERR_BAD_ARG;
+    uint64_t t = sizeof(PkImageHeader) + pk->delta_g1_canon.size() + pk->g_gamma2_z2_canon.size();
+    for (int k = 0; k < 5; ++k) t += pk_bufs(const_cast<zkhip_pk*>(pk), k)->cap;
+    *bytes = t;
+    return ZKHIP_OK;
+}
+int32_t zkhip_pk_export(const zkhip_pk* pk_, uint8_t* out, uint64_t cap) {
+    if (!pk_ || !out) return ZKHIP_ERR_BAD_ARG;
+    zkhip_pk* pk = const_cast<zkhip_pk*>(pk_);
+    zkhip_ctx* ctx = pk->ctx;
+    return guarded(ctx, [&] {
+        uint64_t need = 0;
+        zkhip_pk_export_size(pk, &need);
+        require(cap >= need, ZKHIP_ERR_BAD_ARG, "output buffer too small (see zkhip_pk_export_size)");
+        PkImageHeader h;
+        memset(&h, 0, sizeof(h));
+        memcpy(h.magic, PK_IMAGE_MAGIC, 8);
+        h.curve = pk->curve; h.scheme = pk->scheme;
+        h.m = pk->m; h.w = pk->w; h.l = pk->l; h.hlen = pk->hlen; h.N = pk->N;
+        h.logN = pk->logN; h.c_z = pk->c_z; h.c_h = pk->c_h;
+        h.rank = pk->rank; h.world = pk->world;
+        h.z_lo = pk->z_lo; h.z_n = pk->z_n; h.h_lo = pk->h_lo; h.h_n = pk->h_n;
+        h.len_delta = pk->delta_g1_canon.size(); h.len_g2z2 = pk->g_gamma2_z2_canon.size();
+        for (int k = 0; k < 5; ++k) h.len_buf[k] = pk_bufs(pk, k)->cap;
+        uint8_t* p = out;
+        memcpy(p, &h, sizeof(h)); p += sizeof(h);
+        memcpy(p, pk->delta_g1_canon.data(), h.len_delta); p += h.len_delta;
+        memcpy(p, pk->g_gamma2_z2_canon.data(), h.len_g2z2); p += h.len_g2z2;
+        for (int k = 0; k < 5; ++k) {
+            dev_d2h(p, pk_bufs(pk, k)->p, h.len_buf[k], ctx->stream);
+            p += h.len_buf[k];
+        }
+        stream_sync(ctx->stream);
+    });
+}
+int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk** out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(bytes && out, ZKHIP_ERR_BAD_ARG, "null argument");
+        *out = nullptr;
+        require(len >= sizeof(PkImageHeader), ZKHIP_ERR_PARSE, "key image truncated");
+        PkImageHeader h;
+        memcpy(&h, bytes, sizeof(h));
+        require(!memcmp(h.magic, PK_IMAGE_MAGIC, 8), ZKHIP_ERR_PARSE, "not a key image of this library version (re-import the proving key)");
+        ops_for(h.curve);   // validates the curve id
+        require(h.scheme == 0 || h.scheme == 1, ZKHIP_ERR_PARSE, "key image: unknown scheme");
+        uint64_t total = sizeof(PkImageHeader), rest = len - sizeof(PkImageHeader);
+        const uint64_t parts[7] = {h.len_delta, h.len_g2z2, h.len_buf[0], h.len_buf[1], h.len_buf[2], h.len_buf[3], h.len_buf[4]};
+        for (uint64_t part : parts) {
+            require(part <= rest, ZKHIP_ERR_PARSE, "key image truncated");
+            rest -= part;
+            total += part;
+        }
+        require(total == len, ZKHIP_ERR_PARSE, "trailing bytes after key image");
+        require(h.world >= 1 && h.rank < h.world && h.logN >= 0 && h.logN <= 22 && h.N == ((uint64_t)1 << h.logN) && h.z_n <= h.m + 2 && h.h_n <= h.N &&
+                    h.c_z >= 2 && h.c_z <= 16 && h.c_h >= 2 && h.c_h <= 16,
+                ZKHIP_ERR_PARSE, "key image: inconsistent header");
+        std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
+        pk->curve = h.curve; pk->scheme = h.scheme; pk->ctx = ctx;
+        pk->m = h.m; pk->w = h.w; pk->l = h.l; pk->hlen = h.hlen; pk->N = h.N; pk->logN = h.logN;
+        pk->c_z = h.c_z; pk->c_h = h.c_h; pk->rank = h.rank; pk->world = h.world;
+        pk->z_lo = h.z_lo; pk->z_n = h.z_n; pk->h_lo = h.h_lo; pk->h_n = h.h_n;
+        const uint8_t* p = bytes + sizeof(h);
+        pk->delta_g1_canon.assign(p, p + h.len_delta); p += h.len_delta;
+        pk->g_gamma2_z2_canon.assign(p, p + h.len_g2z2); p += h.len_g2z2;
+        for (int k = 0; k < 5; ++k) {
+            DBuf* b = pk_bufs(pk.get(), k);
+            b->ensure(std::max<uint64_t>(h.len_buf[k], 1));
+            if (h.len_buf[k]) dev_h2d(b->p, p, h.len_buf[k], ctx->stream);
+            b->cap = h.len_buf[k] ? h.len_buf[k] : b->cap;
+            p += h.len_buf[k];
+        }
+        stream_sync(ctx->stream);
+        *out = pk.release();
+    });
+}
+
 // ------------------------------------------------------------------ GM17 (config 5)
 int32_t zkhip_pk_load_gm17(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, zkhip_pk** out) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;

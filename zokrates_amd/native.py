@@ -56,6 +56,7 @@ class Library:
         "zkhip_setup_gm17_size", "zkhip_setup_gm17",
         "zkhip_prog_parse", "zkhip_prog_free", "zkhip_prog_dims", "zkhip_prog_matrix", "zkhip_prog_variable_order",
         "zkhip_prog_r1cs_load", "zkhip_prog_assignment",
+        "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import",
     ]
 
     def __init__(self, path=None):
@@ -99,6 +100,9 @@ class Library:
         L.zkhip_prove_gm17_resident_batch.restype = i32; L.zkhip_prove_gm17_resident_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
         L.zkhip_setup_gm17_size.restype = i32; L.zkhip_setup_gm17_size.argtypes = [vp, vp]
         L.zkhip_setup_gm17.restype = i32; L.zkhip_setup_gm17.argtypes = [vp, vp, vp, vp, vp, vp, u64]
+        L.zkhip_pk_export_size.restype = i32; L.zkhip_pk_export_size.argtypes = [vp, vp]
+        L.zkhip_pk_export.restype = i32; L.zkhip_pk_export.argtypes = [vp, vp, u64]
+        L.zkhip_pk_import.restype = i32; L.zkhip_pk_import.argtypes = [vp, vp, sz, pp]
         L.zkhip_prog_parse.restype = i32; L.zkhip_prog_parse.argtypes = [vp, sz, pp]
         L.zkhip_prog_free.restype = None; L.zkhip_prog_free.argtypes = [vp]
         L.zkhip_prog_dims.restype = i32; L.zkhip_prog_dims.argtypes = [vp, vp]
@@ -203,9 +207,31 @@ class ProvingKey:
             ctx._check(ctx.lib.L.zkhip_pk_load_g16(ctx.h, curve_id, _ptr(data), data.size, C.byref(self.h)))
         else:
             ctx._check(ctx.lib.L.zkhip_pk_load_g16_shard(ctx.h, curve_id, _ptr(data), data.size, rank, world, C.byref(self.h)))
+        self._dims()
+
+    def _dims(self):
         d = np.zeros(4, dtype=np.uint64)
-        ctx._check(ctx.lib.L.zkhip_pk_dims(self.h, _ptr(d)))
+        self.ctx._check(self.ctx.lib.L.zkhip_pk_dims(self.h, _ptr(d)))
         self.m, self.hlen, self.w, self.l = (int(x) for x in d)
+
+    def export_image(self):
+        """The resident (device-layout) form of this key as bytes (`zkhip_pk_export`): what a key cache stores."""
+        size = C.c_uint64()
+        self.ctx._check(self.ctx.lib.L.zkhip_pk_export_size(self.h, C.byref(size)))
+        out = np.zeros(size.value, dtype=np.uint8)
+        self.ctx._check(self.ctx.lib.L.zkhip_pk_export(self.h, _ptr(out), size.value))
+        return out
+
+    @classmethod
+    def from_image(cls, ctx, curve_id, image, scheme="g16"):
+        """`zkhip_pk_import`: no parsing, no conversion — five host-to-device copies."""
+        self = cls.__new__(cls)
+        self.ctx, self.curve_id, self.rank, self.world, self.scheme = ctx, curve_id, 0, 1, scheme
+        image = _u8(image)
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.L.zkhip_pk_import(ctx.h, _ptr(image), image.size, C.byref(self.h)))
+        self._dims()
+        return self
 
     def close(self):
         if self.h:
