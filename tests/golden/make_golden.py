@@ -9,6 +9,8 @@ Sources (all in /root/reference):
   * zokrates_book/src/toolbox/ir.md:15               curve id of bn128
   * zokrates_cli/examples/book/mpc_tutorial/phase1radix2m2   BN254 points (bellman uncompressed BE)
   * zokrates_ast/src/ir/witness.rs:99-156            witness binary layout (restated as a vector)
+  * zokrates_core_test/tests/tests/snark/snark_verify_bls12_377_{1,2,5}.json   three more GM17 / BLS12-377 triples
+                                                     (flattened decimal), expected to verify
   * zokrates_stdlib/tests/tests/snark/gm17.json      the reference's only golden (proof, vk, inputs) triple: GM17 over
                                                      BLS12-377, expected to verify (`"Ok": {"value": true}`)
 """
@@ -118,7 +120,24 @@ def gm17_triple():
             "proof": proof["proof"], "inputs": proof["inputs"], "vk": vk}
 
 
+def gm17_embed_triples():
+    """zokrates_core_test/tests/tests/snark/snark_verify_bls12_377_{1,2,5}.json: (proof[8], inputs[k], vk[16 + 2(k+1)])
+    flattened to decimal strings in proof.json / verification.key order (see the .zok files next to them); all three
+    are expected to verify."""
+    out = []
+    for k in (1, 2, 5):
+        rel = f"zokrates_core_test/tests/tests/snark/snark_verify_bls12_377_{k}.json"
+        t = json.load(open(os.path.join(REF, rel)))["tests"][0]
+        assert t["output"] == {"Ok": {"value": True}}
+        proof, inputs, vk = t["input"]["values"]
+        assert len(proof) == 8 and len(inputs) == k and len(vk) == 16 + 2 * (k + 1)
+        out.append({"source": rel, "proof": proof, "inputs": inputs, "vk": vk})
+    return {"curve": "bls12_377", "expected": True, "layout": "proof: a.x a.y b.x.c0 b.x.c1 b.y.c0 b.y.c1 c.x c.y; "
+            "vk: h(4) g_alpha(2) h_beta(4) g_gamma(2) h_gamma(4) query(2 each)", "triples": out}
+
+
 def main():
+    json.dump(gm17_embed_triples(), open(os.path.join(OUT, "gm17_bls12_377_embed_triples.json"), "w"), indent=1)
     json.dump(gm17_triple(), open(os.path.join(OUT, "gm17_bls12_377_triple.json"), "w"), indent=1)
     json.dump(field_kats(), open(os.path.join(OUT, "bn128_field_kats.json"), "w"), indent=1)
     json.dump(curve_consts(), open(os.path.join(OUT, "bn254_consts.json"), "w"), indent=1)

@@ -317,3 +317,24 @@ def test_embedded_and_native_verification_agree():
     assert gm17.verify(curve, vk, proof, z[1:cs.l]) and gm17.verify_embedded(curve, vk, proof, z[1:cs.l])
     bad = (proof[0], proof[1], pk["g_gamma_z"])
     assert not gm17.verify(curve, vk, bad, z[1:cs.l]) and not gm17.verify_embedded(curve, vk, bad, z[1:cs.l])
+
+
+def test_reference_embed_triples_verify():
+    """Three more reference artefacts (zokrates_core_test/tests/tests/snark/snark_verify_bls12_377_{1,2,5}.json: GM17
+    proofs made with `zokrates setup/generate-proof -b ark -s gm17` over BLS12-377, with 1, 2 and 5 public inputs) pass
+    the oracle's GM17 verification; a wrong input fails."""
+    import json
+    from oracle.fields import BLS12_377
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gm17_bls12_377_embed_triples.json")
+    doc = json.load(open(path))
+    assert len(doc["triples"]) == 3
+    for t in doc["triples"]:
+        p, v = [int(x) for x in t["proof"]], [int(x) for x in t["vk"]]
+        inputs = [int(x) for x in t["inputs"]]
+        g1 = lambda a, i: (a[i], a[i + 1])
+        g2 = lambda a, i: ((a[i], a[i + 1]), (a[i + 2], a[i + 3]))
+        proof = (g1(p, 0), g2(p, 2), g1(p, 6))
+        vk = dict(h_g2=g2(v, 0), g_alpha_g1=g1(v, 4), h_beta_g2=g2(v, 6), g_gamma_g1=g1(v, 10), h_gamma_g2=g2(v, 12),
+                  query=[g1(v, 16 + 2 * i) for i in range(len(inputs) + 1)])
+        assert gm17.verify_embedded(BLS12_377, vk, proof, inputs), t["source"]
+        assert not gm17.verify_embedded(BLS12_377, vk, proof, [inputs[0] + 1] + inputs[1:]), t["source"]
