@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-domain", type=int, default=20)
     ap.add_argument("--curve", default="bn128")
-    ap.add_argument("--kind", default="dense")
+    ap.add_argument("--kind", default="dense", choices=["dense", "sha", "poseidon"])
     ap.add_argument("--scheme", default="g16", choices=["g16", "gm17"])
     ap.add_argument("--witnesses", type=int, default=2, help="distinct assignments kept resident and cycled")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -90,7 +90,12 @@ def main():
 
     curve_id = synth.CURVE_IDS[args.curve]
     ctx = native.Context(int(os.environ.get("ZKHIP_BENCH_DEVICE", local_rank)))   # env override: test hook (all ranks on one GPU)
-    circ = synth.circuit(curve_id, args.log_domain, kind=args.kind)
+    if args.kind == "poseidon":   # BASELINE.json configs[3]: the stdlib Poseidon hash chain, depth 1024 at a 2^18 domain
+        poseidon = importlib.import_module(_pkg + ".poseidon")
+        depth = 1024 << (args.log_domain - 18) if args.log_domain >= 18 else max(1, ((1 << args.log_domain) - 4) // 243)
+        circ = poseidon.chain(curve_id, depth)
+    else:
+        circ = synth.circuit(curve_id, args.log_domain, kind=args.kind)
     cs = native.ConstraintSystem(ctx, curve_id, circ.n, circ.l, circ.w, circ.mats())
     t0 = time.time()
     gm17 = args.scheme == "gm17"
@@ -173,8 +178,10 @@ def main():
     b_alg = gm17_algorithmic_bytes(circ, fq, m, N) if gm17 else proof_algorithmic_bytes(circ, fq)
     workload = (f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints, {args.curve} GM17 (SAP: {m} variables, domain {N}), "
                 f"5 NTTs + 5 MSMs per proof") if gm17 else (
-        f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints (QAP domain 2^{args.log_domain}), "
-        f"{args.curve} Groth16, 7 NTTs + 5 MSMs per proof")
+        (f"Poseidon hash chain depth {circ.depth} (t = 3, 243 constraints per hash), n = {circ.n} constraints (QAP domain 2^{args.log_domain}), "
+         if args.kind == "poseidon" else
+         f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints (QAP domain 2^{args.log_domain}), ")
+        + f"{args.curve} Groth16, 7 NTTs + 5 MSMs per proof")
     out = {
         "metric": "gm17_proofs_per_sec" if gm17 else "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,

@@ -605,6 +605,15 @@ struct Prover {
 
     static CsrDev csr(const zkhip_r1cs* cs, int k) { return CsrDev{ptr<u64>(cs->rp[k]), ptr<u32>(cs->col[k]), cs->val[k].p}; }
 
+    // K1: a = A z, b = B z, c = C z over rows [0, n) (+ the l instance rows of A), zero-filled up to N
+    static void matvec(zkhip_ctx* ctx, const zkhip_r1cs* cs, const Fr* zmont, Fr* a, Fr* b, Fr* c, u64 n, u64 l, u64 N) {
+        int g[3];
+        for (int k = 0; k < 3; ++k) g[k] = matvec_group(cs->nnz[k], cs->n);
+        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), 3), dim3(256), 0, ctx->stream, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
+                  l, N, g[0], g[1], g[2]);
+    }
+    static unsigned gmax_rows(const int g[3]) { return (unsigned)std::max(g[0], std::max(g[1], g[2])); }
+
     // K1-K4 on the device: leaves h (canonical integers, sigma order) in ctx->cur->va
     static void witness_map(zkhip_ctx* ctx, const zkhip_r1cs* cs, NttPlan<C>* pl) {
         Stream s = ctx->stream;
@@ -613,8 +622,7 @@ struct Prover {
         ctx->cur->vb.ensure(N * sizeof(Fr));
         ctx->cur->vc.ensure(N * sizeof(Fr));
         Fr *a = ptr<Fr>(ctx->cur->va), *b = ptr<Fr>(ctx->cur->vb), *c = ptr<Fr>(ctx->cur->vc);
-        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256), 3), dim3(256), 0, s, csr(cs, 0), csr(cs, 1), csr(cs, 2), ptr<Fr>(ctx->cur->zmont), a, b, c,
-                  cs->n, cs->l, N);
+        matvec(ctx, cs, ptr<Fr>(ctx->cur->zmont), a, b, c, cs->n, cs->l, N);
         Fr* v[3] = {a, b, c};
         for (int k = 0; k < 3; ++k) {
             ntt_kind_a<C>(ctx, pl, v[k], true, ptr<Fr>(pl->s_coset));   // ifft, then * g^i   (coset shift)

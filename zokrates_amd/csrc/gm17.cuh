@@ -26,31 +26,24 @@
 
 namespace zk {
 
-// SAP evaluation vectors and the extension of the assignment, one work-item per R1CS row / per extra row:
-//   i < n      : a = <A_i,z>, b = <B_i,z>, c = <C_i,z>, e = (a-b)^2
+// SAP evaluation vectors and the extension of the assignment from the R1CS row products a = A z, b = B z, c = C z
+// (k_matvec), one work-item per R1CS row / per extra row:
+//   i < n      : e = (a_i - b_i)^2
 //   i == n     : the constant row
 //   n < i < n+l: public input x = z[i-n], f = (x-1)^2
 // sa/sc: Montgomery, natural order (the tail [2n+2l-1, D) is zeroed by the caller); ext: canonical integers
 template <class F>
-static __device__ __forceinline__ F csr_row_dot(const CsrDev& M, const F* __restrict__ z, u64 i) {
-    const F* val = (const F*)M.val;
-    F s = F::zero();
-    const u64 e = M.rowptr[i + 1];
-    for (u64 q = M.rowptr[i]; q < e; ++q) s = fe_add(s, fe_mul(val[q], z[M.col[q]]));
-    return s;
-}
-template <class F>
-__global__ void k_sap_rows(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ sa, F* __restrict__ sc, F* __restrict__ ext,
-                           u64 n, u64 l, u64 m) {
+__global__ void k_sap_rows(const F* __restrict__ ra, const F* __restrict__ rb, const F* __restrict__ rc, const F* __restrict__ z,
+                           F* __restrict__ sa, F* __restrict__ sc, F* __restrict__ ext, u64 n, u64 l, u64 m) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + l) return;
     if (i < n) {
-        const F acc[3] = {csr_row_dot<F>(A, z, i), csr_row_dot<F>(B, z, i), csr_row_dot<F>(C, z, i)};
-        const F d = fe_sub(acc[0], acc[1]);
+        const F a = ra[i], b = rb[i];
+        const F d = fe_sub(a, b);
         const F e = fe_sqr(d);
-        sa[2 * i] = fe_add(acc[0], acc[1]);
+        sa[2 * i] = fe_add(a, b);
         sa[2 * i + 1] = d;
-        sc[2 * i] = fe_add(fe_dbl(fe_dbl(acc[2])), e);
+        sc[2 * i] = fe_add(fe_dbl(fe_dbl(rc[i])), e);
         sc[2 * i + 1] = e;
         ext[m + i] = fe_from_mont(e);
     } else if (i == n) {
@@ -238,8 +231,10 @@ struct Gm17 {
             dev_memset(sa + D0, 0, (D - D0) * sizeof(Fr), st);
             dev_memset(sc + D0, 0, (D - D0) * sizeof(Fr), st);
         }
-        ZK_LAUNCH((k_sap_rows<Fr>), dim3(blocks_for(n + l, 256)), dim3(256), 0, st, P::csr(cs, 0), P::csr(cs, 1), P::csr(cs, 2), ptr<Fr>(sl.zmont),
-                  sa, sc, (Fr*)d_scalars, n, l, m);
+        sl.vc.ensure(3 * std::max<u64>(n, 1) * sizeof(Fr));      // the three row-product vectors
+        Fr *ra = ptr<Fr>(sl.vc), *rb = ra + n, *rc = rb + n;
+        if (n) P::matvec(ctx, cs, ptr<Fr>(sl.zmont), ra, rb, rc, n, 0, n);
+        ZK_LAUNCH((k_sap_rows<Fr>), dim3(blocks_for(n + l, 256)), dim3(256), 0, st, ra, rb, rc, ptr<Fr>(sl.zmont), sa, sc, (Fr*)d_scalars, n, l, m);
 
         // ---- the four MSMs over S = [ext_0..ext_{M-1}, rho, 0] share one digit/sort pass
         const MsmShape shz = msm_shape(pk->z_n, Fr::Params::BITS, pk->c_z);

@@ -56,7 +56,8 @@ __global__ void k_points_to_unsat(const Aff<FS>* __restrict__ in, Aff<U>* __rest
 }
 
 static constexpr u32 MSM_NO_DIGIT = 0xffffffffu;
-static constexpr u32 MSM_HEAVY = 32;  // a bucket spread over more slices than this is reduced by a whole workgroup
+static constexpr u32 MSM_HEAVY = 8;   // a bucket spread over more slices than this is reduced by a whole workgroup (32 made
+                                      // repeated witness values — 1024 copies of a round constant's S-box in a Poseidon chain — serialise k_msm_fold_rows: +21 %)
 
 // ---- wave-level helpers (64-wide wavefronts) ----
 #ifdef ZK_EMU

@@ -81,23 +81,49 @@ struct CsrDev {
 };
 // grid.y = 3 (A, B, C).  out_m[i] = <M_i, z> for i < n; A additionally gets z[j] at n + j (j < l)
 // ("input consistency" rows); everything up to N is zero-filled.
+// A row is shared by G consecutive work-items (G = gA/gB/gC, a power of two <= 64 chosen from the matrix's average row
+// length): compiler-made circuits have combinations of tens to hundreds of terms (every partial Poseidon round, every
+// SHA-256 word sum), which one work-item per row would walk serially with a dependent random gather per term.  The G
+// partial sums meet in an LDS tree.  G = 1 is the plain one-row-per-work-item kernel.
 template <class F>
-__global__ void k_matvec(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ oa, F* __restrict__ ob,
-                         F* __restrict__ oc, u64 n, u64 l, u64 N) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+__global__ void __launch_bounds__(256) k_matvec(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ oa, F* __restrict__ ob,
+                                                F* __restrict__ oc, u64 n, u64 l, u64 N, int gA, int gB, int gC) {
+    __shared__ F sh[256];
     const int which = blockIdx.y;
+    const int G = which == 0 ? gA : which == 1 ? gB : gC;
+    const u32 rows_per_block = blockDim.x / (u32)G;
+    if ((u64)blockIdx.x * rows_per_block >= N) return;            // whole workgroup past the end (uniform)
+    const u64 i = (u64)blockIdx.x * rows_per_block + threadIdx.x / (u32)G;
+    const u32 lane = threadIdx.x % (u32)G;
     const CsrDev M = which == 0 ? A : which == 1 ? B : C;
     F* out = which == 0 ? oa : which == 1 ? ob : oc;
     F acc = F::zero();
     if (i < n) {
         const F* val = (const F*)M.val;
         const u64 e = M.rowptr[i + 1];
-        for (u64 k = M.rowptr[i]; k < e; ++k) acc = fe_add(acc, fe_mul(val[k], z[M.col[k]]));
-    } else if (which == 0 && i < n + l) {
+        for (u64 k = M.rowptr[i] + lane; k < e; k += (u32)G) acc = fe_add(acc, fe_mul(val[k], z[M.col[k]]));
+    } else if (which == 0 && i < n + l && lane == 0) {
         acc = z[i - n];
     }
-    out[i] = acc;
+    if (G > 1) {
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (u32 st = (u32)G >> 1; st > 0; st >>= 1) {
+            if (lane < st) {
+                acc = fe_add(acc, sh[threadIdx.x + st]);
+                sh[threadIdx.x] = acc;
+            }
+            __syncthreads();
+        }
+    }
+    if (i < N && lane == 0) out[i] = acc;
+}
+// lanes per row for a matrix with `nnz` entries in `n` rows: the largest power of two <= half the average row length
+static inline int matvec_group(u64 nnz, u64 n) {
+    const u64 avg = n ? nnz / n : 0;
+    int g = 1;
+    while (g < 64 && (u64)g * 4 <= avg) g *= 2;
+    return g;
 }
 
 // ---------------- LDS-resident sub-NTT ----------------
