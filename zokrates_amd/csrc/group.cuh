@@ -39,6 +39,7 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bas
         lds_opt_in(k_msm_fold_rows<F>);
         lds_opt_in(k_msm_fold_cols<F>);
         lds_opt_in(k_msm_fold_final<F, FS>);
+        lds_opt_in(k_msm_fold_final_scan<F, FS>);
         lds_opt_in(k_msm_heavy_reduce<F>);
         once = true;
     }
@@ -58,9 +59,17 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bas
     const u32 CW = std::min<u32>(sh.Lw, 32), HG = std::max<u32>(1, std::min<u32>(8, sh.H));   // 256 work-items for big windows
     ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.W), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
               sh.Lw, sh.H, ptr<Xyzz<F>>(lane.cols));
-    const unsigned TF = std::max<u32>(64, sh.Lw);
-    ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.W + 1), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
-              sh.H, ptr<Xyzz<F>>(lane.partial), ptr<u32>(so.off), P, (u32)sh.W, sh.nkeys - 1, d_window_sums);
+    // the scan form of the last fold step needs Lw + H points of LDS; the double-and-add form (Lw points) is the fallback
+    const unsigned TS = (sh.Lw + sh.H + 63) / 64 * 64;
+    static const bool scan_off = getenv("ZKHIP_FOLD_SCAN") && atoi(getenv("ZKHIP_FOLD_SCAN")) == 0;
+    if (!scan_off && TS <= 512 && (size_t)TS * sizeof(Xyzz<F>) <= 150 * 1024) {
+        ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.W + 1), dim3(TS), TS * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols),
+                  sh.Lw, sh.H, ptr<Xyzz<F>>(lane.partial), ptr<u32>(so.off), P, (u32)sh.W, sh.nkeys - 1, d_window_sums);
+    } else {
+        const unsigned TF = std::max<u32>(64, sh.Lw);
+        ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.W + 1), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
+                  sh.H, ptr<Xyzz<F>>(lane.partial), ptr<u32>(so.off), P, (u32)sh.W, sh.nkeys - 1, d_window_sums);
+    }
     event_record(lane.done, s);
 }
 

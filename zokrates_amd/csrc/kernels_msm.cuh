@@ -422,6 +422,66 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(
     }
 }
 
+// 5c'. the same result with a shorter dependent chain (the fold tail is pure latency: one workgroup per window).
+// Weighted sums become sums of suffix sums — sum_lo (lo+1) C_lo = sum_k S_k with S_k = sum_{lo >= k} C_lo, and
+// sum_hi hi R_hi = sum_{k >= 1} T_k with T_k = sum_{hi >= k} R_hi — so each digit costs one parallel suffix scan plus one
+// tree sum (2 log2 n full additions) instead of a double-and-add per element plus a tree sum, and the column digit
+// (work-items [0, Lw)) and the row digit (work-items [Lw, Lw + H), which also does the log2 Lw doublings) proceed side
+// by side: ~21 sequential curve operations instead of ~51.  blockDim.x >= Lw + H; dynamic LDS blockDim.x points.
+template <class F, class FS>
+__global__ void __launch_bounds__(512) k_msm_fold_final_scan(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
+                                                             const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 P, u32 W,
+                                                             u32 ones_key, Xyzz<FS>* __restrict__ window_sum) {
+    ZK_DYN_SMEM(smem);
+    Xyzz<F>* sh = (Xyzz<F>*)smem;
+    const u32 j = blockIdx.x, t = threadIdx.x;
+    if (j >= W) {
+        if (t == 0) window_sum[j] = xyzz_to_sat<FS>(msm_bucket_sum<F>(partial, off, ones_key, P));
+        return;
+    }
+    const bool is_col = t < Lw, live = t < Lw + H;
+    const u32 li = is_col ? t : t - Lw;                 // index inside the segment
+    const u32 seglen = is_col ? Lw : H;
+    Xyzz<F> v = Xyzz<F>::inf();
+    if (is_col) v = cols[(u64)j * Lw + li];
+    else if (live) v = rows[(u64)j * H + li];
+    sh[t] = v;
+    __syncthreads();
+    const u32 maxlen = Lw > H ? Lw : H;
+    for (u32 d = 1; d < maxlen; d <<= 1) {              // suffix scan inside each segment
+        const bool has = live && li + d < seglen;
+        Xyzz<F> o = Xyzz<F>::inf();
+        if (has) o = sh[t + d];
+        __syncthreads();
+        if (has) {
+            xyzz_add_acc(v, o);
+            sh[t] = v;
+        }
+        __syncthreads();
+    }
+    if (t == Lw) sh[t] = Xyzz<F>::inf();                // T_0 carries weight 0
+    __syncthreads();
+    for (u32 st = maxlen >> 1; st > 0; st >>= 1) {      // tree sum inside each segment
+        if (live && st < seglen && li < st) {
+            Xyzz<F> a = sh[t];
+            xyzz_add_acc(a, sh[t + st]);
+            sh[t] = a;
+        }
+        __syncthreads();
+    }
+    if (t == Lw) {
+        Xyzz<F> hi_sum = sh[t];
+        for (u32 q = Lw; q > 1; q >>= 1) hi_sum = xyzz_dbl_inl(hi_sum);
+        sh[t] = hi_sum;
+    }
+    __syncthreads();
+    if (t == 0) {
+        Xyzz<F> r = sh[0];
+        xyzz_add_acc(r, sh[Lw]);
+        window_sum[j] = xyzz_to_sat<FS>(r);
+    }
+}
+
 // ---- key preparation ----
 // out[p] = (idx < n_src) ? in[idx] : infinity, idx = natural index of sigma position p (h_query layout)
 template <class PT>
