@@ -99,6 +99,24 @@ def test_msm_window_sizes(ctx):
         os.environ.pop("ZKHIP_MSM_C")
 
 
+def test_msm_fold_fallback(ctx):
+    """The double-and-add form of the last fold step (used when Lw + H points do not fit in LDS) gives the same sums
+    as the scan form that normally runs."""
+    rnd = random.Random(10)
+    b1, b2, ks = _rand_points(BN254, 60, rnd)
+    want1, want2 = cpu.msm(0, 1, b1, ks), cpu.msm(0, 2, b2[:20 * 128], ks[:20 * 32])
+    try:
+        for c in (3, 9, 12):
+            os.environ["ZKHIP_MSM_C"] = str(c)
+            for scan in ("1", "0"):
+                os.environ["ZKHIP_FOLD_SCAN"] = scan
+                assert ctx.msm(0, 1, b1, ks) == want1, (c, scan)
+                assert ctx.msm(0, 2, b2[:20 * 128], ks[:20 * 32]) == want2, (c, scan)
+    finally:
+        os.environ.pop("ZKHIP_MSM_C")
+        os.environ.pop("ZKHIP_FOLD_SCAN")
+
+
 def test_msm_skewed_scalars(ctx):
     """Hot buckets: many scalars equal to 1 (the dedicated ones bucket), many copies of one full-width value
     and of -1 (a bucket spread over more than MSM_HEAVY lanes -> workgroup reduction), zeros; several slice

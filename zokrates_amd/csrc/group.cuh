@@ -61,7 +61,7 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bas
               sh.Lw, sh.H, ptr<Xyzz<F>>(lane.cols));
     // the scan form of the last fold step needs Lw + H points of LDS; the double-and-add form (Lw points) is the fallback
     const unsigned TS = (sh.Lw + sh.H + 63) / 64 * 64;
-    static const bool scan_off = getenv("ZKHIP_FOLD_SCAN") && atoi(getenv("ZKHIP_FOLD_SCAN")) == 0;
+    const bool scan_off = env_int("ZKHIP_FOLD_SCAN", 0, 1, 1) == 0;   // development / test hook
     if (!scan_off && TS <= 512 && (size_t)TS * sizeof(Xyzz<F>) <= 150 * 1024) {
         ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.W + 1), dim3(TS), TS * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols),
                   sh.Lw, sh.H, ptr<Xyzz<F>>(lane.partial), ptr<u32>(so.off), P, (u32)sh.W, sh.nkeys - 1, d_window_sums);
