@@ -128,3 +128,30 @@ def test_cli_flow_on_emulator(tmp_path, monkeypatch):
 @pytest.mark.gpu
 def test_cli_flow_on_gpu(tmp_path):
     _cli_flow(tmp_path, lg=10)
+
+
+def test_reference_rng_restatement():
+    """zokrates_amd/rng.py: the ChaCha core against RFC 7539 §2.3.2, the seed derivation of
+    /root/reference/zokrates_proof_systems/src/rng.rs:5-20, and the shape of ark's `Fr::rand`."""
+    import hashlib
+    import struct
+    from zokrates_amd import rng
+    key = struct.unpack("<8I", bytes(range(32)))
+    blk = rng.chacha_block(key, 1 | (0x09000000 << 32), 0x4A000000, 20)
+    assert struct.pack("<16I", *blk).hex().startswith("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e")
+    g = rng.rng_from_entropy("some entropy")
+    assert bytes(struct.pack("<8I", *g.key)) == hashlib.blake2b(b"some entropy").digest()[:32]
+    first = rng.chacha_block(g.key, 0, 0, 12)
+    assert g.next_u64() == first[0] | (first[1] << 32) and g.next_u64() == first[2] | (first[3] << 32)
+    for cid, (p, shave) in rng.FR.items():
+        a, b = rng.rng_from_entropy("x"), rng.rng_from_entropy("x")
+        va = [rng.fr_rand(a, cid) for _ in range(50)]
+        assert va == [rng.fr_rand(b, cid) for _ in range(50)] and all(0 <= v < p for v in va) and len(set(va)) == 50
+        # the accepted limbs are the Montgomery form: value * 2^256 mod p fits the masked width and is below p
+        for v in va:
+            mont = v * (1 << 256) % p
+            assert mont < p and mont >> (256 - shave) == 0
+    # 17 blocks of 16 words: the block counter advances
+    g = rng.rng_from_entropy("y")
+    words = [g.next_u32() for _ in range(40)]
+    assert words[:16] == rng.chacha_block(g.key, 0, 0, 12) and words[16:32] == rng.chacha_block(g.key, 1, 0, 12)
