@@ -339,3 +339,78 @@ def test_cli_key_cache_on_emulator(tmp_path, monkeypatch):
     pj = tmp_path / "proof_nocache.json"
     cli.main(["generate-proof", "-i", str(outp), "-w", str(wit), "-p", str(pkp), "-j", str(pj), "--entropy", "e"])
     assert pj.read_text() == proofs[0]
+
+
+# ------------------------------------------------------------------ the reference backend's own unit test, mirrored
+def _reference_backend_test(ctx, curve, scheme):
+    """/root/reference/zokrates_ark/src/groth16.rs:123-161 and gm17.rs:124-160 (there over BLS12-377 / BW6-761; here over
+    the two curves this backend proves on): the program `(1) * (_0) == ~out_0` with `_0` a public argument, input 42,
+    setup -> generate_proof -> verify.  No witness variable at all (w = 0): every query vector of the key that ranges
+    over the witness is empty."""
+    from oracle import gm17, pairing
+    prog = ir.Prog(curve, [ir.Parameter(1, False)], [ir.Constraint([(0, 1)], [(1, 1)], [(-1, 1)])], return_count=1)
+    p = native.Program(ir.serialize_prog(prog), ctx.lib)
+    assert (p.n, p.l, p.w) == (1, 3, 0) and list(p.variable_order()) == [0, 1, -1]
+    z, inputs = p.assignment(ir.serialize_witness({0: 1, 1: 42, -1: 42}))
+    inp = [int.from_bytes(inputs[32 * i:32 * i + 32].tobytes(), "little") for i in range(2)]
+    assert inp == [42, 42]
+    cs = p.constraint_system(ctx)
+    tox = g16.Toxic.from_seed(curve, 0xBEEF)
+    if scheme == "g16":
+        raw = native.setup_g16(ctx, cs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau))
+        pk = native.ProvingKey(ctx, curve.curve_id, raw)
+        assert (pk.m, pk.w, pk.l, pk.hlen) == (3, 0, 3, 3)
+        proof = formats.proof_from_raw(curve, native.prove_g16(ctx, pk, cs, z, 1111, 2222))
+        vk = formats.ark_pk_deserialize(curve, raw.tobytes())["vk"]
+        assert pairing.groth16_verify(curve, vk, proof, inp)
+        assert not pairing.groth16_verify(curve, vk, proof, [42, 43])
+    else:
+        raw = native.setup_gm17(ctx, cs, (tox.alpha, tox.beta, 1, tox.tau))
+        pk = native.ProvingKey(ctx, curve.curve_id, raw, scheme="gm17")
+        proof = formats.proof_from_raw(curve, native.prove_gm17(ctx, pk, cs, z, 1111, 2222, 3333))
+        vk = gm17.vk_from_pk_bytes(curve, raw)
+        assert vk["h_g2"] == vk["h_gamma_g2"]                       # gamma = 1, as in ark's generate_random_parameters
+        assert gm17.verify(curve, vk, proof, inp)
+        assert not gm17.verify(curve, vk, proof, [42, 43])
+
+
+@pytest.mark.parametrize("scheme", ["g16", "gm17"])
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_reference_backend_unit_test_on_emulator(lib, curve, scheme):
+    ctx = native.Context(0, lib)
+    _reference_backend_test(ctx, curve, scheme)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme", ["g16", "gm17"])
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_reference_backend_unit_test_on_gpu(curve, scheme):
+    ctx = native.Context(0)
+    _reference_backend_test(ctx, curve, scheme)
+    ctx.close()
+
+
+def test_empty_program_on_emulator(lib):
+    """`Prog::default()` (what /root/reference/zokrates_ast/src/ir/serialize.rs:396-430 round-trips): no arguments, no
+    statements — n = 0, one variable (ONE), domain of size 1, every query vector empty or a single point.  Both schemes
+    still produce proofs that verify."""
+    from oracle import gm17, pairing
+    curve = BN254
+    ctx = native.Context(0, lib)
+    p = native.Program(ir.serialize_prog(ir.Prog(curve, [], [], return_count=0)), lib)
+    assert (p.n, p.l, p.w) == (0, 1, 0)
+    z, inputs = p.assignment(ir.serialize_witness({0: 1}))
+    assert inputs.size == 0
+    cs = p.constraint_system(ctx)
+    tox = g16.Toxic.from_seed(curve)
+    raw = native.setup_g16(ctx, cs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau))
+    pk = native.ProvingKey(ctx, 0, raw)
+    assert (pk.m, pk.w, pk.l, pk.hlen) == (1, 0, 1, 0)
+    proof = formats.proof_from_raw(curve, native.prove_g16(ctx, pk, cs, z, 11, 22))
+    assert pairing.groth16_verify(curve, formats.ark_pk_deserialize(curve, raw.tobytes())["vk"], proof, [])
+    raw = native.setup_gm17(ctx, cs, (tox.alpha, tox.beta, 1, tox.tau))
+    pk = native.ProvingKey(ctx, 0, raw, scheme="gm17")
+    proof = formats.proof_from_raw(curve, native.prove_gm17(ctx, pk, cs, z, 1, 2, 3))
+    assert gm17.verify(curve, gm17.vk_from_pk_bytes(curve, raw), proof, [])
+    ctx.close()
