@@ -1,0 +1,67 @@
+"""bench.py itself on CPU: the real script, pointed at the TEST-ONLY emulator build through the ZKHIP_LIBRARY hook, at toy
+sizes — the JSON contract (one line, rank 0 only, the required keys, roofline + cpu_baseline objects), the three
+workloads / two schemes, and the N = 2 path over gloo including the sharded single-proof leg.  Numbers are meaningless
+here; shapes and parity flags are not."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from emu_util import EMU_LIB, emu_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "cpu_baseline"]
+
+
+def run_bench(args, extra_env=None, timeout=900):
+    emu_library()                                            # make sure the emulator build exists
+    env = dict(os.environ, ZKHIP_LIBRARY=EMU_LIB)
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return lines
+
+
+@pytest.mark.parametrize("args,metric", [
+    (["--log-domain", "5"], "groth16_proofs_per_sec"),
+    (["--log-domain", "5", "--scheme", "gm17"], "gm17_proofs_per_sec"),
+    (["--log-domain", "9", "--kind", "poseidon", "--curve", "bls12_381"], "groth16_proofs_per_sec"),
+])
+def test_single_rank_contract(args, metric):
+    lines = run_bench(args + ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["metric"] == metric and d["unit"] == "proofs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_proof_identical"] is True
+    assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000
+
+
+def test_two_ranks_real_bench_script():
+    world = 2
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, ZKHIP_LIBRARY=EMU_LIB, ZKHIP_DIST_BACKEND="gloo", ZKHIP_BENCH_DEVICE="0", RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-domain", "5", "--steps", "2", "--warmup", "1"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # ONE line, from rank 0
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1000.0)) < 1e-6 * d["value"]          # whole-job aggregate over both ranks
+    s = d["sharded_single_proof"]
+    assert s.get("identical_to_unsharded") is True and s["ranks"] == 2, s

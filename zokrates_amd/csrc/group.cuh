@@ -52,7 +52,12 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bas
     ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE>), dim3(blocks_for(nlanes, T)), dim3(T), 0, s, d_bases, ptr<u32>(so.off), ptr<u32>(so.sorted),
               ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), sh.nkeys, P, nlanes);
     if (ev_end) event_record(ev_end, s);
-    ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(256), dim3(T), T * sizeof(Xyzz<F>), s, ptr<u32>(so.off), P, ptr<u32>(lane.heavy) + 1,
+#ifdef ZK_EMU
+    const unsigned heavy_wgs = 4;     // the fibre emulator pays for every work-item of an idle workgroup
+#else
+    const unsigned heavy_wgs = 256;
+#endif
+    ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(heavy_wgs), dim3(T), T * sizeof(Xyzz<F>), s, ptr<u32>(so.off), P, ptr<u32>(lane.heavy) + 1,
               ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.partial));
     ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.W), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial),
               ptr<u32>(so.off), P, sh.K, sh.Lw, ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));

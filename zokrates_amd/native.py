@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(HERE, "libzkhip.so")
+# ZKHIP_LIBRARY: development / test hook — load another build of the same C ABI (tests point bench.py at the TEST-ONLY
+# emulator build to run its multi-rank plumbing on CPU); unset, the in-tree HIP library is the only candidate
+DEFAULT_LIB = os.environ.get("ZKHIP_LIBRARY") or os.path.join(HERE, "libzkhip.so")
 
 CURVE_IDS = {"bn128": 0, "bls12_381": 1}
 FQ_BYTES = {0: 32, 1: 48}
