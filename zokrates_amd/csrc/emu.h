@@ -9,6 +9,7 @@
 // the scheduler until every live fibre of the block has arrived; wave-level exchanges
 // (`__shfl*`, `__ballot`) rendezvous the 64 fibres of a wave the same way.
 #pragma once
+#include <setjmp.h>
 #include <ucontext.h>
 #include <sys/mman.h>
 
@@ -34,14 +35,16 @@ namespace emu {
 
 enum State { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 struct Fiber {
-    ucontext_t ctx;
+    ucontext_t ctx;     // first entry only (gives the fibre its stack)
+    jmp_buf jb;         // every later switch: _setjmp/_longjmp save no signal mask, i.e. make no system call
     int state;
+    bool started;
     dim3 tid;
     unsigned flat;
 };
 struct Global {
     dim3 threadIdx, blockIdx, blockDim, gridDim;
-    ucontext_t sched;
+    jmp_buf sched;
     Fiber* cur = nullptr;
     const std::function<void()>* fn = nullptr;
     unsigned char* smem = nullptr;
@@ -49,6 +52,8 @@ struct Global {
     char* stacks = nullptr;
     size_t stack_bytes = 0;
     unsigned max_fibers = 0;
+    Fiber* fibers = nullptr;   // the current block's work-items
+    unsigned nt = 0, done = 0;
     uint64_t xchg[64 * 32];   // per-wave exchange slots (up to 32 waves of 64 lanes)
 };
 inline Global& G() {
@@ -64,16 +69,32 @@ inline void yield_with(State s) {
     Global& g = G();
     Fiber* f = g.cur;
     f->state = s;
-    swapcontext(&f->ctx, &g.sched);
+    if (_setjmp(f->jb) == 0) _longjmp(g.sched, 1);
 }
 inline void sync_block() { yield_with(WAIT_BLOCK); }
 inline void sync_wave() { yield_with(WAIT_WAVE); }
 
+// A fibre runs work-items back to back for as long as they finish without waiting: a work-item that returns hands its
+// stack to the next one that has not started yet, so kernels without barriers cost one context switch per workgroup
+// (a fresh context costs a system call; later switches are _setjmp/_longjmp), and a work-item that does wait simply leaves the chain suspended in its own slot.
 inline void trampoline() {
     Global& g = G();
-    (*g.fn)();
-    g.cur->state = DONE;
-    swapcontext(&g.cur->ctx, &g.sched);
+    for (;;) {
+        (*g.fn)();
+        Fiber* f = g.cur;
+        f->state = DONE;
+        ++g.done;
+        const unsigned nx = f->flat + 1;
+        if (nx < g.nt && !g.fibers[nx].started) {
+            Fiber& n = g.fibers[nx];
+            n.started = true;
+            g.cur = &n;
+            g.threadIdx = n.tid;
+            continue;
+        }
+        break;
+    }
+    _longjmp(g.sched, 1);
 }
 
 inline void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& fn) {
@@ -103,17 +124,15 @@ inline void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function
                 g.blockIdx = dim3(bx, by, bz);
                 for (unsigned t = 0; t < nt; ++t) {
                     Fiber& f = fibers[t];
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = g.stacks + (size_t)t * STACK;
-                    f.ctx.uc_stack.ss_size = STACK;
-                    f.ctx.uc_link = nullptr;
-                    makecontext(&f.ctx, (void (*)())trampoline, 0);
                     f.state = READY;
+                    f.started = false;
                     f.flat = t;
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                 }
-                unsigned done = 0;
-                while (done < nt) {
+                g.fibers = fibers.data();
+                g.nt = nt;
+                g.done = 0;
+                while (g.done < nt) {
                     bool ran = false;
                     for (unsigned t = 0; t < nt; ++t) {
                         Fiber& f = fibers[t];
@@ -121,8 +140,18 @@ inline void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function
                         ran = true;
                         g.cur = &f;
                         g.threadIdx = f.tid;
-                        swapcontext(&g.sched, &f.ctx);
-                        if (f.state == DONE) ++done;
+                        if (_setjmp(g.sched) == 0) {
+                            if (!f.started) {      // contexts are made lazily: most work-items run inside a predecessor's chain
+                                f.started = true;
+                                getcontext(&f.ctx);
+                                f.ctx.uc_stack.ss_sp = g.stacks + (size_t)t * STACK;
+                                f.ctx.uc_stack.ss_size = STACK;
+                                f.ctx.uc_link = nullptr;
+                                makecontext(&f.ctx, (void (*)())trampoline, 0);
+                                setcontext(&f.ctx);
+                            }
+                            _longjmp(f.jb, 1);
+                        }
                     }
                     // wave rendezvous
                     bool released = false;
@@ -149,7 +178,7 @@ inline void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function
                             if (fibers[t].state == WAIT_BLOCK) fibers[t].state = READY;
                         released = true;
                     }
-                    if (!ran && !released && done < nt) {
+                    if (!ran && !released && g.done < nt) {
                         fprintf(stderr, "emu: deadlock (divergent barrier) in block (%u,%u,%u)\n", bx, by, bz);
                         abort();
                     }
