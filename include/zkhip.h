@@ -200,6 +200,16 @@ int32_t zkhip_prove_gm17_resident(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhi
 int32_t zkhip_prove_gm17_resident_batch(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, uint32_t count,
                                         zkhip_assignment* const* zs, const uint8_t* d1_d2_r, uint8_t* proofs_out,
                                         zkhip_timings* timings);
+/* One GM17 proof across several GPUs, exactly as for Groth16 (zkhip_pk_load_g16_shard ...): rank k loads its index range of
+ * a_query / b_query / c_query_1 / c_query_2 / g_gamma2_z_t, computes the five partial sums over it, the ranks exchange one
+ * zkhip_partial_size-byte record each, zkhip_combine_gm17 adds them and assembles the proof (bit-identical). */
+int32_t zkhip_pk_load_gm17_shard(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, uint32_t rank,
+                                 uint32_t world, zkhip_pk** out);
+int32_t zkhip_prove_gm17_partial(zkhip_ctx* ctx, const zkhip_pk* pk_shard, const zkhip_r1cs* r1cs, const uint8_t* z,
+                                 zkhip_assignment* z_resident, const uint8_t* d1_d2_r, uint8_t* partial_out,
+                                 zkhip_timings* timings);
+int32_t zkhip_combine_gm17(zkhip_ctx* ctx, const zkhip_pk* pk, uint32_t count, const uint8_t* partials,
+                           const uint8_t* d1_d2_r, uint8_t* proof_out);
 /* Replaces `GM17::circuit_specific_setup` at /root/reference/zokrates_ark/src/gm17.rs:25 ([UPSTREAM]
  * ark_gm17::generate_parameters) with the randomness explicit: toxic = alpha, beta, gamma, t (4 x 32 B; ark's
  * generate_random_parameters fixes gamma = 1); g1/g2 as in zkhip_setup_g16. */

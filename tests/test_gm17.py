@@ -347,3 +347,49 @@ def test_reference_embed_triples_verify():
                   query=[g1(v, 16 + 2 * i) for i in range(len(inputs) + 1)])
         assert gm17.verify_embedded(BLS12_377, vk, proof, inputs), t["source"]
         assert not gm17.verify_embedded(BLS12_377, vk, proof, [inputs[0] + 1] + inputs[1:]), t["source"]
+
+
+# ------------------------------------------------------------------ one GM17 proof across several GPUs (virtual ranks)
+def _gm17_sharded_checks(ctx, curve, world, n=21, seed=61):
+    from oracle import cpu
+    cs, z = circuit(curve, n, seed, extra_public=1)
+    tox = gm17.Toxic.from_seed(curve)
+    mats = [csr_of(cs.A), csr_of(cs.B), csr_of(cs.C)]
+    dcs = native.ConstraintSystem(ctx, curve.curve_id, cs.n, cs.l, cs.w, mats)
+    oc = cpu.Circuit.from_csr(curve.curve_id, cs.n, cs.l, cs.w, mats)
+    tb = cpu.gm17_toxic_bytes(tox)
+    raw = cpu.Gm17ProvingKey.setup(oc, tb).serialize()
+    zb = le(z)
+    d1, d2, r_ = 0xabcdef12345 % curve.r, 99, 0x13579bdf2468 % curve.r
+    want = cpu.gm17_trapdoor(oc, tb, zb, d1, r_)
+    shards = [native.ProvingKey(ctx, curve.curve_id, raw, rank=k, world=world, scheme="gm17") for k in range(world)]
+    parts = [native.prove_gm17_partial(ctx, shards[k], dcs, zb, d1, d2, r_) for k in range(world)]
+    assert native.combine_gm17(ctx, shards[0], parts, d1, d2, r_) == want
+    assert native.combine_gm17(ctx, shards[-1], parts[::-1], d1, d2, r_) == want        # order and combining rank do not matter
+    za = native.Assignment(ctx, dcs, zb)
+    parts = [native.prove_gm17_partial(ctx, shards[k], dcs, za, 0, 0, 0) for k in range(world)]
+    assert native.combine_gm17(ctx, shards[0], parts, 0, 0, 0) == cpu.gm17_trapdoor(oc, tb, zb, 0, 0)
+    with pytest.raises(native.ZkhipError):                                              # a shard cannot prove alone
+        native.prove_gm17(ctx, shards[0], dcs, zb, d1, d2, r_)
+    with pytest.raises(native.ZkhipError):                                              # nor be combined as a Groth16 key
+        native.combine_g16(ctx, shards[0], parts, 1, 2)
+    whole = native.ProvingKey(ctx, curve.curve_id, raw, scheme="gm17")
+    assert native.combine_gm17(ctx, whole, [native.prove_gm17_partial(ctx, whole, dcs, zb, d1, d2, r_)], d1, d2, r_) == want
+    # a shard's key image keeps its range
+    sh2 = native.ProvingKey.from_image(ctx, curve.curve_id, shards[1].export_image(), scheme="gm17")
+    assert native.prove_gm17_partial(ctx, sh2, dcs, zb, d1, d2, r_).tobytes() == native.prove_gm17_partial(ctx, shards[1], dcs, zb, d1, d2, r_).tobytes()
+
+
+@pytest.mark.parametrize("curve,world", [(BN254, 2), (BN254, 5), (BLS12_381, 3)], ids=lambda v: getattr(v, "name", str(v)))
+def test_emu_gm17_sharded_virtual_ranks(emu_ctx, curve, world):
+    _gm17_sharded_checks(emu_ctx, curve, world)
+
+
+def test_emu_gm17_more_ranks_than_points(emu_ctx):
+    _gm17_sharded_checks(emu_ctx, BN254, 64, n=3)     # most ranks own an empty range
+
+
+@pytest.mark.gpu
+def test_gpu_gm17_sharded_virtual_ranks(gpu_ctx):
+    _gm17_sharded_checks(gpu_ctx, BN254, 4, n=300)
+    _gm17_sharded_checks(gpu_ctx, BLS12_381, 3, n=100)

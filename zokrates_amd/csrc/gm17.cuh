@@ -169,14 +169,17 @@ struct Gm17 {
         ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(D, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(ctx->tmp),
                   ptr<Aff<Fq>>(pk->h_sigma), D, D, plan->N1, plan->N2);
         stream_sync(ctx->stream);
-        pk->z_lo = 0; pk->z_n = me; pk->h_lo = 0; pk->h_n = D;
-        pk->c_z = msm_shape(me, Fr::Params::BITS).c;
-        pk->c_h = msm_shape(D, Fr::Params::BITS).c;
-        L::template to_unsat<Fq>(ctx, pk->a_ext, 0, me);
-        L::template to_unsat<Fq>(ctx, pk->b1_ext, 0, me);
-        L::template to_unsat<Fq>(ctx, pk->l_ext, 0, me);
-        L::template to_unsat<Fq2>(ctx, pk->b2_ext, 0, me);
-        L::template to_unsat<Fq>(ctx, pk->h_sigma, 0, D);
+        // this rank's share of the bases (everything for world = 1), as in PkLoader::load
+        u64 nominal_z, nominal_h;
+        L::range_of(me, pk->rank, pk->world, pk->z_lo, pk->z_n, nominal_z);
+        L::range_of(D, pk->rank, pk->world, pk->h_lo, pk->h_n, nominal_h);
+        pk->c_z = msm_shape(nominal_z, Fr::Params::BITS).c;
+        pk->c_h = msm_shape(nominal_h, Fr::Params::BITS).c;
+        L::template to_unsat<Fq>(ctx, pk->a_ext, pk->z_lo, pk->z_n);
+        L::template to_unsat<Fq>(ctx, pk->b1_ext, pk->z_lo, pk->z_n);
+        L::template to_unsat<Fq>(ctx, pk->l_ext, pk->z_lo, pk->z_n);
+        L::template to_unsat<Fq2>(ctx, pk->b2_ext, pk->z_lo, pk->z_n);
+        L::template to_unsat<Fq>(ctx, pk->h_sigma, pk->h_lo, pk->h_n);
     }
 
     static void check_match(const zkhip_pk* pk, const zkhip_r1cs* cs) {
@@ -243,11 +246,16 @@ struct Gm17 {
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
-        msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars, shz);
-        msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
-        msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
-        msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
-        msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2]);
+        // (a sharded key covers only its index range of the bases and pairs them with the same range of the scalars)
+        if (pk->z_n) {
+            msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz);
+            msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
+            msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
+            msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
+            msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2]);
+        } else {
+            P::empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
+        }
         event_record(sl.ev[1], st);
 
         // ---- quotient h0 = (U^2 - W)/Z: 2 iNTT, 2 coset NTT, pointwise, coset iNTT (sigma order, canonical)
@@ -261,17 +269,26 @@ struct Gm17 {
         event_record(sl.ev[2], st);
 
         // ---- G = MSM(g_gamma2_z_t, h0)
-        msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va), shh);
-        msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+        if (pk->h_n) {
+            msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh);
+            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+        } else {
+            P::empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
+        }
         P::copy_out(ctx, sl, Wmax);
     }
 
     // C = C1 + rho C2 + rho^2 g_gamma2_z2 + G
     static void finish(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, uint8_t* out, zkhip_timings* tm) {
+        require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "this proving key is one shard of a multi-GPU key: use zkhip_prove_gm17_partial + zkhip_combine_gm17");
         const typename P::Sums g = P::collect(ctx, sl, pk);
         const auto t_fin = std::chrono::steady_clock::now();
         Fr rho;
         memcpy(rho.v, sl.r, 32);
+        assemble(pk, g, rho, out);
+        P::fill_timings(sl, tm, t_fin);
+    }
+    static void assemble(const zkhip_pk* pk, const typename P::Sums& g, const Fr& rho, uint8_t* out) {
         const Fr rho2 = fe_from_mont(fe_sqr(fe_to_mont(rho)));
         uint8_t dec[2 * FQB];
         decode_point<FQB, 2>(pk->g_gamma2_z2_canon.data(), dec);
@@ -295,7 +312,31 @@ struct Gm17 {
         }
         if (!gC.is_inf()) { write_fe(pc.x, out + 6 * FQB); write_fe(pc.y, out + 7 * FQB); }
         out[8 * FQB] = g.a.is_inf(); out[8 * FQB + 1] = g.b2.is_inf(); out[8 * FQB + 2] = gC.is_inf();
-        P::fill_timings(sl, tm, t_fin);
+    }
+    // one rank's share of a proof (as Prover<C>::prove_partial): the five partial sums, raw
+    static void prove_partial(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* z_dev, const uint8_t* rnd,
+                              uint8_t* partial_out, zkhip_timings* tm) {
+        check_d2(rnd);
+        enqueue(ctx, ctx->slots[0], pk, cs, z_host, z_dev, rnd, rnd + 64);
+        const typename P::Sums g = P::collect(ctx, ctx->slots[0], pk);
+        const auto t_fin = std::chrono::steady_clock::now();
+        memcpy(partial_out, &g, sizeof(g));
+        P::fill_timings(ctx->slots[0], tm, t_fin);
+    }
+    static void combine(const zkhip_pk* pk, u32 count, const uint8_t* partials, const uint8_t* rnd, uint8_t* out) {
+        check_d2(rnd);
+        Fr dd = fe_from_bytes_canon<Fr>(rnd), rr = fe_from_bytes_canon<Fr>(rnd + 64);
+        require(canon_lt_mod(dd) && canon_lt_mod(rr), ZKHIP_ERR_BAD_ARG, "d1 or r not a canonical field element");
+        typename P::Sums t;
+        t.a = t.b1 = t.l = t.h = Xyzz<Fq>::inf();
+        t.b2 = Xyzz<Fq2>::inf();
+        for (u32 i = 0; i < count; ++i) {
+            typename P::Sums g;
+            memcpy(&g, partials + (size_t)i * sizeof(g), sizeof(g));
+            t.a = xyzz_add(t.a, g.a); t.b1 = xyzz_add(t.b1, g.b1); t.l = xyzz_add(t.l, g.l); t.h = xyzz_add(t.h, g.h);
+            t.b2 = xyzz_add(t.b2, g.b2);
+        }
+        assemble(pk, t, add_mod(dd, rr), out);
     }
 
     // rnd = d1 | d2 | r (3 x 32 B): d2 is validated and otherwise unused — it cancels out of the proof

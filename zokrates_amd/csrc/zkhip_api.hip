@@ -476,6 +476,40 @@ int32_t zkhip_pk_load_gm17(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, 
         *out = pk.release();
     });
 }
+int32_t zkhip_pk_load_gm17_shard(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, uint32_t rank, uint32_t world, zkhip_pk** out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(bytes && out, ZKHIP_ERR_BAD_ARG, "null argument");
+        *out = nullptr;
+        require(world >= 1 && world <= 64 && rank < world, ZKHIP_ERR_BAD_ARG, "rank / world out of range (1 <= world <= 64)");
+        std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
+        pk->curve = curve;
+        pk->ctx = ctx;
+        pk->rank = rank;
+        pk->world = world;
+        ops_for(curve)->gm17_pk_load(ctx, bytes, len, pk.get());
+        *out = pk.release();
+    });
+}
+int32_t zkhip_prove_gm17_partial(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z, zkhip_assignment* z_resident,
+                                 const uint8_t* d1_d2_r, uint8_t* partial_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && (z || z_resident) && d1_d2_r && partial_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
+        if (!z) require(z_resident->ctx == ctx && z_resident->curve == pk->curve && z_resident->m == r1cs->l + r1cs->w, ZKHIP_ERR_BAD_ARG,
+                        "assignment does not match the constraint system");
+        ops_for(pk->curve)->gm17_prove_partial(ctx, pk, r1cs, z, z ? nullptr : z_resident->scalars.p, d1_d2_r, partial_out, timings);
+    });
+}
+int32_t zkhip_combine_gm17(zkhip_ctx* ctx, const zkhip_pk* pk, uint32_t count, const uint8_t* partials, const uint8_t* d1_d2_r, uint8_t* proof_out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && partials && d1_d2_r && proof_out && count >= 1, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->scheme == 1, ZKHIP_ERR_BAD_ARG, "this is a Groth16 proving key");
+        ops_for(pk->curve)->gm17_combine(pk, count, partials, d1_d2_r, proof_out);
+    });
+}
 int32_t zkhip_prove_gm17(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z, const uint8_t* d1_d2_r,
                          uint8_t* proof_out, zkhip_timings* timings) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;

@@ -55,7 +55,7 @@ class Library:
         "zkhip_pk_load_g16_shard", "zkhip_partial_size", "zkhip_prove_g16_partial", "zkhip_combine_g16", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
         "zkhip_field_op", "zkhip_setup_g16_size", "zkhip_setup_g16", "zkhip_describe",
         "zkhip_pk_load_gm17", "zkhip_prove_gm17", "zkhip_prove_gm17_resident", "zkhip_prove_gm17_resident_batch",
-        "zkhip_setup_gm17_size", "zkhip_setup_gm17",
+        "zkhip_setup_gm17_size", "zkhip_setup_gm17", "zkhip_pk_load_gm17_shard", "zkhip_prove_gm17_partial", "zkhip_combine_gm17",
         "zkhip_prog_parse", "zkhip_prog_free", "zkhip_prog_dims", "zkhip_prog_matrix", "zkhip_prog_variable_order",
         "zkhip_prog_r1cs_load", "zkhip_prog_assignment",
         "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import",
@@ -100,6 +100,9 @@ class Library:
         L.zkhip_prove_gm17.restype = i32; L.zkhip_prove_gm17.argtypes = [vp] * 7
         L.zkhip_prove_gm17_resident.restype = i32; L.zkhip_prove_gm17_resident.argtypes = [vp] * 7
         L.zkhip_prove_gm17_resident_batch.restype = i32; L.zkhip_prove_gm17_resident_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        L.zkhip_pk_load_gm17_shard.restype = i32; L.zkhip_pk_load_gm17_shard.argtypes = [vp, i32, vp, sz, u32, u32, pp]
+        L.zkhip_prove_gm17_partial.restype = i32; L.zkhip_prove_gm17_partial.argtypes = [vp] * 8
+        L.zkhip_combine_gm17.restype = i32; L.zkhip_combine_gm17.argtypes = [vp, vp, u32, vp, vp, vp]
         L.zkhip_setup_gm17_size.restype = i32; L.zkhip_setup_gm17_size.argtypes = [vp, vp]
         L.zkhip_setup_gm17.restype = i32; L.zkhip_setup_gm17.argtypes = [vp, vp, vp, vp, vp, vp, u64]
         L.zkhip_pk_export_size.restype = i32; L.zkhip_pk_export_size.argtypes = [vp, vp]
@@ -201,10 +204,10 @@ class ProvingKey:
         self.scheme = scheme
         data = _u8(data)
         self.h = C.c_void_p()
-        if scheme == "gm17":
-            if world != 1:
-                raise ValueError("GM17 keys are not sharded")
+        if scheme == "gm17" and world == 1:
             ctx._check(ctx.lib.L.zkhip_pk_load_gm17(ctx.h, curve_id, _ptr(data), data.size, C.byref(self.h)))
+        elif scheme == "gm17":
+            ctx._check(ctx.lib.L.zkhip_pk_load_gm17_shard(ctx.h, curve_id, _ptr(data), data.size, rank, world, C.byref(self.h)))
         elif world == 1:
             ctx._check(ctx.lib.L.zkhip_pk_load_g16(ctx.h, curve_id, _ptr(data), data.size, C.byref(self.h)))
         else:
@@ -432,6 +435,29 @@ def prove_gm17(ctx, pk, cs, z, d1, d2, r, want_timings=False):
         z = _u8(z, cs.m * 32)
         ctx._check(ctx.lib.L.zkhip_prove_gm17(ctx.h, pk.h, cs.h, _ptr(z), _ptr(rnd), _ptr(out), C.byref(tm)))
     return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+
+def prove_gm17_partial(ctx, pk_shard, cs, z, d1, d2, r):
+    """One rank's share of a GM17 proof: z is a host assignment or an `Assignment`.  Returns the partial record."""
+    rnd = _rnd96(d1, d2, r)
+    out = np.zeros(partial_size(ctx, pk_shard.curve_id), dtype=np.uint8)
+    tm = Timings()
+    if isinstance(z, Assignment):
+        zp, za = None, z.h
+    else:
+        z = _u8(z, cs.m * 32)
+        zp, za = _ptr(z), None
+    ctx._check(ctx.lib.L.zkhip_prove_gm17_partial(ctx.h, pk_shard.h, cs.h, zp, za, _ptr(rnd), _ptr(out), C.byref(tm)))
+    return out
+
+
+def combine_gm17(ctx, pk, partials, d1, d2, r):
+    nb = FQ_BYTES[pk.curve_id]
+    buf = np.ascontiguousarray(np.concatenate([_u8(p) for p in partials]))
+    rnd = _rnd96(d1, d2, r)
+    out = np.zeros(8 * nb + 3, dtype=np.uint8)
+    ctx._check(ctx.lib.L.zkhip_combine_gm17(ctx.h, pk.h, len(partials), _ptr(buf), _ptr(rnd), _ptr(out)))
+    return out.tobytes()
 
 
 def prove_gm17_resident_batch(ctx, pk, cs, assignments, rnds):

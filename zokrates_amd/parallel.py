@@ -79,10 +79,15 @@ class Ranks:
             self._dist = None
 
 
-def prove_sharded(ranks, ctx, pk_shard, cs, z, r, s):
-    """One proof across all ranks.  `pk_shard` = native.ProvingKey(..., rank=ranks.rank, world=ranks.world); z, r, s are
-    the same on every rank.  Every rank returns the (identical) proof bytes."""
+def prove_sharded(ranks, ctx, pk_shard, cs, z, r, s, d1_d2=None):
+    """One proof across all ranks.  `pk_shard` = native.ProvingKey(..., rank=ranks.rank, world=ranks.world); z and the
+    blinding scalars are the same on every rank (Groth16: r, s; GM17: d1_d2 = (d1, d2) and r, `s` ignored).  Every rank
+    returns the (identical) proof bytes."""
     from . import native
+    if getattr(pk_shard, "scheme", "g16") == "gm17":
+        d1, d2 = d1_d2
+        parts = ranks.all_gather_bytes(native.prove_gm17_partial(ctx, pk_shard, cs, z, d1, d2, r))
+        return native.combine_gm17(ctx, pk_shard, parts, d1, d2, r)
     part = native.prove_g16_partial(ctx, pk_shard, cs, z, r, s)
     parts = ranks.all_gather_bytes(part)
     return native.combine_g16(ctx, pk_shard, parts, r, s)
