@@ -414,3 +414,45 @@ def test_empty_program_on_emulator(lib):
     proof = formats.proof_from_raw(curve, native.prove_gm17(ctx, pk, cs, z, 1, 2, 3))
     assert gm17.verify(curve, gm17.vk_from_pk_bytes(curve, raw), proof, [])
     ctx.close()
+
+
+def test_parser_survives_mutations(lib):
+    """The C ABI never throws across the boundary and never aborts: byte flips, truncations, insertions and stray CBOR
+    structure bytes in an `out` file (and garbage `witness` files) give a parsed program or a ZkhipError — nothing else;
+    an absurd variable id is an error, not a multi-gigabyte allocation."""
+    rnd = random.Random(1)
+    prog = random_prog(BN254, rnd, n=12)
+    good = ir.serialize_prog(prog)
+    parsed = rejected = 0
+    for _ in range(3000):
+        b = bytearray(good)
+        k = rnd.randrange(4)
+        if k == 0:
+            for _ in range(rnd.randrange(1, 4)):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+        elif k == 1:
+            b = b[:rnd.randrange(len(b))]
+        elif k == 2:
+            i = rnd.randrange(len(b))
+            b[i:i] = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9)))
+        else:
+            b[rnd.randrange(120, len(b))] = rnd.choice([0x9F, 0xBF, 0xFF, 0x5F, 0x7F, 0xFB, 0x1B, 0x3B, 0xC0, 0xD8])
+        try:
+            p = native.Program(bytes(b), lib)
+            parsed += 1
+            try:
+                p.assignment(bytes(rnd.randrange(256) for _ in range(8 + 40 * 3)))
+            except native.ZkhipError:
+                pass
+            p.close()
+        except native.ZkhipError:
+            rejected += 1
+    assert parsed > 100 and rejected > 100
+    huge = ir.Prog(BN254, [], [ir.Constraint([((1 << 31) - 2, 1)], [(0, 1)], [(1, 1)])])
+    with pytest.raises(native.ZkhipError) as e:
+        native.Program(ir.serialize_prog(huge), lib)
+    assert e.value.code == -2 and "out of range" in str(e.value)
+    p = native.Program(good, lib)
+    with pytest.raises(native.ZkhipError) as e:
+        p.assignment(struct.pack("<Q", 1) + struct.pack("<q", (1 << 31) - 2) + bytes(32))
+    assert e.value.code == -2

@@ -134,10 +134,12 @@ constexpr uint32_t UNSEEN = 0xffffffffu;
 struct Symbols {
     std::vector<uint32_t> pos, neg;   // tag by ZoKrates id: pos[id] for id >= 0, neg[-id - 1] for id < 0
     std::vector<int64_t> inst, wit;   // ids in allocation order (inst[0] = ~one)
+    uint64_t id_limit = (uint64_t)1 << 31;   // the compiler numbers variables densely: an id far beyond what the file could
+                                             // define is corruption, not a reason to allocate gigabytes of lookup table
     uint32_t& slot(int64_t id) {
         std::vector<uint32_t>& v = id >= 0 ? pos : neg;
         const uint64_t k = id >= 0 ? (uint64_t)id : (uint64_t)(-(id + 1));
-        if (k >= ((uint64_t)1 << 31)) fail(ZKHIP_ERR_PARSE, "variable id out of range");
+        if (k >= id_limit) fail(ZKHIP_ERR_PARSE, "variable id out of range");
         if (k >= v.size()) v.resize(std::max<size_t>(k + 1, v.size() * 2), UNSEEN);
         return v[k];
     }
@@ -248,6 +250,7 @@ struct Builder {
     }
     void run(const uint8_t* bytes, uint64_t par_off, uint64_t par_len, uint64_t st_off, uint64_t st_len, zkhip_prog* out) {
         for (auto& r : rp) r.assign(1, 0);
+        sym.id_limit = std::min<uint64_t>((uint64_t)1 << 31, std::max<uint64_t>((uint64_t)1 << 20, 8 * (par_len + st_len)));
         // symbols[~one] = ConstraintSystem::one()                                   lib.rs:89
         sym.slot(0) = sym.alloc(0, true);
         // arguments, in order: private -> witness, public -> instance               lib.rs:94-113
@@ -387,7 +390,8 @@ void prog_assignment(const zkhip_prog* prog, const uint8_t* wit, size_t len, uin
         if (!ok) fail(ZKHIP_ERR_PARSE, "non-canonical field element in the witness");
         std::vector<uint32_t>& v = id >= 0 ? pos : neg;
         const uint64_t k = id >= 0 ? (uint64_t)id : (uint64_t)(-(id + 1));
-        if (k >= ((uint64_t)1 << 31)) fail(ZKHIP_ERR_PARSE, "variable id out of range in the witness");
+        if (k >= std::min<uint64_t>((uint64_t)1 << 31, std::max<uint64_t>((uint64_t)1 << 20, 64 * count)))
+            fail(ZKHIP_ERR_PARSE, "variable id out of range in the witness");
         if (k >= v.size()) v.resize(std::max<size_t>(k + 1, v.size() * 2), 0);
         if (id < 0 && v[k] == 0) ++n_out;
         v[k] = (uint32_t)(i + 1);
