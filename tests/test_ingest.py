@@ -299,6 +299,13 @@ def _key_image_checks(ctx):
             with pytest.raises(native.ZkhipError) as e:
                 native.ProvingKey.from_image(ctx, 0, bad, scheme=scheme)
             assert e.value.code == -2
+        # header fields the kernels would trust (index range lengths at byte offsets 88 / 104) must match the array sizes
+        for off in (88, 104):
+            bad = image.copy()
+            bad[off:off + 8] = np.frombuffer(struct.pack("<Q", int.from_bytes(image[off:off + 8].tobytes(), "little") + 1), dtype=np.uint8)
+            with pytest.raises(native.ZkhipError) as e:
+                native.ProvingKey.from_image(ctx, 0, bad, scheme=scheme)
+            assert e.value.code == -2
     # a shard keeps its index range
     shard = native.ProvingKey(ctx, 0, native.setup_g16(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau)), rank=1, world=3)
     sh2 = native.ProvingKey.from_image(ctx, 0, shard.export_image())

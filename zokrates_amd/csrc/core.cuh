@@ -1049,6 +1049,7 @@ struct CurveOps {
     u64 (*gm17_key_bytes)(u64, u64, u64);
     void (*gm17_prove_partial)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const void*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*gm17_combine)(const zkhip_pk*, u32, const uint8_t*, const uint8_t*, uint8_t*);
+    size_t unsat_g1_bytes;   // size of one resident G1 base (G2: twice that): lets zkhip_pk_import validate an image's shape
 };
 template <class C>
 static void field_op_dispatch(zkhip_ctx* ctx, int field, int op, u64 count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -1080,6 +1081,7 @@ static CurveOps make_curve_ops() {
     o.gm17_key_bytes = &Gm17<C>::key_bytes;
     o.gm17_prove_partial = &Gm17<C>::prove_partial;
     o.gm17_combine = &Gm17<C>::combine;
+    o.unsat_g1_bytes = unsat_point_bytes<typename C::Fq>();
     return o;
 }
 const CurveOps* curve_ops_bn254();

@@ -430,7 +430,7 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         PkImageHeader h;
         memcpy(&h, bytes, sizeof(h));
         require(!memcmp(h.magic, PK_IMAGE_MAGIC, 8), ZKHIP_ERR_PARSE, "not a key image of this library version (re-import the proving key)");
-        ops_for(h.curve);   // validates the curve id
+        const uint64_t g1b = ops_for(h.curve)->unsat_g1_bytes;   // (validates the curve id)
         require(h.scheme == 0 || h.scheme == 1, ZKHIP_ERR_PARSE, "key image: unknown scheme");
         uint64_t total = sizeof(PkImageHeader), rest = len - sizeof(PkImageHeader);
         const uint64_t parts[7] = {h.len_delta, h.len_g2z2, h.len_buf[0], h.len_buf[1], h.len_buf[2], h.len_buf[3], h.len_buf[4]};
@@ -443,6 +443,13 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         require(h.world >= 1 && h.rank < h.world && h.logN >= 0 && h.logN <= 22 && h.N == ((uint64_t)1 << h.logN) && h.z_n <= h.m + 2 && h.h_n <= h.N &&
                     h.c_z >= 2 && h.c_z <= 16 && h.c_h >= 2 && h.c_h <= 16,
                 ZKHIP_ERR_PARSE, "key image: inconsistent header");
+        // the index ranges must lie inside the key and the five base arrays must have exactly the size the ranges imply:
+        // the kernels trust these numbers
+        const uint64_t zb = std::max<uint64_t>(h.z_n, 1) * g1b, hb = std::max<uint64_t>(h.h_n, 1) * g1b;
+        require(h.m + 2 < ((uint64_t)1 << 31) && h.z_lo <= h.m + 2 && h.z_n <= h.m + 2 - h.z_lo && h.h_lo <= h.N && h.h_n <= h.N - h.h_lo &&
+                    h.len_buf[0] == zb && h.len_buf[1] == zb && h.len_buf[2] == zb && h.len_buf[3] == 2 * zb && h.len_buf[4] == hb &&
+                    h.len_delta <= 4096 && h.len_g2z2 <= 4096,
+                ZKHIP_ERR_PARSE, "key image: array sizes do not match the header");
         std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
         pk->curve = h.curve; pk->scheme = h.scheme; pk->ctx = ctx;
         pk->m = h.m; pk->w = h.w; pk->l = h.l; pk->hlen = h.hlen; pk->N = h.N; pk->logN = h.logN;
