@@ -195,7 +195,7 @@ def main():
         "host_ms": {"setup_gpu": 1000 * t_setup, "pk_load": 1000 * t_pkload, "assignment_h2d": 1000 * t_h2d},
         "device": ctx.describe(),
     }
-    if world > 1 and not gm17:
+    if world > 1:
         # latency mode: ONE proof sharded over all ranks (1/world of the bases per GPU, RCCL all-gather of the partial
         # records); reported next to the throughput metric, never instead of it.  A watchdog guarantees that the
         # throughput line is printed even if this optional leg hangs in a collective (e.g. one rank failed asymmetrically).
@@ -212,16 +212,16 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            shard = native.ProvingKey(ctx, curve_id, pk_bytes, rank=rank, world=world)
+            shard = native.ProvingKey(ctx, curve_id, pk_bytes, rank=rank, world=world, scheme=args.scheme)
             z_common = native.Assignment(ctx, cs, circ.assignment(0x5EED7777))
             times = []
             for i in range(5):
                 barrier_sync()
                 t0 = time.perf_counter()
-                proof = parallel.prove_sharded(ranks, ctx, shard, cs, z_common, 4242 + i, 777 + i)
+                proof = parallel.prove_sharded(ranks, ctx, shard, cs, z_common, 4242 + i, 777 + i, d1_d2=(31 + i, 59))
                 barrier_sync()
                 times.append(ranks.max_over_ranks(time.perf_counter() - t0))
-            whole = native.prove_g16_resident(ctx, pk, cs, z_common, 4242 + 4, 777 + 4)
+            whole = prove_one(z_common, (31 + 4, 59, 4242 + 4) if gm17 else (4242 + 4, 777 + 4))[0]
             out["sharded_single_proof"] = {"ms": 1000.0 * min(times[1:]), "ranks": world, "identical_to_unsharded": bool(proof == whole),
                                            "exchange": "all-gather of one %d-byte record per rank" % native.partial_size(ctx, curve_id)}
         except Exception as e:  # the throughput line must survive a failure of the optional leg

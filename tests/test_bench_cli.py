@@ -47,13 +47,14 @@ def test_single_rank_contract(args, metric):
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000
 
 
-def test_two_ranks_real_bench_script():
+@pytest.mark.parametrize("scheme,port", [("g16", "29541"), ("gm17", "29543")])
+def test_two_ranks_real_bench_script(scheme, port):
     world = 2
     procs = []
     for rank in range(world):
         env = dict(os.environ, ZKHIP_LIBRARY=EMU_LIB, ZKHIP_DIST_BACKEND="gloo", ZKHIP_BENCH_DEVICE="0", RANK=str(rank), LOCAL_RANK=str(rank),
-                   WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-domain", "5", "--steps", "2", "--warmup", "1"],
+                   WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-domain", "5", "--steps", "2", "--warmup", "1", "--scheme", scheme],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (out, err) in zip(procs, outs):
