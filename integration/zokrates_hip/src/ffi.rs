@@ -1,0 +1,30 @@
+//! Hand-written bindings of include/zkhip.h (the subset the adapter needs).  Every function returns 0 on success.
+#![allow(non_camel_case_types)]
+use std::os::raw::c_char;
+
+#[repr(C)] pub struct zkhip_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct zkhip_pk { _p: [u8; 0] }
+#[repr(C)] pub struct zkhip_r1cs { _p: [u8; 0] }
+/// 16 floats: h2d, matvec, ntt, msm_h, msm_z, finish, total, accum_g1, accum_g2, 7 reserved (milliseconds)
+#[repr(C)] #[derive(Default, Clone, Copy)] pub struct zkhip_timings { pub ms: [f32; 16] }
+
+pub const ZKHIP_CURVE_BN128: i32 = 0;
+pub const ZKHIP_CURVE_BLS12_381: i32 = 1;
+
+extern "C" {
+    pub fn zkhip_ctx_create(device: i32, out: *mut *mut zkhip_ctx) -> i32;
+    pub fn zkhip_ctx_free(ctx: *mut zkhip_ctx);
+    pub fn zkhip_last_error(ctx: *const zkhip_ctx) -> *const c_char;
+    pub fn zkhip_pk_load_g16(ctx: *mut zkhip_ctx, curve: i32, bytes: *const u8, len: usize, out: *mut *mut zkhip_pk) -> i32;
+    pub fn zkhip_pk_load_gm17(ctx: *mut zkhip_ctx, curve: i32, bytes: *const u8, len: usize, out: *mut *mut zkhip_pk) -> i32;
+    pub fn zkhip_pk_free(pk: *mut zkhip_pk);
+    pub fn zkhip_r1cs_load(ctx: *mut zkhip_ctx, curve: i32, n: u64, l: u64, w: u64,
+        rp_a: *const u64, col_a: *const u32, val_a: *const u8,
+        rp_b: *const u64, col_b: *const u32, val_b: *const u8,
+        rp_c: *const u64, col_c: *const u32, val_c: *const u8, out: *mut *mut zkhip_r1cs) -> i32;
+    pub fn zkhip_r1cs_free(cs: *mut zkhip_r1cs);
+    pub fn zkhip_prove_g16(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, cs: *const zkhip_r1cs, z: *const u8,
+        r: *const u8, s: *const u8, proof_out: *mut u8, timings: *mut zkhip_timings) -> i32;
+    pub fn zkhip_prove_gm17(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, cs: *const zkhip_r1cs, z: *const u8,
+        d1_d2_r: *const u8, proof_out: *mut u8, timings: *mut zkhip_timings) -> i32;
+}
