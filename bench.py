@@ -238,9 +238,30 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
     elif rank == 0:
         out["cpu_baseline"] = None   # N > 1 or --cpu-seconds 0
+    if rank == 0 and world == 1:
+        out["box_probe"] = box_probe()
     if rank == 0:
         print(json.dumps(out), flush=True)
     ranks.close()
+
+
+def box_probe():
+    """Latency figures of THIS box (tools/box_probe, a stand-alone HIP micro-benchmark built next to libzkhip; run after
+    the timed region): the pool's boxes come in two kinds that differ 2-3.6x on the latency-bound fold kernels
+    (DESIGN.md §8), and these numbers travel with the bench line so that a result can be attributed.  None if the
+    binary is absent or fails."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "box_probe")
+    if not os.access(exe, os.X_OK):
+        return None
+    try:
+        txt = subprocess.run([exe], capture_output=True, text=True, timeout=30).stdout
+        grab = lambda pat: float(re.search(pat, txt).group(1))
+        return {"lone_wave_mad_ns": grab(r"lone wave [\d.]+ ms \(([\d.]+) ns/iter\)"), "lds_hop_ns": grab(r"lds chain: lone wave [\d.]+ ms \(([\d.]+) ns/hop\)"),
+                "global_hop_ns_256KiB": grab(r"over\s+256 KiB: ([\d.]+) ns/hop"), "global_hop_ns_256MiB": grab(r"over 262144 KiB: ([\d.]+) ns/hop")}
+    except Exception:
+        return None
 
 
 def proof_algorithmic_bytes(circ, fq):
