@@ -116,6 +116,12 @@ fn hex_be(le: &[u8]) -> String { let mut v = le.to_vec(); v.reverse(); format!("
 
 /// raw = A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y (canonical LE, `fq` bytes each) + 3 infinity flags
 fn points_from_raw(raw: &[u8], fq: usize) -> (G1Affine, G2Affine, G1Affine) {
+    // a flagged point at infinity arrives with all-zero coordinates; the ark backend prints `zero()` = (0, 1) through
+    // parse_g1 / parse_g2 (zokrates_ark/src/lib.rs:150-218), so y (G2: y.c0) becomes 1 before the hex encoding
+    let mut raw = raw.to_vec();
+    for (flag, y) in [(8 * fq, 1usize), (8 * fq + 1, 4), (8 * fq + 2, 7)] {
+        if raw[flag] != 0 { raw[y * fq] = 1; }
+    }
     let e = |i: usize| hex_be(&raw[i * fq..(i + 1) * fq]);
     (G1Affine(e(0), e(1)), G2Affine::Fq2(G2AffineFq2((e(2), e(3)), (e(4), e(5)))), G1Affine(e(6), e(7)))
 }

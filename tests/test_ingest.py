@@ -309,7 +309,12 @@ def _key_image_checks(ctx):
     # a shard keeps its index range
     shard = native.ProvingKey(ctx, 0, native.setup_g16(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau)), rank=1, world=3)
     sh2 = native.ProvingKey.from_image(ctx, 0, shard.export_image())
-    assert native.prove_g16_partial(ctx, sh2, dcs, le(z), 5, 6).tobytes() == native.prove_g16_partial(ctx, shard, dcs, le(z), 5, 6).tobytes()
+    raw16 = native.setup_g16(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau))
+    others = [native.prove_g16_partial(ctx, native.ProvingKey(ctx, 0, raw16, rank=k, world=3), dcs, le(z), 5, 6) for k in (0, 2)]
+    p_img, p_ref = native.prove_g16_partial(ctx, sh2, dcs, le(z), 5, 6), native.prove_g16_partial(ctx, shard, dcs, le(z), 5, 6)
+    whole = native.prove_g16(ctx, native.ProvingKey(ctx, 0, raw16), dcs, le(z), 5, 6)
+    assert native.combine_g16(ctx, shard, [others[0], p_img, others[1]], 5, 6) == whole
+    assert p_img.tobytes() == p_ref.tobytes()      # canonical records: equal shares are equal bytes
 
 
 def test_key_image_on_emulator(lib):

@@ -12,7 +12,9 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/zkhip.h"
@@ -47,6 +49,29 @@ struct CurveBls381 {
     // /root/reference/zokrates_proof_systems/src/solidity.rs:430-441
     static const u32* g1_gen() { static const u32 t[] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu, 0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u, 0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu, 0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u}; return t; }
     static const u32* g2_gen() { static const u32 t[] = {0xc121bdb8u, 0xd48056c8u, 0xa805bbefu, 0x0bac0326u, 0x7ae3d177u, 0xb4510b64u, 0xfa403b02u, 0xc6e47ad4u, 0x2dc51051u, 0x26080527u, 0xf08f0a91u, 0x024aa2b2u, 0x5d042b7eu, 0xe5ac7d05u, 0x13945d57u, 0x334cf112u, 0xdc7f5049u, 0xb5da61bbu, 0x9920b61au, 0x596bd0d0u, 0x88274f65u, 0x7dacd3a0u, 0x52719f60u, 0x13e02b60u, 0x08b82801u, 0xe1935486u, 0x3baca289u, 0x923ac9ccu, 0x5160d12cu, 0x6d429a69u, 0x8cbdd3a7u, 0xadfd9baau, 0xda2e351au, 0x8cc9cdc6u, 0x727d6e11u, 0x0ce5d527u, 0xf05f79beu, 0xaaa9075fu, 0x5cec1da1u, 0x3f370d27u, 0x572e99abu, 0x267492abu, 0x85a763afu, 0xcb3e287eu, 0x2bc28b99u, 0x32acd2b0u, 0x2ea734ccu, 0x0606c4a0u}; return t; }
+};
+
+// A few host threads that are always joined: if starting one fails (EAGAIN) the work runs on the calling thread instead,
+// and leaving the scope — normally or through an exception — joins whatever was started.
+struct HostThreads {
+    std::vector<std::thread> th;
+    HostThreads() { th.reserve(8); }
+    HostThreads(const HostThreads&) = delete;
+    HostThreads& operator=(const HostThreads&) = delete;
+    template <class Fn>
+    void run(Fn&& fn) {
+        try {
+            th.emplace_back(fn);
+        } catch (const std::system_error&) {
+            fn();
+        }
+    }
+    void join() {
+        for (auto& t : th)
+            if (t.joinable()) t.join();
+        th.clear();
+    }
+    ~HostThreads() { join(); }
 };
 
 struct ApiError {
@@ -129,7 +154,20 @@ struct zkhip_ctx {
     ProofSlot* cur = &slots[0];   // the slot the primitives (ntt, msm, ...) and the next enqueue work in
     DBuf tmp;
     std::vector<std::unique_ptr<NttPlanBase>> plans;
+    // kernels whose dynamic-LDS limit has been raised for this context's device (the attribute is per device: a flag per
+    // process would leave the second GPU of a process at the 64 KiB default)
+    std::unordered_set<const void*> lds_opted;
 };
+// gfx950 has 160 KiB of LDS per CU; anything above the 64 KiB default must be opted into, per kernel and per device
+static inline void lds_opt_in(zkhip_ctx* ctx, const void* kernel) {
+#ifndef ZK_EMU
+    if (ctx->lds_opted.count(kernel)) return;
+    ZK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->lds_opted.insert(kernel);
+#else
+    (void)ctx; (void)kernel;
+#endif
+}
 
 namespace zk {
 
@@ -220,11 +258,8 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
     auto pick_threads = [](u64 butterflies) { return (int)std::min<u64>(1024, std::max<u64>(64, (butterflies + 63) / 64 * 64)); };
     pl->threads_cols = pick_threads((u64)pl->C_cols * pl->N1 / 2);
     pl->threads_rows = pick_threads((u64)R * pl->N2 / 2);
-#ifndef ZK_EMU
-    // gfx950 has 160 KiB of LDS per CU; anything above the 64 KiB default must be opted into
-    ZK_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_cols<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ZK_HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt_rows<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#endif
+    lds_opt_in(ctx, (const void*)k_ntt_cols<Fr>);
+    lds_opt_in(ctx, (const void*)k_ntt_rows<Fr>);
     stream_sync(s);
     return pl;
 }
@@ -271,13 +306,6 @@ struct MsmShape {
     u32 P_env;      // ZKHIP_MSM_P override of the sorted entries per accumulation work-item (0 = per point type)
     u32 Lw, H;      // fold geometry: K = H rows of Lw buckets
 };
-static inline void lds_opt_in_plain(const void* kernel) {
-#ifndef ZK_EMU
-    ZK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#else
-    (void)kernel;
-#endif
-}
 static inline int env_int(const char* name, int lo, int hi, int dflt) {
     if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
     return dflt;
@@ -330,12 +358,8 @@ static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars
     const unsigned T = 256;
     // one workgroup per (chunk of scalars, window): chunks several times larger than a window's bucket count keep the
     // global atomics (one per touched bucket per workgroup) well below one per digit
-    static bool lds_once = false;
-    if (!lds_once) {
-        lds_opt_in_plain((const void*)k_msm_count);
-        lds_opt_in_plain((const void*)k_msm_place);
-        lds_once = true;
-    }
+    lds_opt_in(ctx, (const void*)k_msm_count);
+    lds_opt_in(ctx, (const void*)k_msm_place);
     const u64 want_chunks = std::max<u64>(1, (256 + sh.W - 1) / sh.W);
     const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)sh.K));
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
@@ -761,12 +785,13 @@ struct Prover {
         const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         // five independent Horner chains (W x c doublings each): one host thread per MSM, the G2 chain on this one
         Sums g;
-        std::thread ta([&] { g.a = msm_combine(&h_ws1[0 * Wmax], shz); });
-        std::thread tb([&] { g.b1 = msm_combine(&h_ws1[1 * Wmax], shz); });
-        std::thread tl([&] { g.l = msm_combine(&h_ws1[2 * Wmax], shz); });
-        std::thread th([&] { g.h = msm_combine(&h_ws1[3 * Wmax], shh); });
+        HostThreads th;
+        th.run([&] { g.a = msm_combine(&h_ws1[0 * Wmax], shz); });
+        th.run([&] { g.b1 = msm_combine(&h_ws1[1 * Wmax], shz); });
+        th.run([&] { g.l = msm_combine(&h_ws1[2 * Wmax], shz); });
+        th.run([&] { g.h = msm_combine(&h_ws1[3 * Wmax], shh); });
         g.b2 = msm_combine(h_ws2, shz);
-        ta.join(); tb.join(); tl.join(); th.join();
+        th.join();
         return g;
     }
     // ---- K9: C = s*A + r*B1 - rs*delta_1 + L + H   (App. A.3; alpha/beta/delta terms already inside A, B1, B2)
@@ -782,10 +807,12 @@ struct Prover {
         d1 = PkLoader<C>::to_mont_point(d1);
         // three independent 254-bit scalar multiplications
         Xyzz<Fq> sA, rB1, rsD;
-        std::thread t1([&] { sA = xyzz_mul_limbs(gA, ss.v, Fr::N); });
-        std::thread t2([&] { rB1 = xyzz_mul_limbs(gB1, rr.v, Fr::N); });
-        rsD = xyzz_mul_limbs(Xyzz<Fq>::from_affine(d1), rs.v, Fr::N);
-        t1.join(); t2.join();
+        {
+            HostThreads th;
+            th.run([&] { sA = xyzz_mul_limbs(gA, ss.v, Fr::N); });
+            th.run([&] { rB1 = xyzz_mul_limbs(gB1, rr.v, Fr::N); });
+            rsD = xyzz_mul_limbs(Xyzz<Fq>::from_affine(d1), rs.v, Fr::N);
+        }
         Xyzz<Fq> gC = xyzz_add(sA, rB1);
         gC = xyzz_add(gC, xyzz_neg(rsD));
         gC = xyzz_add(gC, gL);
@@ -823,12 +850,33 @@ struct Prover {
         assemble(pk, g, sl.r, sl.s, out);
         fill_timings(sl, tm, t_fin);
     }
-    // one rank's share of a proof: the five partial sums, raw (XYZZ, saturated Montgomery limbs)
+    // The canonical representative of a group element as an XYZZ record: affine coordinates with ZZ = ZZZ = 1 (Montgomery
+    // one), infinity all-zero.  The projective coordinates an MSM leaves depend on the order in which the bucket sort's
+    // atomics placed the points, i.e. they vary from run to run and from machine to machine while the group element does
+    // not; records that cross a process or machine boundary (zkhip_prove_*_partial) are therefore normalised first, so that
+    // equal partial sums are equal bytes.  Five host inversions per proof share.
+    template <class F>
+    static Xyzz<F> canonical(const Xyzz<F>& p) {
+        if (p.is_inf()) return Xyzz<F>::inf();
+        const Aff<F> a = xyzz_to_affine(p);
+        return {a.x, a.y, F::one(), F::one()};
+    }
+    static void canonicalise(Sums& g) {
+        HostThreads th;
+        th.run([&] { g.a = canonical(g.a); });
+        th.run([&] { g.b1 = canonical(g.b1); });
+        th.run([&] { g.l = canonical(g.l); });
+        th.run([&] { g.h = canonical(g.h); });
+        g.b2 = canonical(g.b2);
+        th.join();
+    }
+    // one rank's share of a proof: the five partial sums as canonical XYZZ records (saturated Montgomery limbs)
     static void prove_partial(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* z_dev, const uint8_t* r,
                               const uint8_t* s_, uint8_t* partial_out, zkhip_timings* tm) {
         enqueue(ctx, ctx->slots[0], pk, cs, z_host, z_dev, r, s_);
-        const Sums g = collect(ctx, ctx->slots[0], pk);
+        Sums g = collect(ctx, ctx->slots[0], pk);
         const auto t_fin = std::chrono::steady_clock::now();
+        canonicalise(g);
         memcpy(partial_out, &g, sizeof(g));
         fill_timings(ctx->slots[0], tm, t_fin);
     }

@@ -296,9 +296,11 @@ struct Gm17 {
         memcpy(&z2, dec, sizeof(z2));
         z2 = L::to_mont_point(z2);
         Xyzz<Fq> t1, t2;
-        std::thread th([&] { t1 = xyzz_mul_limbs(g.b1, rho.v, Fr::N); });
-        t2 = xyzz_mul_limbs(Xyzz<Fq>::from_affine(z2), rho2.v, Fr::N);
-        th.join();
+        {
+            HostThreads th;
+            th.run([&] { t1 = xyzz_mul_limbs(g.b1, rho.v, Fr::N); });
+            t2 = xyzz_mul_limbs(Xyzz<Fq>::from_affine(z2), rho2.v, Fr::N);
+        }
         Xyzz<Fq> gC = xyzz_add(g.l, t1);
         gC = xyzz_add(gC, t2);
         gC = xyzz_add(gC, g.h);
@@ -313,13 +315,14 @@ struct Gm17 {
         if (!gC.is_inf()) { write_fe(pc.x, out + 6 * FQB); write_fe(pc.y, out + 7 * FQB); }
         out[8 * FQB] = g.a.is_inf(); out[8 * FQB + 1] = g.b2.is_inf(); out[8 * FQB + 2] = gC.is_inf();
     }
-    // one rank's share of a proof (as Prover<C>::prove_partial): the five partial sums, raw
+    // one rank's share of a proof (as Prover<C>::prove_partial): the five partial sums, canonical records
     static void prove_partial(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* z_dev, const uint8_t* rnd,
                               uint8_t* partial_out, zkhip_timings* tm) {
         check_d2(rnd);
         enqueue(ctx, ctx->slots[0], pk, cs, z_host, z_dev, rnd, rnd + 64);
-        const typename P::Sums g = P::collect(ctx, ctx->slots[0], pk);
+        typename P::Sums g = P::collect(ctx, ctx->slots[0], pk);
         const auto t_fin = std::chrono::steady_clock::now();
+        P::canonicalise(g);
         memcpy(partial_out, &g, sizeof(g));
         P::fill_timings(ctx->slots[0], tm, t_fin);
     }
@@ -414,7 +417,8 @@ struct Gm17 {
         stream_sync(s);
         std::vector<Fr> av(M, Fr::zero()), cv(M, Fr::zero());
         auto val_at = [&](int k, u64 q) { return fe_to_mont(fe_from_bytes_canon<Fr>(cs->h_val[k].data() + q * 32)); };
-        std::thread ta([&] {
+        HostThreads ta;
+        ta.run([&] {
             for (u64 i = 0; i < n; ++i) {
                 const Fr u_add = fe_add(u[2 * i], u[2 * i + 1]), u_sub = fe_sub(u[2 * i], u[2 * i + 1]);
                 for (u64 q = cs->h_rp[0][i]; q < cs->h_rp[0][i + 1]; ++q) { Fr& x = av[cs->h_col[0][q]]; x = fe_add(x, fe_mul(u_add, val_at(0, q))); }

@@ -5,13 +5,6 @@
 
 namespace zk {
 
-template <class K>
-static void lds_opt_in(K kernel) {
-#ifndef ZK_EMU
-    ZK_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#endif
-}
-
 template <class FS>
 void points_to_unsat(zkhip_ctx* ctx, const Aff<FS>* d_in, void* d_out, u64 n) {
     typedef typename Unsat<FS>::type U;
@@ -34,15 +27,11 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bas
     lane.bucket.ensure((size_t)sh.W * sh.K * sizeof(Xyzz<F>));
     lane.rows.ensure((size_t)sh.W * sh.H * sizeof(Xyzz<F>));
     lane.cols.ensure((size_t)sh.W * sh.Lw * sizeof(Xyzz<F>));
-    static bool once = false;   // per point type (template instance)
-    if (!once) {
-        lds_opt_in(k_msm_fold_rows<F>);
-        lds_opt_in(k_msm_fold_cols<F>);
-        lds_opt_in(k_msm_fold_final<F, FS>);
-        lds_opt_in(k_msm_fold_final_scan<F, FS>);
-        lds_opt_in(k_msm_heavy_reduce<F>);
-        once = true;
-    }
+    lds_opt_in(ctx, (const void*)k_msm_fold_rows<F>);
+    lds_opt_in(ctx, (const void*)k_msm_fold_cols<F>);
+    lds_opt_in(ctx, (const void*)k_msm_fold_final<F, FS>);
+    lds_opt_in(ctx, (const void*)k_msm_fold_final_scan<F, FS>);
+    lds_opt_in(ctx, (const void*)k_msm_heavy_reduce<F>);
     const unsigned T = 256;
     dev_memset(lane.heavy.p, 0, 4, s);
     ZK_LAUNCH(k_msm_lane_keys, dim3(blocks_for(nlanes, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, P, nlanes, ptr<u32>(lane.lane_key));

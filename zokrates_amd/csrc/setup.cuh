@@ -119,9 +119,9 @@ struct Setup {
         stream_sync(s);
         std::vector<Fr> col[3];
         {
-            std::vector<std::thread> th;
+            HostThreads th;
             for (int k = 0; k < 3; ++k)
-                th.emplace_back([&, k] {
+                th.run([&, k] {
                     std::vector<Fr>& acc = col[k];
                     acc.assign(m, Fr::zero());
                     const u64* rp = cs->h_rp[k].data();
@@ -135,7 +135,7 @@ struct Setup {
                     if (k == 0)
                         for (u64 j = 0; j < l; ++j) acc[j] = fe_add(acc[j], u[n + j]);
                 });
-            for (auto& t : th) t.join();
+            th.join();
         }
         DBuf d_a, d_b, d_c, d_lc, d_h;
         d_a.ensure(m * sizeof(Fr)); d_b.ensure(m * sizeof(Fr)); d_c.ensure(m * sizeof(Fr)); d_lc.ensure(m * sizeof(Fr));

@@ -9,7 +9,8 @@ static const CurveOps* ops_for(int curve) {
     if (curve == ZKHIP_CURVE_BLS12_381) return curve_ops_bls381();
     throw ApiError{ZKHIP_ERR_BAD_ARG, "unknown curve id"};
 }
-static std::string g_create_err;
+// errors of calls that have no context (zkhip_ctx_create, zkhip_prog_*): one message per calling thread
+static thread_local std::string g_create_err;
 
 // after a failed call: let whatever was enqueued drain and mark the proof slots free, so the context stays usable
 static void release_slots(zkhip_ctx* ctx) {
@@ -35,9 +36,11 @@ static int32_t guarded(zkhip_ctx* ctx, Fn&& fn) {
         return ZKHIP_ERR_DEVICE;
     } catch (const std::bad_alloc&) {
         (ctx ? ctx->err : g_create_err) = "out of host memory";
+        if (ctx) release_slots(ctx);
         return ZKHIP_ERR_NOMEM;
     } catch (...) {
         (ctx ? ctx->err : g_create_err) = "unexpected internal error";
+        if (ctx) release_slots(ctx);
         return ZKHIP_ERR_DEVICE;
     }
 }
@@ -102,6 +105,10 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
 }
 void zkhip_ctx_free(zkhip_ctx* ctx) {
     if (!ctx) return;
+    try {
+        dev_set(ctx->device);   // the calling thread may be bound to another device
+    } catch (...) {
+    }
     dev_sync_all();
     for (auto& sl : ctx->slots) {
         for (auto& so : sl.sorts) event_destroy(so.ready);

@@ -176,7 +176,14 @@ def proof_json(curve_id, raw_proof, inputs, scheme="g16"):
     """raw_proof: the 8*sz(Fq)+3 bytes of zkhip_prove_g16 / zkhip_prove_gm17; inputs: public values (ints).  The text of
     `proof.json` (both schemes have proof points a (G1), b (G2), c (G1): scheme/groth16.rs:8-16, scheme/gm17.rs:12-17)."""
     nb = FQ_BYTES[curve_id]
-    raw = bytes(raw_proof)
+    raw = bytearray(raw_proof)
+    # A point at infinity arrives as all-zero coordinates plus its flag byte; the reference prints ark's `zero()`, which is
+    # (x, y) = (0, 1) (G2: y = 1 + 0u), through parse_g1 / parse_g2 (zokrates_ark/src/lib.rs:150-218).
+    one = (1).to_bytes(nb, "little")
+    for flag, y_at in ((8 * nb, nb), (8 * nb + 1, 4 * nb), (8 * nb + 2, 7 * nb)):
+        if len(raw) > flag and raw[flag]:
+            raw[y_at:y_at + nb] = one
+    raw = bytes(raw)
     doc = {"scheme": scheme, "curve": CURVE_NAMES[curve_id],
            "proof": {"a": _g1(raw[0:2 * nb], nb), "b": _g2(raw[2 * nb:6 * nb], nb), "c": _g1(raw[6 * nb:8 * nb], nb)},
            "inputs": ["0x" + int(v).to_bytes(32, "big").hex() for v in inputs]}
