@@ -162,7 +162,7 @@ def main():
             traffic = json.load(f).get("G2" if "G2" in name else "G1", {}).get("traffic_bytes_per_launch")
     # the honest bound of this kernel: mixed additions per second against the multiplier-limited rate of the same
     # kernel on synthetic data (tools/accum_bench.hip); W signed windows, one mixed addition per non-zero digit
-    shape_w = {20: 16 if gm17 else 17}.get(args.log_domain)
+    shape_w = {20: 16}.get(args.log_domain)
     compute = None
     if shape_w and args.curve == "bn128":
         madds = (((m + 2) if "G2" in name else (3 * (m + 2) + N)) * shape_w)

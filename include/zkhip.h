@@ -76,6 +76,21 @@ void zkhip_ctx_free(zkhip_ctx* ctx);
 /* Last error text of this context (or of the failed create when ctx == NULL). Never NULL. */
 const char* zkhip_last_error(const zkhip_ctx* ctx);
 
+/* Development / measurement knobs of one context (none changes a result; all are plain fields read by the host code,
+ * nothing consults the environment after zkhip_ctx_create).  ZKHIP_TUNE_MSM_C: window width of the MSM tables built by
+ * later key loads and of later ad-hoc MSMs (0 = automatic); _MSM_WAVES: accumulation waves per SIMD (0 = per point
+ * type); _MSM_LANES: number of slices the sorted list is cut into (0 = one per resident work-item); _MSM_MIN_SLICE: the
+ * finest cut; _FOLD_SCAN: 0 selects the double-and-add form of the last fold step; _SERIAL: 1 puts every kernel on one
+ * stream (un-overlapped per-kernel timing); _NTT_SINGLE_MAX_LOG: largest domain transformed in a single pass. */
+#define ZKHIP_TUNE_MSM_C 1
+#define ZKHIP_TUNE_MSM_WAVES 2
+#define ZKHIP_TUNE_MSM_LANES 3
+#define ZKHIP_TUNE_MSM_MIN_SLICE 4
+#define ZKHIP_TUNE_FOLD_SCAN 5
+#define ZKHIP_TUNE_SERIAL 6
+#define ZKHIP_TUNE_NTT_SINGLE_MAX_LOG 7
+int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value);
+
 /* ---- proving key ----
  * Replaces `ProvingKey::<E>::deserialize_unchecked(proving_key)` at
  * /root/reference/zokrates_ark/src/groth16.rs:40-42: `bytes` is exactly the `proving.key` file the
@@ -218,16 +233,23 @@ int32_t zkhip_setup_gm17(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* 
                          const uint8_t* g2, uint8_t* pk_out, uint64_t pk_cap);
 
 /* ---- "next" row N2: proving-key cache ----
- * zkhip_pk_export writes the *resident* form of a loaded key (Groth16 or GM17, whole or one shard): Montgomery /
- * unsaturated limbs, MSM-ready order, the extended base vectors — the bytes the GPU holds, plus a small header.
+ * zkhip_pk_export writes the *resident* form of a loaded key (Groth16 or GM17, whole or one shard): packed Montgomery
+ * points, MSM-ready order, the extended base vectors — the bytes the GPU holds, plus a small header.
  * zkhip_pk_import brings such an image back with five host-to-device copies and no parsing or conversion, taking
  * `ProvingKey::deserialize_unchecked` (/root/reference/zokrates_ark/src/groth16.rs:40-42; one Fq multiplication per
- * coordinate and a single-threaded read in the reference) off the per-invocation path.  The library does no file I/O:
- * the caller stores the image wherever it likes, keyed e.g. by the SHA-256 of the `proving.key` it came from
- * (`python -m zokrates_amd.cli generate-proof --key-cache DIR` does exactly that).  An image is tied to the library
- * build that wrote it (magic + layout version); a foreign image is rejected with ZKHIP_ERR_PARSE. */
+ * coordinate and a single-threaded read in the reference) off the per-invocation path.
+ * A resident key is a set of five MSM tables: level 0 = the key's points, levels 1 .. W-1 their precomputed window
+ * multiples 2^(c j) P.  The default image carries level 0 only and the import recomputes the other
+ * levels on the device (~0.1 s for a 2^20-constraint key, less than reading them from a disk); with
+ * ZKHIP_PK_IMAGE_FULL the image carries every level (16x the size) and the import is copies only.
+ * The library does no file I/O: the caller stores the image wherever it likes, keyed e.g. by the SHA-256 of the
+ * `proving.key` it came from (`python -m zokrates_amd.cli generate-proof --key-cache DIR` does exactly that).  An image
+ * is tied to the library build that wrote it (magic + layout version); a foreign image is rejected with ZKHIP_ERR_PARSE. */
+#define ZKHIP_PK_IMAGE_FULL 1u
 int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes);
 int32_t zkhip_pk_export(const zkhip_pk* pk, uint8_t* out, uint64_t cap);
+int32_t zkhip_pk_export_size_ex(const zkhip_pk* pk, uint32_t flags, uint64_t* bytes);
+int32_t zkhip_pk_export_ex(const zkhip_pk* pk, uint32_t flags, uint8_t* out, uint64_t cap);
 int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk** out);
 
 /* ---- "next" row N1: ZoKrates' own input files (host only: no context, no device work) ----

@@ -44,8 +44,8 @@ def test_field_ops(ctx, curve):
 @pytest.mark.parametrize("single_max", [10, 1])
 def test_ntt(ctx, curve, single_max):
     """single_max = 1 forces the two-pass (cols + rows, sigma-order) path on small domains."""
-    os.environ["ZKHIP_NTT_SINGLE_MAX_LOG"] = str(single_max)
     c2 = native.Context(0, emu_library())   # fresh plan cache
+    c2.tune("ntt_single_max_log", single_max)
     rnd = random.Random(6)
     try:
         for logn in ((0, 1, 2, 5) if single_max == 10 else (2, 3, 5, 6)):
@@ -53,7 +53,6 @@ def test_ntt(ctx, curve, single_max):
             for d in ("fft", "ifft", "coset_fft", "coset_ifft"):
                 assert c2.ntt(curve.curve_id, a, d).tobytes() == cpu.ntt(curve.curve_id, a, d).tobytes(), (logn, d)
     finally:
-        os.environ.pop("ZKHIP_NTT_SINGLE_MAX_LOG")
         c2.close()
 
 
@@ -93,10 +92,10 @@ def test_msm_window_sizes(ctx):
     want = cpu.msm(0, 1, b1, ks)
     try:
         for c in (2, 3, 5, 8, 13):
-            os.environ["ZKHIP_MSM_C"] = str(c)
+            ctx.tune("msm_c", c)
             assert ctx.msm(0, 1, b1, ks) == want, c
     finally:
-        os.environ.pop("ZKHIP_MSM_C")
+        ctx.tune("msm_c", 0)
 
 
 def test_msm_fold_fallback(ctx):
@@ -107,20 +106,20 @@ def test_msm_fold_fallback(ctx):
     want1, want2 = cpu.msm(0, 1, b1, ks), cpu.msm(0, 2, b2[:20 * 128], ks[:20 * 32])
     try:
         for c in (3, 9, 12):
-            os.environ["ZKHIP_MSM_C"] = str(c)
-            for scan in ("1", "0"):
-                os.environ["ZKHIP_FOLD_SCAN"] = scan
+            ctx.tune("msm_c", c)
+            for scan in (1, 0):
+                ctx.tune("fold_scan", scan)
                 assert ctx.msm(0, 1, b1, ks) == want1, (c, scan)
                 assert ctx.msm(0, 2, b2[:20 * 128], ks[:20 * 32]) == want2, (c, scan)
     finally:
-        os.environ.pop("ZKHIP_MSM_C")
-        os.environ.pop("ZKHIP_FOLD_SCAN")
+        ctx.tune("msm_c", 0)
+        ctx.tune("fold_scan", 1)
 
 
 def test_msm_skewed_scalars(ctx):
-    """Hot buckets: many scalars equal to 1 (the dedicated ones bucket), many copies of one full-width value
-    and of -1 (a bucket spread over more than MSM_HEAVY lanes -> workgroup reduction), zeros; several slice
-    lengths P so that buckets straddle lane boundaries in every way."""
+    """Hot buckets: many scalars equal to 1, many copies of one full-width value and of -1 (a bucket spread over more
+    than MSM_HEAVY slices -> workgroup reduction), zeros; several cuts of the sorted list (number of slices, finest
+    slice) so that buckets straddle slice boundaries in every way."""
     curve = BN254
     rnd = random.Random(9)
     n = 150
@@ -135,15 +134,17 @@ def test_msm_skewed_scalars(ctx):
     want1 = cpu.msm(0, 1, b1, le(ks))
     want2 = cpu.msm(0, 2, b2, le(ks[:24]))
     try:
-        for P, c in ((1, 4), (2, 5), (3, 3), (7, 6), (32, 4)):
-            os.environ["ZKHIP_MSM_P"] = str(P)
-            os.environ["ZKHIP_MSM_C"] = str(c)
-            assert ctx.msm(0, 1, b1, le(ks)) == want1, (P, c)
-            if P in (2, 32):
-                assert ctx.msm(0, 2, b2, le(ks[:24])) == want2, (P, c)
+        for P, lanes, c in ((1, 0, 4), (2, 0, 5), (3, 0, 3), (7, 0, 6), (32, 0, 4), (1, 11, 5), (1, 3, 7), (1, 1, 4)):
+            ctx.tune("msm_min_slice", P)
+            ctx.tune("msm_lanes", lanes)
+            ctx.tune("msm_c", c)
+            assert ctx.msm(0, 1, b1, le(ks)) == want1, (P, lanes, c)
+            if P in (2, 32) or lanes == 3:
+                assert ctx.msm(0, 2, b2, le(ks[:24])) == want2, (P, lanes, c)
     finally:
-        os.environ.pop("ZKHIP_MSM_P")
-        os.environ.pop("ZKHIP_MSM_C")
+        ctx.tune("msm_min_slice", 8)
+        ctx.tune("msm_lanes", 0)
+        ctx.tune("msm_c", 0)
 
 
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)

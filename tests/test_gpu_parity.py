@@ -106,11 +106,13 @@ def test_msm_skewed_scalars(ctx):
     assert ctx.msm(0, 1, g1, ks) == want1
     assert ctx.msm(0, 2, g2[:4000 * 128], ks[:4000 * 32]) == cpu.msm(0, 2, g2[:4000 * 128], ks[:4000 * 32])
     try:
-        for P in (1, 5, 64, 1000):
-            os.environ["ZKHIP_MSM_P"] = str(P)
-            assert ctx.msm(0, 1, g1, ks) == want1, P
+        for P, lanes in ((1, 0), (5, 0), (64, 0), (1000, 0), (1, 1000), (1, 77777)):
+            ctx.tune("msm_min_slice", P)
+            ctx.tune("msm_lanes", lanes)
+            assert ctx.msm(0, 1, g1, ks) == want1, (P, lanes)
     finally:
-        os.environ.pop("ZKHIP_MSM_P")
+        ctx.tune("msm_min_slice", 8)
+        ctx.tune("msm_lanes", 0)
 
 
 def test_msm_edge_points(ctx):
@@ -127,11 +129,11 @@ def test_msm_edge_points(ctx):
     assert ctx.msm(0, 1, b1, le(ks)) == cpu.msm(0, 1, b1, le(ks))
     assert ctx.msm(0, 1, b1, np.zeros(n * 32, dtype=np.uint8))[-1] == 1
     for c in (2, 7, 11, 16):
-        os.environ["ZKHIP_MSM_C"] = str(c)
+        ctx.tune("msm_c", c)
         try:
             assert ctx.msm(0, 1, b1, le(ks)) == cpu.msm(0, 1, b1, le(ks)), c
         finally:
-            os.environ.pop("ZKHIP_MSM_C")
+            ctx.tune("msm_c", 0)
 
 
 @pytest.mark.parametrize("curve,logn,kind", [

@@ -91,6 +91,7 @@ struct DBuf {
     DBuf& operator=(const DBuf&) = delete;
     ~DBuf() { dev_free(p); }
     void swap(DBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
+    void release() { dev_free(p); p = nullptr; cap = 0; }
     void ensure(size_t bytes) {
         if (bytes <= cap) return;
         dev_free(p);
@@ -148,6 +149,15 @@ struct zkhip_ctx {
     Stream stream = 0;        // main stream: staging, sort, mat-vec, NTTs (high priority: short kernels the H MSM waits for)
     Stream out_stream = 0;    // copies the window sums out once every MSM of a proof is done
     bool serial = false;      // ZKHIP_SERIAL=1: every MSM on the main stream (debugging / per-kernel timing)
+    int cus = 256;            // compute units of the device: sizes the accumulation launch (one slice per resident work-item)
+    // tunables (zkhip_ctx_tune; the environment variables ZKHIP_SERIAL, ZKHIP_MSM_C, ZKHIP_MSM_WAVES and
+    // ZKHIP_NTT_SINGLE_MAX_LOG give their initial values, read ONCE when the context is created)
+    int msm_c_env = 0;        // window width of the tables built / ad-hoc MSMs run from now on (0 = automatic)
+    int msm_waves = 0;        // accumulation waves per SIMD (0 = per point type)
+    u32 msm_lanes = 0;        // slices of the sorted list (0 = one per resident work-item)
+    u32 msm_min_slice = 8;    // finest cut of the sorted list
+    bool fold_scan = true;    // scan form of the last fold step (else double-and-add)
+    int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     std::string err;
     std::string desc;
     ProofSlot slots[ZK_NSLOTS];
@@ -215,9 +225,7 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
     pl->curve = C::ID;
     pl->logN = logN;
     pl->N = (u64)1 << logN;
-    int single_max = 10;   // largest domain handled by one LDS-resident pass
-    if (const char* e = getenv("ZKHIP_NTT_SINGLE_MAX_LOG")) single_max = std::max(0, std::min(NTT_MAX_SUBLOG, atoi(e)));
-    pl->log1 = logN <= single_max ? 0 : logN / 2;
+    pl->log1 = logN <= ctx->ntt_single_max ? 0 : logN / 2;
     pl->log2 = logN - pl->log1;
     pl->N1 = 1u << pl->log1;
     pl->N2 = 1u << pl->log2;
@@ -301,50 +309,61 @@ static void ntt_kind_b(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, boo
 struct MsmShape {
     u64 n;
     int c, W;
-    u32 K;          // buckets per window = 2^(c-1)
-    u32 nkeys;      // W * K + 1: every (window, bucket) plus the "ones" bucket
-    u32 P_env;      // ZKHIP_MSM_P override of the sorted entries per accumulation work-item (0 = per point type)
+    u32 K;          // buckets per set = 2^(c-1)
+    u32 sets;       // bucket sets: 1 when the bases carry precomputed window multiples (all windows share one set), else W
+    u32 nkeys;      // sets * K
     u32 Lw, H;      // fold geometry: K = H rows of Lw buckets
+    bool shared() const { return sets == 1 && W > 1; }
 };
 static inline int env_int(const char* name, int lo, int hi, int dflt) {
     if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
     return dflt;
 }
-static inline MsmShape msm_shape(u64 n, int scalar_bits, int force_c = 0) {
+static constexpr int MSM_MAX_C = 16;   // the sort's LDS histogram: 2^(c-1) counters of 4 B
+// `table`: the bases carry precomputed window multiples 2^(c j) P (resident keys); otherwise one bucket set per window.
+static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, bool table, int force_c = 0) {
     MsmShape s;
     s.n = n;
-    // Window width: about log2(n) - 5 (measured optimum at 2^20: 15), but never one that leaves the top window
-    // with only a few significant bits — its handful of buckets would each receive a large share of all points
-    // (same-address atomics in the sort, one bucket spread over thousands of slices).
     const int lg = ilog2_floor(std::max<u64>(n, 1));
-    const int want = std::max(2, std::min(16, lg - 5));
-    s.c = want;
-    for (int d = 0; d <= 14; ++d) {
-        bool found = false;
-        for (int cand : {want + d, want - d}) {
-            if (cand < 2 || cand > 16) continue;
-            const int W = (scalar_bits + 1 + cand - 1) / cand;
-            const int top_bits = scalar_bits + 1 - (W - 1) * cand;
-            if (top_bits >= cand || (n >> (top_bits - 1)) <= 4096) { s.c = cand; found = true; break; }   // <= 4096 points per top bucket
+    if (table) {
+        // one fold per MSM whatever c is, so c only trades additions (n * W) against buckets (2^(c-1)): as wide as the
+        // sort's histogram allows once there are a few points per bucket
+        s.c = std::max(2, std::min(MSM_MAX_C, lg + 1));
+    } else {
+        // Window width: about log2(n) - 5 (measured optimum at 2^20: 15), but never one that leaves the top window
+        // with only a few significant bits — its handful of buckets would each receive a large share of all points
+        // (same-address atomics in the sort, one bucket spread over thousands of slices).
+        const int want = std::max(2, std::min(MSM_MAX_C, lg - 5));
+        s.c = want;
+        for (int d = 0; d <= 14; ++d) {
+            bool found = false;
+            for (int cand : {want + d, want - d}) {
+                if (cand < 2 || cand > MSM_MAX_C) continue;
+                const int W = (scalar_bits + 1 + cand - 1) / cand;
+                const int top_bits = scalar_bits + 1 - (W - 1) * cand;
+                if (top_bits >= cand || (n >> (top_bits - 1)) <= 4096) { s.c = cand; found = true; break; }   // <= 4096 points per top bucket
+            }
+            if (found) break;
         }
-        if (found) break;
     }
-    s.c = env_int("ZKHIP_MSM_C", 2, 16, s.c);
+    if (ctx && ctx->msm_c_env) s.c = ctx->msm_c_env;
     if (force_c) s.c = force_c;
     s.W = (scalar_bits + 1 + s.c - 1) / s.c;
     s.K = 1u << (s.c - 1);
-    s.nkeys = (u32)s.W * s.K + 1;
-    s.P_env = (u32)env_int("ZKHIP_MSM_P", 1, 4096, 0);
+    s.sets = table ? 1 : (u32)s.W;
+    s.nkeys = s.sets * s.K;
     s.Lw = std::min<u32>(s.K, 256);
     s.H = s.K / s.Lw;
     return s;
 }
 
-// classification + digits + counting sort on the main stream; leaves so.off / so.sorted describing every bucket's point list
-static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars, const MsmShape& sh) {
+// digits + counting sort on the main stream; leaves so.off / so.sorted describing every bucket's point list.
+// level_stride: distance between two levels of the base tables this sort will be paired with (table mode), else 0.
+static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars, const MsmShape& sh, u64 level_stride) {
     Stream s = ctx->stream;
     const u64 nk = sh.nkeys;
     require(sh.n * (u64)sh.W < ((u64)1 << 32) - sh.nkeys, ZKHIP_ERR_BAD_ARG, "MSM too large for 32-bit sort offsets");
+    require(level_stride * (u64)sh.W < ((u64)1 << 31) && sh.n < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "MSM too large for 31-bit table indices");
     so.wm.ensure(sh.n * 32);
     so.sorted.ensure(sh.n * sh.W * 4);
     so.cnt.ensure(nk * 4);
@@ -364,45 +383,51 @@ static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars
     const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)sh.K));
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
     const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;
-    const size_t hist_bytes = ((size_t)sh.K + 1) * 4;
+    const size_t hist_bytes = (size_t)sh.K * 4;
+    const u32 key_stride = sh.sets == 1 ? 0 : sh.K;
     ZK_LAUNCH(k_scalars_to_word_major, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, ptr<u32>(so.wm));
-    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, ptr<u32>(so.cnt));
+    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride,
+              ptr<u32>(so.cnt));
     ZK_LAUNCH(k_scan_local, dim3(nchunks), dim3(SCAN_THREADS), 0, s, ptr<u32>(so.cnt), ptr<u32>(so.off), ptr<u32>(so.chunk_sum), nk);
     ZK_LAUNCH(k_scan_chunks, dim3(1), dim3(SCAN_THREADS), 0, s, ptr<u32>(so.chunk_sum), nchunks, ptr<u32>(so.grand));
     ZK_LAUNCH(k_scan_add, dim3(blocks_for(nk + 1, T)), dim3(T), 0, s, ptr<u32>(so.off), ptr<u32>(so.chunk_sum), nk, ptr<u32>(so.grand));
-    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, ptr<u32>(so.off),
-              ptr<u32>(so.cursor), ptr<u32>(so.sorted));
+    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride,
+              level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
     event_record(so.ready, s);
 }
 
-// bucket accumulation + fold for one base set; window sums land in d_window_sums[0..W], entry W = the ones bucket.
+// bucket accumulation + fold for one base table; the bucket sets' weighted sums land in d_window_sums[0..sets).
 // Defined in group.cuh and instantiated once per (curve, group) in its own translation unit (bn254_g1.hip, ...):
 // the elliptic-curve kernels are by far the most expensive code to compile.
 // Runs on lane.stream after so.ready; lane.done is recorded behind the last kernel.
-// `d_bases_unsat` are affine points in the unsaturated working form (points_to_unsat); the window sums come back in the
-// saturated Montgomery form.
+// `d_table` holds packed affine points (AffPacked, level-major when it carries window multiples); the sums come back in
+// the saturated Montgomery form.
 template <class F>
-void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bases_unsat, const MsmShape& sh, Xyzz<F>* d_window_sums,
+void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<F>* d_window_sums,
              Event ev_begin, Event ev_end);
-// affine points, saturated Montgomery form -> unsaturated working form of the MSM kernels (fieldu.cuh); on ctx->stream
+// affine points, saturated Montgomery form -> packed working form of the MSM kernels (level 0 of a table); on ctx->stream
 template <class F>
-void points_to_unsat(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
-template <class F> static constexpr size_t unsat_point_bytes() { return sizeof(Aff<typename Unsat<F>::type>); }
+void points_to_packed(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
+// levels 1 .. W-1 (2^(c j) P) behind a level 0 of `count` points; synchronises ctx->stream
+template <class F>
+void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int c, int W);
+template <class F> static constexpr size_t packed_point_bytes() { return sizeof(AffPacked<typename Unsat<F>::type>); }
 // fixed-base tables / multiplications for setup (N3); also per-group code
 template <class F>
 void fixed_base_table(zkhip_ctx* ctx, const Aff<F>* h_pj, int nwin, DBuf& tbl);
 template <class F>
 void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scalars, u64 count, Aff<F>* d_out);
 
-// host Horner over window sums: sum_j 2^(c j) S_j, plus the ones bucket
+// the MSM's value from its bucket-set sums: the single sum of a table MSM, else the host Horner step sum_j 2^(c j) S_j
 template <class F>
 static Xyzz<F> msm_combine(const Xyzz<F>* ws, const MsmShape& sh) {
+    if (sh.sets == 1) return ws[0];
     Xyzz<F> acc = Xyzz<F>::inf();
     for (int j = sh.W - 1; j >= 0; --j) {
         for (int i = 0; i < sh.c; ++i) acc = xyzz_dbl(acc);
         acc = xyzz_add(acc, ws[j]);
     }
-    return xyzz_add(acc, ws[sh.W]);
+    return acc;
 }
 
 // ------------------------------------------------------------------ byte codecs (host)
@@ -596,26 +621,41 @@ struct PkLoader {
         add_into<Fq, 2>(ctx, pk->a_ext, 0, alpha_g1);
         add_into<Fq, 2>(ctx, pk->b1_ext, 0, beta_g1);
         add_into<Fq2, 4>(ctx, pk->b2_ext, 0, beta_g2);
-        // this rank's share of the bases (everything for world = 1)
+        finish_tables(ctx, pk, me, N);
+    }
+    // this rank's share of the bases (everything for world = 1) as MSM tables: level 0 = the packed working form of the
+    // range's points, levels 1 .. W-1 their window multiples 2^(c j) P (a 2^20 BN254 key: 16 levels, 6 GiB of the 288)
+    static void finish_tables(zkhip_ctx* ctx, zkhip_pk* pk, u64 me, u64 hdom) {
         u64 nominal_z, nominal_h;
         range_of(me, pk->rank, pk->world, pk->z_lo, pk->z_n, nominal_z);
-        range_of(N, pk->rank, pk->world, pk->h_lo, pk->h_n, nominal_h);
-        pk->c_z = msm_shape(nominal_z, C::Fr::Params::BITS).c;
-        pk->c_h = msm_shape(nominal_h, C::Fr::Params::BITS).c;
-        // the MSM kernels work on unsaturated limbs (fieldu.cuh): convert every base once, here
-        to_unsat<Fq>(ctx, pk->a_ext, pk->z_lo, pk->z_n);
-        to_unsat<Fq>(ctx, pk->b1_ext, pk->z_lo, pk->z_n);
-        to_unsat<Fq>(ctx, pk->l_ext, pk->z_lo, pk->z_n);
-        to_unsat<Fq2>(ctx, pk->b2_ext, pk->z_lo, pk->z_n);
-        to_unsat<Fq>(ctx, pk->h_sigma, pk->h_lo, pk->h_n);
+        range_of(hdom, pk->rank, pk->world, pk->h_lo, pk->h_n, nominal_h);
+        const MsmShape shz = msm_shape(ctx, nominal_z, C::Fr::Params::BITS, true), shh = msm_shape(ctx, nominal_h, C::Fr::Params::BITS, true);
+        pk->c_z = shz.c;
+        pk->c_h = shh.c;
+        to_table<Fq>(ctx, pk->a_ext, pk->z_lo, pk->z_n, shz);
+        to_table<Fq>(ctx, pk->b1_ext, pk->z_lo, pk->z_n, shz);
+        to_table<Fq>(ctx, pk->l_ext, pk->z_lo, pk->z_n, shz);
+        to_table<Fq2>(ctx, pk->b2_ext, pk->z_lo, pk->z_n, shz);
+        to_table<Fq>(ctx, pk->h_sigma, pk->h_lo, pk->h_n, shh);
+    }
+    // levels 1 .. W-1 of the five tables of a key whose level 0 is in place (zkhip_pk_import of a compact image)
+    static void table_levels(zkhip_ctx* ctx, zkhip_pk* pk) {
+        const MsmShape shz = msm_shape(ctx, pk->z_n, C::Fr::Params::BITS, true, pk->c_z), shh = msm_shape(ctx, pk->h_n, C::Fr::Params::BITS, true, pk->c_h);
+        msm_table_levels<Fq>(ctx, pk->a_ext.p, pk->z_n, shz.c, shz.W);
+        msm_table_levels<Fq>(ctx, pk->b1_ext.p, pk->z_n, shz.c, shz.W);
+        msm_table_levels<Fq>(ctx, pk->l_ext.p, pk->z_n, shz.c, shz.W);
+        msm_table_levels<Fq2>(ctx, pk->b2_ext.p, pk->z_n, shz.c, shz.W);
+        msm_table_levels<Fq>(ctx, pk->h_sigma.p, pk->h_n, shh.c, shh.W);
     }
     template <class F>
-    static void to_unsat(zkhip_ctx* ctx, DBuf& buf, u64 lo, u64 count) {
+    static void to_table(zkhip_ctx* ctx, DBuf& buf, u64 lo, u64 count, const MsmShape& sh) {
         DBuf out;
-        out.ensure(std::max<u64>(count, 1) * unsat_point_bytes<F>());
-        if (count) points_to_unsat<F>(ctx, ptr<Aff<F>>(buf) + lo, out.p, count);
+        out.ensure(std::max<u64>(count, 1) * (u64)sh.W * packed_point_bytes<F>());
+        if (count) points_to_packed<F>(ctx, ptr<Aff<F>>(buf) + lo, out.p, count);
         stream_sync(ctx->stream);
         buf.swap(out);
+        out.release();                        // the saturated copy goes before the levels' workspace is allocated
+        msm_table_levels<F>(ctx, buf.p, count, sh.c, sh.W);
     }
 };
 
@@ -703,14 +743,14 @@ struct Prover {
 
         // ---- MSMs over S = [z_0..z_{m-1}, r, s]: A, B1, L in G1 and B2 in G2 share one digit/sort pass
         // (a sharded key covers only its index range of the bases, and pairs them with the same range of the scalars)
-        const MsmShape shz = msm_shape(pk->z_n, Fr::Params::BITS, pk->c_z);
-        const MsmShape shh = msm_shape(pk->h_n, Fr::Params::BITS, pk->c_h);
-        const int Wmax = std::max(shz.W, shh.W) + 1;   // + the ones bucket
-        sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // window sums: 4 G1 sets + 1 G2 set
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const int Wmax = (int)std::max(shz.sets, shh.sets);   // bucket-set sums per MSM (1: the tables carry the window multiples)
+        sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // 4 G1 MSMs + 1 G2 MSM
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
         if (pk->z_n) {
-            msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz);
+            msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
             msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
             msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
             msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
@@ -726,7 +766,7 @@ struct Prover {
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
         if (pk->h_n) {
-            msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh);
+            msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
             msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
         } else {
             empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
@@ -778,9 +818,9 @@ struct Prover {
         require(sl.busy, ZKHIP_ERR_DEVICE, "internal: no proof in flight in this slot");
         event_sync(sl.ev[3]);
         sl.busy = false;
-        const MsmShape shz = msm_shape(pk->z_n, Fr::Params::BITS, pk->c_z);
-        const MsmShape shh = msm_shape(pk->h_n, Fr::Params::BITS, pk->c_h);
-        const int Wmax = std::max(shz.W, shh.W) + 1;
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const int Wmax = (int)std::max(shz.sets, shh.sets);
         const Xyzz<Fq>* h_ws1 = (const Xyzz<Fq>*)sl.h_ws;
         const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         // five independent Horner chains (W x c doublings each): one host thread per MSM, the G2 chain on this one
@@ -960,15 +1000,16 @@ struct Prover {
         ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(n * NC, 256)), dim3(256), 0, s, ptr<Fq>(d_bases), ptr<Fq>(d_bases), n * NC);
         ctx->cur->scalars.ensure(n * 32);
         dev_h2d(ctx->cur->scalars.p, scalars, n * 32, s);
-        const MsmShape sh = msm_shape(n, Fr::Params::BITS);
-        d_ws.ensure((size_t)(sh.W + 1) * sizeof(Xyzz<F>));
-        msm_prepare(ctx, ctx->cur->sorts[0], ptr<u32>(ctx->cur->scalars), sh);
-        DBuf d_unsat;
-        d_unsat.ensure(n * unsat_point_bytes<F>());
-        points_to_unsat<F>(ctx, ptr<Aff<F>>(d_bases), d_unsat.p, n);
-        msm_run<F>(ctx, ctx->cur->lanes[0], ctx->cur->sorts[0], d_unsat.p, sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
+        // ad-hoc bases: no table of window multiples (building one costs ~15x the MSM itself), one bucket set per window
+        const MsmShape sh = msm_shape(ctx, n, Fr::Params::BITS, false);
+        d_ws.ensure((size_t)sh.sets * sizeof(Xyzz<F>));
+        msm_prepare(ctx, ctx->cur->sorts[0], ptr<u32>(ctx->cur->scalars), sh, 0);
+        DBuf d_packed;
+        d_packed.ensure(n * packed_point_bytes<F>());
+        points_to_packed<F>(ctx, ptr<Aff<F>>(d_bases), d_packed.p, n);
+        msm_run<F>(ctx, ctx->cur->lanes[0], ctx->cur->sorts[0], d_packed.p, sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
         stream_wait_event(s, ctx->cur->lanes[0].done);
-        std::vector<Xyzz<F>> ws(sh.W + 1);
+        std::vector<Xyzz<F>> ws(sh.sets);
         dev_d2h(ws.data(), d_ws.p, ws.size() * sizeof(Xyzz<F>), s);
         stream_sync(s);
         Xyzz<F> res = msm_combine(ws.data(), sh);
@@ -1073,6 +1114,7 @@ struct Prover {
 namespace zk {
 struct CurveOps {
     void (*pk_load)(zkhip_ctx*, const uint8_t*, size_t, zkhip_pk*);
+    void (*pk_table_levels)(zkhip_ctx*, zkhip_pk*);
     void (*r1cs_load)(zkhip_ctx*, zkhip_r1cs*, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]);
     void (*prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*prove_resident)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, void*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
@@ -1097,7 +1139,8 @@ struct CurveOps {
     u64 (*gm17_key_bytes)(u64, u64, u64);
     void (*gm17_prove_partial)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const void*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*gm17_combine)(const zkhip_pk*, u32, const uint8_t*, const uint8_t*, uint8_t*);
-    size_t unsat_g1_bytes;   // size of one resident G1 base (G2: twice that): lets zkhip_pk_import validate an image's shape
+    size_t packed_g1_bytes;  // size of one resident G1 base (G2: twice that): lets zkhip_pk_import validate an image's shape
+    int fr_bits;             // scalar width: the number of table levels follows from it and the window width
 };
 template <class C>
 static void field_op_dispatch(zkhip_ctx* ctx, int field, int op, u64 count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -1108,6 +1151,7 @@ template <class C>
 static CurveOps make_curve_ops() {
     CurveOps o;
     o.pk_load = &PkLoader<C>::load;
+    o.pk_table_levels = &PkLoader<C>::table_levels;
     o.r1cs_load = &Prover<C>::r1cs_load;
     o.prove = &Prover<C>::prove_host;
     o.prove_resident = &Prover<C>::prove_resident;
@@ -1129,7 +1173,8 @@ static CurveOps make_curve_ops() {
     o.gm17_key_bytes = &Gm17<C>::key_bytes;
     o.gm17_prove_partial = &Gm17<C>::prove_partial;
     o.gm17_combine = &Gm17<C>::combine;
-    o.unsat_g1_bytes = unsat_point_bytes<typename C::Fq>();
+    o.packed_g1_bytes = packed_point_bytes<typename C::Fq>();
+    o.fr_bits = C::Fr::Params::BITS;
     return o;
 }
 const CurveOps* curve_ops_bn254();

@@ -432,6 +432,48 @@ ZK_HD Fe<P> fu_to_fe(const Fu<P>& a) {
     fe_reduce_once(r);                            // < 2p -> canonical
     return fe_to_mont(r);
 }
+// ---- packed form: the integer value of a TIGHT element, < 2^(32W), in W 32-bit words ----
+// What the resident MSM base tables hold (one 16-byte-aligned run of words per coordinate: a BN254 G1 point is one 64-byte
+// line instead of 72 bytes straddling two) and what the NTT vectors hold between passes.  Packing propagates every carry;
+// unpacking is shifts and masks, the top limb keeps whatever is left.
+template <class P>
+ZK_HD void fu_pack(const Fu<P>& a, u32* w) {
+    constexpr int N = Fu<P>::N, B = Fu<P>::B, W = P::N;
+    u32 l[N];
+    u32 c = 0;
+    ZK_UNROLL for (int i = 0; i < N; ++i) {
+        u32 t = a.v[i] + c;
+        if (i < N - 1) { l[i] = t & Fu<P>::M; c = t >> B; } else l[i] = t;
+    }
+    ZK_UNROLL for (int k = 0; k < W; ++k) {
+        const int bit = 32 * k, li = bit / B, sh = bit % B;
+        u64 acc = (u64)l[li] >> sh;
+        int have = B - sh;
+        ZK_UNROLL for (int q = 1; q < 3; ++q)
+            if (li + q < N && have < 32) { acc |= (u64)l[li + q] << have; have += B; }
+        w[k] = (u32)acc;
+    }
+}
+template <class P>
+ZK_HD Fu<P> fu_unpack(const u32* w) {
+    constexpr int N = Fu<P>::N, B = Fu<P>::B, W = P::N;
+    Fu<P> s;
+    ZK_UNROLL for (int i = 0; i < N; ++i) {
+        const int bit = B * i, wi = bit >> 5, sh = bit & 31;
+        u64 two = wi < W ? w[wi] : 0;
+        if (wi + 1 < W) two |= (u64)w[wi + 1] << 32;
+        s.v[i] = i < N - 1 ? ((u32)(two >> sh) & Fu<P>::M) : (u32)(two >> sh);
+    }
+    return s;
+}
+template <class P> ZK_HD void fu_pack(const Fu2<P>& a, u32* w) { fu_pack(a.c0, w); fu_pack(a.c1, w + P::N); }
+template <class F> struct PackedWords;   // 32-bit words of one packed coordinate
+template <class P> struct PackedWords<Fu<P>> { static constexpr int N = P::N; };
+template <class P> struct PackedWords<Fu2<P>> { static constexpr int N = 2 * P::N; };
+template <class F> struct FuUnpack;
+template <class P> struct FuUnpack<Fu<P>> { ZK_HD static Fu<P> get(const u32* w) { return fu_unpack<P>(w); } };
+template <class P> struct FuUnpack<Fu2<P>> { ZK_HD static Fu2<P> get(const u32* w) { return {fu_unpack<P>(w), fu_unpack<P>(w + P::N)}; } };
+
 template <class P> ZK_HD Fu2<P> fu_from_fe(const Fe2<P>& a) { return {fu_from_fe(a.c0), fu_from_fe(a.c1)}; }
 template <class P> ZK_HD Fe2<P> fu_to_fe(const Fu2<P>& a) { return {fu_to_fe(a.c0), fu_to_fe(a.c1)}; }
 

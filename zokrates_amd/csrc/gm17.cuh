@@ -169,17 +169,7 @@ struct Gm17 {
         ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(D, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(ctx->tmp),
                   ptr<Aff<Fq>>(pk->h_sigma), D, D, plan->N1, plan->N2);
         stream_sync(ctx->stream);
-        // this rank's share of the bases (everything for world = 1), as in PkLoader::load
-        u64 nominal_z, nominal_h;
-        L::range_of(me, pk->rank, pk->world, pk->z_lo, pk->z_n, nominal_z);
-        L::range_of(D, pk->rank, pk->world, pk->h_lo, pk->h_n, nominal_h);
-        pk->c_z = msm_shape(nominal_z, Fr::Params::BITS).c;
-        pk->c_h = msm_shape(nominal_h, Fr::Params::BITS).c;
-        L::template to_unsat<Fq>(ctx, pk->a_ext, pk->z_lo, pk->z_n);
-        L::template to_unsat<Fq>(ctx, pk->b1_ext, pk->z_lo, pk->z_n);
-        L::template to_unsat<Fq>(ctx, pk->l_ext, pk->z_lo, pk->z_n);
-        L::template to_unsat<Fq2>(ctx, pk->b2_ext, pk->z_lo, pk->z_n);
-        L::template to_unsat<Fq>(ctx, pk->h_sigma, pk->h_lo, pk->h_n);
+        L::finish_tables(ctx, pk, me, D);
     }
 
     static void check_match(const zkhip_pk* pk, const zkhip_r1cs* cs) {
@@ -240,15 +230,15 @@ struct Gm17 {
         ZK_LAUNCH((k_sap_rows<Fr>), dim3(blocks_for(n + l, 256)), dim3(256), 0, st, ra, rb, rc, ptr<Fr>(sl.zmont), sa, sc, (Fr*)d_scalars, n, l, m);
 
         // ---- the four MSMs over S = [ext_0..ext_{M-1}, rho, 0] share one digit/sort pass
-        const MsmShape shz = msm_shape(pk->z_n, Fr::Params::BITS, pk->c_z);
-        const MsmShape shh = msm_shape(pk->h_n, Fr::Params::BITS, pk->c_h);
-        const int Wmax = std::max(shz.W, shh.W) + 1;
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const int Wmax = (int)std::max(shz.sets, shh.sets);
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
         // (a sharded key covers only its index range of the bases and pairs them with the same range of the scalars)
         if (pk->z_n) {
-            msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz);
+            msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
             msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
             msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
             msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
@@ -270,7 +260,7 @@ struct Gm17 {
 
         // ---- G = MSM(g_gamma2_z_t, h0)
         if (pk->h_n) {
-            msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh);
+            msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
             msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
         } else {
             P::empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);

@@ -6,27 +6,46 @@
 namespace zk {
 
 template <class FS>
-void points_to_unsat(zkhip_ctx* ctx, const Aff<FS>* d_in, void* d_out, u64 n) {
+void points_to_packed(zkhip_ctx* ctx, const Aff<FS>* d_in, void* d_out, u64 n) {
     typedef typename Unsat<FS>::type U;
-    ZK_LAUNCH((k_points_to_unsat<FS, U>), dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_in, (Aff<U>*)d_out, n);
+    ZK_LAUNCH((k_points_to_packed<FS, U>), dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_in, (AffPacked<U>*)d_out, n);
+}
+
+// levels 1 .. W-1 of a base table whose level 0 (count points) is in place; level j starts at j * count.  Bases are
+// processed in chunks so that the transient XYZZ / prefix-product workspace stays below ~1 GiB whatever the key size.
+template <class FS>
+void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int c, int W) {
+    typedef typename Unsat<FS>::type F;
+    if (W <= 1 || count == 0) return;
+    const u64 chunk = std::min<u64>(count, std::max<u64>(1024, ((u64)768 << 20) / ((u64)(W - 1) * (sizeof(Xyzz<F>) + sizeof(F)))));
+    DBuf tmp, pre;
+    tmp.ensure((u64)(W - 1) * chunk * sizeof(Xyzz<F>));
+    pre.ensure((u64)(W - 1) * chunk * sizeof(F));
+    for (u64 i0 = 0; i0 < count; i0 += chunk) {
+        const u64 cnt = std::min(chunk, count - i0);
+        ZK_LAUNCH((k_msm_table_levels<F, FS>), dim3(blocks_for(cnt, 256)), dim3(256), 0, ctx->stream, (AffPacked<F>*)d_table, count, i0, cnt, c, W,
+                  ptr<Xyzz<F>>(tmp), ptr<F>(pre));
+    }
+    stream_sync(ctx->stream);
 }
 
 template <class FS>
-void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bases_unsat, const MsmShape& sh, Xyzz<FS>* d_window_sums,
+void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<FS>* d_window_sums,
              Event ev_begin, Event ev_end) {
     typedef typename Unsat<FS>::type F;   // the kernels run on the unsaturated field
-    const Aff<F>* d_bases = (const Aff<F>*)d_bases_unsat;
+    const AffPacked<F>* d_bases = (const AffPacked<F>*)d_table;
     Stream s = ctx->serial ? ctx->stream : lane.stream;
     stream_wait_event(s, so.ready);
-    // slice length of the balanced accumulation, the first bucket of every slice, the buckets needing a workgroup
-    const u32 P = sh.P_env ? sh.P_env : MsmTuning<F>::SLICE;
+    // one slice of the sorted list per work-item the machine holds (never finer than MSM_MIN_SLICE entries)
+    const u64 machine = ctx->msm_lanes ? (u64)ctx->msm_lanes : (u64)ctx->cus * 4 * 64 * (ctx->msm_waves ? ctx->msm_waves : MsmTuning<F>::ACCUM_WPE);
+    const u32 nlanes = (u32)std::max<u64>(1, std::min<u64>(machine, (sh.n * (u64)sh.W + ctx->msm_min_slice - 1) / ctx->msm_min_slice));
+    const MsmCut cut{nlanes, ctx->msm_min_slice};
     lane.heavy.ensure(((size_t)sh.nkeys + 1) * 4);            // [0] = count, [1..] = keys
-    const u32 nlanes = (u32)((sh.n * (u64)sh.W + P - 1) / P);
     lane.lane_key.ensure((size_t)nlanes * 4);
     lane.partial.ensure(((size_t)sh.nkeys + nlanes) * sizeof(Xyzz<F>));
-    lane.bucket.ensure((size_t)sh.W * sh.K * sizeof(Xyzz<F>));
-    lane.rows.ensure((size_t)sh.W * sh.H * sizeof(Xyzz<F>));
-    lane.cols.ensure((size_t)sh.W * sh.Lw * sizeof(Xyzz<F>));
+    lane.bucket.ensure((size_t)sh.nkeys * sizeof(Xyzz<F>));
+    lane.rows.ensure((size_t)sh.sets * sh.H * sizeof(Xyzz<F>));
+    lane.cols.ensure((size_t)sh.sets * sh.Lw * sizeof(Xyzz<F>));
     lds_opt_in(ctx, (const void*)k_msm_fold_rows<F>);
     lds_opt_in(ctx, (const void*)k_msm_fold_cols<F>);
     lds_opt_in(ctx, (const void*)k_msm_fold_final<F, FS>);
@@ -34,35 +53,34 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_bas
     lds_opt_in(ctx, (const void*)k_msm_heavy_reduce<F>);
     const unsigned T = 256;
     dev_memset(lane.heavy.p, 0, 4, s);
-    ZK_LAUNCH(k_msm_lane_keys, dim3(blocks_for(nlanes, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, P, nlanes, ptr<u32>(lane.lane_key));
-    ZK_LAUNCH(k_msm_find_heavy, dim3(blocks_for(sh.nkeys, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, P, ptr<u32>(lane.heavy) + 1,
+    ZK_LAUNCH(k_msm_lane_keys, dim3(blocks_for(nlanes, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.lane_key));
+    ZK_LAUNCH(k_msm_find_heavy, dim3(blocks_for(sh.nkeys, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.heavy) + 1,
               ptr<u32>(lane.heavy));
     if (ev_begin) event_record(ev_begin, s);
     ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE>), dim3(blocks_for(nlanes, T)), dim3(T), 0, s, d_bases, ptr<u32>(so.off), ptr<u32>(so.sorted),
-              ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), sh.nkeys, P, nlanes);
+              ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), sh.nkeys, cut);
     if (ev_end) event_record(ev_end, s);
 #ifdef ZK_EMU
     const unsigned heavy_wgs = 4;     // the fibre emulator pays for every work-item of an idle workgroup
 #else
     const unsigned heavy_wgs = 256;
 #endif
-    ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(heavy_wgs), dim3(T), T * sizeof(Xyzz<F>), s, ptr<u32>(so.off), P, ptr<u32>(lane.heavy) + 1,
+    ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(heavy_wgs), dim3(T), T * sizeof(Xyzz<F>), s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.heavy) + 1,
               ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.partial));
-    ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.W), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial),
-              ptr<u32>(so.off), P, sh.K, sh.Lw, ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));
+    ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.sets), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial),
+              ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));
     const u32 CW = std::min<u32>(sh.Lw, 32), HG = std::max<u32>(1, std::min<u32>(8, sh.H));   // 256 work-items for big windows
-    ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.W), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
+    ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.sets), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
               sh.Lw, sh.H, ptr<Xyzz<F>>(lane.cols));
     // the scan form of the last fold step needs Lw + H points of LDS; the double-and-add form (Lw points) is the fallback
     const unsigned TS = (sh.Lw + sh.H + 63) / 64 * 64;
-    const bool scan_off = env_int("ZKHIP_FOLD_SCAN", 0, 1, 1) == 0;   // development / test hook
-    if (!scan_off && TS <= 512 && (size_t)TS * sizeof(Xyzz<F>) <= 150 * 1024) {
-        ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.W + 1), dim3(TS), TS * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols),
-                  sh.Lw, sh.H, ptr<Xyzz<F>>(lane.partial), ptr<u32>(so.off), P, (u32)sh.W, sh.nkeys - 1, d_window_sums);
+    if (ctx->fold_scan && TS <= 512 && (size_t)TS * sizeof(Xyzz<F>) <= 150 * 1024) {
+        ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.sets), dim3(TS), TS * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols),
+                  sh.Lw, sh.H, d_window_sums);
     } else {
         const unsigned TF = std::max<u32>(64, sh.Lw);
-        ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.W + 1), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
-                  sh.H, ptr<Xyzz<F>>(lane.partial), ptr<u32>(so.off), P, (u32)sh.W, sh.nkeys - 1, d_window_sums);
+        ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.sets), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
+                  sh.H, d_window_sums);
     }
     event_record(lane.done, s);
 }
@@ -83,7 +101,8 @@ void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scal
 
 #define ZK_INSTANTIATE_GROUP(F)                                                                                         \
     template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event);          \
-    template void points_to_unsat<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                     \
+    template void points_to_packed<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                    \
+    template void msm_table_levels<F>(zkhip_ctx*, void*, u64, int, int);                         \
     template void fixed_base_table<F>(zkhip_ctx*, const Aff<F>*, int, DBuf&);                                           \
     template void fixed_base_mul<F>(zkhip_ctx*, const DBuf&, int, const u32*, u64, Aff<F>*);
 

@@ -4,20 +4,21 @@
 // App. A.5), the five calls of which dominate `Groth16::prove`
 // (/root/reference/zokrates_ark/src/groth16.rs:44).  Same mathematics (bucket method), different
 // schedule: instead of one CPU thread per window walking all scalars, the device
-//   1. classifies every scalar — 0 is dropped, 1 goes to a dedicated "ones" bucket (ark special-cases
-//      both; real witnesses are mostly bits) — and recodes the rest into W signed c-bit digits
-//      (half the buckets: 2^(c-1) per window),
-//   2. counting-sorts the (window, bucket) keys so that every bucket's points are contiguous,
-//   3. accumulates with XYZZ mixed additions in a *load-balanced* way: every work-item owns P
-//      consecutive entries of the sorted list, whatever buckets they belong to, and emits one partial
-//      sum per bucket it touches (a segmented reduction; slot = key + lane is collision free),
-//   4. buckets that ended up spread over many lanes are reduced by a whole workgroup each,
-//   5. folds each window's buckets with the running-sum trick (partials are combined on the fly),
-//      many work-items per window plus an LDS tree, leaving W window sums (+ the ones bucket) for
-//      the host's Horner step.
+//   1. recodes every scalar into W signed c-bit digits (half the buckets: K = 2^(c-1) per set; zero digits are dropped, so
+//      a scalar 0 costs nothing and a scalar 1 is one entry of bucket 0),
+//   2. counting-sorts the (bucket set, bucket) keys so that every bucket's points are contiguous,
+//   3. accumulates with XYZZ mixed additions in a *load-balanced* way: the sorted list is cut into as many equal slices
+//      as the machine holds work-items, whatever buckets they cover, and every work-item emits one partial sum per
+//      bucket it touches (a segmented reduction; slot = key + lane is collision free),
+//   4. buckets that ended up spread over many slices are reduced by a whole workgroup each,
+//   5. folds each set's buckets (sum of (b+1) B_b) in a two-digit form with scan tails.
+// Resident keys carry PRECOMPUTED WINDOW MULTIPLES: table level j holds 2^(c j) P for every base P, so digit j of a scalar
+// pairs with level j of its base and ALL windows share ONE bucket set ("shared" mode: one fold per MSM instead of W, no
+// Horner step, buckets hundreds of points deep).  Ad-hoc bases (zkhip_msm_g1/g2) have no table: W bucket sets and a
+// host Horner step over the W window sums, through the same kernels.
 // One digit/sort pass is shared by every base set that uses the same scalars (a_query, b_g1_query,
 // b_g2_query and l_query all pair with z).  The result is the exact group element, so it is
-// independent of c, P, of the summation order and of how ark itself schedules the sum.
+// independent of c, of the slice length, of the summation order and of how ark itself schedules the sum.
 #pragma once
 #include "devrt.h"
 #include "ec.cuh"
@@ -25,13 +26,14 @@
 namespace zk {
 
 // per point type tuning (measured on MI355X with tools/accum_bench.hip, 2^24 mixed additions on the unsaturated field:
-// G1 1.22 ms at 3 waves per SIMD / slices of 32; G2 3.17 ms at 2 waves per SIMD / slices of 32).  *_WPE = waves per SIMD the register allocator must
-// leave room for; SLICE = sorted entries per accumulation work-item.
-template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3; static constexpr u32 SLICE = 32; };
-template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; static constexpr u32 SLICE = 16; };
-template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; static constexpr u32 SLICE = 32; };
-template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3; static constexpr u32 SLICE = 32; };
-template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2; static constexpr u32 SLICE = 32; };
+// G1 1.22 ms at 3 waves per SIMD; G2 3.17 ms at 2 waves per SIMD).  *_WPE = waves per SIMD the register allocator must
+// leave room for; the accumulation kernel is launched with exactly that many waves per SIMD on every CU, one slice each.
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3; };
+template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; };
+template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2; };
+static constexpr u32 MSM_MIN_SLICE = 8;   // default for the finest cut of the sorted list (small inputs leave work-items idle)
 
 // The kernels below work on points over the UNSATURATED field types of fieldu.cuh (Fu / Fu2); only the window sums
 // leaving k_msm_fold_final go back to the saturated Montgomery form the host code uses.
@@ -44,40 +46,54 @@ ZK_HD Xyzz<FS> xyzz_to_sat(const Xyzz<U>& p) {
     if (p.is_inf()) return Xyzz<FS>::inf();
     return {to_sat(p.x), to_sat(p.y), to_sat(p.zz), to_sat(p.zzz)};
 }
-// affine points: saturated Montgomery -> unsaturated working form (key load)
+// ---- packed affine points: what the resident base tables hold ----
+// x | y as packed integers (fu_pack: the value of x*R' mod p in 32-bit words), infinity all-zero.  A BN254 G1 point is one
+// aligned 64-byte line (the 9 x 29-bit working form is 72 bytes and straddles two), G2 128 bytes; BLS12-381 96 / 192.
+template <class F>
+struct alignas(16) AffPacked {
+    static constexpr int NW = PackedWords<F>::N;
+    u32 w[2 * NW];
+};
+template <class F>
+ZK_HD Aff<F> aff_unpack(const u32* w) {
+    return {FuUnpack<F>::get(w), FuUnpack<F>::get(w + PackedWords<F>::N)};
+}
+template <class F>
+ZK_HD void aff_pack(const Aff<F>& p, AffPacked<F>* out) {   // coordinates TIGHT with value < 2^(32 W) (products: < 2p)
+    fu_pack(p.x, out->w);
+    fu_pack(p.y, out->w + PackedWords<F>::N);
+}
+template <class F>
+__device__ __forceinline__ void aff_load_words(const AffPacked<F>* __restrict__ tbl, u64 idx, u32* w) {
+    const uint4* src = (const uint4*)(tbl + idx);
+    ZK_UNROLL for (int q = 0; q < AffPacked<F>::NW / 2; ++q) {
+        const uint4 t = src[q];
+        w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+    }
+}
+// affine points: saturated Montgomery -> packed working form (key load, level 0 of a table)
 template <class FS, class U>
-__global__ void k_points_to_unsat(const Aff<FS>* __restrict__ in, Aff<U>* __restrict__ out, u64 n) {
+__global__ void k_points_to_packed(const Aff<FS>* __restrict__ in, AffPacked<U>* __restrict__ out, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Aff<FS> p = in[i];
     Aff<U> q = Aff<U>::inf();
     if (!p.is_inf()) { q.x = fu_from_fe(p.x); q.y = fu_from_fe(p.y); }
-    out[i] = q;
+    aff_pack(q, out + i);
 }
 
 static constexpr u32 MSM_NO_DIGIT = 0xffffffffu;
-static constexpr u32 MSM_HEAVY = 8;   // a bucket spread over more slices than this is reduced by a whole workgroup (32 made
-                                      // repeated witness values — 1024 copies of a round constant's S-box in a Poseidon chain — serialise k_msm_fold_rows: +21 %)
+static constexpr u32 MSM_HEAVY = 16;  // a bucket spread over more slices than this is reduced by a whole workgroup (a value repeated
+                                      // across a witness — the constant in every first S-box of a Poseidon chain, the ones of a
+                                      // boolean-heavy assignment — would otherwise be summed serially by one work-item of the fold)
 
-// ---- wave-level helpers (64-wide wavefronts) ----
-#ifdef ZK_EMU
-static inline unsigned long long wave_ballot(bool p) { return emu::wave_ballot(p); }
-static inline int wave_lane() { return (int)(emu::G().cur->flat & 63); }
-#else
-static __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
-static __device__ __forceinline__ int wave_lane() { return (int)__lane_id(); }
-#endif
-static __device__ __forceinline__ int first_lane(unsigned long long m) { return m ? __builtin_ctzll(m) : 0; }
-static __device__ __forceinline__ u32 lanes_below(unsigned long long m, int lane) {
-    return (u32)__builtin_popcountll(m & (((unsigned long long)1 << lane) - 1));
-}
-
-// ---- 1. classification, signed-digit recoding, counting sort — window-major, histograms in LDS ----
-// One scalar produces W digits that land in W different key ranges; doing that with one global atomic per digit makes the
-// sort atomic-bound (17.8 M atomics per pass at 2^20).  Here a workgroup owns ONE window of a chunk of scalars, so all its
-// keys fall into that window's K buckets: the histogram lives in LDS (K x 4 B <= 128 KB) and only one global atomic
-// per touched (workgroup, bucket) remains.  Scalars are first transposed to word-major order so that a window reads the
-// two 32-bit words it needs with unit stride.
+// ---- 1. signed-digit recoding, counting sort — window-major, histograms in LDS ----
+// One scalar produces W digits; doing the sort with one global atomic per digit makes it atomic-bound (17.8 M atomics per
+// pass at 2^20).  Here a workgroup owns ONE window of a chunk of scalars, so all its keys fall into one set of K buckets:
+// the histogram lives in LDS (K x 4 B <= 128 KB) and only one global atomic per touched (workgroup, bucket) remains.
+// Scalars are first transposed to word-major order so that a window reads the two 32-bit words it needs with unit stride.
+// key = j * key_stride + bucket (key_stride = K: one bucket set per window; 0: all windows share one set);
+// sorted entry = (j * idx_stride + i) | sign << 31 (idx_stride = table level stride, 0 without a table).
 static __global__ void k_scalars_to_word_major(const u32* __restrict__ scalars, u64 n, u32* __restrict__ wm) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -110,66 +126,56 @@ static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ w
     }
     return raw ? raw - 1 : MSM_NO_DIGIT;
 }
-static __device__ __forceinline__ bool msm_scalar_is_one(const u32* __restrict__ wm, u64 n, u64 i) {
-    u32 rest = 0;
-    for (int w = 1; w < 8; ++w) rest |= wm[(u64)w * n + i];
-    return rest == 0 && wm[i] == 1;
-}
-// grid (nchunks, W); dynamic LDS (K + 1) x 4 B.  cnt[key] += number of digits with that key in this chunk;
-// scalars equal to 1 go to the dedicated key W*K instead of (window 0, bucket 0).
-static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32* __restrict__ cnt) {
+// grid (nchunks, W); dynamic LDS K x 4 B.  cnt[key] += number of digits with that key in this chunk.
+static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride,
+                                                        u32* __restrict__ cnt) {
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
     const u32 K = 1u << (c - 1);
     const int j = blockIdx.y;
-    for (u32 b = threadIdx.x; b <= K; b += blockDim.x) hist[b] = 0;   // hist[K] counts the ones
+    for (u32 b = threadIdx.x; b < K; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
-        u32 slot = d & 0x7fffffffu;
-        if (j == 0 && d == 0 && msm_scalar_is_one(wm, n, i)) slot = K;
-        atomicAdd(&hist[slot], 1u);
+        atomicAdd(&hist[d & 0x7fffffffu], 1u);
     }
     __syncthreads();
     for (u32 b = threadIdx.x; b < K; b += blockDim.x)
-        if (hist[b]) atomicAdd(&cnt[(u64)j * K + b], hist[b]);
-    if (threadIdx.x == 0 && hist[K]) atomicAdd(&cnt[(u64)W * K], hist[K]);
+        if (hist[b]) atomicAdd(&cnt[(u64)j * key_stride + b], hist[b]);
 }
 // same geometry; after the scan: reserve this workgroup's run inside every bucket it touches (one global atomic per
-// bucket), then place the entries with LDS atomics.  sorted[pos] = point index | sign << 31.
-static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, const u32* __restrict__ off,
-                                                        u32* __restrict__ cursor, u32* __restrict__ sorted) {
+// bucket), then place the entries with LDS atomics.
+static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride,
+                                                        u64 idx_stride, const u32* __restrict__ off, u32* __restrict__ cursor,
+                                                        u32* __restrict__ sorted) {
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
     const u32 K = 1u << (c - 1);
     const int j = blockIdx.y;
-    for (u32 b = threadIdx.x; b <= K; b += blockDim.x) hist[b] = 0;
+    for (u32 b = threadIdx.x; b < K; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
-        u32 slot = d & 0x7fffffffu;
-        if (j == 0 && d == 0 && msm_scalar_is_one(wm, n, i)) slot = K;
-        atomicAdd(&hist[slot], 1u);
+        atomicAdd(&hist[d & 0x7fffffffu], 1u);
     }
     __syncthreads();
-    for (u32 b = threadIdx.x; b <= K; b += blockDim.x) {
+    for (u32 b = threadIdx.x; b < K; b += blockDim.x) {
         const u32 have = hist[b];
         if (!have) continue;
-        const u64 key = b < K ? (u64)j * K + b : (u64)W * K;
+        const u64 key = (u64)j * key_stride + b;
         hist[b] = off[key] + atomicAdd(&cursor[key], have);   // global position of this workgroup's first entry
     }
     __syncthreads();
+    const u32 level = (u32)((u64)j * idx_stride);
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
-        u32 slot = d & 0x7fffffffu;
-        if (j == 0 && d == 0 && msm_scalar_is_one(wm, n, i)) slot = K;
-        const u32 pos = atomicAdd(&hist[slot], 1u);
-        sorted[pos] = (u32)i | (d & 0x80000000u);
+        const u32 pos = atomicAdd(&hist[d & 0x7fffffffu], 1u);
+        sorted[pos] = (level + (u32)i) | (d & 0x80000000u);
     }
 }
 
@@ -231,10 +237,21 @@ static __global__ void k_scan_add(u32* __restrict__ off, const u32* __restrict__
     if (i == total) off[total] = *grand_total;   // sentinel: off has total+1 entries
 }
 
-// ---- 3a. first key of every lane's slice of the sorted list (upper bound over the offsets) ----
-static __global__ void k_msm_lane_keys(const u32* __restrict__ off, u32 nkeys, u32 P, u32 nlanes, u32* __restrict__ lane_key) {
+// ---- 3a. slices of the sorted list ----
+// The list (length total = off[nkeys], known only on the device) is cut into nlanes slices of P = max(ceil(total / nlanes),
+// min_slice) entries: with nlanes = the number of work-items the machine holds, every work-item of the accumulation
+// kernel does the same number of additions in ONE round of workgroups, whatever the scalars look like.
+struct MsmCut { u32 nlanes, min_slice; };
+static __device__ __forceinline__ u32 msm_slice_len(const u32* __restrict__ off, u32 nkeys, MsmCut cut) {
+    const u32 total = off[nkeys];
+    const u32 P = (total + cut.nlanes - 1) / cut.nlanes;
+    return P > cut.min_slice ? P : cut.min_slice;
+}
+// first key of every lane's slice (upper bound over the offsets)
+static __global__ void k_msm_lane_keys(const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32* __restrict__ lane_key) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nlanes) return;
+    if (g >= cut.nlanes) return;
+    const u32 P = msm_slice_len(off, nkeys, cut);
     const u64 pos = (u64)g * P;
     if (pos >= off[nkeys]) { lane_key[g] = nkeys; return; }
     u32 lo = 0, hi = nkeys;          // invariant: off[lo] <= pos < off[hi]
@@ -245,9 +262,11 @@ static __global__ void k_msm_lane_keys(const u32* __restrict__ off, u32 nkeys, u
     lane_key[g] = lo;
 }
 // buckets whose entries span more than MSM_HEAVY lanes
-static __global__ void k_msm_find_heavy(const u32* __restrict__ off, u32 nkeys, u32 P, u32* __restrict__ heavy_list, u32* __restrict__ heavy_count) {
+static __global__ void k_msm_find_heavy(const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32* __restrict__ heavy_list,
+                                        u32* __restrict__ heavy_count) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nkeys) return;
+    const u32 P = msm_slice_len(off, nkeys, cut);
     const u32 b = off[k], e = off[k + 1];
     if (e > b && (e - 1) / P - b / P + 1 > MSM_HEAVY) heavy_list[atomicAdd(heavy_count, 1u)] = k;
 }
@@ -256,37 +275,43 @@ static __global__ void k_msm_find_heavy(const u32* __restrict__ off, u32 nkeys, 
 // Lane g owns sorted entries [g*P, (g+1)*P).  Whenever the walk crosses into another bucket the running sum is
 // written to partial[key + g]: along the sorted list (lane, key) only ever increase, so key + lane is unique,
 // and bucket `key` finds its partials at the contiguous slots key + g for the lanes g its range overlaps.
+// An entry names a table slot (level * stride + point index); the base is fetched packed (one 64-byte line for BN254 G1)
+// one entry ahead and unpacked into 29/28-bit limbs when it is used.
 template <class F, int WPE>
-__global__ void __launch_bounds__(256, WPE) k_msm_accum(const Aff<F>* __restrict__ bases, const u32* __restrict__ off, const u32* __restrict__ sorted,
-                                                    const u32* __restrict__ lane_key, Xyzz<F>* __restrict__ partial, u32 nkeys, u32 P,
-                                                    u32 nlanes) {
+__global__ void __launch_bounds__(256, WPE) k_msm_accum(const AffPacked<F>* __restrict__ bases, const u32* __restrict__ off, const u32* __restrict__ sorted,
+                                                    const u32* __restrict__ lane_key, Xyzz<F>* __restrict__ partial, u32 nkeys, MsmCut cut) {
+    constexpr int NW2 = 2 * AffPacked<F>::NW;
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nlanes) return;
+    if (g >= cut.nlanes) return;
     u32 cur = lane_key[g];
     if (cur >= nkeys) return;
     const u32 total = off[nkeys];
-    const u32 p0 = g * P;
-    const u32 p1 = p0 + P < total ? p0 + P : total;
+    const u32 P = msm_slice_len(off, nkeys, cut);
+    const u64 p0 = (u64)g * P;
+    const u64 p1 = p0 + P < total ? p0 + P : total;
     u32 end = off[cur + 1];
     Xyzz<F> acc = Xyzz<F>::inf();
     u32 e = sorted[p0];
-    Aff<F> pt = bases[e & 0x7fffffffu];
-    for (u32 pos = p0; pos < p1; ++pos) {
+    u32 w[NW2];
+    aff_load_words<F>(bases, e & 0x7fffffffu, w);
+    for (u64 pos = p0; pos < p1; ++pos) {
         u32 e_next = e;
-        Aff<F> pt_next = pt;
+        u32 w_next[NW2];
+        ZK_UNROLL for (int q = 0; q < NW2; ++q) w_next[q] = w[q];
         if (pos + 1 < p1) {            // fetch the next base while this one is being added
             e_next = sorted[pos + 1];
-            pt_next = bases[e_next & 0x7fffffffu];
+            aff_load_words<F>(bases, e_next & 0x7fffffffu, w_next);
         }
         if (pos == end) {
             partial[(u64)cur + g] = acc;
             acc = Xyzz<F>::inf();
             do { ++cur; end = off[cur + 1]; } while (end <= pos);
         }
+        Aff<F> pt = aff_unpack<F>(w);
         if (e & 0x80000000u) pt.y = fe_neg(pt.y);
         if (!pt.is_inf()) xyzz_madd_acc<true>(acc, pt);
         e = e_next;
-        pt = pt_next;
+        ZK_UNROLL for (int q = 0; q < NW2; ++q) w[q] = w_next[q];
     }
     partial[(u64)cur + g] = acc;
 }
@@ -319,10 +344,11 @@ __device__ __forceinline__ void block_tree_sum(Xyzz<F>* sh) {
 
 // ---- 4. heavy buckets: one workgroup each, result into the bucket's first slot ----
 template <class F>
-__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_heavy_reduce(const u32* __restrict__ off, u32 P, const u32* __restrict__ heavy_list,
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_heavy_reduce(const u32* __restrict__ off, u32 nkeys, MsmCut cut, const u32* __restrict__ heavy_list,
                                                            const u32* __restrict__ heavy_count, Xyzz<F>* __restrict__ partial) {
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
+    const u32 P = msm_slice_len(off, nkeys, cut);
     const u32 nh = *heavy_count;
     for (u32 h = blockIdx.x; h < nh; h += gridDim.x) {
         const u32 key = heavy_list[h];
@@ -354,14 +380,15 @@ __device__ __forceinline__ Xyzz<F> xyzz_mul_small(const Xyzz<F>& p, u32 k) {
 // Both digit sums are plain (unweighted) reductions over all buckets — wide and shallow — and only the Lw + H
 // row/column totals per window need a (short) double-and-add.
 //
-// 5a. one workgroup per (row, window): combine each bucket's partials, keep the bucket value for the column pass,
+// 5a. one workgroup per (row, bucket set): combine each bucket's partials, keep the bucket value for the column pass,
 //     tree-sum the row.
 template <class F>
-__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 P, u32 K, u32 Lw,
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32 K, u32 Lw,
                                                         Xyzz<F>* __restrict__ bucket, Xyzz<F>* __restrict__ rows) {
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.y, hi = blockIdx.x, lo = threadIdx.x;
+    const u32 P = msm_slice_len(off, nkeys, cut);
     const u32 key = j * K + hi * Lw + lo;
     Xyzz<F> v = msm_bucket_sum<F>(partial, off, key, P);
     bucket[key] = v;
@@ -390,18 +417,13 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(c
     }
     if (hg == 0) cols[(u64)j * Lw + lo] = sh[threadIdx.x];
 }
-// 5c. one workgroup per window: the two weighted digit sums; workgroup W delivers the ones bucket.
+// 5c. one workgroup per bucket set: the two weighted digit sums.
 template <class F, class FS>
 __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
-                                                         const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 P, u32 W,
-                                                         u32 ones_key, Xyzz<FS>* __restrict__ window_sum) {
+                                                         Xyzz<FS>* __restrict__ window_sum) {
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x;
-    if (j >= W) {
-        if (t == 0) window_sum[j] = xyzz_to_sat<FS>(msm_bucket_sum<F>(partial, off, ones_key, P));
-        return;
-    }
     // sum_hi hi * R_hi, then times Lw (a power of two: log2 doublings)
     Xyzz<F> term = Xyzz<F>::inf();
     for (u32 hi = t; hi < H; hi += blockDim.x) xyzz_add_acc(term, xyzz_mul_small(rows[(u64)j * H + hi], hi));
@@ -430,15 +452,10 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(
 // by side: ~21 sequential curve operations instead of ~51.  blockDim.x >= Lw + H; dynamic LDS blockDim.x points.
 template <class F, class FS>
 __global__ void __launch_bounds__(512) k_msm_fold_final_scan(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
-                                                             const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 P, u32 W,
-                                                             u32 ones_key, Xyzz<FS>* __restrict__ window_sum) {
+                                                             Xyzz<FS>* __restrict__ window_sum) {
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x;
-    if (j >= W) {
-        if (t == 0) window_sum[j] = xyzz_to_sat<FS>(msm_bucket_sum<F>(partial, off, ones_key, P));
-        return;
-    }
     const bool is_col = t < Lw, live = t < Lw + H;
     const u32 li = is_col ? t : t - Lw;                 // index inside the segment
     const u32 seglen = is_col ? Lw : H;
@@ -479,6 +496,42 @@ __global__ void __launch_bounds__(512) k_msm_fold_final_scan(const Xyzz<F>* __re
         Xyzz<F> r = sh[0];
         xyzz_add_acc(r, sh[Lw]);
         window_sum[j] = xyzz_to_sat<FS>(r);
+    }
+}
+
+// ---- precomputed window multiples (key load) ----
+// tbl[j * stride + i] = 2^(c j) * tbl[i] for j = 1 .. W-1 and i in [i0, i0 + cnt): one work-item per base walks the
+// doublings (XYZZ, kept in `tmp`), then turns its W-1 points back into affine form with ONE field inversion (Montgomery's
+// trick over its own ZZZ values, prefix products in `pre`) and packs them.  tmp / pre: (W-1) x cnt entries, level-major.
+template <class F, class FS>
+__global__ void __launch_bounds__(256) k_msm_table_levels(AffPacked<F>* __restrict__ tbl, u64 stride, u64 i0, u64 cnt, int c, int W,
+                                                           Xyzz<F>* __restrict__ tmp, F* __restrict__ pre) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    u32 w[2 * AffPacked<F>::NW];
+    aff_load_words<F>(tbl, i0 + i, w);
+    Xyzz<F> P = Xyzz<F>::from_affine(aff_unpack<F>(w));
+    F acc = F::one();
+    for (int j = 1; j < W; ++j) {
+        for (int b = 0; b < c; ++b) P = xyzz_dbl(P);
+        tmp[(u64)(j - 1) * cnt + i] = P;
+        if (!P.is_inf()) {
+            pre[(u64)(j - 1) * cnt + i] = acc;
+            acc = ec_mul(acc, P.zzz);
+        }
+    }
+    F inv = fu_from_fe(fe_inv(fu_to_fe(acc)));   // acc is a product of non-zero ZZZ values
+    for (int j = W - 1; j >= 1; --j) {
+        const Xyzz<F> Q = tmp[(u64)(j - 1) * cnt + i];
+        Aff<F> a = Aff<F>::inf();
+        if (!Q.is_inf()) {
+            const F i3 = ec_mul(inv, pre[(u64)(j - 1) * cnt + i]);   // 1 / ZZZ_j
+            inv = ec_mul(inv, Q.zzz);
+            const F i2 = ec_sqr(ec_mul(Q.zz, i3));                   // (ZZ / ZZZ)^2 = 1 / ZZ
+            a.x = ec_mul(Q.x, i2);
+            a.y = ec_mul(Q.y, i3);
+        }
+        aff_pack(a, tbl + (u64)j * stride + i0 + i);
     }
 }
 

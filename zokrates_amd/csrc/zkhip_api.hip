@@ -78,6 +78,9 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->stream = stream_create_high_priority();
         ctx->out_stream = stream_create();
         ctx->serial = getenv("ZKHIP_SERIAL") != nullptr;
+        ctx->msm_c_env = env_int("ZKHIP_MSM_C", 2, MSM_MAX_C, 0);
+        ctx->msm_waves = env_int("ZKHIP_MSM_WAVES", 1, 8, 0);
+        ctx->ntt_single_max = env_int("ZKHIP_NTT_SINGLE_MAX_LOG", 0, NTT_MAX_SUBLOG, 10);
         Stream lane_streams[ZK_NLANES];
         for (auto& st : lane_streams) st = stream_create();
         for (auto& sl : ctx->slots) {
@@ -99,6 +102,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         snprintf(buf, sizeof(buf), "zkhip on %s (%s), %d CUs, %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
                  prop.totalGlobalMem / 1073741824.0);
         ctx->desc = buf;
+        ctx->cus = std::max(1, prop.multiProcessorCount);
 #endif
         *out = ctx.release();
     });
@@ -124,6 +128,22 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
     stream_destroy(ctx->out_stream);
     stream_destroy(ctx->stream);
     delete ctx;
+}
+int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        auto in = [&](int lo, int hi) { require(value >= lo && value <= hi, ZKHIP_ERR_BAD_ARG, "tunable value out of range"); };
+        switch (which) {
+            case ZKHIP_TUNE_MSM_C: if (value) in(2, MSM_MAX_C); ctx->msm_c_env = value; break;
+            case ZKHIP_TUNE_MSM_WAVES: in(0, 8); ctx->msm_waves = value; break;
+            case ZKHIP_TUNE_MSM_LANES: in(0, 1 << 24); ctx->msm_lanes = (u32)value; break;
+            case ZKHIP_TUNE_MSM_MIN_SLICE: in(1, 1 << 20); ctx->msm_min_slice = (u32)value; break;
+            case ZKHIP_TUNE_FOLD_SCAN: in(0, 1); ctx->fold_scan = value != 0; break;
+            case ZKHIP_TUNE_SERIAL: in(0, 1); dev_sync_all(); ctx->serial = value != 0; break;
+            case ZKHIP_TUNE_NTT_SINGLE_MAX_LOG: in(0, NTT_MAX_SUBLOG); dev_sync_all(); ctx->ntt_single_max = value; ctx->plans.clear(); break;
+            default: throw ApiError{ZKHIP_ERR_BAD_ARG, "unknown tunable"};
+        }
+    });
 }
 const char* zkhip_last_error(const zkhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -379,55 +399,67 @@ int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs*
 }
 
 // ------------------------------------------------------------------ N2: device-layout image of a loaded key
-// "ZKHIPPK" + layout version; bump the version whenever the resident layout (unsaturated limbs, sigma order, the
-// extended base vectors) changes: an image is only meaningful to the library build that wrote it
-static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '1'};
+// "ZKHIPPK" + layout version; bump the version whenever the resident layout (packed points, sigma order, the extended base
+// vectors, table levels) changes: an image is only meaningful to the library build that wrote it.
+// An image holds either level 0 of the five base tables (compact: the window multiples are recomputed on the device at
+// import, ~0.1 s for a 2^20 key — less than reading the 6 GiB they occupy from any disk) or all levels
+// (ZKHIP_PK_IMAGE_FULL: import is five host-to-device copies and nothing else).
+static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '2'};
 struct PkImageHeader {
     char magic[8];
     int32_t curve, scheme;
     uint64_t m, w, l, hlen, N;
-    int32_t logN, c_z, c_h, reserved;
+    int32_t logN, c_z, c_h, full;     // full: 0 = level 0 only, 1 = every level
     uint32_t rank, world;
     uint64_t z_lo, z_n, h_lo, h_n;
     uint64_t len_delta, len_g2z2, len_buf[5];
 };
 static DBuf* pk_bufs(zkhip_pk* pk, int k) { DBuf* b[5] = {&pk->a_ext, &pk->b1_ext, &pk->l_ext, &pk->b2_ext, &pk->h_sigma}; return b[k]; }
-int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes) {
-    if (!pk || !bytes) return ZKHIP_ERR_BAD_ARG;
+static int pk_levels(int curve, int c) { const int bits = ops_for(curve)->fr_bits; return (bits + 1 + c - 1) / c; }
+// bytes of table k of this key in an image: count x (1 | levels) x point size
+static uint64_t pk_image_part(int curve, int k, uint64_t z_n, uint64_t h_n, int c_z, int c_h, bool full) {
+    const uint64_t g1b = ops_for(curve)->packed_g1_bytes;
+    const uint64_t count = std::max<uint64_t>(k == 4 ? h_n : z_n, 1), pt = k == 3 ? 2 * g1b : g1b;
+    return count * pt * (full ? (uint64_t)pk_levels(curve, k == 4 ? c_h : c_z) : 1);
+}
+int32_t zkhip_pk_export_size_ex(const zkhip_pk* pk, uint32_t flags, uint64_t* bytes) {
+    if (!pk || !bytes || (flags & ~(uint32_t)ZKHIP_PK_IMAGE_FULL)) return ZKHIP_ERR_BAD_ARG;
     uint64_t t = sizeof(PkImageHeader) + pk->delta_g1_canon.size() + pk->g_gamma2_z2_canon.size();
-    for (int k = 0; k < 5; ++k) t += pk_bufs(const_cast<zkhip_pk*>(pk), k)->cap;
+    for (int k = 0; k < 5; ++k) t += pk_image_part(pk->curve, k, pk->z_n, pk->h_n, pk->c_z, pk->c_h, flags & ZKHIP_PK_IMAGE_FULL);
     *bytes = t;
     return ZKHIP_OK;
 }
-int32_t zkhip_pk_export(const zkhip_pk* pk_, uint8_t* out, uint64_t cap) {
-    if (!pk_ || !out) return ZKHIP_ERR_BAD_ARG;
+int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes) { return zkhip_pk_export_size_ex(pk, 0, bytes); }
+int32_t zkhip_pk_export_ex(const zkhip_pk* pk_, uint32_t flags, uint8_t* out, uint64_t cap) {
+    if (!pk_ || !out || (flags & ~(uint32_t)ZKHIP_PK_IMAGE_FULL)) return ZKHIP_ERR_BAD_ARG;
     zkhip_pk* pk = const_cast<zkhip_pk*>(pk_);
     zkhip_ctx* ctx = pk->ctx;
     return guarded(ctx, [&] {
         uint64_t need = 0;
-        zkhip_pk_export_size(pk, &need);
+        zkhip_pk_export_size_ex(pk, flags, &need);
         require(cap >= need, ZKHIP_ERR_BAD_ARG, "output buffer too small (see zkhip_pk_export_size)");
         PkImageHeader h;
         memset(&h, 0, sizeof(h));
         memcpy(h.magic, PK_IMAGE_MAGIC, 8);
         h.curve = pk->curve; h.scheme = pk->scheme;
         h.m = pk->m; h.w = pk->w; h.l = pk->l; h.hlen = pk->hlen; h.N = pk->N;
-        h.logN = pk->logN; h.c_z = pk->c_z; h.c_h = pk->c_h;
+        h.logN = pk->logN; h.c_z = pk->c_z; h.c_h = pk->c_h; h.full = (flags & ZKHIP_PK_IMAGE_FULL) ? 1 : 0;
         h.rank = pk->rank; h.world = pk->world;
         h.z_lo = pk->z_lo; h.z_n = pk->z_n; h.h_lo = pk->h_lo; h.h_n = pk->h_n;
         h.len_delta = pk->delta_g1_canon.size(); h.len_g2z2 = pk->g_gamma2_z2_canon.size();
-        for (int k = 0; k < 5; ++k) h.len_buf[k] = pk_bufs(pk, k)->cap;
+        for (int k = 0; k < 5; ++k) h.len_buf[k] = pk_image_part(pk->curve, k, pk->z_n, pk->h_n, pk->c_z, pk->c_h, h.full);
         uint8_t* p = out;
         memcpy(p, &h, sizeof(h)); p += sizeof(h);
         memcpy(p, pk->delta_g1_canon.data(), h.len_delta); p += h.len_delta;
         memcpy(p, pk->g_gamma2_z2_canon.data(), h.len_g2z2); p += h.len_g2z2;
         for (int k = 0; k < 5; ++k) {
-            dev_d2h(p, pk_bufs(pk, k)->p, h.len_buf[k], ctx->stream);
+            dev_d2h(p, pk_bufs(pk, k)->p, h.len_buf[k], ctx->stream);     // level 0 leads every table
             p += h.len_buf[k];
         }
         stream_sync(ctx->stream);
     });
 }
+int32_t zkhip_pk_export(const zkhip_pk* pk, uint8_t* out, uint64_t cap) { return zkhip_pk_export_ex(pk, 0, out, cap); }
 int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk** out) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
@@ -437,7 +469,7 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         PkImageHeader h;
         memcpy(&h, bytes, sizeof(h));
         require(!memcmp(h.magic, PK_IMAGE_MAGIC, 8), ZKHIP_ERR_PARSE, "not a key image of this library version (re-import the proving key)");
-        const uint64_t g1b = ops_for(h.curve)->unsat_g1_bytes;   // (validates the curve id)
+        const CurveOps* ops = ops_for(h.curve);   // (validates the curve id)
         require(h.scheme == 0 || h.scheme == 1, ZKHIP_ERR_PARSE, "key image: unknown scheme");
         uint64_t total = sizeof(PkImageHeader), rest = len - sizeof(PkImageHeader);
         const uint64_t parts[7] = {h.len_delta, h.len_g2z2, h.len_buf[0], h.len_buf[1], h.len_buf[2], h.len_buf[3], h.len_buf[4]};
@@ -447,16 +479,15 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
             total += part;
         }
         require(total == len, ZKHIP_ERR_PARSE, "trailing bytes after key image");
-        require(h.world >= 1 && h.rank < h.world && h.logN >= 0 && h.logN <= 22 && h.N == ((uint64_t)1 << h.logN) && h.z_n <= h.m + 2 && h.h_n <= h.N &&
-                    h.c_z >= 2 && h.c_z <= 16 && h.c_h >= 2 && h.c_h <= 16,
+        require(h.world >= 1 && h.rank < h.world && h.logN >= 0 && h.logN <= 2 * NTT_MAX_SUBLOG && h.N == ((uint64_t)1 << h.logN) && h.z_n <= h.m + 2 &&
+                    h.h_n <= h.N && h.c_z >= 2 && h.c_z <= MSM_MAX_C && h.c_h >= 2 && h.c_h <= MSM_MAX_C && (h.full == 0 || h.full == 1),
                 ZKHIP_ERR_PARSE, "key image: inconsistent header");
         // the index ranges must lie inside the key and the five base arrays must have exactly the size the ranges imply:
         // the kernels trust these numbers
-        const uint64_t zb = std::max<uint64_t>(h.z_n, 1) * g1b, hb = std::max<uint64_t>(h.h_n, 1) * g1b;
-        require(h.m + 2 < ((uint64_t)1 << 31) && h.z_lo <= h.m + 2 && h.z_n <= h.m + 2 - h.z_lo && h.h_lo <= h.N && h.h_n <= h.N - h.h_lo &&
-                    h.len_buf[0] == zb && h.len_buf[1] == zb && h.len_buf[2] == zb && h.len_buf[3] == 2 * zb && h.len_buf[4] == hb &&
-                    h.len_delta <= 4096 && h.len_g2z2 <= 4096,
-                ZKHIP_ERR_PARSE, "key image: array sizes do not match the header");
+        bool sizes_ok = h.m + 2 < ((uint64_t)1 << 31) && h.z_lo <= h.m + 2 && h.z_n <= h.m + 2 - h.z_lo && h.h_lo <= h.N && h.h_n <= h.N - h.h_lo &&
+                        h.len_delta <= 4096 && h.len_g2z2 <= 4096;
+        for (int k = 0; k < 5 && sizes_ok; ++k) sizes_ok = h.len_buf[k] == pk_image_part(h.curve, k, h.z_n, h.h_n, h.c_z, h.c_h, h.full);
+        require(sizes_ok, ZKHIP_ERR_PARSE, "key image: array sizes do not match the header");
         std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
         pk->curve = h.curve; pk->scheme = h.scheme; pk->ctx = ctx;
         pk->m = h.m; pk->w = h.w; pk->l = h.l; pk->hlen = h.hlen; pk->N = h.N; pk->logN = h.logN;
@@ -467,12 +498,12 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         pk->g_gamma2_z2_canon.assign(p, p + h.len_g2z2); p += h.len_g2z2;
         for (int k = 0; k < 5; ++k) {
             DBuf* b = pk_bufs(pk.get(), k);
-            b->ensure(std::max<uint64_t>(h.len_buf[k], 1));
-            if (h.len_buf[k]) dev_h2d(b->p, p, h.len_buf[k], ctx->stream);
-            b->cap = h.len_buf[k] ? h.len_buf[k] : b->cap;
+            b->ensure(pk_image_part(h.curve, k, h.z_n, h.h_n, h.c_z, h.c_h, true));
+            dev_h2d(b->p, p, h.len_buf[k], ctx->stream);
             p += h.len_buf[k];
         }
         stream_sync(ctx->stream);
+        if (!h.full) ops->pk_table_levels(ctx, pk.get());       // recompute the window multiples behind level 0
         *out = pk.release();
     });
 }
