@@ -64,7 +64,8 @@ typedef struct zkhip_timings {
     float total_ms;     /* wall clock of the whole call                              */
     float kernel_msm_accum_g1_ms; /* sum of G1 bucket-accumulation kernel time       */
     float kernel_msm_accum_g2_ms; /* G2 bucket-accumulation kernel time              */
-    float reserved[7];
+    float kernel_ntt_ms;          /* the transform passes + quotient kernel, first launch to last (events) */
+    float reserved[6];
 } zkhip_timings;
 
 /* ---- context ---- */
@@ -81,7 +82,8 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
  * later key loads and of later ad-hoc MSMs (0 = automatic); _MSM_WAVES: accumulation waves per SIMD (0 = per point
  * type); _MSM_LANES: number of slices the sorted list is cut into (0 = one per resident work-item); _MSM_MIN_SLICE: the
  * finest cut; _FOLD_SCAN: 0 selects the double-and-add form of the last fold step; _SERIAL: 1 puts every kernel on one
- * stream (un-overlapped per-kernel timing); _NTT_SINGLE_MAX_LOG: largest domain transformed in a single pass. */
+ * stream (un-overlapped per-kernel timing); _NTT_SINGLE_MAX_LOG: largest domain transformed in a single pass;
+ * _NTT_COLS: adjacent columns per workgroup of the NTT cols pass; _SLOTS: proofs in flight in the batch calls (1..4). */
 #define ZKHIP_TUNE_MSM_C 1
 #define ZKHIP_TUNE_MSM_WAVES 2
 #define ZKHIP_TUNE_MSM_LANES 3
@@ -89,6 +91,8 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_FOLD_SCAN 5
 #define ZKHIP_TUNE_SERIAL 6
 #define ZKHIP_TUNE_NTT_SINGLE_MAX_LOG 7
+#define ZKHIP_TUNE_NTT_COLS 8
+#define ZKHIP_TUNE_SLOTS 9
 int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value);
 
 /* ---- proving key ----

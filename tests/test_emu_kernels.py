@@ -48,7 +48,7 @@ def test_ntt(ctx, curve, single_max):
     c2.tune("ntt_single_max_log", single_max)
     rnd = random.Random(6)
     try:
-        for logn in ((0, 1, 2, 5) if single_max == 10 else (2, 3, 5, 6)):
+        for logn in ((0, 1, 2, 5, 7, 10) if single_max == 10 else (2, 3, 5, 6, 7, 9)):     # even / odd sub-lengths, N1 != N2
             a = le([rnd.randrange(curve.r) for _ in range(1 << logn)])
             for d in ("fft", "ifft", "coset_fft", "coset_ifft"):
                 assert c2.ntt(curve.curve_id, a, d).tobytes() == cpu.ntt(curve.curve_id, a, d).tobytes(), (logn, d)

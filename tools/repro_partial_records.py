@@ -1,13 +1,14 @@
 """Reproduces the round-1 GPUTEST failure: two zkhip_prove_gm17_partial calls on the SAME shard, n = 300.
 Raw XYZZ records differ between calls on a real GPU (within-bucket order is decided by atomics); canonical records do not.
-    ZKHIP_LIBRARY=<libzkhip.so to test> python tools/repro_partial_records.py
+    [ZKHIP_PKG=zokrates_amd_v1] python tools/repro_partial_records.py      (zokrates_amd_v1 = the round-1 package + library)
 """
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from zokrates_amd import native
+import importlib
+native = importlib.import_module(os.environ.get("ZKHIP_PKG", "zokrates_amd") + ".native")   # ZKHIP_PKG=zokrates_amd_v1: the round-1 build
 from oracle import cpu, gm17
 from oracle.fields import BN254
 from test_gm17 import circuit, csr_of, le

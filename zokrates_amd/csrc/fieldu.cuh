@@ -24,6 +24,9 @@ template <class P> struct UCfg;
 // with 14 limbs an inlined G2 mixed addition is > 100 KB of code, so BLS12-381 keeps it as a call)
 template <> struct UCfg<Bn254Fq> { static constexpr int B = 29, N = 9; static constexpr bool FQ2_INLINE = true; };
 template <> struct UCfg<Bls381Fq> { static constexpr int B = 28, N = 14; static constexpr bool FQ2_INLINE = false; };
+// the scalar fields (NTT passes, kernels_ntt.cuh): both moduli are <= 255 bits
+template <> struct UCfg<Bn254Fr> { static constexpr int B = 29, N = 9; static constexpr bool FQ2_INLINE = false; };
+template <> struct UCfg<Bls381Fr> { static constexpr int B = 29, N = 9; static constexpr bool FQ2_INLINE = false; };
 
 // ---- compile-time constants: p, -p^-1, powers of two mod p and bias multiples of p, all in B-bit limbs ----
 template <class P>

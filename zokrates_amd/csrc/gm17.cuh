@@ -31,41 +31,45 @@ namespace zk {
 //   i < n      : e = (a_i - b_i)^2
 //   i == n     : the constant row
 //   n < i < n+l: public input x = z[i-n], f = (x-1)^2
-// sa/sc: Montgomery, natural order (the tail [2n+2l-1, D) is zeroed by the caller); ext: canonical integers
-template <class F>
-__global__ void k_sap_rows(const F* __restrict__ ra, const F* __restrict__ rb, const F* __restrict__ rc, const F* __restrict__ z,
-                           F* __restrict__ sa, F* __restrict__ sc, F* __restrict__ ext, u64 n, u64 l, u64 m) {
+// ra/rb/rc/z and sa/sc: R'-form (kernels_ntt.cuh), natural order (the tail [2n+2l-1, D) is zeroed by the caller);
+// ext: canonical integers
+template <class P>
+__global__ void k_sap_rows(const Fe<P>* __restrict__ ra, const Fe<P>* __restrict__ rb, const Fe<P>* __restrict__ rc, const Fe<P>* __restrict__ z,
+                           Fe<P>* __restrict__ sa, Fe<P>* __restrict__ sc, Fe<P>* __restrict__ ext, u64 n, u64 l, u64 m) {
+    typedef Fe<P> F;
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + l) return;
     if (i < n) {
         const F a = ra[i], b = rb[i];
         const F d = fe_sub(a, b);
-        const F e = fe_sqr(d);
+        const F e = rp_sqr(d);
         sa[2 * i] = fe_add(a, b);
         sa[2 * i + 1] = d;
         sc[2 * i] = fe_add(fe_dbl(fe_dbl(rc[i])), e);
         sc[2 * i + 1] = e;
-        ext[m + i] = fe_from_mont(e);
+        ext[m + i] = rp_to_plain(e);
     } else if (i == n) {
-        sa[2 * n] = F::one();
-        sc[2 * n] = F::one();
+        sa[2 * n] = rp_one<P>();
+        sc[2 * n] = rp_one<P>();
     } else {
         const u64 j = i - n;   // 1 <= j < l
-        const F x = z[j];
-        const F d = fe_sub(x, F::one());
-        const F f = fe_sqr(d);
-        sa[2 * n + 2 * j - 1] = fe_add(x, F::one());
+        const F x = z[j], one = rp_one<P>();
+        const F d = fe_sub(x, one);
+        const F f = rp_sqr(d);
+        sa[2 * n + 2 * j - 1] = fe_add(x, one);
         sa[2 * n + 2 * j] = d;
         sc[2 * n + 2 * j - 1] = fe_add(fe_dbl(fe_dbl(x)), f);
         sc[2 * n + 2 * j] = f;
-        ext[m + n - 1 + j] = fe_from_mont(f);
+        ext[m + n - 1 + j] = rp_to_plain(f);
     }
 }
-// quotient evaluations on the coset: out = (a^2 - c) * zinv
-template <class F>
-__global__ void k_sap_quotient(const F* __restrict__ a, const F* __restrict__ c, F zinv, F* __restrict__ out, u64 n) {
+// quotient evaluations on the coset: out = (a^2 - c) * zinv     (R'-form operands < 2^256, canonical R'-form out)
+template <class P>
+__global__ void k_sap_quotient(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ c, Fe<P> zinv, Fe<P>* __restrict__ out, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = fe_mul(fe_sub(fe_sqr(a[i]), c[i]), zinv);
+    if (i >= n) return;
+    const Fu<P> aa = fu_sqr_inl(fu_unpack<P>(a[i].v));
+    out[i] = rp_canon(fu_mul_inl(fe_sub_k<8>(aa, fu_unpack<P>(c[i].v)), fu_unpack<P>(zinv.v)));
 }
 // setup: the per-variable key scalars (canonical) from u_i(t) = a[i], w_i(t) = c[i]
 //   aq = gamma a;  c1 = gamma^2 c + (alpha+beta) gamma a;  c2 = 2 gamma^2 Z a;  vq = gamma c + (alpha+beta) a
@@ -212,13 +216,12 @@ struct Gm17 {
         sl.zmont.ensure(m * 32);
         dev_h2d(d_scalars + M * 32, sl.r, 32, st);
         dev_memset(d_scalars + (M + 1) * 32, 0, 32, st);
-        ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, st, (const Fr*)d_scalars, ptr<Fr>(sl.zmont), m);
+        ZK_LAUNCH((k_mul_const<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, st, (const Fr*)d_scalars, ptr<Fr>(sl.zmont), m, pl->k_to_rp);   // R'-form
         event_record(sl.ev[0], st);
 
         // ---- SAP rows + the extension of the assignment (K1')
-        sl.va.ensure(D * sizeof(Fr));
-        sl.vb.ensure(D * sizeof(Fr));
-        Fr *sa = ptr<Fr>(sl.va), *sc = ptr<Fr>(sl.vb);
+        sl.va.ensure(2 * D * sizeof(Fr));      // the two evaluation vectors back to back: they share every NTT launch
+        Fr *sa = ptr<Fr>(sl.va), *sc = sa + D;
         const u64 D0 = 2 * n + 2 * (l - 1) + 1;
         if (D0 < D) {
             dev_memset(sa + D0, 0, (D - D0) * sizeof(Fr), st);
@@ -227,7 +230,7 @@ struct Gm17 {
         sl.vc.ensure(3 * std::max<u64>(n, 1) * sizeof(Fr));      // the three row-product vectors
         Fr *ra = ptr<Fr>(sl.vc), *rb = ra + n, *rc = rb + n;
         if (n) P::matvec(ctx, cs, ptr<Fr>(sl.zmont), ra, rb, rc, n, 0, n);
-        ZK_LAUNCH((k_sap_rows<Fr>), dim3(blocks_for(n + l, 256)), dim3(256), 0, st, ra, rb, rc, ptr<Fr>(sl.zmont), sa, sc, (Fr*)d_scalars, n, l, m);
+        ZK_LAUNCH((k_sap_rows<typename Fr::Params>), dim3(blocks_for(n + l, 256)), dim3(256), 0, st, ra, rb, rc, ptr<Fr>(sl.zmont), sa, sc, (Fr*)d_scalars, n, l, m);
 
         // ---- the four MSMs over S = [ext_0..ext_{M-1}, rho, 0] share one digit/sort pass
         const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
@@ -249,13 +252,12 @@ struct Gm17 {
         event_record(sl.ev[1], st);
 
         // ---- quotient h0 = (U^2 - W)/Z: 2 iNTT, 2 coset NTT, pointwise, coset iNTT (sigma order, canonical)
-        Fr* v[2] = {sa, sc};
-        for (int k = 0; k < 2; ++k) {
-            ntt_kind_a<C>(ctx, pl, v[k], true, ptr<Fr>(pl->s_coset));
-            ntt_kind_b<C>(ctx, pl, v[k], false, nullptr);
-        }
-        ZK_LAUNCH((k_sap_quotient<Fr>), dim3(blocks_for(D, 256)), dim3(256), 0, st, sa, sc, pl->zinv, sa, D);
-        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_cosetinv_canon));
+        event_record(sl.ntt_b, st);
+        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_coset), 2, D);
+        ntt_kind_b<C>(ctx, pl, sa, false, nullptr, 2, D);
+        ZK_LAUNCH((k_sap_quotient<typename Fr::Params>), dim3(blocks_for(D, 256)), dim3(256), 0, st, sa, sc, pl->zinv_rp, sa, D);
+        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_cosetinv_canon), 1, 0, 1);
+        event_record(sl.ntt_e, st);
         event_record(sl.ev[2], st);
 
         // ---- G = MSM(g_gamma2_z_t, h0)
@@ -351,15 +353,16 @@ struct Gm17 {
         memset(&acc, 0, sizeof(acc));
         const auto t0 = std::chrono::steady_clock::now();
         try {
-            for (u32 i = 0; i < count + ZK_NSLOTS - 1; ++i) {
+            const u32 NS = (u32)ctx->nslots;   // proofs in flight
+            for (u32 i = 0; i < count + NS - 1; ++i) {
                 if (i < count) {
                     check_d2(rnd + (size_t)i * 96);
-                    enqueue(ctx, ctx->slots[i % ZK_NSLOTS], pk, cs, z_host ? z_host + (size_t)i * m * 32 : nullptr, z_host ? nullptr : z_dev[i],
+                    enqueue(ctx, ctx->slots[i % NS], pk, cs, z_host ? z_host + (size_t)i * m * 32 : nullptr, z_host ? nullptr : z_dev[i],
                             rnd + (size_t)i * 96, rnd + (size_t)i * 96 + 64);
                 }
-                if (i >= ZK_NSLOTS - 1 && i - (ZK_NSLOTS - 1) < count) {
-                    const u32 j = i - (ZK_NSLOTS - 1);
-                    finish(ctx, ctx->slots[j % ZK_NSLOTS], pk, proofs_out + (size_t)j * proof_bytes, &one);
+                if (i >= NS - 1 && i - (NS - 1) < count) {
+                    const u32 j = i - (NS - 1);
+                    finish(ctx, ctx->slots[j % NS], pk, proofs_out + (size_t)j * proof_bytes, &one);
                     float* a = (float*)&acc; const float* b = (const float*)&one;
                     for (size_t k = 0; k < sizeof(acc) / sizeof(float); ++k) a[k] += b[k];
                 }

@@ -4,18 +4,27 @@
 // reached from /root/reference/zokrates_ark/src/groth16.rs:44.
 //
 // NTT structure (four-step, N = N1*N2, both <= 2^11): a transform is two passes over HBM,
-//   "cols" pass: N2/C workgroups, each stages C adjacent columns x N1 rows in LDS (C*32 B contiguous
-//                per row -> full 128-B lines for C = 4), runs the N1-point sub-NTT there,
-//   "rows" pass: each workgroup stages R contiguous rows of N2 elements and runs the N2-point sub-NTT.
+//   "cols" pass: each workgroup stages C adjacent columns x N1 rows in LDS and runs the N1-point sub-NTTs there,
+//   "rows" pass: each workgroup stages R contiguous rows of N2 elements and runs the N2-point sub-NTTs.
 // Every element-wise factor (inter-pass twiddle w^(a*b), 1/N, coset powers g^i, the Montgomery exit)
-// is a table multiply fused into a pass's load ("pre") or store ("post"), so a transform touches each
-// element exactly twice.  Natural-order input gives the digit-swapped "sigma" order
+// is a table multiply fused into a pass's store ("post"), so a transform touches each element exactly twice.
+// Natural-order input gives the digit-swapped "sigma" order
 //   position p = k1*N2 + k2  holds  X[k1 + N1*k2]
 // and sigma-order input gives natural-order output; the prover alternates the two kinds and never
 // permutes (h_query is permuted once at key load instead).
+//
+// Arithmetic: the passes compute in the UNSATURATED 9 x 29-bit representation of fieldu.cuh (lazy Comba Montgomery
+// product with R' = 2^261: 1.9x the multiplier throughput of saturated 8 x 32-bit CIOS; both Fr moduli are <= 255 bits).
+// The NTT vectors therefore hold x * R' mod p ("R'-form"), packed into the same 32 bytes per element (fu_pack); a value
+// is unpacked when a pass loads it, lives as 9 limb planes in LDS, and is packed again when the pass stores it.
+// Sub-NTTs are radix-4 decimation-in-frequency butterflies in registers (two radix-2 stages per LDS round trip and
+// barrier; a last radix-2 stage when log2 n is odd): 4 field multiplications per butterfly, none in the last round.
+// Kernels that touch R'-form data outside the passes (mat-vec output, quotient, GM17 rows) use the rp_* helpers below.
 #pragma once
+#include <vector>
+
 #include "devrt.h"
-#include "field.cuh"
+#include "fieldu.cuh"
 
 namespace zk {
 
@@ -29,6 +38,42 @@ template <class F>
 __global__ void k_from_mont(const F* __restrict__ in, F* __restrict__ out, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fe_from_mont(in[i]);
+}
+// ---- R'-form helpers: canonical packed integers of x * R' mod p, held in Fe words (add / sub / dbl are the plain
+// modular ones of field.cuh; only products need the R' Montgomery product) ----
+template <class P>
+ZK_HD Fe<P> rp_canon(const Fu<P>& r) {   // TIGHT, value < 2p -> canonical packed words
+    Fe<P> o;
+    fu_pack(r, o.v);
+    fe_reduce_once(o);
+    return o;
+}
+template <class P> ZK_HD Fe<P> rp_mul(const Fe<P>& a, const Fe<P>& b) { return rp_canon(fu_mul_inl(fu_unpack<P>(a.v), fu_unpack<P>(b.v))); }
+template <class P> ZK_HD Fe<P> rp_sqr(const Fe<P>& a) { const Fu<P> u = fu_unpack<P>(a.v); return rp_canon(fu_sqr_inl(u)); }
+template <class P> ZK_HD Fe<P> rp_one() { return rp_canon(Fu<P>::one()); }
+template <class P>
+ZK_HD Fe<P> rp_to_plain(const Fe<P>& a) {   // x * R' -> x (canonical integer)
+    Fu<P> unit = Fu<P>::zero();
+    unit.v[0] = 1;
+    return rp_canon(fu_mul_inl(fu_unpack<P>(a.v), unit));
+}
+// out[i] = in[i] * k / R   (k = R' * R mod p turns a canonical integer into R'-form; k = R' mod p turns the saturated
+// Montgomery form into R'-form)
+template <class F>
+__global__ void k_mul_const(const F* __restrict__ in, F* __restrict__ out, u64 n, F k) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fe_mul(in[i], k);
+}
+template <class F>
+__global__ void k_from_rp(const F* __restrict__ in, F* __restrict__ out, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rp_to_plain(in[i]);
+}
+// packed words -> the 9-limb working form (root tables of the sub-NTTs)
+template <class P>
+__global__ void k_unpack_table(const Fe<P>* __restrict__ in, Fu<P>* __restrict__ out, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fu_unpack<P>(in[i].v);
 }
 // op: 0 add, 1 sub, 2 mul — operands and result in Montgomery form
 template <class F>
@@ -65,12 +110,16 @@ __global__ void k_sigma_permute(const F* __restrict__ in, F* __restrict__ out, u
     if (dir == 0) out[p] = in[nat];
     else out[nat] = in[p];
 }
-// quotient evaluations: out = (a*b - c) * zinv        (App. A.3: division by the constant Z(g) on the coset)
-template <class F>
-__global__ void k_quotient(const F* __restrict__ a, const F* __restrict__ b, const F* __restrict__ c, F zinv, F* __restrict__ out,
+// quotient evaluations: out = (a*b - c) * zinv        (App. A.3: division by the constant Z(g) on the coset); R'-form
+// operands (any packed value < 2^256), zinv in R'-form, canonical R'-form out
+template <class P>
+__global__ void k_quotient(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ b, const Fe<P>* __restrict__ c, Fe<P> zinv, Fe<P>* __restrict__ out,
                            u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = fe_mul(fe_sub(fe_mul(a[i], b[i]), c[i]), zinv);
+    if (i >= n) return;
+    const Fu<P> ab = fu_mul_inl(fu_unpack<P>(a[i].v), fu_unpack<P>(b[i].v));          // < 2p
+    const Fu<P> d = fe_sub_k<8>(ab, fu_unpack<P>(c[i].v));                              // c < 2^256 < 8p
+    out[i] = rp_canon(fu_mul_inl(d, fu_unpack<P>(zinv.v)));
 }
 
 // ---------------- K1: sparse mat-vec ----------------
@@ -127,100 +176,191 @@ static inline int matvec_group(u64 nnz, u64 n) {
 }
 
 // ---------------- LDS-resident sub-NTT ----------------
-// Elements live in two uint4 planes (limbs 0-3 / 4-7) so that consecutive lanes touch consecutive
-// 16-B slots (conflict-free ds_read_b128/ds_write_b128); sequences are padded by one slot.
-template <class F>
-__device__ __forceinline__ F lds_get(const uint4* lo, const uint4* hi, int idx) {
-    static_assert(F::N == 8, "Fr is 8 x 32-bit limbs");
-    uint4 a = lo[idx], b = hi[idx];
-    F r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+// An element is nine 29-bit limbs; limb l of slot s lives at lds[l * PL + s] (nine planes), so consecutive work-items
+// touch consecutive 4-byte words of a plane.  Slots are padded by one per 32 elements (the radix-4 butterflies of the
+// late rounds stride by 4, 16, 64 elements) and every sequence starts SS slots after the previous one.
+static __device__ __forceinline__ int ntt_slot(int e) { return e + (e >> 5); }
+static inline int ntt_seq_stride(int n) { return n + (n >> 5) + 1; }
+template <class P>
+__device__ __forceinline__ Fu<P> lds_get_u(const u32* lds, int PL, int slot) {
+    Fu<P> r;
+    ZK_UNROLL for (int l = 0; l < Fu<P>::N; ++l) r.v[l] = lds[l * PL + slot];
     return r;
 }
-template <class F>
-__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, int idx, const F& r) {
-    lo[idx] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    hi[idx] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+template <class P>
+__device__ __forceinline__ void lds_put_u(u32* lds, int PL, int slot, const Fu<P>& x) {
+    ZK_UNROLL for (int l = 0; l < Fu<P>::N; ++l) lds[l * PL + slot] = x.v[l];
 }
 
-// In-place radix-2 DIF over `nseq` sequences of n = 2^logn points (stride n+1 slots); result is left in
-// bit-reversed index order.  roots[j * rstride] = w_n^j for j < n/2.
-template <class F>
-__device__ __forceinline__ void lds_ntt_dif(uint4* lo, uint4* hi, int logn, int nseq, const F* __restrict__ roots, int rstride) {
+// Twiddle plan of an n-point sub-NTT: the factors in exactly the order the butterflies consume them, limb-major
+// (limb l of entry i at plan[l * plen + i]), so that a wavefront's 64 work-items read 64 consecutive words per limb.
+// Entries: for every radix-4 round with sub-length L > 4 (L = n, n/4, ...), q = L/4 values of w_L^pos, then q of w_L^(2 pos),
+// then q of w_L^(3 pos); the last entry is w_4 = w_n^(n/4).
+static inline u32 ntt_plan_len(int logn) {
+    u32 len = 1;
+    for (int L = 1 << logn; L > 4; L >>= 2) len += 3 * (u32)(L >> 2);
+    return len;
+}
+// src[i] = exponent e of entry i (the entry is w_n^e); built on the host, gathered from the root table on the device
+static inline void ntt_plan_exponents(int logn, std::vector<u32>& src) {
+    const u32 n = 1u << logn;
+    src.clear();
+    for (u32 L = n; L > 4; L >>= 2) {
+        const u32 q = L >> 2, tws = n / L;
+        for (u32 k = 1; k <= 3; ++k)
+            for (u32 pos = 0; pos < q; ++pos) src.push_back(k * pos * tws);
+    }
+    src.push_back(n >> 2);
+}
+template <class P>
+__global__ void k_ntt_plan_gather(const Fu<P>* __restrict__ roots, int rstride, const u32* __restrict__ src, u32 plen, u32* __restrict__ plan) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plen) return;
+    const Fu<P> w = roots[(size_t)src[i] * rstride];
+    ZK_UNROLL for (int l = 0; l < Fu<P>::N; ++l) plan[(size_t)l * plen + i] = w.v[l];
+}
+template <class P>
+__device__ __forceinline__ Fu<P> ntt_plan_get(const u32* __restrict__ plan, u32 plen, u32 i) {
+    Fu<P> r;
+    ZK_UNROLL for (int l = 0; l < Fu<P>::N; ++l) r.v[l] = plan[(size_t)l * plen + i];
+    return r;
+}
+
+// In-place DIF over `nseq` sequences of n = 2^logn points; the result is left in bit-reversed index order.
+// Radix-4 butterflies = two radix-2 stages each:
+//   (a, b, c, d) at i, i+q, i+2q, i+3q (q = L/4)  ->  a+b+c+d | (a-b+c-d) w^2pos | (a-c + w4(b-d)) w^pos | (a-c - w4(b-d)) w^3pos
+// Value bounds (fieldu.cuh): inputs < 2p; sums/differences < 12p; products < 2p; the untwiddled output is brought back
+// below 2p by fe_relax.  The last round of an even-length transform has trivial twiddles and leaves values < 12p, which
+// the store path of the passes accepts.
+template <class P>
+__device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn, int nseq, const u32* __restrict__ plan, u32 plen) {
+    typedef Fu<P> U;
     const int n = 1 << logn;
-    const int halfn = n >> 1;
-    const int total = nseq * halfn;
-    const int nthreads = blockDim.x;
-    for (int s = 0; s < logn; ++s) {
-        const int half = halfn >> s;
-        for (int b = threadIdx.x; b < total; b += nthreads) {
-            const int seq = b / halfn, bb = b - seq * halfn;
-            const int grp = bb / half, pos = bb - grp * half;
-            const int i0 = seq * (n + 1) + grp * 2 * half + pos;
-            const int i1 = i0 + half;
-            F u = lds_get<F>(lo, hi, i0), v = lds_get<F>(lo, hi, i1);
-            F d = fe_sub(u, v);
-            if (pos) d = fe_mul(d, roots[(size_t)(pos << s) * rstride]);
-            lds_put(lo, hi, i0, fe_add(u, v));
-            lds_put(lo, hi, i1, d);
+    const int T = blockDim.x;
+    if (logn >= 2) {
+        const int per_seq = n >> 2, nbf = nseq * per_seq;
+        u32 off = 0;
+        for (int L = n; L >= 4; L >>= 2) {
+            const int q = L >> 2;
+            for (int b = threadIdx.x; b < nbf; b += T) {
+                const int seq = b / per_seq, bb = b - seq * per_seq;
+                const int grp = bb / q, pos = bb - grp * q;
+                const int base = seq * SS, i0 = grp * L + pos;
+                const int s0 = base + ntt_slot(i0), s1 = base + ntt_slot(i0 + q), s2 = base + ntt_slot(i0 + 2 * q), s3 = base + ntt_slot(i0 + 3 * q);
+                // ordered to keep few values alive: (b, d) first, each output stored as soon as it exists
+                U t2, t3;
+                {
+                    const U bq = lds_get_u<P>(lds, PL, s1), d = lds_get_u<P>(lds, PL, s3);
+                    t2 = fe_add(bq, d);
+                    t3 = fu_mul_inl(fe_sub_k<4>(bq, d), ntt_plan_get<P>(plan, plen, plen - 1));   // * w4
+                }
+                U t0, t1;
+                {
+                    const U a = lds_get_u<P>(lds, PL, s0), c = lds_get_u<P>(lds, PL, s2);
+                    t0 = fe_add(a, c);
+                    t1 = fe_sub_k<4>(a, c);
+                }
+                lds_put_u<P>(lds, PL, s0, fe_relax(fe_add(t0, t2)));
+                if (L > 4) {
+                    lds_put_u<P>(lds, PL, s1, fu_mul_inl(fe_sub_k<8>(t0, t2), ntt_plan_get<P>(plan, plen, off + q + pos)));
+                    lds_put_u<P>(lds, PL, s2, fu_mul_inl(fe_add(t1, t3), ntt_plan_get<P>(plan, plen, off + pos)));
+                    lds_put_u<P>(lds, PL, s3, fu_mul_inl(fe_sub_k<4>(t1, t3), ntt_plan_get<P>(plan, plen, off + 2 * q + pos)));
+                } else {
+                    lds_put_u<P>(lds, PL, s1, fe_sub_k<8>(t0, t2));
+                    lds_put_u<P>(lds, PL, s2, fe_add(t1, t3));
+                    lds_put_u<P>(lds, PL, s3, fe_sub_k<4>(t1, t3));
+                }
+            }
+            off += 3 * (u32)q;
+            __syncthreads();
+        }
+    }
+    if (logn & 1) {   // the last radix-2 stage (pairs of neighbours, no twiddle)
+        const int per_seq = n >> 1, nb2 = nseq * per_seq;
+        for (int b = threadIdx.x; b < nb2; b += T) {
+            const int seq = b / per_seq, k = b - seq * per_seq;
+            const int s0 = seq * SS + ntt_slot(2 * k), s1 = seq * SS + ntt_slot(2 * k + 1);
+            const U u = lds_get_u<P>(lds, PL, s0), v = lds_get_u<P>(lds, PL, s1);
+            lds_put_u<P>(lds, PL, s0, fe_add(u, v));
+            lds_put_u<P>(lds, PL, s1, fe_sub_k<4>(u, v));
         }
         __syncthreads();
     }
 }
 static __device__ __forceinline__ int bitrev_n(int x, int logn) { return logn ? (int)(__brev((unsigned)x) >> (32 - logn)) : 0; }
 
-// "cols" pass: the matrix is n1 x n2 row-major; this workgroup owns columns [c0, c0 + C).
-template <class F>
-__global__ void k_ntt_cols(F* __restrict__ data, int log_n1, u32 n2, int C, const F* __restrict__ roots, int rstride,
-                           const F* __restrict__ pre, const F* __restrict__ post) {
+// one element between HBM (32 packed bytes, R'-form, any value < 2^256) and the working form
+template <class P>
+__device__ __forceinline__ Fu<P> ntt_load(const uint4* __restrict__ data, size_t g) {
+    const uint4 lo = data[2 * g], hi = data[2 * g + 1];
+    const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return fe_relax(fu_unpack<P>(w));
+}
+// x: TIGHT, value < 32p.  With a post factor the product is < 2p; without one fe_relax leaves < 2p; `canon` adds the
+// final conditional subtraction (the Montgomery exit of the last transform must leave canonical integers: MSM digits).
+template <class P>
+__device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu<P> x, const uint4* __restrict__ post, int canon) {
+    if (post) {
+        const uint4 lo = post[2 * g], hi = post[2 * g + 1];
+        const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        x = fu_mul_inl(x, fu_unpack<P>(w));
+    } else {
+        x = fe_relax(x);
+    }
+    Fe<P> o;
+    fu_pack(x, o.v);
+    if (canon) fe_reduce_once(o);
+    data[2 * g] = make_uint4(o.v[0], o.v[1], o.v[2], o.v[3]);
+    data[2 * g + 1] = make_uint4(o.v[4], o.v[5], o.v[6], o.v[7]);
+}
+
+// "cols" pass: the matrix is n1 x n2 row-major; this workgroup owns columns [c0, c0 + C).  grid.y = vectors
+// (consecutive vectors are vec_stride elements apart).
+template <class P>
+__global__ void __launch_bounds__(512, 4) k_ntt_cols(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n1, u32 n2, int C, const u32* __restrict__ plan,
+                                                     u32 plen, const Fe<P>* __restrict__ post_, int canon) {
     ZK_DYN_SMEM(smem);
+    static_assert(P::N == 8, "Fr is 8 x 32-bit words");
+    u32* lds = (u32*)smem;
+    uint4* data = (uint4*)(data_ + (size_t)blockIdx.y * vec_stride);
+    const uint4* post = (const uint4*)post_;
     const int n1 = 1 << log_n1;
-    uint4* lo = (uint4*)smem;
-    uint4* hi = lo + (size_t)C * (n1 + 1);
+    const int SS = n1 + (n1 >> 5) + 1, PL = C * SS;
     const u32 c0 = blockIdx.x * C;
     const int total = C * n1;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int a = e / C, j = e - a * C;
-        const size_t g = (size_t)a * n2 + c0 + j;
-        F x = data[g];
-        if (pre) x = fe_mul(x, pre[g]);
-        lds_put(lo, hi, j * (n1 + 1) + a, x);
+        lds_put_u<P>(lds, PL, j * SS + ntt_slot(a), ntt_load<P>(data, (size_t)a * n2 + c0 + j));
     }
     __syncthreads();
-    lds_ntt_dif<F>(lo, hi, log_n1, C, roots, rstride);
+    lds_ntt_dif4<P>(lds, PL, SS, log_n1, C, plan, plen);
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int k = e / C, j = e - k * C;
-        const size_t g = (size_t)k * n2 + c0 + j;
-        F x = lds_get<F>(lo, hi, j * (n1 + 1) + bitrev_n(k, log_n1));
-        if (post) x = fe_mul(x, post[g]);
-        data[g] = x;
+        ntt_store<P>(data, (size_t)k * n2 + c0 + j, lds_get_u<P>(lds, PL, j * SS + ntt_slot(bitrev_n(k, log_n1))), post, canon);
     }
 }
 
 // "rows" pass: this workgroup owns rows [r0, r0 + R) of n2 contiguous elements each.
-template <class F>
-__global__ void k_ntt_rows(F* __restrict__ data, int log_n2, int R, const F* __restrict__ roots, int rstride,
-                           const F* __restrict__ pre, const F* __restrict__ post) {
+template <class P>
+__global__ void __launch_bounds__(512, 4) k_ntt_rows(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n2, int R, const u32* __restrict__ plan, u32 plen,
+                                                     const Fe<P>* __restrict__ post_, int canon) {
     ZK_DYN_SMEM(smem);
+    u32* lds = (u32*)smem;
+    uint4* data = (uint4*)(data_ + (size_t)blockIdx.y * vec_stride);
+    const uint4* post = (const uint4*)post_;
     const int n2 = 1 << log_n2;
-    uint4* lo = (uint4*)smem;
-    uint4* hi = lo + (size_t)R * (n2 + 1);
+    const int SS = n2 + (n2 >> 5) + 1, PL = R * SS;
     const size_t base = (size_t)blockIdx.x * R * n2;
     const int total = R * n2;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int r = e >> log_n2, i = e & (n2 - 1);
-        F x = data[base + e];
-        if (pre) x = fe_mul(x, pre[base + e]);
-        lds_put(lo, hi, r * (n2 + 1) + i, x);
+        lds_put_u<P>(lds, PL, r * SS + ntt_slot(i), ntt_load<P>(data, base + e));
     }
     __syncthreads();
-    lds_ntt_dif<F>(lo, hi, log_n2, R, roots, rstride);
+    lds_ntt_dif4<P>(lds, PL, SS, log_n2, R, plan, plen);
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int r = e >> log_n2, k = e & (n2 - 1);
-        F x = lds_get<F>(lo, hi, r * (n2 + 1) + bitrev_n(k, log_n2));
-        if (post) x = fe_mul(x, post[base + e]);
-        data[base + e] = x;
+        ntt_store<P>(data, base + e, lds_get_u<P>(lds, PL, r * SS + ntt_slot(bitrev_n(k, log_n2))), post, canon);
     }
 }
 

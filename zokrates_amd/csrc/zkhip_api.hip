@@ -81,6 +81,8 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->msm_c_env = env_int("ZKHIP_MSM_C", 2, MSM_MAX_C, 0);
         ctx->msm_waves = env_int("ZKHIP_MSM_WAVES", 1, 8, 0);
         ctx->ntt_single_max = env_int("ZKHIP_NTT_SINGLE_MAX_LOG", 0, NTT_MAX_SUBLOG, 10);
+        ctx->ntt_cols = env_int("ZKHIP_NTT_COLS", 1, 8, 2);
+        ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
         Stream lane_streams[ZK_NLANES];
         for (auto& st : lane_streams) st = stream_create();
         for (auto& sl : ctx->slots) {
@@ -92,6 +94,8 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
                 sl.acc_e[k] = event_create();
             }
             for (auto& e : sl.ev) e = event_create();
+            sl.ntt_b = event_create();
+            sl.ntt_e = event_create();
         }
 #ifdef ZK_EMU
         ctx->desc = "zkhip TEST EMULATOR (not a product build)";
@@ -122,6 +126,8 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
             event_destroy(sl.acc_e[k]);
         }
         for (auto& e : sl.ev) event_destroy(e);
+        event_destroy(sl.ntt_b);
+        event_destroy(sl.ntt_e);
         host_free_pinned(sl.h_ws);
     }
     for (int k = 0; k < ZK_NLANES; ++k) stream_destroy(ctx->slots[0].lanes[k].stream);
@@ -141,6 +147,8 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_FOLD_SCAN: in(0, 1); ctx->fold_scan = value != 0; break;
             case ZKHIP_TUNE_SERIAL: in(0, 1); dev_sync_all(); ctx->serial = value != 0; break;
             case ZKHIP_TUNE_NTT_SINGLE_MAX_LOG: in(0, NTT_MAX_SUBLOG); dev_sync_all(); ctx->ntt_single_max = value; ctx->plans.clear(); break;
+            case ZKHIP_TUNE_SLOTS: in(1, ZK_NSLOTS); dev_sync_all(); ctx->nslots = value; break;
+            case ZKHIP_TUNE_NTT_COLS: in(1, 8); dev_sync_all(); ctx->ntt_cols = value; ctx->plans.clear(); break;
             default: throw ApiError{ZKHIP_ERR_BAD_ARG, "unknown tunable"};
         }
     });

@@ -28,7 +28,7 @@ class ZkhipError(RuntimeError):
 class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "h2d_ms", "matvec_ms", "ntt_ms", "msm_h_ms", "msm_z_ms", "finish_ms", "total_ms",
-        "kernel_msm_accum_g1_ms", "kernel_msm_accum_g2_ms")] + [("reserved", C.c_float * 7)]
+        "kernel_msm_accum_g1_ms", "kernel_msm_accum_g2_ms", "kernel_ntt_ms")] + [("reserved", C.c_float * 6)]
 
     def as_dict(self):
         return {n: float(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
@@ -154,7 +154,7 @@ class Context:
         self._check(self.lib.L.zkhip_describe(self.h, buf, 256))
         return buf.value.decode()
 
-    TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7}
+    TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7, "ntt_cols": 8, "slots": 9}
 
     def tune(self, name, value):
         """`zkhip_ctx_tune`: development / measurement knobs (window width, slices, fold form, serial streams ...)."""
