@@ -236,6 +236,34 @@ int32_t zkhip_setup_gm17_size(const zkhip_r1cs* r1cs, uint64_t* pk_bytes);
 int32_t zkhip_setup_gm17(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, const uint8_t* toxic, const uint8_t* g1,
                          const uint8_t* g2, uint8_t* pk_out, uint64_t pk_cap);
 
+/* ---- one proof across several GPUs of ONE process (§8b "multi-GPU handled inside one context") ----
+ * A caller behind the reference's trait (`Backend::generate_proof`, /root/reference/zokrates_proof_systems/src/lib.rs:98-112,
+ * call site /root/reference/zokrates_cli/src/ops/generate_proof.rs:187) is a single process without a collective
+ * library; zkhip_multi gives it the latency mode of the sharded entry points above without one.  It owns one context
+ * per listed device (a device may be listed more than once: the members then share it, which is how the path is tested
+ * on a one-GPU box), member k holds shard k of n of the proving key (1/n of every base table) and a replica of the
+ * constraint system.  zkhip_prove_*_multi runs the members' shares on one host thread each — assignment upload,
+ * replicated mat-vec / NTT stage, the five MSMs over the member's index ranges — collects the n canonical partial
+ * records (zkhip_partial_size bytes each, produced in host memory: nothing larger ever has to cross between devices)
+ * and assembles the proof on the calling thread.  The result is bit-identical to the single-GPU proof.
+ * zkhip_multi_ctx lends a member's context (e.g. to run zkhip_setup_g16 on member 0); errors of the zkhip_multi_* /
+ * zkhip_prove_*_multi calls are reported by zkhip_multi_last_error. */
+typedef struct zkhip_multi zkhip_multi;
+int32_t zkhip_ctx_create_multi(const int32_t* devices, int32_t n, zkhip_multi** out);
+void zkhip_multi_free(zkhip_multi* m);
+int32_t zkhip_multi_size(const zkhip_multi* m);
+zkhip_ctx* zkhip_multi_ctx(zkhip_multi* m, int32_t member);
+const char* zkhip_multi_last_error(const zkhip_multi* m);
+int32_t zkhip_multi_r1cs_load(zkhip_multi* m, int32_t curve, uint64_t n, uint64_t l, uint64_t w, const uint64_t* rowptr_a,
+                              const uint32_t* col_a, const uint8_t* val_a, const uint64_t* rowptr_b, const uint32_t* col_b,
+                              const uint8_t* val_b, const uint64_t* rowptr_c, const uint32_t* col_c, const uint8_t* val_c);
+int32_t zkhip_multi_pk_load_g16(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len);
+int32_t zkhip_multi_pk_load_gm17(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len);
+int32_t zkhip_prove_g16_multi(zkhip_multi* m, const uint8_t* z, const uint8_t* r, const uint8_t* s, uint8_t* proof_out,
+                              zkhip_timings* timings);
+int32_t zkhip_prove_gm17_multi(zkhip_multi* m, const uint8_t* z, const uint8_t* d1_d2_r, uint8_t* proof_out,
+                               zkhip_timings* timings);
+
 /* ---- "next" row N2: proving-key cache ----
  * zkhip_pk_export writes the *resident* form of a loaded key (Groth16 or GM17, whole or one shard): packed Montgomery
  * points, MSM-ready order, the extended base vectors — the bytes the GPU holds, plus a small header.

@@ -66,3 +66,5 @@ def test_two_ranks_real_bench_script(scheme, port):
     assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1000.0)) < 1e-6 * d["value"]          # whole-job aggregate over both ranks
     s = d["sharded_single_proof"]
     assert s.get("identical_to_unsharded") is True and s["ranks"] == 2, s
+    mm = d["multi_single_proof"]                      # the in-library path: rank 0 drives one member per rank's device
+    assert mm.get("identical_to_unsharded") is True and mm["members"] == 2, mm

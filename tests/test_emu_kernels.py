@@ -243,6 +243,18 @@ def test_error_paths(ctx):
     with pytest.raises(native.ZkhipError) as e:
         native.prove_g16(ctx, pk, cs, z, 1, 2)
     assert e.value.code == -1
+    for bad in (BN254.r, (1 << 256) - 1):         # an entry >= r: ark's FromBytes rejects it, and so do all three entry points
+        z = oc.assignment().copy()
+        z[3 * 32:4 * 32] = np.frombuffer(int(bad).to_bytes(32, "little"), dtype=np.uint8)
+        with pytest.raises(native.ZkhipError) as e:
+            native.prove_g16(ctx, pk, cs, z, 1, 2)
+        assert e.value.code == -1 and "canonical" in str(e.value)
+        with pytest.raises(native.ZkhipError) as e:
+            native.Assignment(ctx, cs, z)
+        assert e.value.code == -1
+        with pytest.raises(native.ZkhipError):
+            native.prove_g16_partial(ctx, pk, cs, z, 1, 2)
+    assert native.prove_g16(ctx, pk, cs, oc.assignment(), 1, 2) == cpu.trapdoor(oc, tox, oc.assignment(), 1, 2)   # the context stays usable
     oc2 = cpu.Circuit.synth(0, 9, 1)               # key / circuit mismatch
     cs2 = native.ConstraintSystem(ctx, 0, oc2.n, oc2.l, oc2.w, [oc2.csr(k) for k in range(3)])
     with pytest.raises(native.ZkhipError):

@@ -1,0 +1,122 @@
+"""One proof across several GPUs of ONE process through the C ABI alone (zkhip_ctx_create_multi, zkhip_multi_*,
+zkhip_prove_g16_multi / zkhip_prove_gm17_multi): no Python collective, no torch.  The members may share a device, which
+is how the path runs on a one-GPU box; the result must equal the single-context proof and the oracle's closed form.
+Reference behaviour to match: one `generate_proof` call, one proof (zokrates_cli/src/ops/generate_proof.rs:187)."""
+import numpy as np
+import pytest
+
+from emu_util import emu_library
+from oracle import cpu
+from oracle import groth16 as g16
+from oracle import gm17
+from oracle.fields import BN254, BLS12_381
+from zokrates_amd import native, synth
+
+
+def _checks(lib, devices, curve, log_domain, kind="dense"):
+    cid = curve.curve_id
+    circ = synth.circuit(cid, log_domain, kind=kind, seed=0xD1CE + log_domain)
+    z = circ.assignment(0x5EED + log_domain)
+    oc = cpu.Circuit.from_csr(cid, circ.n, circ.l, circ.w, circ.mats())
+    multi = native.Multi(devices, lib)
+    assert len(multi) == len(devices)
+    try:
+        multi.load_constraint_system(cid, circ.n, circ.l, circ.w, circ.mats())
+        # Groth16
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        raw = cpu.ProvingKey.setup(oc, tox).serialize()
+        multi.load_proving_key(cid, raw)
+        r, s = 0x1234567 % curve.r, 0x7654321 % curve.r
+        got, tm = multi.prove_g16(z, r, s, want_timings=True)
+        assert got == cpu.trapdoor(oc, tox, z, r, s)
+        assert tm["total_ms"] > 0
+        assert multi.prove_g16(z, 0, 0) == cpu.trapdoor(oc, tox, z, 0, 0)
+        # the same proof from one context holding the whole key
+        ctx = multi.member_context(0)
+        cs = native.ConstraintSystem(ctx, cid, circ.n, circ.l, circ.w, circ.mats())
+        assert native.prove_g16(ctx, native.ProvingKey(ctx, cid, raw), cs, z, r, s) == got
+        with pytest.raises(native.ZkhipError):          # a Groth16 key does not prove GM17
+            multi.prove_gm17(z, 1, 2, 3)
+        # GM17 on the same members
+        tox17 = gm17.Toxic.from_seed(curve)
+        tb17 = cpu.gm17_toxic_bytes(tox17)
+        raw17 = cpu.Gm17ProvingKey.setup(oc, tb17).serialize()
+        multi.load_proving_key(cid, raw17, scheme="gm17")
+        d1, d2, r_ = 0xabcdef % curve.r, 77, 0x13579 % curve.r
+        assert multi.prove_gm17(z, d1, d2, r_) == cpu.gm17_trapdoor(oc, tb17, z, d1, r_)
+        # errors surface with the member's message
+        with pytest.raises(native.ZkhipError) as e:
+            multi.load_proving_key(cid, raw17[:-3], scheme="gm17")
+        assert e.value.code == -2 and "member" in str(e.value)
+        with pytest.raises(native.ZkhipError):          # the failed load left no key behind
+            multi.prove_gm17(z, d1, d2, r_)
+    finally:
+        multi.close()
+
+
+@pytest.mark.parametrize("curve,ndev", [(BN254, 3), (BLS12_381, 2)], ids=lambda v: getattr(v, "name", str(v)))
+def test_emu_multi_device(curve, ndev):
+    _checks(emu_library(), [0] * ndev, curve, 5)
+
+
+def test_emu_multi_more_members_than_points():
+    _checks(emu_library(), [0] * 9, BN254, 2)
+
+
+def test_multi_bad_arguments():
+    lib = emu_library()
+    with pytest.raises(native.ZkhipError):
+        native.Multi([], lib)
+    with pytest.raises(native.ZkhipError):
+        native.Multi([0, 7], lib)            # the emulator has one device
+
+
+@pytest.mark.gpu
+def test_gpu_multi_device_two_members_one_gpu():
+    lib = native.default_library()
+    _checks(lib, [0, 0], BN254, 12)
+    _checks(lib, [0, 0, 0], BLS12_381, 8, kind="sha")
+
+
+@pytest.mark.gpu
+def test_gpu_multi_device_all_gpus():
+    """Every GPU of the box as one member each (one on a single-GPU box; the driver's 8-GPU node runs the real thing)."""
+    lib = native.default_library()
+    n = lib.device_count()
+    _checks(lib, list(range(n)), BN254, 13)
+
+
+@pytest.mark.gpu
+def test_gpu_config3_2e22_eight_members():
+    """BASELINE.json configs[2]: the synthetic 2^22-constraint BN254 circuit, ONE Groth16 proof across 8 members (1/8 of
+    every base table each; they share the box's GPU(s)), against the C++ oracle's closed form (Fr arithmetic and three
+    fixed-base multiplications at this size) and against the whole key on one context."""
+    import os
+    lg = int(os.environ.get("ZKHIP_TEST_CONFIG3_LOG", "22"))
+    lib = native.default_library()
+    ndev = lib.device_count()
+    multi = native.Multi([k % ndev for k in range(8)], lib)
+    try:
+        circ = synth.circuit(0, lg, kind="dense")
+        z = circ.assignment(0x5EED0022)
+        ctx = multi.member_context(0)
+        cs = native.ConstraintSystem(ctx, 0, circ.n, circ.l, circ.w, circ.mats())
+        tox = synth.toxic_waste(0)
+        raw = native.setup_g16(ctx, cs, tox)
+        assert raw.size > (1 << lg) * 64 * 5
+        multi.load_constraint_system(0, circ.n, circ.l, circ.w, circ.mats())
+        multi.load_proving_key(0, raw)
+        r, s = 0x123456789abcdef0123, 0xfedcba9876543210fed
+        got, tm = multi.prove_g16(z, r, s, want_timings=True)
+        oc = cpu.Circuit.from_csr(0, circ.n, circ.l, circ.w, circ.mats())
+        tb = b"".join(int(v).to_bytes(32, "little") for v in tox)
+        assert got == cpu.trapdoor(oc, tb, z, r, s)
+        multi.close()                                               # (frees the borrowed member context too)
+        ctx = native.Context(0, lib)
+        cs = native.ConstraintSystem(ctx, 0, circ.n, circ.l, circ.w, circ.mats())
+        whole = native.ProvingKey(ctx, 0, raw)                      # 24 GiB of tables at 2^22
+        assert native.prove_g16(ctx, whole, cs, z, r, s) == got
+        ctx.close()
+        print("config 3: 2^%d constraints, 8 members on %d GPU(s): %.1f ms per proof (slowest member phases: %s)" % (lg, ndev, tm["total_ms"], tm))
+    finally:
+        multi.close()

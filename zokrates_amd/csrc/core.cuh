@@ -132,7 +132,7 @@ static constexpr int ZK_NLANES = 5;   // A, B1, L (G1), B2 (G2) over z; H over h
 static constexpr int ZK_NSLOTS = 4;   // most proofs in flight (zkhip_prove_g16*_batch pipelines consecutive proofs; ctx->nslots of them are used)
 // everything one proof in flight owns: its scalars, NTT vectors, sort results, MSM workspaces, window sums and events
 struct ProofSlot {
-    DBuf scalars, zmont, va, vb, vc, ws1, ws2;
+    DBuf scalars, zmont, va, vb, vc, ws1, ws2, zflag;   // zflag: one word, set by k_check_canonical when a host assignment is staged
     MsmSort sorts[2];
     MsmLane lanes[ZK_NLANES];
     void* h_ws = nullptr;      // pinned host copy of the window sums
@@ -750,12 +750,19 @@ struct Prover {
     }
 
     // z -> HBM (canonical integers; slots m, m+1 are reserved for r, s)
-    static void upload_z(zkhip_ctx* ctx, DBuf& dst, u64 m, const uint8_t* z) {
+    static void upload_z(zkhip_ctx* ctx, DBuf& dst, u64 m, const uint8_t* z, DBuf& flag) {
         Fr z0 = fe_from_bytes_canon<Fr>(z);
         Fr one = Fr::zero(); one.v[0] = 1;
         require(z0.equals(one), ZKHIP_ERR_BAD_ARG, "z[0] must be 1 (ark instance variable 0 is the constant ONE)");
         dst.ensure((m + 2) * 32);
         dev_h2d(dst.p, z, m * 32, ctx->stream);
+        // every entry must be a canonical field element (checked on the device; the verdict is read with the results)
+        flag.ensure(4);
+        dev_memset(flag.p, 0, 4, ctx->stream);
+        ZK_LAUNCH((k_check_canonical<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, ctx->stream, ptr<Fr>(dst), m, ptr<u32>(flag));
+    }
+    static void require_canonical(u32 flag) {
+        require(flag == 0, ZKHIP_ERR_BAD_ARG, "an assignment entry is not a canonical field element (>= r)");
     }
     // r, s into the tail slots; Montgomery copy of z for the mat-vec
     static void stage_scalars(zkhip_ctx* ctx, NttPlan<C>* pl, void* d_scalars, u64 m, const uint8_t* r, const uint8_t* s_) {
@@ -786,10 +793,12 @@ struct Prover {
         ctx->cur = &sl;
         Stream st = ctx->stream;
         if (z_host) {
-            upload_z(ctx, sl.scalars, m, z_host);
+            upload_z(ctx, sl.scalars, m, z_host, sl.zflag);
         } else {
             sl.scalars.ensure((m + 2) * 32);
             dev_d2d(sl.scalars.p, src_dev, m * 32, st);
+            sl.zflag.ensure(4);
+            dev_memset(sl.zflag.p, 0, 4, st);      // a resident assignment was checked when it was uploaded
         }
         void* d_scalars = sl.scalars.p;
         stage_scalars(ctx, pl, d_scalars, m, r, s_);
@@ -836,14 +845,16 @@ struct Prover {
         Stream so = ctx->serial ? st : ctx->out_stream;
         for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(so, sl.lanes[k].done);
         const size_t b1 = (size_t)4 * Wmax * sizeof(Xyzz<Fq>), b2 = (size_t)Wmax * sizeof(Xyzz<Fq2>);
-        if (sl.h_ws_cap < b1 + b2) {
+        if (sl.h_ws_cap < b1 + b2 + 4) {
             host_free_pinned(sl.h_ws);
             sl.h_ws = nullptr; sl.h_ws_cap = 0;
-            sl.h_ws = host_alloc_pinned(b1 + b2);
-            sl.h_ws_cap = b1 + b2;
+            sl.h_ws = host_alloc_pinned(b1 + b2 + 4);
+            sl.h_ws_cap = b1 + b2 + 4;
         }
         dev_d2h(sl.h_ws, ws1, b1, so);
         dev_d2h((uint8_t*)sl.h_ws + b1, sl.ws2.p, b2, so);
+        sl.zflag.ensure(4);
+        dev_d2h((uint8_t*)sl.h_ws + b1 + b2, sl.zflag.p, 4, so);   // written on the main stream before ev[0], which every lane waits for
         event_record(sl.ev[3], so);
         sl.busy = true;
     }
@@ -877,6 +888,9 @@ struct Prover {
         const int Wmax = (int)std::max(shz.sets, shh.sets);
         const Xyzz<Fq>* h_ws1 = (const Xyzz<Fq>*)sl.h_ws;
         const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
+        u32 zflag;
+        memcpy(&zflag, (const uint8_t*)(h_ws2 + Wmax), 4);
+        require_canonical(zflag);
         // five independent Horner chains (W x c doublings each): one host thread per MSM, the G2 chain on this one
         Sums g;
         HostThreads th;
@@ -1036,8 +1050,12 @@ struct Prover {
         }
     }
     static void assignment_upload(zkhip_ctx* ctx, zkhip_assignment* a, const uint8_t* z) {
-        upload_z(ctx, a->scalars, a->m, z);
+        DBuf flag;
+        upload_z(ctx, a->scalars, a->m, z, flag);
+        u32 verdict = 0;
+        dev_d2h(&verdict, flag.p, 4, ctx->stream);
         stream_sync(ctx->stream);
+        require_canonical(verdict);
     }
 
     // generic MSM primitive (bases in ark encoding)
@@ -1110,7 +1128,7 @@ struct Prover {
         NttPlan<C>* pl = get_plan<C>(ctx, cs->logN);
         const u64 m = cs->l + cs->w;
         uint8_t zero[32] = {0};
-        upload_z(ctx, ctx->cur->scalars, m, z);
+        upload_z(ctx, ctx->cur->scalars, m, z, ctx->cur->zflag);
         stage_scalars(ctx, pl, ctx->cur->scalars.p, m, zero, zero);
         witness_map(ctx, cs, pl);
         ctx->cur->vb.ensure(pl->N * sizeof(Fr));

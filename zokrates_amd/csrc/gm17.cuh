@@ -209,8 +209,13 @@ struct Gm17 {
             Fr one = Fr::zero(); one.v[0] = 1;
             require(z0.equals(one), ZKHIP_ERR_BAD_ARG, "z[0] must be 1 (ark instance variable 0 is the constant ONE)");
             dev_h2d(sl.scalars.p, z_host, m * 32, st);
+            sl.zflag.ensure(4);
+            dev_memset(sl.zflag.p, 0, 4, st);
+            ZK_LAUNCH((k_check_canonical<Fr>), dim3(blocks_for(m, 256)), dim3(256), 0, st, ptr<Fr>(sl.scalars), m, ptr<u32>(sl.zflag));
         } else {
             dev_d2d(sl.scalars.p, src_dev, m * 32, st);
+            sl.zflag.ensure(4);
+            dev_memset(sl.zflag.p, 0, 4, st);
         }
         uint8_t* d_scalars = (uint8_t*)sl.scalars.p;
         sl.zmont.ensure(m * 32);

@@ -28,9 +28,17 @@ namespace zk {
 // per point type tuning (measured on MI355X with tools/accum_bench.hip, 2^24 mixed additions on the unsaturated field:
 // G1 1.22 ms at 3 waves per SIMD; G2 3.17 ms at 2 waves per SIMD).  *_WPE = waves per SIMD the register allocator must
 // leave room for; the accumulation kernel is launched with exactly that many waves per SIMD on every CU, one slice each.
+#ifndef ZK_G2_ACCUM_WPE
+#define ZK_G2_ACCUM_WPE 2
+#endif
+#ifndef ZK_G2_TOUCH_PREFETCH
+#define ZK_G2_TOUCH_PREFETCH 0
+#endif
+template <class F> struct MsmPrefetch { static constexpr bool TOUCH = false; };
+template <class P_> struct MsmPrefetch<Fu2<P_>> { static constexpr bool TOUCH = ZK_G2_TOUCH_PREFETCH != 0; };
 template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3; };
 template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; };
-template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = 2; };
 template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3; };
 template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2; };
 static constexpr u32 MSM_MIN_SLICE = 8;   // default for the finest cut of the sorted list (small inputs leave work-items idle)
@@ -292,6 +300,32 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(const AffPacked<F>* __re
     u32 end = off[cur + 1];
     Xyzz<F> acc = Xyzz<F>::inf();
     u32 e = sorted[p0];
+    if (MsmPrefetch<F>::TOUCH) {
+        // register-starved point types: the next base is only TOUCHED one entry ahead (one word: the line travels to the
+        // cache) and loaded when it is used, instead of being held in 32-48 registers through a whole addition
+        u32 sink = 0;
+        for (u64 pos = p0; pos < p1; ++pos) {
+            u32 e_next = e;
+            if (pos + 1 < p1) {
+                e_next = sorted[pos + 1];
+                sink |= ((const volatile u32*)(bases + (e_next & 0x7fffffffu)))[0];
+            }
+            if (pos == end) {
+                partial[(u64)cur + g] = acc;
+                acc = Xyzz<F>::inf();
+                do { ++cur; end = off[cur + 1]; } while (end <= pos);
+            }
+            u32 w[NW2];
+            aff_load_words<F>(bases, e & 0x7fffffffu, w);
+            Aff<F> pt = aff_unpack<F>(w);
+            if (e & 0x80000000u) pt.y = fe_neg(pt.y);
+            if (!pt.is_inf()) xyzz_madd_acc<true>(acc, pt);
+            e = e_next;
+        }
+        (void)sink;   // the volatile loads stay
+        partial[(u64)cur + g] = acc;
+        return;
+    }
     u32 w[NW2];
     aff_load_words<F>(bases, e & 0x7fffffffu, w);
     for (u64 pos = p0; pos < p1; ++pos) {

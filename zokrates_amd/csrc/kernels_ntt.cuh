@@ -75,6 +75,19 @@ __global__ void k_unpack_table(const Fe<P>* __restrict__ in, Fu<P>* __restrict__
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fu_unpack<P>(in[i].v);
 }
+// flag |= 1 if any of the n scalars (canonical-integer words) is >= the modulus: such an entry would overflow the MSM's
+// signed-digit recoding (ark's FromBytes rejects it)
+template <class F>
+__global__ void k_check_canonical(const F* __restrict__ x, u64 n, u32* __restrict__ flag) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const F v = x[i];
+    bool lt = false, decided = false;
+    ZK_UNROLL for (int k = F::N - 1; k >= 0; --k) {
+        if (!decided && v.v[k] != F::Params::mod(k)) { lt = v.v[k] < F::Params::mod(k); decided = true; }
+    }
+    if (!lt) atomicOr(flag, 1u);
+}
 // op: 0 add, 1 sub, 2 mul — operands and result in Montgomery form
 template <class F>
 __global__ void k_field_op(const F* __restrict__ a, const F* __restrict__ b, F* __restrict__ out, u64 n, int op) {

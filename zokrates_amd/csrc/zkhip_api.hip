@@ -516,6 +516,137 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
     });
 }
 
+// ------------------------------------------------------------------ one proof across several GPUs of one process
+struct zkhip_multi {
+    std::vector<zkhip_ctx*> ctx;     // one per member; a device may appear more than once
+    std::vector<zkhip_pk*> pk;       // member k: shard k of n
+    std::vector<zkhip_r1cs*> cs;     // replicas
+    int scheme = -1;                 // of the loaded key: 0 Groth16, 1 GM17
+    std::string err;
+};
+}  // extern "C"
+// run fn(k) for every member — one host thread each (contexts are independent; the test emulator is single-threaded) —
+// and keep the first failure
+template <class Fn>
+static int32_t multi_each(zkhip_multi* m, Fn&& fn) {
+    const size_t n = m->ctx.size();
+    std::vector<int32_t> rc(n, ZKHIP_OK);
+    std::vector<std::string> msg(n);
+    auto body = [&](size_t k) {
+        rc[k] = fn(k);
+        if (rc[k] != ZKHIP_OK) msg[k] = zkhip_last_error(m->ctx[k]);
+    };
+#ifdef ZK_EMU
+    for (size_t k = 0; k < n; ++k) body(k);
+#else
+    {
+        HostThreads th;
+        for (size_t k = 1; k < n; ++k) th.run([&, k] { body(k); });
+        body(0);
+    }
+#endif
+    for (size_t k = 0; k < n; ++k)
+        if (rc[k] != ZKHIP_OK) {
+            m->err = "member " + std::to_string(k) + ": " + msg[k];
+            return rc[k];
+        }
+    return ZKHIP_OK;
+}
+extern "C" {
+static void multi_drop_keys(zkhip_multi* m) {
+    for (auto*& p : m->pk) { zkhip_pk_free(p); p = nullptr; }
+    m->scheme = -1;
+}
+int32_t zkhip_ctx_create_multi(const int32_t* devices, int32_t n, zkhip_multi** out) {
+    if (!out) { g_create_err = "out is NULL"; return ZKHIP_ERR_BAD_ARG; }
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) { g_create_err = "device list empty or longer than 64"; return ZKHIP_ERR_BAD_ARG; }
+    std::unique_ptr<zkhip_multi> m(new (std::nothrow) zkhip_multi());
+    if (!m) { g_create_err = "out of host memory"; return ZKHIP_ERR_NOMEM; }
+    for (int32_t k = 0; k < n; ++k) {
+        zkhip_ctx* c = nullptr;
+        const int32_t rc = zkhip_ctx_create(devices[k], &c);
+        if (rc != ZKHIP_OK) {
+            for (auto* q : m->ctx) zkhip_ctx_free(q);
+            return rc;        // message already in the per-thread create error
+        }
+        m->ctx.push_back(c);
+    }
+    m->pk.assign(n, nullptr);
+    m->cs.assign(n, nullptr);
+    *out = m.release();
+    return ZKHIP_OK;
+}
+void zkhip_multi_free(zkhip_multi* m) {
+    if (!m) return;
+    multi_drop_keys(m);
+    for (auto* c : m->cs) zkhip_r1cs_free(c);
+    for (auto* c : m->ctx) zkhip_ctx_free(c);
+    delete m;
+}
+int32_t zkhip_multi_size(const zkhip_multi* m) { return m ? (int32_t)m->ctx.size() : 0; }
+zkhip_ctx* zkhip_multi_ctx(zkhip_multi* m, int32_t member) { return (m && member >= 0 && (size_t)member < m->ctx.size()) ? m->ctx[member] : nullptr; }
+const char* zkhip_multi_last_error(const zkhip_multi* m) { return m ? m->err.c_str() : g_create_err.c_str(); }
+int32_t zkhip_multi_r1cs_load(zkhip_multi* m, int32_t curve, uint64_t n, uint64_t l, uint64_t w, const uint64_t* rowptr_a, const uint32_t* col_a,
+                              const uint8_t* val_a, const uint64_t* rowptr_b, const uint32_t* col_b, const uint8_t* val_b, const uint64_t* rowptr_c,
+                              const uint32_t* col_c, const uint8_t* val_c) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    for (auto*& c : m->cs) { zkhip_r1cs_free(c); c = nullptr; }
+    return multi_each(m, [&](size_t k) {
+        return zkhip_r1cs_load(m->ctx[k], curve, n, l, w, rowptr_a, col_a, val_a, rowptr_b, col_b, val_b, rowptr_c, col_c, val_c, &m->cs[k]);
+    });
+}
+int32_t zkhip_multi_pk_load_g16(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    multi_drop_keys(m);
+    const uint32_t world = (uint32_t)m->ctx.size();
+    const int32_t rc = multi_each(m, [&](size_t k) { return zkhip_pk_load_g16_shard(m->ctx[k], curve, bytes, len, (uint32_t)k, world, &m->pk[k]); });
+    if (rc == ZKHIP_OK) m->scheme = 0; else multi_drop_keys(m);
+    return rc;
+}
+int32_t zkhip_multi_pk_load_gm17(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    multi_drop_keys(m);
+    const uint32_t world = (uint32_t)m->ctx.size();
+    const int32_t rc = multi_each(m, [&](size_t k) { return zkhip_pk_load_gm17_shard(m->ctx[k], curve, bytes, len, (uint32_t)k, world, &m->pk[k]); });
+    if (rc == ZKHIP_OK) m->scheme = 1; else multi_drop_keys(m);
+    return rc;
+}
+static int32_t multi_prove(zkhip_multi* m, int scheme, const uint8_t* z, const uint8_t* rnd, const uint8_t* s_, uint8_t* proof_out, zkhip_timings* timings) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    if (!z || !rnd || !proof_out || (scheme == 0 && !s_)) { m->err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
+    if (m->scheme != scheme || !m->cs[0]) { m->err = "load the constraint system and a proving key of this scheme first"; return ZKHIP_ERR_BAD_ARG; }
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t rec = 0;
+    zkhip_partial_size(m->pk[0]->curve, &rec);
+    const size_t n = m->ctx.size();
+    std::vector<uint8_t> records(n * rec);
+    std::vector<zkhip_timings> tm(n);
+    int32_t rc = multi_each(m, [&](size_t k) {
+        return scheme == 0 ? zkhip_prove_g16_partial(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, s_, &records[k * rec], &tm[k])
+                           : zkhip_prove_gm17_partial(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, &records[k * rec], &tm[k]);
+    });
+    if (rc != ZKHIP_OK) return rc;
+    rc = scheme == 0 ? zkhip_combine_g16(m->ctx[0], m->pk[0], (uint32_t)n, records.data(), rnd, s_, proof_out)
+                     : zkhip_combine_gm17(m->ctx[0], m->pk[0], (uint32_t)n, records.data(), rnd, proof_out);
+    if (rc != ZKHIP_OK) { m->err = std::string("combine: ") + zkhip_last_error(m->ctx[0]); return rc; }
+    if (timings) {   // the slowest member per phase; total = wall clock of the whole call
+        *timings = tm[0];
+        for (size_t k = 1; k < n; ++k) {
+            float* a = (float*)timings; const float* b = (const float*)&tm[k];
+            for (size_t q = 0; q < sizeof(zkhip_timings) / sizeof(float); ++q) a[q] = std::max(a[q], b[q]);
+        }
+        timings->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return ZKHIP_OK;
+}
+int32_t zkhip_prove_g16_multi(zkhip_multi* m, const uint8_t* z, const uint8_t* r, const uint8_t* s, uint8_t* proof_out, zkhip_timings* timings) {
+    return multi_prove(m, 0, z, r, s, proof_out, timings);
+}
+int32_t zkhip_prove_gm17_multi(zkhip_multi* m, const uint8_t* z, const uint8_t* d1_d2_r, uint8_t* proof_out, zkhip_timings* timings) {
+    return multi_prove(m, 1, z, d1_d2_r, nullptr, proof_out, timings);
+}
+
 // ------------------------------------------------------------------ GM17 (config 5)
 int32_t zkhip_pk_load_gm17(zkhip_ctx* ctx, int32_t curve, const uint8_t* bytes, size_t len, zkhip_pk** out) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;

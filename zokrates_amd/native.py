@@ -60,6 +60,8 @@ class Library:
         "zkhip_prog_r1cs_load", "zkhip_prog_assignment",
         "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import", "zkhip_pk_export_size_ex", "zkhip_pk_export_ex",
         "zkhip_ctx_tune",
+        "zkhip_ctx_create_multi", "zkhip_multi_free", "zkhip_multi_size", "zkhip_multi_ctx", "zkhip_multi_last_error", "zkhip_multi_r1cs_load",
+        "zkhip_multi_pk_load_g16", "zkhip_multi_pk_load_gm17", "zkhip_prove_g16_multi", "zkhip_prove_gm17_multi",
     ]
 
     def __init__(self, path=None):
@@ -74,6 +76,16 @@ class Library:
         L.zkhip_ctx_create.restype = i32; L.zkhip_ctx_create.argtypes = [i32, pp]
         L.zkhip_ctx_free.restype = None; L.zkhip_ctx_free.argtypes = [vp]
         L.zkhip_ctx_tune.restype = i32; L.zkhip_ctx_tune.argtypes = [vp, i32, i32]
+        L.zkhip_ctx_create_multi.restype = i32; L.zkhip_ctx_create_multi.argtypes = [vp, i32, pp]
+        L.zkhip_multi_free.restype = None; L.zkhip_multi_free.argtypes = [vp]
+        L.zkhip_multi_size.restype = i32; L.zkhip_multi_size.argtypes = [vp]
+        L.zkhip_multi_ctx.restype = vp; L.zkhip_multi_ctx.argtypes = [vp, i32]
+        L.zkhip_multi_last_error.restype = C.c_char_p; L.zkhip_multi_last_error.argtypes = [vp]
+        L.zkhip_multi_r1cs_load.restype = i32; L.zkhip_multi_r1cs_load.argtypes = [vp, i32, u64, u64, u64] + [vp] * 9
+        L.zkhip_multi_pk_load_g16.restype = i32; L.zkhip_multi_pk_load_g16.argtypes = [vp, i32, vp, sz]
+        L.zkhip_multi_pk_load_gm17.restype = i32; L.zkhip_multi_pk_load_gm17.argtypes = [vp, i32, vp, sz]
+        L.zkhip_prove_g16_multi.restype = i32; L.zkhip_prove_g16_multi.argtypes = [vp] * 6
+        L.zkhip_prove_gm17_multi.restype = i32; L.zkhip_prove_gm17_multi.argtypes = [vp] * 5
         L.zkhip_last_error.restype = C.c_char_p; L.zkhip_last_error.argtypes = [vp]
         L.zkhip_pk_load_g16.restype = i32; L.zkhip_pk_load_g16.argtypes = [vp, i32, vp, sz, pp]
         L.zkhip_pk_free.restype = None; L.zkhip_pk_free.argtypes = [vp]
@@ -546,6 +558,82 @@ class Program:
     def close(self):
         if self.h:
             self.lib.L.zkhip_prog_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Multi:
+    """`zkhip_multi`: ONE proof across several GPUs of this process (no collective library, no Python in the data path):
+    member k holds shard k of n of the key and a replica of the constraint system.  `devices` may repeat a device."""
+
+    def __init__(self, devices, library=None):
+        self.lib = library or default_library()
+        self.h = C.c_void_p()
+        dev = np.asarray(list(devices), dtype=np.int32)
+        rc = self.lib.L.zkhip_ctx_create_multi(_ptr(dev), int(dev.size), C.byref(self.h))
+        if rc != 0:
+            raise ZkhipError(rc, self.lib.L.zkhip_last_error(None).decode())
+        self.curve_id = None
+        self.m = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ZkhipError(rc, self.lib.L.zkhip_multi_last_error(self.h).decode())
+
+    def __len__(self):
+        return int(self.lib.L.zkhip_multi_size(self.h))
+
+    def member_context(self, k=0):
+        """A borrowed `Context` of member k (do not close it): e.g. to run the setup on the same device."""
+        ctx = Context.__new__(Context)
+        ctx.lib = self.lib
+        ctx.h = C.c_void_p(self.lib.L.zkhip_multi_ctx(self.h, k))
+        ctx.close = lambda: None
+        return ctx
+
+    def load_constraint_system(self, curve_id, n, l, w, mats):
+        keep = []
+        args = []
+        for rp, col, val in mats:
+            rp = np.ascontiguousarray(rp, dtype=np.uint64); col = np.ascontiguousarray(col, dtype=np.uint32); val = _u8(val)
+            keep += [rp, col, val]
+            args += [_ptr(rp), _ptr(col), _ptr(val)]
+        self._check(self.lib.L.zkhip_multi_r1cs_load(self.h, curve_id, n, l, w, *args))
+        self.curve_id, self.m = curve_id, l + w
+
+    def load_proving_key(self, curve_id, pk_bytes, scheme="g16"):
+        b = _u8(pk_bytes)
+        fn = self.lib.L.zkhip_multi_pk_load_gm17 if scheme == "gm17" else self.lib.L.zkhip_multi_pk_load_g16
+        self._check(fn(self.h, curve_id, _ptr(b), b.size))
+        self.curve_id = curve_id
+
+    def prove_g16(self, z, r, s, want_timings=False):
+        nb = FQ_BYTES[self.curve_id]
+        z = _u8(z, self.m * 32)
+        rb = np.frombuffer(int(r).to_bytes(32, "little"), dtype=np.uint8)
+        sb = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8)
+        out = np.zeros(8 * nb + 3, dtype=np.uint8)
+        tm = Timings()
+        self._check(self.lib.L.zkhip_prove_g16_multi(self.h, _ptr(z), _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm)))
+        return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+    def prove_gm17(self, z, d1, d2, r, want_timings=False):
+        nb = FQ_BYTES[self.curve_id]
+        z = _u8(z, self.m * 32)
+        rnd = _rnd96(d1, d2, r)
+        out = np.zeros(8 * nb + 3, dtype=np.uint8)
+        tm = Timings()
+        self._check(self.lib.L.zkhip_prove_gm17_multi(self.h, _ptr(z), _ptr(rnd), _ptr(out), C.byref(tm)))
+        return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+    def close(self):
+        if self.h:
+            self.lib.L.zkhip_multi_free(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
