@@ -18,7 +18,7 @@ def pytest_configure(config):
 # The hot-path parity file (fields, NTT, MSM, witness map, full proofs: SURVEY.md §8a rows K1-K9) runs first, then the
 # other files in the order below, so that under `-x` a failure in a peripheral feature can never hide the hot path.
 _FILE_ORDER = ["test_gpu_parity.py", "test_oracle_c.py", "test_oracle_py.py", "test_abi.py", "test_emu_kernels.py", "test_multi_device.py",
-               "test_gm17.py", "test_ingest.py", "test_poseidon.py", "test_random_circuits.py", "test_formats.py"]
+               "test_gm17.py", "test_ingest.py", "test_ingest_reference_shapes.py", "test_poseidon.py", "test_random_circuits.py", "test_formats.py"]
 
 
 def pytest_collection_modifyitems(session, config, items):
