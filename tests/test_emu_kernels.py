@@ -91,7 +91,7 @@ def test_msm_window_sizes(ctx):
     b1, _, ks = _rand_points(BN254, 40, rnd)
     want = cpu.msm(0, 1, b1, ks)
     try:
-        for c in (2, 3, 5, 8, 13):
+        for c in (2, 3, 5, 8, 13, 17):               # 17: the sort's histogram is split over two workgroups per window
             ctx.tune("msm_c", c)
             assert ctx.msm(0, 1, b1, ks) == want, c
     finally:
@@ -204,6 +204,27 @@ def test_sharded_proof_virtual_ranks(ctx, curve, world):
         native.prove_g16(ctx, shards[0], cs, z, r_, s_)
     whole = native.ProvingKey(ctx, curve.curve_id, raw)
     assert native.combine_g16(ctx, whole, [native.prove_g16_partial(ctx, whole, cs, z, r_, s_)], r_, s_) == want
+
+
+def test_prove_with_wide_windows():
+    """Tables built for c = 17 and 18 (2^16 / 2^17 shared buckets, the sort's histogram split over 2 / 4 workgroups per
+    window, fold with more rows than the scan form holds): the proof does not depend on the window width."""
+    c2 = native.Context(0, emu_library())
+    try:
+        oc = cpu.Circuit.synth(0, 40, 7)
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(BN254))
+        raw = cpu.ProvingKey.setup(oc, tox).serialize()
+        cs = native.ConstraintSystem(c2, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+        z = oc.assignment()
+        want = cpu.trapdoor(oc, tox, z, 11, 13)
+        for c in (17, 18, 4):
+            c2.tune("msm_c", c)
+            pk = native.ProvingKey(c2, 0, raw)
+            assert native.prove_g16(c2, pk, cs, z, 11, 13) == want, c
+            img = pk.export_image(full=(c == 4))
+            assert native.prove_g16(c2, native.ProvingKey.from_image(c2, 0, img), cs, z, 11, 13) == want, c
+    finally:
+        c2.close()
 
 
 def test_two_pass_prove(ctx):

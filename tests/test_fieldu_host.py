@@ -10,10 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "..", "zokrates_amd", "csrc")
 
 
-@pytest.mark.parametrize("name", ["fieldu_ops", "fieldu_curve"])
+@pytest.mark.parametrize("name", ["fieldu_ops", "fieldu_curve", "fieldu_fused"])
 def test_unsaturated_field_host(name, tmp_path):
     exe = str(tmp_path / name)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wno-unknown-pragmas", "-I", CSRC, os.path.join(HERE, "host", name + ".cpp"), "-o", exe])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wno-unknown-pragmas", "-DZK_FQ2_KARATSUBA=1", "-DZK_LAZY_Y3_G1=1", "-I", CSRC, os.path.join(HERE, "host", name + ".cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failures" in out.stdout

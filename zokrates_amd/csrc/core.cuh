@@ -374,7 +374,8 @@ static inline int env_int(const char* name, int lo, int hi, int dflt) {
     if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
     return dflt;
 }
-static constexpr int MSM_MAX_C = 16;   // the sort's LDS histogram: 2^(c-1) counters of 4 B
+static constexpr int MSM_MAX_C = 18;   // widest window (the sort's LDS histogram holds 2^15 counters: wider windows split their buckets)
+static constexpr int MSM_AUTO_MAX_C = 16;   // widest window chosen automatically
 // `table`: the bases carry precomputed window multiples 2^(c j) P (resident keys); otherwise one bucket set per window.
 static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, bool table, int force_c = 0) {
     MsmShape s;
@@ -383,17 +384,17 @@ static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, b
     if (table) {
         // one fold per MSM whatever c is, so c only trades additions (n * W) against buckets (2^(c-1)): as wide as the
         // sort's histogram allows once there are a few points per bucket
-        s.c = std::max(2, std::min(MSM_MAX_C, lg + 1));
+        s.c = std::max(2, std::min(MSM_AUTO_MAX_C, lg + 1));
     } else {
         // Window width: about log2(n) - 5 (measured optimum at 2^20: 15), but never one that leaves the top window
         // with only a few significant bits — its handful of buckets would each receive a large share of all points
         // (same-address atomics in the sort, one bucket spread over thousands of slices).
-        const int want = std::max(2, std::min(MSM_MAX_C, lg - 5));
+        const int want = std::max(2, std::min(MSM_AUTO_MAX_C, lg - 5));
         s.c = want;
         for (int d = 0; d <= 14; ++d) {
             bool found = false;
             for (int cand : {want + d, want - d}) {
-                if (cand < 2 || cand > MSM_MAX_C) continue;
+                if (cand < 2 || cand > MSM_AUTO_MAX_C) continue;
                 const int W = (scalar_bits + 1 + cand - 1) / cand;
                 const int top_bits = scalar_bits + 1 - (W - 1) * cand;
                 if (top_bits >= cand || (n >> (top_bits - 1)) <= 4096) { s.c = cand; found = true; break; }   // <= 4096 points per top bucket
@@ -434,19 +435,20 @@ static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars
     // global atomics (one per touched bucket per workgroup) well below one per digit
     lds_opt_in(ctx, (const void*)k_msm_count);
     lds_opt_in(ctx, (const void*)k_msm_place);
-    const u64 want_chunks = std::max<u64>(1, (256 + sh.W - 1) / sh.W);
-    const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)sh.K));
+    const u32 kh = std::min<u32>(sh.K, 1u << 15), nsplit = sh.K / kh;
+    const u64 want_chunks = std::max<u64>(1, (256 + sh.W * nsplit - 1) / (sh.W * nsplit));
+    const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)kh));
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
     const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;
-    const size_t hist_bytes = (size_t)sh.K * 4;
+    const size_t hist_bytes = (size_t)kh * 4;
     const u32 key_stride = sh.sets == 1 ? 0 : sh.K;
     ZK_LAUNCH(k_scalars_to_word_major, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, ptr<u32>(so.wm));
-    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride,
+    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, nsplit), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride, kh,
               ptr<u32>(so.cnt));
     ZK_LAUNCH(k_scan_local, dim3(nchunks), dim3(SCAN_THREADS), 0, s, ptr<u32>(so.cnt), ptr<u32>(so.off), ptr<u32>(so.chunk_sum), nk);
     ZK_LAUNCH(k_scan_chunks, dim3(1), dim3(SCAN_THREADS), 0, s, ptr<u32>(so.chunk_sum), nchunks, ptr<u32>(so.grand));
     ZK_LAUNCH(k_scan_add, dim3(blocks_for(nk + 1, T)), dim3(T), 0, s, ptr<u32>(so.off), ptr<u32>(so.chunk_sum), nk, ptr<u32>(so.grand));
-    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride,
+    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, nsplit), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride, kh,
               level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
     event_record(so.ready, s);
 }

@@ -135,8 +135,11 @@ inline bool trace_enabled() {
     static const bool on = getenv("ZKHIP_TRACE") != nullptr;
     return on;
 }
+// (an empty grid — a key or program with a zero-length vector — is a no-op, as it is on the test emulator; HIP rejects it)
+inline bool grid_nonempty(const dim3& g) { return g.x != 0 && g.y != 0 && g.z != 0; }
 #define ZK_LAUNCH(kernel, grid, block, smem, stream, ...)                                 \
     do {                                                                                  \
+        if (!zk::grid_nonempty(dim3(grid))) break;                                        \
         if (zk::trace_enabled()) fprintf(stderr, "[zkhip] launch %s ...", #kernel);       \
         hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);               \
         zk::dev_check_last();                                                             \

@@ -48,6 +48,37 @@ template <bool HOT, class F> ZK_HD F ecs(const F& a) { return ec_sqr(a); }
 template <bool HOT, class P> ZK_HD Fu2<P> ecm(const Fu2<P>& a, const Fu2<P>& b) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_mul_inl(a, b) : fu2_mul_call(a, b); }
 template <bool HOT, class P> ZK_HD Fu2<P> ecs(const Fu2<P>& a) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_sqr_inl(a) : fu2_sqr_call(a); }
 
+// a*b - c*d, the tail of Y3 = R (Q - X3) - Y1 PPP: ONE reduction (per component) instead of two products and a subtraction
+// on the hot path of the unsaturated fields; plain arithmetic elsewhere.  Result < 3p.
+// Measured on MI355X (same box, 2^20 BN254, serial kernel time, profiles/r2f_fused_arithmetic_ab.txt): the fused Y3 makes
+// the G2 accumulation 33 % faster (6.18 -> 4.12 ms: fewer live Fq2 temporaries, far fewer spills) and leaves G1 unchanged
+// at twice the registers (84 -> 168), so it is on for Fq2 only; the three-product Fq2 form (fu2_mul_kara) saves a sixth
+// of the multiply-adds but costs registers the G2 kernel does not have: 4.12 -> 4.4 ms with the fused Y3, so it is off.
+#ifndef ZK_LAZY_Y3_G1
+#define ZK_LAZY_Y3_G1 0
+#endif
+#ifndef ZK_LAZY_Y3_G2
+#define ZK_LAZY_Y3_G2 1
+#endif
+template <bool HOT, class F> ZK_HD F ec_mulsub(const F& a, const F& b, const F& c, const F& d) { return fe_sub_k<2>(ecm<HOT>(a, b), ecm<HOT>(c, d)); }
+template <bool HOT, class P> ZK_HD Fu<P> ec_mulsub(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d) {
+    if (!ZK_LAZY_Y3_G1) return fe_sub_k<2>(ecm<HOT>(a, b), ecm<HOT>(c, d));
+    return fu_mul2_inl(a, b, c, fe_sub_k<8>(Fu<P>::zero(), d));
+}
+template <bool HOT, class P> ZK_HD Fu2<P> ec_mulsub(const Fu2<P>& a, const Fu2<P>& b, const Fu2<P>& c, const Fu2<P>& d) {
+    if (ZK_LAZY_Y3_G2 && (HOT || UCfg<P>::FQ2_INLINE)) return fu2_mulsub_inl(a, b, c, d);
+    return fe_sub_k<2>(ecm<HOT>(a, b), ecm<HOT>(c, d));
+}
+#ifndef ZK_FQ2_KARATSUBA
+#define ZK_FQ2_KARATSUBA 0
+#endif
+// the hot Fq2 product: three limb products (fieldu.cuh fu2_mul_kara) when the first operand is < 4p per component
+template <bool HOT, class P> ZK_HD Fu2<P> ecm_k(const Fu2<P>& a, const Fu2<P>& b) {
+    if (HOT && ZK_FQ2_KARATSUBA) return fu2_mul_kara(a, b);
+    return ecm<HOT>(a, b);
+}
+template <bool HOT, class F> ZK_HD F ecm_k(const F& a, const F& b) { return ecm<HOT>(a, b); }
+
 // Bounds for the unsaturated field (fieldu.cuh): products come out < 2p; the comments "< kp" track the integer values so
 // that every sub<K> has value(b) < K*p and every stored coordinate stays < 8p (X < 3p after fe_relax, Y < 4p, ZZ/ZZZ < 2p).
 // For the saturated field sub<K> is the plain modular subtraction and fe_relax the identity.
@@ -172,19 +203,20 @@ ZK_HD void xyzz_madd_acc(Xyzz<F>& a, const Aff<F>& p) {   // a += p, p affine an
         a.x = p.x; a.y = p.y; a.zz = F::one(); a.zzz = F::one();
         return;
     }
-    F Pp = fe_sub_k<4>(ecm<HOT>(p.x, a.zz), a.x);           // X1 < 3p;  Pp < 6p
-    F R = fe_sub_k<4>(ecm<HOT>(p.y, a.zzz), a.y);           // Y1 < 4p;  R < 6p
+    // (products take the operand that may reach 4p first: the three-product Fq2 form bounds its first operand)
+    F Pp = fe_sub_k<4>(ecm_k<HOT>(a.zz, p.x), a.x);         // X1 < 3p;  Pp < 6p
+    F R = fe_sub_k<4>(ecm_k<HOT>(a.zzz, p.y), a.y);         // Y1 < 3p;  R < 6p
     if (fe_is_zero_modp(Pp)) {
         a = fe_is_zero_modp(R) ? xyzz_dbl_affine_inl<HOT>(p) : Xyzz<F>::inf();
         return;
     }
     F PP = ecs<HOT>(Pp);
-    F PPP = ecm<HOT>(Pp, PP);
-    F Q = ecm<HOT>(a.x, PP);
-    a.zz = ecm<HOT>(a.zz, PP);
-    a.zzz = ecm<HOT>(a.zzz, PPP);
+    F PPP = ecm<HOT>(Pp, PP);                                // Pp < 6p: the four-product form
+    F Q = ecm_k<HOT>(a.x, PP);
+    a.zz = ecm_k<HOT>(a.zz, PP);
+    a.zzz = ecm_k<HOT>(a.zzz, PPP);
     F X3 = fe_relax(fe_sub_k<4>(fe_sub_k<2>(ecs<HOT>(R), PPP), fe_dbl(Q)));   // < 2 + 2 + 4 = 8p before, < 3p after
-    a.y = fe_sub_k<2>(ecm<HOT>(R, fe_sub_k<4>(Q, X3)), ecm<HOT>(a.y, PPP));       // < 4p
+    a.y = ec_mulsub<HOT>(R, fe_sub_k<4>(Q, X3), a.y, PPP);                    // one reduction: < 3p
     a.x = X3;
 }
 template <class F>

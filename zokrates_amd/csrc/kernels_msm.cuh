@@ -134,47 +134,53 @@ static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ w
     }
     return raw ? raw - 1 : MSM_NO_DIGIT;
 }
-// grid (nchunks, W); dynamic LDS K x 4 B.  cnt[key] += number of digits with that key in this chunk.
-static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride,
+// grid (nchunks, W, K / kh); dynamic LDS kh x 4 B.  cnt[key] += number of digits with that key in this chunk.
+// A workgroup histograms the buckets [z * kh, (z + 1) * kh) of its window (kh = min(K, 2^15): the histogram fits LDS up to
+// c = 16; wider windows split their buckets over blockIdx.z and every split rescans the chunk's digits).
+static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
                                                         u32* __restrict__ cnt) {
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
     const u32 K = 1u << (c - 1);
     const int j = blockIdx.y;
-    for (u32 b = threadIdx.x; b < K; b += blockDim.x) hist[b] = 0;
+    const u32 b0 = blockIdx.z * kh;
+    for (u32 b = threadIdx.x; b < kh; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
-        atomicAdd(&hist[d & 0x7fffffffu], 1u);
+        const u32 b = (d & 0x7fffffffu) - b0;
+        if (b < kh) atomicAdd(&hist[b], 1u);
     }
     __syncthreads();
-    for (u32 b = threadIdx.x; b < K; b += blockDim.x)
-        if (hist[b]) atomicAdd(&cnt[(u64)j * key_stride + b], hist[b]);
+    for (u32 b = threadIdx.x; b < kh; b += blockDim.x)
+        if (hist[b]) atomicAdd(&cnt[(u64)j * key_stride + b0 + b], hist[b]);
 }
 // same geometry; after the scan: reserve this workgroup's run inside every bucket it touches (one global atomic per
 // bucket), then place the entries with LDS atomics.
-static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride,
+static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
                                                         u64 idx_stride, const u32* __restrict__ off, u32* __restrict__ cursor,
                                                         u32* __restrict__ sorted) {
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
     const u32 K = 1u << (c - 1);
     const int j = blockIdx.y;
-    for (u32 b = threadIdx.x; b < K; b += blockDim.x) hist[b] = 0;
+    const u32 b0 = blockIdx.z * kh;
+    for (u32 b = threadIdx.x; b < kh; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
-        atomicAdd(&hist[d & 0x7fffffffu], 1u);
+        const u32 b = (d & 0x7fffffffu) - b0;
+        if (b < kh) atomicAdd(&hist[b], 1u);
     }
     __syncthreads();
-    for (u32 b = threadIdx.x; b < K; b += blockDim.x) {
+    for (u32 b = threadIdx.x; b < kh; b += blockDim.x) {
         const u32 have = hist[b];
         if (!have) continue;
-        const u64 key = (u64)j * key_stride + b;
+        const u64 key = (u64)j * key_stride + b0 + b;
         hist[b] = off[key] + atomicAdd(&cursor[key], have);   // global position of this workgroup's first entry
     }
     __syncthreads();
@@ -182,7 +188,9 @@ static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict_
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
-        const u32 pos = atomicAdd(&hist[d & 0x7fffffffu], 1u);
+        const u32 b = (d & 0x7fffffffu) - b0;
+        if (b >= kh) continue;
+        const u32 pos = atomicAdd(&hist[b], 1u);
         sorted[pos] = (level + (u32)i) | (d & 0x80000000u);
     }
 }
