@@ -5,6 +5,7 @@ use std::os::raw::c_char;
 #[repr(C)] pub struct zkhip_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct zkhip_pk { _p: [u8; 0] }
 #[repr(C)] pub struct zkhip_r1cs { _p: [u8; 0] }
+#[repr(C)] pub struct zkhip_multi { _p: [u8; 0] }
 /// 16 floats: h2d, matvec, ntt, msm_h, msm_z, finish, total, accum_g1, accum_g2, 7 reserved (milliseconds)
 #[repr(C)] #[derive(Default, Clone, Copy)] pub struct zkhip_timings { pub ms: [f32; 16] }
 
@@ -27,4 +28,18 @@ extern "C" {
         r: *const u8, s: *const u8, proof_out: *mut u8, timings: *mut zkhip_timings) -> i32;
     pub fn zkhip_prove_gm17(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, cs: *const zkhip_r1cs, z: *const u8,
         d1_d2_r: *const u8, proof_out: *mut u8, timings: *mut zkhip_timings) -> i32;
+    // one proof across several GPUs of this process
+    pub fn zkhip_ctx_create_multi(devices: *const i32, n: i32, out: *mut *mut zkhip_multi) -> i32;
+    pub fn zkhip_multi_free(m: *mut zkhip_multi);
+    pub fn zkhip_multi_last_error(m: *const zkhip_multi) -> *const c_char;
+    pub fn zkhip_multi_r1cs_load(m: *mut zkhip_multi, curve: i32, n: u64, l: u64, w: u64,
+        rp_a: *const u64, col_a: *const u32, val_a: *const u8,
+        rp_b: *const u64, col_b: *const u32, val_b: *const u8,
+        rp_c: *const u64, col_c: *const u32, val_c: *const u8) -> i32;
+    pub fn zkhip_multi_pk_load_g16(m: *mut zkhip_multi, curve: i32, bytes: *const u8, len: usize) -> i32;
+    pub fn zkhip_multi_pk_load_gm17(m: *mut zkhip_multi, curve: i32, bytes: *const u8, len: usize) -> i32;
+    pub fn zkhip_prove_g16_multi(m: *mut zkhip_multi, z: *const u8, r: *const u8, s: *const u8, proof_out: *mut u8,
+        timings: *mut zkhip_timings) -> i32;
+    pub fn zkhip_prove_gm17_multi(m: *mut zkhip_multi, z: *const u8, d1_d2_r: *const u8, proof_out: *mut u8,
+        timings: *mut zkhip_timings) -> i32;
 }
