@@ -149,7 +149,11 @@ struct zkhip_ctx {
     int device = 0;
     Stream stream = 0;        // main stream: staging, sort, mat-vec, NTTs (high priority: short kernels the H MSM waits for)
     Stream out_stream = 0;    // copies the window sums out once every MSM of a proof is done
+    Stream ntt_stream = 0;    // the mat-vec / NTT / h-sort pipeline of a proof in flight (high priority): off the main stream, so that
+                              // the next proof's staging and z-sort (what its four big MSMs wait for) do not queue behind it
+    Stream ws = 0;            // the stream the mat-vec / NTT helpers launch on right now (ntt_stream inside a proof, else `stream`)
     bool serial = false;      // ZKHIP_SERIAL=1: every MSM on the main stream (debugging / per-kernel timing)
+    bool shared_lane_streams = false;   // lane k of every slot on one stream (the round-1 schedule; measurement hook)
     int cus = 256;            // compute units of the device: sizes the accumulation launch (one slice per resident work-item)
     // tunables (zkhip_ctx_tune; the environment variables ZKHIP_SERIAL, ZKHIP_MSM_C, ZKHIP_MSM_WAVES and
     // ZKHIP_NTT_SINGLE_MAX_LOG give their initial values, read ONCE when the context is created)
@@ -329,14 +333,14 @@ template <class C>
 static void ntt_cols(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, int nvec = 1, u64 vec_stride = 0,
                      int canon = 0) {
     typedef typename C::Fr Fr;
-    ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3(pl->N2 / pl->C_cols, nvec), dim3(pl->threads_cols), pl->smem_cols, ctx->stream, data, vec_stride,
+    ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3(pl->N2 / pl->C_cols, nvec), dim3(pl->threads_cols), pl->smem_cols, ctx->ws, data, vec_stride,
               pl->log1, pl->N2, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon);
 }
 template <class C>
 static void ntt_rows(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, int nvec = 1, u64 vec_stride = 0,
                      int canon = 0) {
     typedef typename C::Fr Fr;
-    ZK_LAUNCH((k_ntt_rows<typename Fr::Params>), dim3(pl->N1 / pl->R_rows, nvec), dim3(pl->threads_rows), pl->smem_rows, ctx->stream, data, vec_stride,
+    ZK_LAUNCH((k_ntt_rows<typename Fr::Params>), dim3(pl->N1 / pl->R_rows, nvec), dim3(pl->threads_rows), pl->smem_rows, ctx->ws, data, vec_stride,
               pl->log2, pl->R_rows, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, canon);
 }
 // natural order in -> sigma order out
@@ -415,8 +419,7 @@ static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, b
 
 // digits + counting sort on the main stream; leaves so.off / so.sorted describing every bucket's point list.
 // level_stride: distance between two levels of the base tables this sort will be paired with (table mode), else 0.
-static inline void msm_prepare(zkhip_ctx* ctx, MsmSort& so, const u32* d_scalars, const MsmShape& sh, u64 level_stride) {
-    Stream s = ctx->stream;
+static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32* d_scalars, const MsmShape& sh, u64 level_stride) {
     const u64 nk = sh.nkeys;
     require(sh.n * (u64)sh.W < ((u64)1 << 32) - sh.nkeys, ZKHIP_ERR_BAD_ARG, "MSM too large for 32-bit sort offsets");
     require(level_stride * (u64)sh.W < ((u64)1 << 31) && sh.n < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "MSM too large for 31-bit table indices");
@@ -730,7 +733,7 @@ struct Prover {
     static void matvec(zkhip_ctx* ctx, const zkhip_r1cs* cs, const Fr* zmont, Fr* a, Fr* b, Fr* c, u64 n, u64 l, u64 N) {
         int g[3];
         for (int k = 0; k < 3; ++k) g[k] = matvec_group(cs->nnz[k], cs->n);
-        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), 3), dim3(256), 0, ctx->stream, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
+        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), 3), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
                   l, N, g[0], g[1], g[2]);
     }
     static unsigned gmax_rows(const int g[3]) { return (unsigned)std::max(g[0], std::max(g[1], g[2])); }
@@ -738,7 +741,7 @@ struct Prover {
     // K1-K4 on the device: leaves h (canonical integers, sigma order) in ctx->cur->va.  The three vectors a, b, c live
     // back to back in va and go through every pass together (one launch per pass, grid.y = 3).
     static void witness_map(zkhip_ctx* ctx, const zkhip_r1cs* cs, NttPlan<C>* pl) {
-        Stream s = ctx->stream;
+        Stream s = ctx->ws;
         const u64 N = pl->N;
         ctx->cur->va.ensure(3 * N * sizeof(Fr));
         Fr *a = ptr<Fr>(ctx->cur->va), *b = a + N, *c = b + N;
@@ -794,6 +797,7 @@ struct Prover {
         memcpy(sl.s, s_, 32);
         ctx->cur = &sl;
         Stream st = ctx->stream;
+        ctx->ws = st;
         if (z_host) {
             upload_z(ctx, sl.scalars, m, z_host, sl.zflag);
         } else {
@@ -815,7 +819,7 @@ struct Prover {
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
         if (pk->z_n) {
-            msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
+            msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
             msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
             msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
             msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
@@ -825,13 +829,17 @@ struct Prover {
         }
         event_record(sl.ev[1], st);
 
-        // ---- K1-K4
+        // ---- K1-K4 and the h-sort, on the NTT stream: the main stream is free for the next proof's staging and z-sort
+        Stream wn = ctx->serial ? st : ctx->ntt_stream;
+        stream_wait_event(wn, sl.ev[0]);
+        ctx->ws = wn;
         witness_map(ctx, cs, pl);
-        event_record(sl.ev[2], st);
+        ctx->ws = ctx->stream;
+        event_record(sl.ev[2], wn);
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
         if (pk->h_n) {
-            msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
+            msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
             msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
         } else {
             empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
@@ -1079,7 +1087,7 @@ struct Prover {
         // ad-hoc bases: no table of window multiples (building one costs ~15x the MSM itself), one bucket set per window
         const MsmShape sh = msm_shape(ctx, n, Fr::Params::BITS, false);
         d_ws.ensure((size_t)sh.sets * sizeof(Xyzz<F>));
-        msm_prepare(ctx, ctx->cur->sorts[0], ptr<u32>(ctx->cur->scalars), sh, 0);
+        msm_prepare(ctx, s, ctx->cur->sorts[0], ptr<u32>(ctx->cur->scalars), sh, 0);
         DBuf d_packed;
         d_packed.ensure(n * packed_point_bytes<F>());
         points_to_packed<F>(ctx, ptr<Aff<F>>(d_bases), d_packed.p, n);
@@ -1102,6 +1110,7 @@ struct Prover {
     static void ntt_api(zkhip_ctx* ctx, u32 log_n, int dir, uint8_t* data) {
         NttPlan<C>* pl = get_plan<C>(ctx, (int)log_n);
         Stream s = ctx->stream;
+        ctx->ws = s;
         const u64 N = pl->N;
         const unsigned T = 256, B = blocks_for(N, T);
         ctx->cur->va.ensure(N * sizeof(Fr));
@@ -1127,6 +1136,7 @@ struct Prover {
     }
 
     static void witness_map_api(zkhip_ctx* ctx, const zkhip_r1cs* cs, const uint8_t* z, uint8_t* h_out) {
+        ctx->ws = ctx->stream;
         NttPlan<C>* pl = get_plan<C>(ctx, cs->logN);
         const u64 m = cs->l + cs->w;
         uint8_t zero[32] = {0};

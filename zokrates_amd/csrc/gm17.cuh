@@ -203,6 +203,7 @@ struct Gm17 {
         memset(sl.s, 0, 32);
         ctx->cur = &sl;
         Stream st = ctx->stream;
+        ctx->ws = st;
         sl.scalars.ensure((M + 2) * 32);
         if (z_host) {
             Fr z0 = fe_from_bytes_canon<Fr>(z_host);
@@ -246,7 +247,7 @@ struct Gm17 {
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
         // (a sharded key covers only its index range of the bases and pairs them with the same range of the scalars)
         if (pk->z_n) {
-            msm_prepare(ctx, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
+            msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
             msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
             msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
             msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
@@ -257,17 +258,22 @@ struct Gm17 {
         event_record(sl.ev[1], st);
 
         // ---- quotient h0 = (U^2 - W)/Z: 2 iNTT, 2 coset NTT, pointwise, coset iNTT (sigma order, canonical)
-        event_record(sl.ntt_b, st);
+        // the transforms and the h-sort run on the NTT stream (the SAP rows above feed the z-sort and stay on the main one)
+        Stream wn = ctx->serial ? st : ctx->ntt_stream;
+        stream_wait_event(wn, sl.ev[1]);
+        ctx->ws = wn;
+        event_record(sl.ntt_b, wn);
         ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_coset), 2, D);
         ntt_kind_b<C>(ctx, pl, sa, false, nullptr, 2, D);
-        ZK_LAUNCH((k_sap_quotient<typename Fr::Params>), dim3(blocks_for(D, 256)), dim3(256), 0, st, sa, sc, pl->zinv_rp, sa, D);
+        ZK_LAUNCH((k_sap_quotient<typename Fr::Params>), dim3(blocks_for(D, 256)), dim3(256), 0, wn, sa, sc, pl->zinv_rp, sa, D);
         ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_cosetinv_canon), 1, 0, 1);
-        event_record(sl.ntt_e, st);
-        event_record(sl.ev[2], st);
+        ctx->ws = ctx->stream;
+        event_record(sl.ntt_e, wn);
+        event_record(sl.ev[2], wn);
 
         // ---- G = MSM(g_gamma2_z_t, h0)
         if (pk->h_n) {
-            msm_prepare(ctx, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
+            msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
             msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
         } else {
             P::empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);

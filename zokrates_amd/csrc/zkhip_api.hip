@@ -77,18 +77,26 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->device = device;
         ctx->stream = stream_create_high_priority();
         ctx->out_stream = stream_create();
+        ctx->ntt_stream = stream_create_high_priority();
+        ctx->ws = ctx->stream;
         ctx->serial = getenv("ZKHIP_SERIAL") != nullptr;
         ctx->msm_c_env = env_int("ZKHIP_MSM_C", 2, MSM_MAX_C, 0);
         ctx->msm_waves = env_int("ZKHIP_MSM_WAVES", 1, 8, 0);
         ctx->ntt_single_max = env_int("ZKHIP_NTT_SINGLE_MAX_LOG", 0, NTT_MAX_SUBLOG, 10);
         ctx->ntt_cols = env_int("ZKHIP_NTT_COLS", 1, 8, 2);
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
+        // every (slot, lane) has a stream of its own: with one stream per lane shared by the slots, the accumulation of
+        // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
+        // fold workgroup holding the machine 16 % of the time); ZKHIP_SHARED_LANE_STREAMS=1 restores that schedule
+        const bool shared_lanes = env_int("ZKHIP_SHARED_LANE_STREAMS", 0, 1, 0) != 0;
         Stream lane_streams[ZK_NLANES];
-        for (auto& st : lane_streams) st = stream_create();
+        if (shared_lanes)
+            for (auto& st : lane_streams) st = stream_create();
+        ctx->shared_lane_streams = shared_lanes;
         for (auto& sl : ctx->slots) {
             for (auto& so : sl.sorts) so.ready = event_create();
             for (int k = 0; k < ZK_NLANES; ++k) {
-                sl.lanes[k].stream = lane_streams[k];     // lane k of every slot shares one stream
+                sl.lanes[k].stream = shared_lanes ? lane_streams[k] : stream_create();
                 sl.lanes[k].done = event_create();
                 sl.acc_b[k] = event_create();
                 sl.acc_e[k] = event_create();
@@ -130,8 +138,10 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
         event_destroy(sl.ntt_e);
         host_free_pinned(sl.h_ws);
     }
-    for (int k = 0; k < ZK_NLANES; ++k) stream_destroy(ctx->slots[0].lanes[k].stream);
+    for (int q = 0; q < (ctx->shared_lane_streams ? 1 : ZK_NSLOTS); ++q)
+        for (int k = 0; k < ZK_NLANES; ++k) stream_destroy(ctx->slots[q].lanes[k].stream);
     stream_destroy(ctx->out_stream);
+    stream_destroy(ctx->ntt_stream);
     stream_destroy(ctx->stream);
     delete ctx;
 }
