@@ -89,6 +89,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
         // fold workgroup holding the machine 16 % of the time); ZKHIP_SHARED_LANE_STREAMS=1 restores that schedule
         const bool shared_lanes = env_int("ZKHIP_SHARED_LANE_STREAMS", 0, 1, 0) != 0;
+        const bool g2_first = env_int("ZKHIP_G2_PRIORITY", 0, 1, 1) != 0;
         Stream lane_streams[ZK_NLANES];
         if (shared_lanes)
             for (auto& st : lane_streams) st = stream_create();
@@ -96,7 +97,9 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         for (auto& sl : ctx->slots) {
             for (auto& so : sl.sorts) so.ready = event_create();
             for (int k = 0; k < ZK_NLANES; ++k) {
-                sl.lanes[k].stream = shared_lanes ? lane_streams[k] : stream_create();
+                // lane 3 is the G2 MSM: the longest accumulation AND the longest fold tail of a proof; at high priority its
+                // workgroups are dispatched first, it finishes early and its tail hides under the G1 accumulations
+                sl.lanes[k].stream = shared_lanes ? lane_streams[k] : (k == 3 && g2_first ? stream_create_high_priority() : stream_create());
                 sl.lanes[k].done = event_create();
                 sl.acc_b[k] = event_create();
                 sl.acc_e[k] = event_create();
