@@ -22,11 +22,17 @@ namespace zk {
 template <class P> struct UCfg;
 // FQ2_INLINE: whether the Fq2 product is inlined into the curve formulas (see the measurements next to ZK_FU_MUL_INLINE;
 // with 14 limbs an inlined G2 mixed addition is > 100 KB of code, so BLS12-381 keeps it as a call)
-template <> struct UCfg<Bn254Fq> { static constexpr int B = 29, N = 9; static constexpr bool FQ2_INLINE = true; };
-template <> struct UCfg<Bls381Fq> { static constexpr int B = 28, N = 14; static constexpr bool FQ2_INLINE = false; };
+#ifndef ZK_MUL_NQ
+#define ZK_MUL_NQ 1
+#endif
+#ifndef ZK_MUL_CHAIN
+#define ZK_MUL_CHAIN 0
+#endif
+template <> struct UCfg<Bn254Fq> { static constexpr int B = 29, N = 9, MUL_NQ = ZK_MUL_NQ; static constexpr bool FQ2_INLINE = true, MUL_CHAIN = ZK_MUL_CHAIN != 0; };
+template <> struct UCfg<Bls381Fq> { static constexpr int B = 28, N = 14, MUL_NQ = 1; static constexpr bool FQ2_INLINE = false, MUL_CHAIN = false; };
 // the scalar fields (NTT passes, kernels_ntt.cuh): both moduli are <= 255 bits
-template <> struct UCfg<Bn254Fr> { static constexpr int B = 29, N = 9; static constexpr bool FQ2_INLINE = false; };
-template <> struct UCfg<Bls381Fr> { static constexpr int B = 29, N = 9; static constexpr bool FQ2_INLINE = false; };
+template <> struct UCfg<Bn254Fr> { static constexpr int B = 29, N = 9, MUL_NQ = ZK_MUL_NQ; static constexpr bool FQ2_INLINE = false, MUL_CHAIN = ZK_MUL_CHAIN != 0; };
+template <> struct UCfg<Bls381Fr> { static constexpr int B = 29, N = 9, MUL_NQ = ZK_MUL_NQ; static constexpr bool FQ2_INLINE = false, MUL_CHAIN = ZK_MUL_CHAIN != 0; };
 
 // ---- compile-time constants: p, -p^-1, powers of two mod p and bias multiples of p, all in B-bit limbs ----
 template <class P>
@@ -191,141 +197,94 @@ template <class P> ZK_HD Fu<P> fe_sub(const Fu<P>& a, const Fu<P>& b) { return f
 // obeys the same bounds as any other; the all-zero sentinel of the point at infinity stays all-zero
 template <class P> ZK_HD Fu<P> fe_neg(const Fu<P>& a) { return a.is_zero() ? a : fe_sub_k<2>(Fu<P>::zero(), a); }
 
-// Montgomery product a*b/R' (product scanning; the column accumulator never overflows for TIGHT operands)
-template <class P>
-ZK_HD Fu<P> fu_mul_inl(const Fu<P>& a, const Fu<P>& b) {
+// ---- the products ----
+// Product scanning (Comba): column k collects a_i * b_(k-i) and m_i * p_(k-i) in 64-bit accumulators that never overflow
+// for TIGHT operands, m_k makes the column's low B bits vanish, the rest carries into column k+1.
+// How the multiply-adds of one column are issued can matter: written as ONE accumulator the column is a chain of up to
+// 18 dependent v_mad_u64_u32 (hipcc starts the next column in a fresh register and pays a 64-bit add per column to join
+// them).  UCfg::MUL_NQ > 1 feeds each column's partial products to several accumulators round-robin and MUL_CHAIN keeps
+// the compiler from re-splitting the carry chain.  In isolation at 3 wavefronts per SIMD that is worth +24 %
+// (tools/mul29_bench.hip: 137.7 -> 171.4 G products/s with 2 accumulators + chain); inside the curve and NTT kernels,
+// whose formulas already offer several independent products, it is worth nothing (same-box A/B, profiles/r2_ab_runs.txt:
+// 87.3 vs 88.8 proofs/s) and the 14-limb BLS12-381 G1 unit then takes 40 minutes to compile — so the default is the
+// single accumulator (MUL_NQ = 1, MUL_CHAIN = 0), and the knobs stay for the next compiler.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_CARRY_CHAIN(x) asm volatile("" : "+v"(x))
+#else
+#define ZK_CARRY_CHAIN(x)
+#endif
+// one Montgomery reduction over `NT` operand pairs: r = (sum_t x[t] * y[t]) / R'.  x[t], y[t]: pointers to N limbs.
+// SQR (NT = 1, x = y): the cross terms are taken once against the doubled limb.
+template <class P, int NT, bool SQR>
+ZK_HD Fu<P> fu_dot_inl(const u32* const (&x)[NT], const u32* const (&y)[NT]) {
     typedef UConst<P> C;
-    constexpr int N = Fu<P>::N, B = Fu<P>::B;
+    constexpr int N = Fu<P>::N, B = Fu<P>::B, NQ = UCfg<P>::MUL_NQ;
     constexpr u32 M = Fu<P>::M;
-    u32 m[N];
+    u32 m[N], x2[N];
+    if (SQR) { ZK_UNROLL for (int i = 0; i < N; ++i) x2[i] = x[0][i] << 1; }
     Fu<P> r;
     u64 acc = 0;
-    ZK_UNROLL for (int k = 0; k < N; ++k) {
-        ZK_UNROLL for (int i = 0; i < k; ++i) {
-            acc += (u64)a.v[i] * b.v[k - i];
-            acc += (u64)m[i] * C::p(k - i);
+    ZK_UNROLL for (int k = 0; k < 2 * N - 1; ++k) {
+        u64 q[NQ];
+        ZK_UNROLL for (int t = 0; t < NQ; ++t) q[t] = 0;
+        int slot = 0;
+        ZK_UNROLL for (int i = 0; i < N; ++i) {
+            const int j = k - i;
+            if (j < 0 || j >= N) continue;
+            const bool last = k < N && i == k;          // the x_k * y_0 terms close the column (m_k follows them)
+            if (SQR) {
+                if (2 * i < k) { q[slot % NQ] += (u64)x2[i] * x[0][j]; ++slot; }
+            } else if (!last) {
+                ZK_UNROLL for (int t = 0; t < NT; ++t) { q[slot % NQ] += (u64)x[t][i] * y[t][j]; ++slot; }
+            }
+            if (i < k && j >= 1) { q[slot % NQ] += (u64)m[i] * C::p(j); ++slot; }
         }
-        acc += (u64)a.v[k] * b.v[0];
-        m[k] = ((u32)acc * C::NINV) & M;
-        acc += (u64)m[k] * C::p(0);
-        acc >>= B;
-    }
-    ZK_UNROLL for (int k = N; k < 2 * N - 1; ++k) {
-        ZK_UNROLL for (int i = k - N + 1; i < N; ++i) {
-            acc += (u64)a.v[i] * b.v[k - i];
-            acc += (u64)m[i] * C::p(k - i);
+        ZK_UNROLL for (int t = 0; t < NQ; ++t) acc += q[t];
+        if (SQR) {
+            if ((k & 1) == 0) acc += (u64)x[0][k / 2] * x[0][k / 2];
+        } else if (k < N) {
+            ZK_UNROLL for (int t = 0; t < NT; ++t) acc += (u64)x[t][k] * y[t][0];
         }
-        r.v[k - N] = (u32)acc & M;
+        if (k < N) {
+            m[k] = ((u32)acc * C::NINV) & M;
+            acc += (u64)m[k] * C::p(0);
+        } else {
+            r.v[k - N] = (u32)acc & M;
+        }
         acc >>= B;
+        if (UCfg<P>::MUL_CHAIN) { ZK_CARRY_CHAIN(acc); }
     }
     r.v[N - 1] = (u32)acc;
     return r;
 }
-// a*a/R': the cross terms a_i*a_j (i < j) are taken once against the doubled limb, N(N+1)/2 products instead of N^2
+// Montgomery product a*b/R'
+template <class P>
+ZK_HD Fu<P> fu_mul_inl(const Fu<P>& a, const Fu<P>& b) {
+    const u32* const x[1] = {a.v};
+    const u32* const y[1] = {b.v};
+    return fu_dot_inl<P, 1, false>(x, y);
+}
+// a*a/R': N(N+1)/2 products instead of N^2
 template <class P>
 ZK_HD Fu<P> fu_sqr_inl(const Fu<P>& a) {
-    typedef UConst<P> C;
-    constexpr int N = Fu<P>::N, B = Fu<P>::B;
-    constexpr u32 M = Fu<P>::M;
-    u32 m[N], a2[N];
-    ZK_UNROLL for (int i = 0; i < N; ++i) a2[i] = a.v[i] << 1;
-    Fu<P> r;
-    u64 acc = 0;
-    ZK_UNROLL for (int k = 0; k < N; ++k) {
-        ZK_UNROLL for (int i = 0; i < k; ++i) {
-            if (2 * i < k) acc += (u64)a2[i] * a.v[k - i];
-            acc += (u64)m[i] * C::p(k - i);
-        }
-        if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
-        m[k] = ((u32)acc * C::NINV) & M;
-        acc += (u64)m[k] * C::p(0);
-        acc >>= B;
-    }
-    ZK_UNROLL for (int k = N; k < 2 * N - 1; ++k) {
-        ZK_UNROLL for (int i = k - N + 1; i < N; ++i) {
-            if (2 * i < k) acc += (u64)a2[i] * a.v[k - i];
-            acc += (u64)m[i] * C::p(k - i);
-        }
-        if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
-        r.v[k - N] = (u32)acc & M;
-        acc >>= B;
-    }
-    r.v[N - 1] = (u32)acc;
-    return r;
+    const u32* const x[1] = {a.v};
+    return fu_dot_inl<P, 1, true>(x, x);
 }
 // (a*b + c*d)/R' with one reduction — the building block of the Fq2 product
 template <class P>
 ZK_HD Fu<P> fu_mul2_inl(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d) {
-    typedef UConst<P> C;
-    constexpr int N = Fu<P>::N, B = Fu<P>::B;
-    constexpr u32 M = Fu<P>::M;
-    u32 m[N];
-    Fu<P> r;
-    u64 acc = 0;
-    ZK_UNROLL for (int k = 0; k < N; ++k) {
-        ZK_UNROLL for (int i = 0; i < k; ++i) {
-            acc += (u64)a.v[i] * b.v[k - i];
-            acc += (u64)c.v[i] * d.v[k - i];
-            acc += (u64)m[i] * C::p(k - i);
-        }
-        acc += (u64)a.v[k] * b.v[0];
-        acc += (u64)c.v[k] * d.v[0];
-        m[k] = ((u32)acc * C::NINV) & M;
-        acc += (u64)m[k] * C::p(0);
-        acc >>= B;
-    }
-    ZK_UNROLL for (int k = N; k < 2 * N - 1; ++k) {
-        ZK_UNROLL for (int i = k - N + 1; i < N; ++i) {
-            acc += (u64)a.v[i] * b.v[k - i];
-            acc += (u64)c.v[i] * d.v[k - i];
-            acc += (u64)m[i] * C::p(k - i);
-        }
-        r.v[k - N] = (u32)acc & M;
-        acc >>= B;
-    }
-    r.v[N - 1] = (u32)acc;
-    return r;
+    const u32* const x[2] = {a.v, c.v};
+    const u32* const y[2] = {b.v, d.v};
+    return fu_dot_inl<P, 2, false>(x, y);
 }
 // (a*b + c*d + e*f + g*h)/R' with one reduction: four products of TIGHT operands still fit the 64-bit column accumulators
 // (4 * 9 * 2^58 + 9 * 2^58 < 2^63.4).  Operand values < 8p: result < (4 * 64 p^2) / R' + p < 3p for both base fields' R' >= 2^7 p.
 template <class P>
 ZK_HD Fu<P> fu_mul4_inl(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d, const Fu<P>& e, const Fu<P>& f, const Fu<P>& g,
                         const Fu<P>& h) {
-    typedef UConst<P> C;
-    constexpr int N = Fu<P>::N, B = Fu<P>::B;
-    constexpr u32 M = Fu<P>::M;
-    u32 m[N];
-    Fu<P> r;
-    u64 acc = 0;
-    ZK_UNROLL for (int k = 0; k < N; ++k) {
-        ZK_UNROLL for (int i = 0; i < k; ++i) {
-            acc += (u64)a.v[i] * b.v[k - i];
-            acc += (u64)c.v[i] * d.v[k - i];
-            acc += (u64)e.v[i] * f.v[k - i];
-            acc += (u64)g.v[i] * h.v[k - i];
-            acc += (u64)m[i] * C::p(k - i);
-        }
-        acc += (u64)a.v[k] * b.v[0];
-        acc += (u64)c.v[k] * d.v[0];
-        acc += (u64)e.v[k] * f.v[0];
-        acc += (u64)g.v[k] * h.v[0];
-        m[k] = ((u32)acc * C::NINV) & M;
-        acc += (u64)m[k] * C::p(0);
-        acc >>= B;
-    }
-    ZK_UNROLL for (int k = N; k < 2 * N - 1; ++k) {
-        ZK_UNROLL for (int i = k - N + 1; i < N; ++i) {
-            acc += (u64)a.v[i] * b.v[k - i];
-            acc += (u64)c.v[i] * d.v[k - i];
-            acc += (u64)e.v[i] * f.v[k - i];
-            acc += (u64)g.v[i] * h.v[k - i];
-            acc += (u64)m[i] * C::p(k - i);
-        }
-        r.v[k - N] = (u32)acc & M;
-        acc >>= B;
-    }
-    r.v[N - 1] = (u32)acc;
-    return r;
+    const u32* const x[4] = {a.v, c.v, e.v, g.v};
+    const u32* const y[4] = {b.v, d.v, f.v, h.v};
+    return fu_dot_inl<P, 4, false>(x, y);
 }
 // out-of-line forms (operands by value in VGPRs) — what the curve code calls; see fe_mul_nc in field.cuh
 template <class P> ZK_HD_CALL Fu<P> fu_mul(const Fu<P> a, const Fu<P> b) { return fu_mul_inl(a, b); }
