@@ -1,0 +1,30 @@
+#!/bin/bash
+# final verification of a round on the GPU box: smoke, the whole -m gpu suite, the default bench line (with the CPU
+# baseline), the other configurations of BASELINE.json.  Usage: bash tools/gpu_final.sh <tag>
+set -u
+tag=${1:-final}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+cd "$root"
+git rev-parse HEAD > "$out/head.txt" 2>/dev/null || true
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1 || { echo "SMOKE FAILED: giving the box back"; tail -5 "$out/smoke.log"; exit 0; }
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
+timeout 600 python bench.py > "$out/bench_default.json" 2> "$out/bench.err"
+timeout 600 python bench.py --scheme gm17 > "$out/bench_gm17.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --curve bls12_381 --log-domain 18 --kind poseidon > "$out/bench_poseidon_bls12_381_2e18.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --kind sha --cpu-seconds 0 > "$out/bench_sha_like.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --cpu-seconds 0 --constraints 1048576 --steps 16 > "$out/bench_n2e20_literal_domain2e21.json" 2>> "$out/bench.err"
+timeout 900 python bench.py --cpu-seconds 0 --log-domain 22 --steps 8 --members 8 > "$out/bench_config3_2e22_members8.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --cpu-seconds 0 --members 8 --steps 16 > "$out/bench_2e20_members8.json" 2>> "$out/bench.err"
+cat "$out/smoke.log" | tail -1; tail -12 "$out/pytest_gpu.log"
+for f in default gm17 poseidon_bls12_381_2e18 sha_like n2e20_literal_domain2e21 config3_2e22_members8 2e20_members8; do python - "$out/bench_$f.json" <<'PY'
+import json,sys
+for line in open(sys.argv[1]):
+    try:
+        d=json.loads(line); c=d.get('cpu_baseline') or {}; m=d.get('multi_single_proof') or {}
+        print(sys.argv[1].split('/')[-1][6:-5], round(d['value'],2), 'proofs/s |', round(d['single_proof_ms'],2),'ms single |', round(d['single_proof_from_host_ms'],2), 'from host | cpu', c.get('value'), c.get('gpu_proof_identical'), '| multi', m.get('ms'), m.get('identical_to_unsharded'), '| ntt frac_serial', (d.get('roofline_ntt') or {}).get('frac_serial'))
+    except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+done
+tail -3 "$out/bench.err"
