@@ -123,9 +123,19 @@ inline void event_destroy(Event e) { (void)hipEventDestroy(e); }
 inline void event_record(Event e, Stream s) { ZK_HIP_CHECK(hipEventRecord(e, s)); }
 inline void event_sync(Event e) { ZK_HIP_CHECK(hipEventSynchronize(e)); }
 inline void stream_wait_event(Stream s, Event e) { ZK_HIP_CHECK(hipStreamWaitEvent(s, e, 0)); }
+// Both events have been recorded; the caller has waited for the work it depends on, but an event on ANOTHER stream (the
+// main stream's "MSMs issued" marker, say) may still sit in a hardware queue behind a different context's kernels —
+// streams outnumber hardware queues — so "not ready" is answered by waiting, not by failing the proof.
 inline float event_elapsed_ms(Event a, Event b) {
     float ms = 0;
-    ZK_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    hipError_t e = hipEventElapsedTime(&ms, a, b);
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        ZK_HIP_CHECK(hipEventSynchronize(a));
+        ZK_HIP_CHECK(hipEventSynchronize(b));
+        e = hipEventElapsedTime(&ms, a, b);
+    }
+    ZK_HIP_CHECK(e);
     return ms;
 }
 inline void dev_check_last() { ZK_HIP_CHECK(hipGetLastError()); }
