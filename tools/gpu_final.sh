@@ -17,7 +17,17 @@ timeout 600 python bench.py --kind sha --cpu-seconds 0 > "$out/bench_sha_like.js
 timeout 600 python bench.py --cpu-seconds 0 --constraints 1048576 --steps 16 > "$out/bench_n2e20_literal_domain2e21.json" 2>> "$out/bench.err"
 timeout 900 python bench.py --cpu-seconds 0 --log-domain 22 --steps 8 --members 8 > "$out/bench_config3_2e22_members8.json" 2>> "$out/bench.err"
 timeout 600 python bench.py --cpu-seconds 0 --members 8 --steps 16 > "$out/bench_2e20_members8.json" 2>> "$out/bench.err"
+# the N > 1 code path of bench.py on real hardware: two ranks sharing this box's one GPU (gloo instead of RCCL, which wants
+# one device per rank); rank 0 also drives the in-library multi leg
+ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 \
+  bench.py --gpus 2 --steps 8 --warmup 2 > "$out/bench_two_ranks_one_gpu.json" 2>> "$out/bench.err"
 cat "$out/smoke.log" | tail -1; tail -12 "$out/pytest_gpu.log"
+python - "$out/bench_two_ranks_one_gpu.json" <<'PY'
+import json,sys
+for line in open(sys.argv[1]):
+    if line.startswith('{'):
+        d=json.loads(line); print('two ranks on one GPU:', round(d['value'],2), 'proofs/s aggregate, n_gpus', d['n_gpus'], '| sharded', d.get('sharded_single_proof'), '| multi', {k:v for k,v in (d.get('multi_single_proof') or {}).items() if k in ('ms','members','distinct_gpus','identical_to_unsharded','error')})
+PY
 for f in default gm17 poseidon_bls12_381_2e18 sha_like n2e20_literal_domain2e21 config3_2e22_members8 2e20_members8; do python - "$out/bench_$f.json" <<'PY'
 import json,sys
 for line in open(sys.argv[1]):

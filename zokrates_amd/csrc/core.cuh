@@ -164,6 +164,7 @@ struct zkhip_ctx {
     bool fold_scan = true;    // scan form of the last fold step (else double-and-add)
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
+    u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
     int nslots = 3;           // proofs in flight in the batch calls (<= ZK_NSLOTS; measured 2 / 3 / 4: 72.0 / 76.0 / 74.8 proofs/s)
     std::string err;
     std::string desc;
@@ -439,7 +440,7 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     lds_opt_in(ctx, (const void*)k_msm_count);
     lds_opt_in(ctx, (const void*)k_msm_place);
     const u32 kh = std::min<u32>(sh.K, 1u << 15), nsplit = sh.K / kh;
-    const u64 want_chunks = std::max<u64>(1, (256 + sh.W * nsplit - 1) / (sh.W * nsplit));
+    const u64 want_chunks = std::max<u64>(1, (ctx->sort_wgs + sh.W * nsplit - 1) / (sh.W * nsplit));
     const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)kh));
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
     const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;

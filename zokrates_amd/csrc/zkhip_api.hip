@@ -85,6 +85,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->ntt_single_max = env_int("ZKHIP_NTT_SINGLE_MAX_LOG", 0, NTT_MAX_SUBLOG, 10);
         ctx->ntt_cols = env_int("ZKHIP_NTT_COLS", 1, 8, 2);
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
+        ctx->sort_wgs = (u32)env_int("ZKHIP_SORT_WGS", 16, 4096, 256);
         // every (slot, lane) has a stream of its own: with one stream per lane shared by the slots, the accumulation of
         // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
         // fold workgroup holding the machine 16 % of the time); ZKHIP_SHARED_LANE_STREAMS=1 restores that schedule

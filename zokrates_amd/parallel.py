@@ -26,8 +26,10 @@ class Ranks:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if self.backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                # LOCAL_RANK, unless the launcher narrowed this process's view to one device
+                dev = self.local_rank if self.local_rank < torch.cuda.device_count() else 0
+                torch.cuda.set_device(dev)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
             else:
                 dist.init_process_group(self.backend)
 
