@@ -263,6 +263,13 @@ int32_t zkhip_prove_g16_multi(zkhip_multi* m, const uint8_t* z, const uint8_t* r
                               zkhip_timings* timings);
 int32_t zkhip_prove_gm17_multi(zkhip_multi* m, const uint8_t* z, const uint8_t* d1_d2_r, uint8_t* proof_out,
                                zkhip_timings* timings);
+/* Throughput mode of the same object (SURVEY.md §8e "replicas"): zkhip_multi_pk_load_g16_replicas puts the WHOLE key on every
+ * member, zkhip_prove_g16_multi_batch splits `count` independent proofs (z: count x m x 32 B, rs: count x 64 B = r | s,
+ * proofs_out: count x proof bytes) into one contiguous block per member and runs the members' pipelined batch calls on
+ * one host thread each — no communication at all; what a long-lived prover service behind the trait would call. */
+int32_t zkhip_multi_pk_load_g16_replicas(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len);
+int32_t zkhip_prove_g16_multi_batch(zkhip_multi* m, uint32_t count, const uint8_t* z, const uint8_t* rs, uint8_t* proofs_out,
+                                    zkhip_timings* timings);
 
 /* ---- "next" row N2: proving-key cache ----
  * zkhip_pk_export writes the *resident* form of a loaded key (Groth16 or GM17, whole or one shard): packed Montgomery

@@ -42,4 +42,8 @@ extern "C" {
         timings: *mut zkhip_timings) -> i32;
     pub fn zkhip_prove_gm17_multi(m: *mut zkhip_multi, z: *const u8, d1_d2_r: *const u8, proof_out: *mut u8,
         timings: *mut zkhip_timings) -> i32;
+    // throughput mode: whole key per member, `count` independent proofs dealt over the members
+    pub fn zkhip_multi_pk_load_g16_replicas(m: *mut zkhip_multi, curve: i32, bytes: *const u8, len: usize) -> i32;
+    pub fn zkhip_prove_g16_multi_batch(m: *mut zkhip_multi, count: u32, z: *const u8, rs: *const u8, proofs_out: *mut u8,
+        timings: *mut zkhip_timings) -> i32;
 }

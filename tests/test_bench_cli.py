@@ -68,3 +68,5 @@ def test_two_ranks_real_bench_script(scheme, port):
     assert s.get("identical_to_unsharded") is True and s["ranks"] == 2, s
     mm = d["multi_single_proof"]                      # the in-library path: rank 0 drives one member per rank's device
     assert mm.get("identical_to_unsharded") is True and mm["members"] == 2, mm
+    if scheme == "g16":                               # and its throughput mode (whole key per member, proofs dealt over the members)
+        assert mm["replicas_batch"]["first_identical_to_unsharded"] is True and mm["replicas_batch"]["proofs"] == 16, mm

@@ -37,6 +37,17 @@ def _checks(lib, devices, curve, log_domain, kind="dense"):
         assert native.prove_g16(ctx, native.ProvingKey(ctx, cid, raw), cs, z, r, s) == got
         with pytest.raises(native.ZkhipError):          # a Groth16 key does not prove GM17
             multi.prove_gm17(z, 1, 2, 3)
+        # throughput mode on the same members: whole key everywhere, independent proofs dealt round-robin
+        multi.load_proving_key_replicas(cid, raw)
+        zs = [circ.assignment(0x5EED + 7 * i) for i in range(2 * len(devices) + 1)]
+        rss = [(1000 + i, 2000 + 3 * i) for i in range(len(zs))]
+        proofs, _ = multi.prove_g16_batch(zs, rss)
+        assert proofs == [cpu.trapdoor(oc, tox, zs[i], *rss[i]) for i in range(len(zs))]
+        assert multi.prove_g16_batch(zs[:1], rss[:1])[0] == proofs[:1]          # fewer proofs than members
+        assert multi.prove_g16_batch([], [])[0] == []
+        with pytest.raises(native.ZkhipError):          # whole keys do not take part in a sharded proof
+            multi.prove_g16(z, r, s)
+        multi.load_proving_key(cid, raw)
         # GM17 on the same members
         tox17 = gm17.Toxic.from_seed(curve)
         tb17 = cpu.gm17_toxic_bytes(tox17)

@@ -536,6 +536,7 @@ struct zkhip_multi {
     std::vector<zkhip_pk*> pk;       // member k: shard k of n
     std::vector<zkhip_r1cs*> cs;     // replicas
     int scheme = -1;                 // of the loaded key: 0 Groth16, 1 GM17
+    bool replicas = false;           // every member holds the WHOLE key (throughput mode) instead of shard k of n
     std::string err;
 };
 }  // extern "C"
@@ -570,6 +571,7 @@ extern "C" {
 static void multi_drop_keys(zkhip_multi* m) {
     for (auto*& p : m->pk) { zkhip_pk_free(p); p = nullptr; }
     m->scheme = -1;
+    m->replicas = false;
 }
 int32_t zkhip_ctx_create_multi(const int32_t* devices, int32_t n, zkhip_multi** out) {
     if (!out) { g_create_err = "out is NULL"; return ZKHIP_ERR_BAD_ARG; }
@@ -626,10 +628,49 @@ int32_t zkhip_multi_pk_load_gm17(zkhip_multi* m, int32_t curve, const uint8_t* b
     if (rc == ZKHIP_OK) m->scheme = 1; else multi_drop_keys(m);
     return rc;
 }
+// throughput mode: the whole key on every member; zkhip_prove_g16_multi_batch deals independent proofs round-robin
+int32_t zkhip_multi_pk_load_g16_replicas(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    multi_drop_keys(m);
+    const int32_t rc = multi_each(m, [&](size_t k) { return zkhip_pk_load_g16(m->ctx[k], curve, bytes, len, &m->pk[k]); });
+    if (rc == ZKHIP_OK) { m->scheme = 0; m->replicas = true; } else multi_drop_keys(m);
+    return rc;
+}
+int32_t zkhip_prove_g16_multi_batch(zkhip_multi* m, uint32_t count, const uint8_t* z, const uint8_t* rs, uint8_t* proofs_out, zkhip_timings* timings) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    if ((!z || !rs || !proofs_out) && count) { m->err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
+    if (m->scheme != 0 || !m->replicas || !m->cs[0]) {
+        m->err = "load the constraint system and zkhip_multi_pk_load_g16_replicas first";
+        return ZKHIP_ERR_BAD_ARG;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t n = m->ctx.size();
+    const uint64_t zb = (uint64_t)m->pk[0]->m * 32;
+    const size_t proof_bytes = (m->pk[0]->curve == ZKHIP_CURVE_BN128 ? 32 : 48) * 8 + 3;
+    // member k proves the contiguous block [lo_k, hi_k) of the batch through its own pipelined batch call
+    std::vector<zkhip_timings> tm(n);
+    const int32_t rc = multi_each(m, [&](size_t k) {
+        const uint64_t lo = (uint64_t)count * k / n, hi = (uint64_t)count * (k + 1) / n;
+        memset(&tm[k], 0, sizeof(tm[k]));
+        if (hi == lo) return (int32_t)ZKHIP_OK;
+        return zkhip_prove_g16_batch(m->ctx[k], m->pk[k], m->cs[k], (uint32_t)(hi - lo), z + lo * zb, rs + lo * 64, proofs_out + lo * proof_bytes, &tm[k]);
+    });
+    if (rc != ZKHIP_OK) return rc;
+    if (timings) {
+        memset(timings, 0, sizeof(*timings));
+        for (size_t k = 0; k < n; ++k) {
+            float* a = (float*)timings; const float* b = (const float*)&tm[k];
+            for (size_t q = 0; q < sizeof(zkhip_timings) / sizeof(float); ++q) a[q] += b[q];
+        }
+        timings->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return ZKHIP_OK;
+}
 static int32_t multi_prove(zkhip_multi* m, int scheme, const uint8_t* z, const uint8_t* rnd, const uint8_t* s_, uint8_t* proof_out, zkhip_timings* timings) {
     if (!m) return ZKHIP_ERR_BAD_ARG;
     if (!z || !rnd || !proof_out || (scheme == 0 && !s_)) { m->err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
     if (m->scheme != scheme || !m->cs[0]) { m->err = "load the constraint system and a proving key of this scheme first"; return ZKHIP_ERR_BAD_ARG; }
+    if (m->replicas) { m->err = "the members hold whole keys (replicas): use zkhip_prove_g16_multi_batch, or load the key sharded"; return ZKHIP_ERR_BAD_ARG; }
     const auto t0 = std::chrono::steady_clock::now();
     uint64_t rec = 0;
     zkhip_partial_size(m->pk[0]->curve, &rec);

@@ -62,6 +62,7 @@ class Library:
         "zkhip_ctx_tune",
         "zkhip_ctx_create_multi", "zkhip_multi_free", "zkhip_multi_size", "zkhip_multi_ctx", "zkhip_multi_last_error", "zkhip_multi_r1cs_load",
         "zkhip_multi_pk_load_g16", "zkhip_multi_pk_load_gm17", "zkhip_prove_g16_multi", "zkhip_prove_gm17_multi",
+        "zkhip_multi_pk_load_g16_replicas", "zkhip_prove_g16_multi_batch",
     ]
 
     def __init__(self, path=None):
@@ -86,6 +87,8 @@ class Library:
         L.zkhip_multi_pk_load_gm17.restype = i32; L.zkhip_multi_pk_load_gm17.argtypes = [vp, i32, vp, sz]
         L.zkhip_prove_g16_multi.restype = i32; L.zkhip_prove_g16_multi.argtypes = [vp] * 6
         L.zkhip_prove_gm17_multi.restype = i32; L.zkhip_prove_gm17_multi.argtypes = [vp] * 5
+        L.zkhip_multi_pk_load_g16_replicas.restype = i32; L.zkhip_multi_pk_load_g16_replicas.argtypes = [vp, i32, vp, sz]
+        L.zkhip_prove_g16_multi_batch.restype = i32; L.zkhip_prove_g16_multi_batch.argtypes = [vp, u32, vp, vp, vp, vp]
         L.zkhip_last_error.restype = C.c_char_p; L.zkhip_last_error.argtypes = [vp]
         L.zkhip_pk_load_g16.restype = i32; L.zkhip_pk_load_g16.argtypes = [vp, i32, vp, sz, pp]
         L.zkhip_pk_free.restype = None; L.zkhip_pk_free.argtypes = [vp]
@@ -611,6 +614,25 @@ class Multi:
         fn = self.lib.L.zkhip_multi_pk_load_gm17 if scheme == "gm17" else self.lib.L.zkhip_multi_pk_load_g16
         self._check(fn(self.h, curve_id, _ptr(b), b.size))
         self.curve_id = curve_id
+
+    def load_proving_key_replicas(self, curve_id, pk_bytes):
+        """Throughput mode: the whole Groth16 key on every member (`zkhip_multi_pk_load_g16_replicas`)."""
+        b = _u8(pk_bytes)
+        self._check(self.lib.L.zkhip_multi_pk_load_g16_replicas(self.h, curve_id, _ptr(b), b.size))
+        self.curve_id = curve_id
+
+    def prove_g16_batch(self, zs, rss):
+        """Independent proofs dealt over the members (`zkhip_prove_g16_multi_batch`): zs = list of host assignments,
+        rss = list of (r, s).  Returns (list of proof bytes, timings dict)."""
+        nb = FQ_BYTES[self.curve_id]
+        count = len(zs)
+        z = np.ascontiguousarray(np.concatenate([_u8(a, self.m * 32) for a in zs])) if count else np.zeros(1, dtype=np.uint8)
+        rs = np.frombuffer(b"".join(int(r).to_bytes(32, "little") + int(s).to_bytes(32, "little") for r, s in rss) or b"\0", dtype=np.uint8)
+        out = np.zeros(max(count, 1) * (8 * nb + 3), dtype=np.uint8)
+        tm = Timings()
+        self._check(self.lib.L.zkhip_prove_g16_multi_batch(self.h, count, _ptr(z), _ptr(rs), _ptr(out), C.byref(tm)))
+        pb = 8 * nb + 3
+        return [out[i * pb:(i + 1) * pb].tobytes() for i in range(count)], tm.as_dict()
 
     def prove_g16(self, z, r, s, want_timings=False):
         nb = FQ_BYTES[self.curve_id]
