@@ -83,7 +83,9 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
  * type); _MSM_LANES: number of slices the sorted list is cut into (0 = one per resident work-item); _MSM_MIN_SLICE: the
  * finest cut; _FOLD_SCAN: 0 selects the double-and-add form of the last fold step; _SERIAL: 1 puts every kernel on one
  * stream (un-overlapped per-kernel timing); _NTT_SINGLE_MAX_LOG: largest domain transformed in a single pass;
- * _NTT_COLS: adjacent columns per workgroup of the NTT cols pass; _SLOTS: proofs in flight in the batch calls (1..4). */
+ * _NTT_COLS: adjacent columns per workgroup of the NTT cols pass; _SLOTS: proofs in flight in the batch calls (1..4);
+ * _Z_GATE: which accumulations over the assignment wait for the witness map of their proof (0 none, 1 the three G1
+ * lanes — the default —, 2 the G2 lane as well). */
 #define ZKHIP_TUNE_MSM_C 1
 #define ZKHIP_TUNE_MSM_WAVES 2
 #define ZKHIP_TUNE_MSM_LANES 3
@@ -93,6 +95,7 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_NTT_SINGLE_MAX_LOG 7
 #define ZKHIP_TUNE_NTT_COLS 8
 #define ZKHIP_TUNE_SLOTS 9
+#define ZKHIP_TUNE_Z_GATE 10
 int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value);
 
 /* ---- proving key ----

@@ -162,6 +162,7 @@ struct zkhip_ctx {
     u32 msm_lanes = 0;        // slices of the sorted list (0 = one per resident work-item)
     u32 msm_min_slice = 8;    // finest cut of the sorted list
     bool fold_scan = true;    // scan form of the last fold step (else double-and-add)
+    int z_gate = 1;           // which accumulations over z wait for the witness map of their proof: 0 none, 1 the G1 lanes, 2 all
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
     u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
@@ -177,6 +178,8 @@ struct zkhip_ctx {
     std::unordered_set<const void*> lds_opted;
 };
 // gfx950 has 160 KiB of LDS per CU; anything above the 64 KiB default must be opted into, per kernel and per device
+// the z-lane gate of the proof being enqueued (see Prover::enqueue)
+static inline int z_gate(const zkhip_ctx* ctx) { return ctx->serial ? 0 : ctx->z_gate; }
 static inline void lds_opt_in(zkhip_ctx* ctx, const void* kernel) {
 #ifndef ZK_EMU
     if (ctx->lds_opted.count(kernel)) return;
@@ -465,7 +468,7 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
 // the saturated Montgomery form.
 template <class F>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<F>* d_window_sums,
-             Event ev_begin, Event ev_end);
+             Event ev_begin, Event ev_end, Event accum_after = nullptr);
 // affine points, saturated Montgomery form -> packed working form of the MSM kernels (level 0 of a table); on ctx->stream
 template <class F>
 void points_to_packed(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
@@ -819,24 +822,37 @@ struct Prover {
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // 4 G1 MSMs + 1 G2 MSM
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
+        // An accumulation kernel is sized to fill the machine, saturates the integer multiplier and nothing preempts it:
+        // whatever arrives beside it waits for a place or crawls (kernel traces, profiles/r2_single_proof_traces.md: a
+        // 0.14 ms mat-vec took 4 ms, a 0.2 ms transform pass 3 ms), h arrives late and the H MSM trails alone behind
+        // everything.  So the G2 lane (the longest chain of a proof) starts at once, the witness map runs beside it, and
+        // the G1 lanes over z wait for h (`z_gate`; 2 = the G2 lane waits as well).
+        const int gate = z_gate(ctx);
         if (pk->z_n) {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
-            msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
-            msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
-            msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
-            msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2]);
-        } else {
-            empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
+            if (gate < 2)
+                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
         }
-        event_record(sl.ev[1], st);
 
         // ---- K1-K4 and the h-sort, on the NTT stream: the main stream is free for the next proof's staging and z-sort
         Stream wn = ctx->serial ? st : ctx->ntt_stream;
         stream_wait_event(wn, sl.ev[0]);
+        event_record(sl.ev[1], wn);
         ctx->ws = wn;
         witness_map(ctx, cs, pl);
         ctx->ws = ctx->stream;
         event_record(sl.ev[2], wn);
+
+        if (pk->z_n) {
+            const Event h_ready = gate ? sl.ev[2] : nullptr;
+            if (gate >= 2)
+                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
+            msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
+            msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
+            msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
+        } else {
+            empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
+        }
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
         if (pk->h_n) {

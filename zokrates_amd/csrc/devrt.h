@@ -159,6 +159,15 @@ inline bool grid_nonempty(const dim3& g) { return g.x != 0 && g.y != 0 && g.z !=
         }                                                                                 \
     } while (0)
 #define ZK_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+// Issue priority of a wave (s_setprio, 0..3).  An accumulation kernel saturates the integer multiplier of every SIMD it
+// sits on and the arbiter serves the OLDEST wave first, so a short kernel that arrives beside it only gets the cycles it
+// leaves (kernel traces: a 0.14 ms mat-vec took 4 ms, a 0.05 ms bucket reduction 3.5 ms).  The short, latency-bound
+// kernels of a proof — sort, scans, folds, mat-vec, transforms — raise their priority first thing; the accumulation
+// kernels stay at 0.
+#ifndef ZK_WAVE_PRIO
+#define ZK_WAVE_PRIO 3
+#endif
+#define ZK_PRIO_HIGH() __builtin_amdgcn_s_setprio(ZK_WAVE_PRIO)
 
 #else  // ---------------------------- emulator ----------------------------
 
@@ -190,6 +199,7 @@ inline void dev_check_last() {}
 #define ZK_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch(dim3(grid), dim3(block), (size_t)(smem), [&]() { kernel(__VA_ARGS__); })
 #define ZK_DYN_SMEM(name) unsigned char* name = emu::dyn_smem()
+#define ZK_PRIO_HIGH() ((void)0)
 
 #endif
 

@@ -36,6 +36,7 @@ namespace zk {
 template <class P>
 __global__ void k_sap_rows(const Fe<P>* __restrict__ ra, const Fe<P>* __restrict__ rb, const Fe<P>* __restrict__ rc, const Fe<P>* __restrict__ z,
                            Fe<P>* __restrict__ sa, Fe<P>* __restrict__ sc, Fe<P>* __restrict__ ext, u64 n, u64 l, u64 m) {
+    ZK_PRIO_HIGH();
     typedef Fe<P> F;
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + l) return;
@@ -66,6 +67,7 @@ __global__ void k_sap_rows(const Fe<P>* __restrict__ ra, const Fe<P>* __restrict
 // quotient evaluations on the coset: out = (a^2 - c) * zinv     (R'-form operands < 2^256, canonical R'-form out)
 template <class P>
 __global__ void k_sap_quotient(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ c, Fe<P> zinv, Fe<P>* __restrict__ out, u64 n) {
+    ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Fu<P> aa = fu_sqr_inl(fu_unpack<P>(a[i].v));
@@ -237,6 +239,7 @@ struct Gm17 {
         Fr *ra = ptr<Fr>(sl.vc), *rb = ra + n, *rc = rb + n;
         if (n) P::matvec(ctx, cs, ptr<Fr>(sl.zmont), ra, rb, rc, n, 0, n);
         ZK_LAUNCH((k_sap_rows<typename Fr::Params>), dim3(blocks_for(n + l, 256)), dim3(256), 0, st, ra, rb, rc, ptr<Fr>(sl.zmont), sa, sc, (Fr*)d_scalars, n, l, m);
+        event_record(sl.ev[1], st);
 
         // ---- the four MSMs over S = [ext_0..ext_{M-1}, rho, 0] share one digit/sort pass
         const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
@@ -246,16 +249,13 @@ struct Gm17 {
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
         // (a sharded key covers only its index range of the bases and pairs them with the same range of the scalars)
+        // (the G1 lanes wait for the transforms, as in Prover::enqueue: the G2 lane starts at once)
+        const int gate = z_gate(ctx);
         if (pk->z_n) {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
-            msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
-            msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0]);
-            msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1]);
-            msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2]);
-        } else {
-            P::empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
+            if (gate < 2)
+                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
         }
-        event_record(sl.ev[1], st);
 
         // ---- quotient h0 = (U^2 - W)/Z: 2 iNTT, 2 coset NTT, pointwise, coset iNTT (sigma order, canonical)
         // the transforms and the h-sort run on the NTT stream (the SAP rows above feed the z-sort and stay on the main one)
@@ -270,6 +270,17 @@ struct Gm17 {
         ctx->ws = ctx->stream;
         event_record(sl.ntt_e, wn);
         event_record(sl.ev[2], wn);
+
+        if (pk->z_n) {
+            const Event h_ready = gate ? sl.ev[2] : nullptr;
+            if (gate >= 2)
+                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
+            msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
+            msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
+            msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
+        } else {
+            P::empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
+        }
 
         // ---- G = MSM(g_gamma2_z_t, h0)
         if (pk->h_n) {

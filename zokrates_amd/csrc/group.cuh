@@ -31,7 +31,7 @@ void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int c, int W) {
 
 template <class FS>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<FS>* d_window_sums,
-             Event ev_begin, Event ev_end) {
+             Event ev_begin, Event ev_end, Event accum_after) {
     typedef typename Unsat<FS>::type F;   // the kernels run on the unsaturated field
     const AffPacked<F>* d_bases = (const AffPacked<F>*)d_table;
     Stream s = ctx->serial ? ctx->stream : lane.stream;
@@ -50,25 +50,18 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_tab
     lds_opt_in(ctx, (const void*)k_msm_fold_cols<F>);
     lds_opt_in(ctx, (const void*)k_msm_fold_final<F, FS>);
     lds_opt_in(ctx, (const void*)k_msm_fold_final_scan<F, FS>);
-    lds_opt_in(ctx, (const void*)k_msm_heavy_reduce<F>);
     const unsigned T = 256;
     dev_memset(lane.heavy.p, 0, 4, s);
     ZK_LAUNCH(k_msm_lane_keys, dim3(blocks_for(nlanes, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.lane_key));
     ZK_LAUNCH(k_msm_find_heavy, dim3(blocks_for(sh.nkeys, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.heavy) + 1,
               ptr<u32>(lane.heavy));
+    if (accum_after && !ctx->serial) stream_wait_event(s, accum_after);   // (the slicing above only needs the sort)
     if (ev_begin) event_record(ev_begin, s);
     ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE>), dim3(blocks_for(nlanes, T)), dim3(T), 0, s, d_bases, ptr<u32>(so.off), ptr<u32>(so.sorted),
               ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), sh.nkeys, cut);
     if (ev_end) event_record(ev_end, s);
-#ifdef ZK_EMU
-    const unsigned heavy_wgs = 4;     // the fibre emulator pays for every work-item of an idle workgroup
-#else
-    const unsigned heavy_wgs = 256;
-#endif
-    ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(heavy_wgs), dim3(T), T * sizeof(Xyzz<F>), s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.heavy) + 1,
-              ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.partial));
     ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.sets), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial),
-              ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));
+              ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));
     const u32 CW = std::min<u32>(sh.Lw, 32), HG = std::max<u32>(1, std::min<u32>(8, sh.H));   // 256 work-items for big windows
     ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.sets), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
               sh.Lw, sh.H, ptr<Xyzz<F>>(lane.cols));
@@ -100,7 +93,7 @@ void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scal
 }
 
 #define ZK_INSTANTIATE_GROUP(F)                                                                                         \
-    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event);          \
+    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event, Event);   \
     template void points_to_packed<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                    \
     template void msm_table_levels<F>(zkhip_ctx*, void*, u64, int, int);                         \
     template void fixed_base_table<F>(zkhip_ctx*, const Aff<F>*, int, DBuf&);                                           \

@@ -103,6 +103,7 @@ static constexpr u32 MSM_HEAVY = 16;  // a bucket spread over more slices than t
 // key = j * key_stride + bucket (key_stride = K: one bucket set per window; 0: all windows share one set);
 // sorted entry = (j * idx_stride + i) | sign << 31 (idx_stride = table level stride, 0 without a table).
 static __global__ void k_scalars_to_word_major(const u32* __restrict__ scalars, u64 n, u32* __restrict__ wm) {
+    ZK_PRIO_HIGH();
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4* sp = (const uint4*)(scalars + i * 8);
@@ -139,6 +140,7 @@ static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ w
 // c = 16; wider windows split their buckets over blockIdx.z and every split rescans the chunk's digits).
 static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
                                                         u32* __restrict__ cnt) {
+    ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
     const u32 K = 1u << (c - 1);
@@ -162,6 +164,7 @@ static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict_
 static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
                                                         u64 idx_stride, const u32* __restrict__ off, u32* __restrict__ cursor,
                                                         u32* __restrict__ sorted) {
+    ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
     const u32 K = 1u << (c - 1);
@@ -201,6 +204,7 @@ static constexpr int SCAN_PER_THREAD = 16;
 static constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_PER_THREAD;
 
 static __global__ void k_scan_local(const u32* __restrict__ cnt, u32* __restrict__ off, u32* __restrict__ chunk_sum, u64 total) {
+    ZK_PRIO_HIGH();
     __shared__ u32 sh[SCAN_THREADS];
     const u64 base = (u64)blockIdx.x * SCAN_CHUNK + (u64)threadIdx.x * SCAN_PER_THREAD;
     u32 v[SCAN_PER_THREAD];
@@ -225,6 +229,7 @@ static __global__ void k_scan_local(const u32* __restrict__ cnt, u32* __restrict
 }
 // single workgroup: exclusive scan of the chunk sums in place (nchunks <= a few thousand); writes the grand total
 static __global__ void k_scan_chunks(u32* __restrict__ chunk_sum, u32 nchunks, u32* __restrict__ grand_total) {
+    ZK_PRIO_HIGH();
     __shared__ u32 sh[SCAN_THREADS];
     __shared__ u32 carry;
     if (threadIdx.x == 0) carry = 0;
@@ -248,6 +253,7 @@ static __global__ void k_scan_chunks(u32* __restrict__ chunk_sum, u32 nchunks, u
     if (threadIdx.x == 0) *grand_total = carry;
 }
 static __global__ void k_scan_add(u32* __restrict__ off, const u32* __restrict__ chunk_sum, u64 total, const u32* __restrict__ grand_total) {
+    ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) off[i] += chunk_sum[i / SCAN_CHUNK];
     if (i == total) off[total] = *grand_total;   // sentinel: off has total+1 entries
@@ -265,6 +271,7 @@ static __device__ __forceinline__ u32 msm_slice_len(const u32* __restrict__ off,
 }
 // first key of every lane's slice (upper bound over the offsets)
 static __global__ void k_msm_lane_keys(const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32* __restrict__ lane_key) {
+    ZK_PRIO_HIGH();
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= cut.nlanes) return;
     const u32 P = msm_slice_len(off, nkeys, cut);
@@ -280,6 +287,7 @@ static __global__ void k_msm_lane_keys(const u32* __restrict__ off, u32 nkeys, M
 // buckets whose entries span more than MSM_HEAVY lanes
 static __global__ void k_msm_find_heavy(const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32* __restrict__ heavy_list,
                                         u32* __restrict__ heavy_count) {
+    ZK_PRIO_HIGH();
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nkeys) return;
     const u32 P = msm_slice_len(off, nkeys, cut);
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(const AffPacked<F>* __re
 
 // sum of one bucket's partials (after the heavy pass the first slot of a heavy bucket holds its total)
 template <class F>
-__device__ __forceinline__ Xyzz<F> msm_bucket_sum(const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 key, u32 P) {
+__device__ __forceinline__ Xyzz<F> msm_bucket_sum(const Xyzz<F>* partial, const u32* __restrict__ off, u32 key, u32 P) {
     const u32 b = off[key], e = off[key + 1];
     if (e <= b) return Xyzz<F>::inf();
     const u32 g0 = b / P, g1 = (e - 1) / P;
@@ -384,26 +392,6 @@ __device__ __forceinline__ void block_tree_sum(Xyzz<F>* sh) {
     }
 }
 
-// ---- 4. heavy buckets: one workgroup each, result into the bucket's first slot ----
-template <class F>
-__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_heavy_reduce(const u32* __restrict__ off, u32 nkeys, MsmCut cut, const u32* __restrict__ heavy_list,
-                                                           const u32* __restrict__ heavy_count, Xyzz<F>* __restrict__ partial) {
-    ZK_DYN_SMEM(smem);
-    Xyzz<F>* sh = (Xyzz<F>*)smem;
-    const u32 P = msm_slice_len(off, nkeys, cut);
-    const u32 nh = *heavy_count;
-    for (u32 h = blockIdx.x; h < nh; h += gridDim.x) {
-        const u32 key = heavy_list[h];
-        const u32 g0 = off[key] / P, g1 = (off[key + 1] - 1) / P;
-        Xyzz<F> s = Xyzz<F>::inf();
-        for (u32 g = g0 + threadIdx.x; g <= g1; g += blockDim.x) xyzz_add_acc(s, partial[(u64)key + g]);
-        sh[threadIdx.x] = s;
-        block_tree_sum<F>(sh);
-        if (threadIdx.x == 0) partial[(u64)key + g0] = sh[0];
-        __syncthreads();
-    }
-}
-
 // k * p for a small unsigned k (left-to-right double-and-add over the significant bits only)
 template <class F>
 __device__ __forceinline__ Xyzz<F> xyzz_mul_small(const Xyzz<F>& p, u32 k) {
@@ -423,15 +411,32 @@ __device__ __forceinline__ Xyzz<F> xyzz_mul_small(const Xyzz<F>& p, u32 k) {
 // row/column totals per window need a (short) double-and-add.
 //
 // 5a. one workgroup per (row, bucket set): combine each bucket's partials, keep the bucket value for the column pass,
-//     tree-sum the row.
+//     tree-sum the row.  A heavy bucket (more than MSM_HEAVY partials; k_msm_find_heavy lists them) is first summed by
+//     the whole workgroup of its row into its first slot — no kernel of its own: a launch that only finds an empty list
+//     still waits for a place on a machine full of accumulation waves (5 ms in a trace).
 template <class F>
-__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(const Xyzz<F>* __restrict__ partial, const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32 K, u32 Lw,
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(Xyzz<F>* partial, const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32 K, u32 Lw,
+                                                        const u32* __restrict__ heavy_list, const u32* __restrict__ heavy_count,
                                                         Xyzz<F>* __restrict__ bucket, Xyzz<F>* __restrict__ rows) {
+    ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.y, hi = blockIdx.x, lo = threadIdx.x;
     const u32 P = msm_slice_len(off, nkeys, cut);
-    const u32 key = j * K + hi * Lw + lo;
+    const u32 row0 = j * K + hi * Lw;
+    const u32 nh = *heavy_count;
+    for (u32 h = 0; h < nh; ++h) {
+        const u32 hk = heavy_list[h];
+        if (hk - row0 >= Lw) continue;           // (uniform over the workgroup)
+        const u32 g0 = off[hk] / P, g1 = (off[hk + 1] - 1) / P;
+        Xyzz<F> s = Xyzz<F>::inf();
+        for (u32 g = g0 + lo; g <= g1; g += blockDim.x) xyzz_add_acc(s, partial[(u64)hk + g]);
+        sh[lo] = s;
+        block_tree_sum<F>(sh);
+        if (lo == 0) partial[(u64)hk + g0] = sh[0];
+        __syncthreads();
+    }
+    const u32 key = row0 + lo;
     Xyzz<F> v = msm_bucket_sum<F>(partial, off, key, P);
     bucket[key] = v;
     sh[lo] = v;
@@ -442,6 +447,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(c
 //     blockDim = (CW, HG); grid = (Lw / CW, W).
 template <class F>
 __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(const Xyzz<F>* __restrict__ bucket, u32 K, u32 Lw, u32 H, Xyzz<F>* __restrict__ cols) {
+    ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.y, lo = blockIdx.x * blockDim.x + threadIdx.x, hg = threadIdx.y, HG = blockDim.y;
@@ -463,6 +469,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(c
 template <class F, class FS>
 __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
                                                          Xyzz<FS>* __restrict__ window_sum) {
+    ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x;
@@ -495,6 +502,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(
 template <class F, class FS>
 __global__ void __launch_bounds__(512) k_msm_fold_final_scan(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
                                                              Xyzz<FS>* __restrict__ window_sum) {
+    ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x;

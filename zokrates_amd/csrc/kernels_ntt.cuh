@@ -31,6 +31,7 @@ namespace zk {
 // ---------------- element-wise ----------------
 template <class F>
 __global__ void k_to_mont(const F* __restrict__ in, F* __restrict__ out, u64 n) {
+    ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fe_to_mont(in[i]);
 }
@@ -61,11 +62,13 @@ ZK_HD Fe<P> rp_to_plain(const Fe<P>& a) {   // x * R' -> x (canonical integer)
 // Montgomery form into R'-form)
 template <class F>
 __global__ void k_mul_const(const F* __restrict__ in, F* __restrict__ out, u64 n, F k) {
+    ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fe_mul(in[i], k);
 }
 template <class F>
 __global__ void k_from_rp(const F* __restrict__ in, F* __restrict__ out, u64 n) {
+    ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rp_to_plain(in[i]);
 }
@@ -79,6 +82,7 @@ __global__ void k_unpack_table(const Fe<P>* __restrict__ in, Fu<P>* __restrict__
 // signed-digit recoding (ark's FromBytes rejects it)
 template <class F>
 __global__ void k_check_canonical(const F* __restrict__ x, u64 n, u32* __restrict__ flag) {
+    ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const F v = x[i];
@@ -128,6 +132,7 @@ __global__ void k_sigma_permute(const F* __restrict__ in, F* __restrict__ out, u
 template <class P>
 __global__ void k_quotient(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ b, const Fe<P>* __restrict__ c, Fe<P> zinv, Fe<P>* __restrict__ out,
                            u64 n) {
+    ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Fu<P> ab = fu_mul_inl(fu_unpack<P>(a[i].v), fu_unpack<P>(b[i].v));          // < 2p
@@ -150,6 +155,7 @@ struct CsrDev {
 template <class F>
 __global__ void __launch_bounds__(256) k_matvec(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ oa, F* __restrict__ ob,
                                                 F* __restrict__ oc, u64 n, u64 l, u64 N, int gA, int gB, int gC) {
+    ZK_PRIO_HIGH();
     __shared__ F sh[256];
     const int which = blockIdx.y;
     const int G = which == 0 ? gA : which == 1 ? gB : gC;
@@ -332,6 +338,7 @@ __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu
 template <class P>
 __global__ void __launch_bounds__(512, 4) k_ntt_cols(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n1, u32 n2, int C, const u32* __restrict__ plan,
                                                      u32 plen, const Fe<P>* __restrict__ post_, int canon) {
+    ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     static_assert(P::N == 8, "Fr is 8 x 32-bit words");
     u32* lds = (u32*)smem;
@@ -357,6 +364,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_cols(Fe<P>* __restrict__ data_, 
 template <class P>
 __global__ void __launch_bounds__(512, 4) k_ntt_rows(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n2, int R, const u32* __restrict__ plan, u32 plen,
                                                      const Fe<P>* __restrict__ post_, int canon) {
+    ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     u32* lds = (u32*)smem;
     uint4* data = (uint4*)(data_ + (size_t)blockIdx.y * vec_stride);
