@@ -85,7 +85,8 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
  * stream (un-overlapped per-kernel timing); _NTT_SINGLE_MAX_LOG: largest domain transformed in a single pass;
  * _NTT_COLS: adjacent columns per workgroup of the NTT cols pass; _SLOTS: proofs in flight in the batch calls (1..4);
  * _Z_GATE: which accumulations over the assignment wait for the witness map of their proof (0 none, 1 the three G1
- * lanes — the default —, 2 the G2 lane as well). */
+ * lanes — the default —, 2 the G2 lane as well); _FUSE_Z: 0 runs the three G1 MSMs over the assignment as separate
+ * launches instead of one; _MSM_FUSED_WAVES: accumulation waves per SIMD of that one launch (0 = per point type). */
 #define ZKHIP_TUNE_MSM_C 1
 #define ZKHIP_TUNE_MSM_WAVES 2
 #define ZKHIP_TUNE_MSM_LANES 3
@@ -96,6 +97,8 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_NTT_COLS 8
 #define ZKHIP_TUNE_SLOTS 9
 #define ZKHIP_TUNE_Z_GATE 10
+#define ZKHIP_TUNE_FUSE_Z 11
+#define ZKHIP_TUNE_MSM_FUSED_WAVES 12
 int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value);
 
 /* ---- proving key ----

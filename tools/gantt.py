@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-stream listing of ONE isolated proof out of a rocprofv3 rocpd database (--kernel-trace) of a bench run.
 The run's isolated single proofs (bench.py times them after the pipelined region) show up as clusters of kernels
-separated by host-side gaps; a cluster with exactly five final fold kernels is one proof.  Prints, for the chosen
+separated by host-side gaps; a cluster with exactly one G2 accumulation is one proof.  Prints, for the chosen
 cluster, every kernel as (start offset us, duration us, stream, name) and the critical facts: when each MSM lane's
 accumulation starts/ends, when its fold ends, and how much of the span has an accumulation kernel in flight.
 Usage: gantt.py results.db [which=-4]      (index into the list of single-proof clusters; -4 = a resident-input one)"""
@@ -30,7 +30,7 @@ def main():
         cur_c.append(r)
         hi = r[2] if hi is None else max(hi, r[2])
     clusters.append(cur_c)
-    singles = [c for c in clusters if sum("fold_final" in r[0] for r in c) == 5]
+    singles = [c for c in clusters if sum("k_msm_accum" in r[0] and "Fu2" in r[0] for r in c) == 1]   # one G2 accumulation = one proof
     print("%d clusters, %d of them single proofs" % (len(clusters), len(singles)))
     if not singles:
         return

@@ -162,6 +162,8 @@ struct zkhip_ctx {
     u32 msm_lanes = 0;        // slices of the sorted list (0 = one per resident work-item)
     u32 msm_min_slice = 8;    // finest cut of the sorted list
     bool fold_scan = true;    // scan form of the last fold step (else double-and-add)
+    bool fuse_z = true;       // A, B1 and L of a proof (one sorted list) as ONE slicing / accumulation / fold launch each
+    int msm_fused_waves = 0;  // accumulation waves per SIMD of that launch (0 = per point type)
     int z_gate = 1;           // which accumulations over z wait for the witness map of their proof: 0 none, 1 the G1 lanes, 2 all
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
@@ -469,6 +471,9 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
 template <class F>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<F>* d_window_sums,
              Event ev_begin, Event ev_end, Event accum_after = nullptr);
+template <class F>
+void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* const* d_tables, int nt, const MsmShape& sh, Xyzz<F>* d_window_sums,
+                    u32 sum_stride, Event ev_begin, Event ev_end, Event accum_after);
 // affine points, saturated Montgomery form -> packed working form of the MSM kernels (level 0 of a table); on ctx->stream
 template <class F>
 void points_to_packed(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
@@ -847,9 +852,7 @@ struct Prover {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
                 msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
-            msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
-            msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
-            msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
+            run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready);
         } else {
             empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
         }
@@ -863,6 +866,24 @@ struct Prover {
         }
 
         copy_out(ctx, sl, Wmax);
+    }
+
+    // ---- A, B1, L: the three G1 MSMs over the sorted assignment (window sums to ws1 + {0, 1, 2} * Wmax)
+    static void run_z_g1(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const MsmShape& shz, Xyzz<Fq>* ws1, int Wmax, Event h_ready) {
+        if (ctx->fuse_z) {
+            const void* tabs[3] = {pk->a_ext.p, pk->b1_ext.p, pk->l_ext.p};
+            msm_run_tables<Fq>(ctx, sl.lanes[0], sl.sorts[0], tabs, 3, shz, ws1, (u32)Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
+            Stream s0 = ctx->serial ? ctx->stream : sl.lanes[0].stream;      // lanes 1 and 2 are part of lane 0's launches
+            for (int k = 1; k < 3; ++k) {
+                event_record(sl.acc_b[k], s0);
+                event_record(sl.acc_e[k], s0);
+                event_record(sl.lanes[k].done, s0);
+            }
+            return;
+        }
+        msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
+        msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
+        msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
     }
 
     // ---- window sums to the host, on a stream of their own so that the main stream can start the next proof

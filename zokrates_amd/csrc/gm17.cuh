@@ -275,9 +275,7 @@ struct Gm17 {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
                 msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
-            msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
-            msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
-            msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
+            P::run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready);
         } else {
             P::empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
         }

@@ -29,23 +29,30 @@ void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int c, int W) {
     stream_sync(ctx->stream);
 }
 
+// `nt` MSMs over ONE sorted list (tables[t] -> d_window_sums + t * sum_stride): one slicing, one accumulation launch, one
+// fold — A, B1 and L of a proof share the sort of the assignment, and as one launch their residency is what the grid says
+// (three separate accumulations pack five waves per SIMD and leave no room for a 128-register fold wave).
 template <class FS>
-void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<FS>* d_window_sums,
-             Event ev_begin, Event ev_end, Event accum_after) {
+void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* const* d_tables, int nt, const MsmShape& sh, Xyzz<FS>* d_window_sums,
+                    u32 sum_stride, Event ev_begin, Event ev_end, Event accum_after) {
     typedef typename Unsat<FS>::type F;   // the kernels run on the unsaturated field
-    const AffPacked<F>* d_bases = (const AffPacked<F>*)d_table;
+    require(nt >= 1 && nt <= MSM_MAX_TABLES, ZKHIP_ERR_BAD_ARG, "internal: number of tables of one MSM launch");
+    MsmTables tables{};
+    for (int t = 0; t < nt; ++t) tables.p[t] = d_tables[t];
     Stream s = ctx->serial ? ctx->stream : lane.stream;
     stream_wait_event(s, so.ready);
     // one slice of the sorted list per work-item the machine holds (never finer than MSM_MIN_SLICE entries)
-    const u64 machine = ctx->msm_lanes ? (u64)ctx->msm_lanes : (u64)ctx->cus * 4 * 64 * (ctx->msm_waves ? ctx->msm_waves : MsmTuning<F>::ACCUM_WPE);
+    const int wpe = ctx->msm_waves ? ctx->msm_waves : (nt > 1 ? std::max(1, (ctx->msm_fused_waves ? ctx->msm_fused_waves : MsmTuning<F>::FUSED_WPE)) : MsmTuning<F>::ACCUM_WPE);
+    const u64 machine = ctx->msm_lanes ? (u64)ctx->msm_lanes : (u64)ctx->cus * 4 * 64 * wpe / (nt > 1 && !ctx->msm_waves ? nt : 1);
     const u32 nlanes = (u32)std::max<u64>(1, std::min<u64>(machine, (sh.n * (u64)sh.W + ctx->msm_min_slice - 1) / ctx->msm_min_slice));
     const MsmCut cut{nlanes, ctx->msm_min_slice};
+    const u64 partial_stride = (u64)sh.nkeys + nlanes;
     lane.heavy.ensure(((size_t)sh.nkeys + 1) * 4);            // [0] = count, [1..] = keys
     lane.lane_key.ensure((size_t)nlanes * 4);
-    lane.partial.ensure(((size_t)sh.nkeys + nlanes) * sizeof(Xyzz<F>));
-    lane.bucket.ensure((size_t)sh.nkeys * sizeof(Xyzz<F>));
-    lane.rows.ensure((size_t)sh.sets * sh.H * sizeof(Xyzz<F>));
-    lane.cols.ensure((size_t)sh.sets * sh.Lw * sizeof(Xyzz<F>));
+    lane.partial.ensure((size_t)nt * partial_stride * sizeof(Xyzz<F>));
+    lane.bucket.ensure((size_t)nt * sh.nkeys * sizeof(Xyzz<F>));
+    lane.rows.ensure((size_t)nt * sh.sets * sh.H * sizeof(Xyzz<F>));
+    lane.cols.ensure((size_t)nt * sh.sets * sh.Lw * sizeof(Xyzz<F>));
     lds_opt_in(ctx, (const void*)k_msm_fold_rows<F>);
     lds_opt_in(ctx, (const void*)k_msm_fold_cols<F>);
     lds_opt_in(ctx, (const void*)k_msm_fold_final<F, FS>);
@@ -57,25 +64,30 @@ void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_tab
               ptr<u32>(lane.heavy));
     if (accum_after && !ctx->serial) stream_wait_event(s, accum_after);   // (the slicing above only needs the sort)
     if (ev_begin) event_record(ev_begin, s);
-    ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE>), dim3(blocks_for(nlanes, T)), dim3(T), 0, s, d_bases, ptr<u32>(so.off), ptr<u32>(so.sorted),
-              ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), sh.nkeys, cut);
+    ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE>), dim3(blocks_for(nlanes, T), nt), dim3(T), 0, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
+              ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), partial_stride, sh.nkeys, cut);
     if (ev_end) event_record(ev_end, s);
-    ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.sets), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial),
+    ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.sets, nt), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
               ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));
     const u32 CW = std::min<u32>(sh.Lw, 32), HG = std::max<u32>(1, std::min<u32>(8, sh.H));   // 256 work-items for big windows
-    ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.sets), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
+    ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.sets, nt), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
               sh.Lw, sh.H, ptr<Xyzz<F>>(lane.cols));
     // the scan form of the last fold step needs Lw + H points of LDS; the double-and-add form (Lw points) is the fallback
     const unsigned TS = (sh.Lw + sh.H + 63) / 64 * 64;
     if (ctx->fold_scan && TS <= 512 && (size_t)TS * sizeof(Xyzz<F>) <= 150 * 1024) {
-        ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.sets), dim3(TS), TS * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols),
-                  sh.Lw, sh.H, d_window_sums);
+        ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.sets, nt), dim3(TS), TS * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols),
+                  sh.Lw, sh.H, d_window_sums, sum_stride);
     } else {
         const unsigned TF = std::max<u32>(64, sh.Lw);
-        ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.sets), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
-                  sh.H, d_window_sums);
+        ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.sets, nt), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
+                  sh.H, d_window_sums, sum_stride);
     }
     event_record(lane.done, s);
+}
+template <class FS>
+void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<FS>* d_window_sums,
+             Event ev_begin, Event ev_end, Event accum_after) {
+    msm_run_tables<FS>(ctx, lane, so, &d_table, 1, sh, d_window_sums, 0, ev_begin, ev_end, accum_after);
 }
 
 template <class F>
@@ -94,6 +106,7 @@ void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scal
 
 #define ZK_INSTANTIATE_GROUP(F)                                                                                         \
     template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event, Event);   \
+    template void msm_run_tables<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void* const*, int, const MsmShape&, Xyzz<F>*, u32, Event, Event, Event); \
     template void points_to_packed<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                    \
     template void msm_table_levels<F>(zkhip_ctx*, void*, u64, int, int);                         \
     template void fixed_base_table<F>(zkhip_ctx*, const Aff<F>*, int, DBuf&);                                           \

@@ -36,11 +36,20 @@ namespace zk {
 #endif
 template <class F> struct MsmPrefetch { static constexpr bool TOUCH = false; };
 template <class P_> struct MsmPrefetch<Fu2<P_>> { static constexpr bool TOUCH = ZK_G2_TOUCH_PREFETCH != 0; };
-template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3; };
-template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2; };
-template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = 2; };
-template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3; };
-template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2; };
+// ACCUM_WPE: accumulation waves per SIMD of one MSM; FUSED_WPE: of a launch that runs several MSMs over one sorted list
+#ifndef ZK_G1_FUSED_WPE
+#define ZK_G1_FUSED_WPE 5
+#endif
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE; };
+template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = 2, FUSED_WPE = ZK_G2_ACCUM_WPE; };
+template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2, FUSED_WPE = 1; };
+// the base tables of the MSMs one launch serves (A, B1 and L of a proof share the sort of the assignment)
+static constexpr int MSM_MAX_TABLES = 3;
+struct MsmTables {
+    const void* p[MSM_MAX_TABLES];
+};
 static constexpr u32 MSM_MIN_SLICE = 8;   // default for the finest cut of the sorted list (small inputs leave work-items idle)
 
 // The kernels below work on points over the UNSATURATED field types of fieldu.cuh (Fu / Fu2); only the window sums
@@ -302,9 +311,11 @@ static __global__ void k_msm_find_heavy(const u32* __restrict__ off, u32 nkeys, 
 // An entry names a table slot (level * stride + point index); the base is fetched packed (one 64-byte line for BN254 G1)
 // one entry ahead and unpacked into 29/28-bit limbs when it is used.
 template <class F, int WPE>
-__global__ void __launch_bounds__(256, WPE) k_msm_accum(const AffPacked<F>* __restrict__ bases, const u32* __restrict__ off, const u32* __restrict__ sorted,
-                                                    const u32* __restrict__ lane_key, Xyzz<F>* __restrict__ partial, u32 nkeys, MsmCut cut) {
+__global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const u32* __restrict__ off, const u32* __restrict__ sorted,
+                                                    const u32* __restrict__ lane_key, Xyzz<F>* __restrict__ partial, u64 partial_stride, u32 nkeys, MsmCut cut) {
     constexpr int NW2 = 2 * AffPacked<F>::NW;
+    const AffPacked<F>* __restrict__ bases = (const AffPacked<F>*)tables.p[blockIdx.y];   // blockIdx.y: which MSM of the launch
+    partial += (u64)blockIdx.y * partial_stride;
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= cut.nlanes) return;
     u32 cur = lane_key[g];
@@ -415,12 +426,15 @@ __device__ __forceinline__ Xyzz<F> xyzz_mul_small(const Xyzz<F>& p, u32 k) {
 //     the whole workgroup of its row into its first slot — no kernel of its own: a launch that only finds an empty list
 //     still waits for a place on a machine full of accumulation waves (5 ms in a trace).
 template <class F>
-__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(Xyzz<F>* partial, const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32 K, u32 Lw,
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(Xyzz<F>* partial, u64 partial_stride, const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32 K, u32 Lw,
                                                         const u32* __restrict__ heavy_list, const u32* __restrict__ heavy_count,
                                                         Xyzz<F>* __restrict__ bucket, Xyzz<F>* __restrict__ rows) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
+    partial += (u64)blockIdx.z * partial_stride;           // blockIdx.z: which MSM of the launch
+    bucket += (u64)blockIdx.z * nkeys;
+    rows += (u64)blockIdx.z * gridDim.y * gridDim.x;
     const u32 j = blockIdx.y, hi = blockIdx.x, lo = threadIdx.x;
     const u32 P = msm_slice_len(off, nkeys, cut);
     const u32 row0 = j * K + hi * Lw;
@@ -451,6 +465,8 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(c
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.y, lo = blockIdx.x * blockDim.x + threadIdx.x, hg = threadIdx.y, HG = blockDim.y;
+    bucket += (u64)blockIdx.z * gridDim.y * K;             // blockIdx.z: which MSM of the launch (nkeys = sets * K)
+    cols += (u64)blockIdx.z * gridDim.y * Lw;
     Xyzz<F> s = Xyzz<F>::inf();
     for (u32 hi = hg; hi < H; hi += HG) xyzz_add_acc(s, bucket[(u64)j * K + (u64)hi * Lw + lo]);
     sh[hg * blockDim.x + threadIdx.x] = s;
@@ -468,11 +484,14 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(c
 // 5c. one workgroup per bucket set: the two weighted digit sums.
 template <class F, class FS>
 __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
-                                                         Xyzz<FS>* __restrict__ window_sum) {
+                                                         Xyzz<FS>* __restrict__ window_sum, u32 sum_stride) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x;
+    rows += (u64)blockIdx.y * gridDim.x * H;               // blockIdx.y: which MSM of the launch
+    cols += (u64)blockIdx.y * gridDim.x * Lw;
+    window_sum += (u64)blockIdx.y * sum_stride;
     // sum_hi hi * R_hi, then times Lw (a power of two: log2 doublings)
     Xyzz<F> term = Xyzz<F>::inf();
     for (u32 hi = t; hi < H; hi += blockDim.x) xyzz_add_acc(term, xyzz_mul_small(rows[(u64)j * H + hi], hi));
@@ -501,11 +520,14 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(
 // by side: ~21 sequential curve operations instead of ~51.  blockDim.x >= Lw + H; dynamic LDS blockDim.x points.
 template <class F, class FS>
 __global__ void __launch_bounds__(512) k_msm_fold_final_scan(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
-                                                             Xyzz<FS>* __restrict__ window_sum) {
+                                                             Xyzz<FS>* __restrict__ window_sum, u32 sum_stride) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x;
+    rows += (u64)blockIdx.y * gridDim.x * H;               // blockIdx.y: which MSM of the launch
+    cols += (u64)blockIdx.y * gridDim.x * Lw;
+    window_sum += (u64)blockIdx.y * sum_stride;
     const bool is_col = t < Lw, live = t < Lw + H;
     const u32 li = is_col ? t : t - Lw;                 // index inside the segment
     const u32 seglen = is_col ? Lw : H;

@@ -86,6 +86,8 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->ntt_cols = env_int("ZKHIP_NTT_COLS", 1, 8, 2);
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
+        ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
+        ctx->msm_fused_waves = env_int("ZKHIP_MSM_FUSED_WAVES", 1, 8, 0);
         ctx->sort_wgs = (u32)env_int("ZKHIP_SORT_WGS", 16, 4096, 256);
         // every (slot, lane) has a stream of its own: with one stream per lane shared by the slots, the accumulation of
         // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
@@ -164,6 +166,8 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_NTT_SINGLE_MAX_LOG: in(0, NTT_MAX_SUBLOG); dev_sync_all(); ctx->ntt_single_max = value; ctx->plans.clear(); break;
             case ZKHIP_TUNE_SLOTS: in(1, ZK_NSLOTS); dev_sync_all(); ctx->nslots = value; break;
             case ZKHIP_TUNE_Z_GATE: in(0, 2); ctx->z_gate = value; break;
+            case ZKHIP_TUNE_FUSE_Z: in(0, 1); ctx->fuse_z = value != 0; break;
+            case ZKHIP_TUNE_MSM_FUSED_WAVES: in(0, 8); ctx->msm_fused_waves = value; break;
             case ZKHIP_TUNE_NTT_COLS: in(1, 8); dev_sync_all(); ctx->ntt_cols = value; ctx->plans.clear(); break;
             default: throw ApiError{ZKHIP_ERR_BAD_ARG, "unknown tunable"};
         }
