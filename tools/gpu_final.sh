@@ -10,6 +10,20 @@ cd "$root"
 git rev-parse HEAD > "$out/head.txt" 2>/dev/null || true
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1 || { echo "SMOKE FAILED: giving the box back"; tail -5 "$out/smoke.log"; exit 0; }
 timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
+# HBM traffic of the accumulation / transform kernels for the bench lines below: two PMC passes (their own runs, kernel trace
+# only), one stream; a pass that does not finish in 200 s is given up (the committed profiles/pmc_traffic.json stays)
+( cd /tmp && export TMPDIR=/tmp
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    ZKHIP_SERIAL=1 timeout 200 rocprofv3 --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 > "$out/prof_pmc_$ctr.log" 2>&1
+    db=$(find "$out/prof_pmc_$ctr" -name "*.db" 2>/dev/null | head -1)
+    [ -n "$db" ] && python "$root/tools/pmc_stats.py" "$db" "$out/${tag}_pmc_$ctr.md" > /dev/null
+  done
+  f=$(find "$out/prof_pmc_FETCH_SIZE" -name "*.db" 2>/dev/null | head -1); w=$(find "$out/prof_pmc_WRITE_SIZE" -name "*.db" 2>/dev/null | head -1)
+  if [ -n "$f" ] && [ -n "$w" ]; then
+    python "$root/tools/pmc_traffic.py" "$f" "$w" "$out/pmc_traffic.json" "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate runs), ZKHIP_SERIAL=1 python bench.py --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0; profiles/${tag}_pmc_FETCH_SIZE.md, ${tag}_pmc_WRITE_SIZE.md" > /dev/null \
+      && cp "$out/pmc_traffic.json" "$root/profiles/pmc_traffic.json" && echo "pmc_traffic.json refreshed"
+  else echo "PMC passes incomplete: profiles/pmc_traffic.json unchanged"; fi
+  find "$out" -name "*.db" -size +8M -delete )
 timeout 600 python bench.py > "$out/bench_default.json" 2> "$out/bench.err"
 timeout 600 python bench.py --scheme gm17 > "$out/bench_gm17.json" 2>> "$out/bench.err"
 timeout 600 python bench.py --curve bls12_381 --log-domain 18 --kind poseidon > "$out/bench_poseidon_bls12_381_2e18.json" 2>> "$out/bench.err"

@@ -38,6 +38,9 @@ for tag, needles in (("G1", ("k_msm_accum", "Fu<", "Bn254Fq")), ("G2", ("k_msm_a
     if nf and nw:
         out[tag] = {"launches_fetch_pass": nf, "launches_write_pass": nw, "fetch_kb_raw": f / nf, "write_kb_raw": w / nw,
                     "traffic_bytes_per_launch": int(2 * 1024 * f / nf + 1024 * w / nw)}
+nq_all, _ = pick(fetch, "k_quotient")
+if "G1" in out and nq_all:
+    out["G1"]["launches_per_proof"] = out["G1"]["launches_fetch_pass"] / nq_all   # 2: (a, b_g1, l) as one launch + h_query
 nf, f = pick(fetch, "k_ntt_")
 nw, w = pick(write, "k_ntt_")
 nq, _ = pick(fetch, "k_quotient")
