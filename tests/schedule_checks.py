@@ -1,0 +1,39 @@
+"""Shared by tests/test_emu_kernels.py (emulator) and tests/test_gpu_parity.py (MI355X): the scheduling knobs of a context
+do not change a proof."""
+import numpy as np
+
+from oracle import cpu
+from oracle import groth16 as g16
+from oracle.fields import BN254
+from zokrates_amd import native
+
+
+def schedule_invariance(c2, logn=5, kinds=("dense", "sha")):
+    """The order in which a proof's kernels are released (`z_gate`), A / B1 / L as one launch or three (`fuse_z`) and the
+    slices per launch (`msm_fused_waves`) are scheduling only: the proof bytes do not move, single or pipelined,
+    Groth16 or GM17.  """
+    from oracle import gm17
+    for kind in kinds:
+        oc = cpu.Circuit.synth(0, (1 << logn) - 2, 0x5C4ED + logn, kind)
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(BN254))
+        cs = native.ConstraintSystem(c2, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+        pk = native.ProvingKey(c2, 0, cpu.ProvingKey.setup(oc, tox).serialize())
+        z = oc.assignment()
+        rs = [(11, 13), (0, 5), (7, 0), (1 << 200, 3)]
+        want = [cpu.trapdoor(oc, tox, z, a, b) for a, b in rs]
+        gtox = gm17.Toxic.from_seed(BN254)
+        gpk = native.ProvingKey(c2, 0, cpu.Gm17ProvingKey.setup(oc, cpu.gm17_toxic_bytes(gtox)).serialize(), scheme="gm17")
+        gwant = None
+        try:
+            for gate in (0, 1, 2):
+                for fuse, waves in ((1, 0), (1, 3), (0, 0)):
+                    c2.tune("z_gate", gate); c2.tune("fuse_z", fuse); c2.tune("msm_fused_waves", waves)
+                    assert native.prove_g16(c2, pk, cs, z, *rs[0]) == want[0], (kind, gate, fuse, waves)
+                    proofs, _ = native.prove_g16_batch(c2, pk, cs, np.concatenate([z] * len(rs)), rs)
+                    assert proofs == want, (kind, gate, fuse, waves)
+                    g = native.prove_gm17(c2, gpk, cs, z, 21, 22, 23)
+                    gwant = gwant or g
+                    assert g == gwant, (kind, gate, fuse, waves)
+        finally:
+            c2.tune("z_gate", 1); c2.tune("fuse_z", 1); c2.tune("msm_fused_waves", 0)
+        assert gwant == cpu.gm17_trapdoor(oc, cpu.gm17_toxic_bytes(gtox), z, 21, 23)

@@ -13,6 +13,7 @@ from oracle.fields import BN254, BLS12_381
 from zokrates_amd import native
 
 from emu_util import emu_library
+from schedule_checks import schedule_invariance
 
 CURVES = [BN254, BLS12_381]
 
@@ -225,6 +226,10 @@ def test_prove_with_wide_windows():
             assert native.prove_g16(c2, native.ProvingKey.from_image(c2, 0, img), cs, z, 11, 13) == want, c
     finally:
         c2.close()
+
+
+def test_schedule_does_not_change_proofs(ctx):
+    schedule_invariance(ctx, logn=5, kinds=("dense",))
 
 
 def test_two_pass_prove(ctx):

@@ -171,6 +171,13 @@ def test_prove_matches_oracle(ctx, curve, logn, kind):
     assert native.prove_g16(ctx, pk, cs, z, r_, s_) == got
 
 
+def test_schedule_does_not_change_proofs(ctx):
+    """Gate / fused-launch / slices-per-launch settings (zkhip_ctx_tune) on the device: same proof bytes, single and
+    pipelined, Groth16 and GM17; dense and boolean-heavy witnesses (heavy buckets inside the fused row fold)."""
+    from schedule_checks import schedule_invariance
+    schedule_invariance(ctx, logn=12)
+
+
 def test_pairing_accepts_device_proof(ctx):
     """O3: the verification equation of zokrates_proof_systems/src/scheme/groth16.rs:156-172 accepts the
     device proof and rejects a mutated one (to_token.rs:68-71)."""
