@@ -23,7 +23,7 @@ ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python -m torch.distrib
   bench.py --gpus 2 --steps 8 --warmup 2 > "$out/bench_two_ranks_one_gpu.json" 2>> "$out/bench.err"
 # HBM traffic of the accumulation / transform kernels -> profiles/pmc_traffic.json (what the NEXT bench lines report as
 # roofline.traffic): two PMC passes (their own runs, kernel trace only), one stream; a pass that does not finish in 200 s is
-# given up.  LAST: bench runs that followed a PMC pass on the same box came out 5-40 % slow (r2_final vs r2_final_bench).
+# given up.  Last, so that a profiler pass that hangs (one did: 900 s) cannot cost the bench lines.
 [ -z "${SKIP_PMC:-}" ] && ( cd /tmp && export TMPDIR=/tmp
   for ctr in FETCH_SIZE WRITE_SIZE; do
     ZKHIP_SERIAL=1 timeout 200 rocprofv3 --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 > "$out/prof_pmc_$ctr.log" 2>&1

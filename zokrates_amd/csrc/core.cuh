@@ -164,6 +164,7 @@ struct zkhip_ctx {
     bool fold_scan = true;    // scan form of the last fold step (else double-and-add)
     bool fuse_z = true;       // A, B1 and L of a proof (one sorted list) as ONE slicing / accumulation / fold launch each
     int msm_fused_waves = 0;  // accumulation waves per SIMD of that launch (0 = per point type)
+    int msm_g1_waves = 0, msm_g2_waves = 0;   // slices per SIMD lane of a single-table G1 / G2 accumulation (0 = per point type)
     int z_gate = 1;           // which accumulations over z wait for the witness map of their proof: 0 none, 1 the G1 lanes, 2 all
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)

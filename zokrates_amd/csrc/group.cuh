@@ -42,7 +42,10 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     Stream s = ctx->serial ? ctx->stream : lane.stream;
     stream_wait_event(s, so.ready);
     // one slice of the sorted list per work-item the machine holds (never finer than MSM_MIN_SLICE entries)
-    const int wpe = ctx->msm_waves ? ctx->msm_waves : (nt > 1 ? std::max(1, (ctx->msm_fused_waves ? ctx->msm_fused_waves : MsmTuning<F>::FUSED_WPE)) : MsmTuning<F>::ACCUM_WPE);
+    // (the slices may outnumber the work-items the kernel's registers let the machine hold: SLICE_WPE >= ACCUM_WPE)
+    const int single = MsmTuning<F>::IS_EXT ? (ctx->msm_g2_waves ? ctx->msm_g2_waves : MsmTuning<F>::SLICE_WPE)
+                                            : (ctx->msm_g1_waves ? ctx->msm_g1_waves : MsmTuning<F>::SLICE_WPE);
+    const int wpe = ctx->msm_waves ? ctx->msm_waves : (nt > 1 ? std::max(1, (ctx->msm_fused_waves ? ctx->msm_fused_waves : MsmTuning<F>::FUSED_WPE)) : single);
     const u64 machine = ctx->msm_lanes ? (u64)ctx->msm_lanes : (u64)ctx->cus * 4 * 64 * wpe / (nt > 1 && !ctx->msm_waves ? nt : 1);
     const u32 nlanes = (u32)std::max<u64>(1, std::min<u64>(machine, (sh.n * (u64)sh.W + ctx->msm_min_slice - 1) / ctx->msm_min_slice));
     const MsmCut cut{nlanes, ctx->msm_min_slice};

@@ -40,11 +40,18 @@ template <class P_> struct MsmPrefetch<Fu2<P_>> { static constexpr bool TOUCH = 
 #ifndef ZK_G1_FUSED_WPE
 #define ZK_G1_FUSED_WPE 5
 #endif
-template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE; };
-template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2; };
-template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = 2, FUSED_WPE = ZK_G2_ACCUM_WPE; };
-template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3; };
-template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2, FUSED_WPE = 1; };
+#ifndef ZK_G1_SLICE_WPE
+#define ZK_G1_SLICE_WPE 3
+#endif
+#ifndef ZK_G2_SLICE_WPE
+#define ZK_G2_SLICE_WPE ZK_G2_ACCUM_WPE
+#endif
+// (ACCUM_WPE is the kernel's register budget, SLICE_WPE / FUSED_WPE how finely the sorted list is cut: slices per SIMD lane)
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false; };
+template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = 2, FUSED_WPE = ZK_G2_ACCUM_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true; };
+template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true; };
 // the base tables of the MSMs one launch serves (A, B1 and L of a proof share the sort of the assignment)
 static constexpr int MSM_MAX_TABLES = 3;
 struct MsmTables {

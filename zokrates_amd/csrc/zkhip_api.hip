@@ -88,6 +88,8 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
         ctx->msm_fused_waves = env_int("ZKHIP_MSM_FUSED_WAVES", 1, 8, 0);
+        ctx->msm_g1_waves = env_int("ZKHIP_MSM_G1_WAVES", 1, 16, 0);
+        ctx->msm_g2_waves = env_int("ZKHIP_MSM_G2_WAVES", 1, 16, 0);
         ctx->sort_wgs = (u32)env_int("ZKHIP_SORT_WGS", 16, 4096, 256);
         // every (slot, lane) has a stream of its own: with one stream per lane shared by the slots, the accumulation of
         // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
