@@ -335,8 +335,12 @@ __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu
 
 // "cols" pass: the matrix is n1 x n2 row-major; this workgroup owns columns [c0, c0 + C).  grid.y = vectors
 // (consecutive vectors are vec_stride elements apart).
+// workgroups of 512 work-items per CU the transform kernels are compiled for (4: 64 VGPRs, a few spilled; 3: 85 VGPRs)
+#ifndef ZK_NTT_WGS_PER_CU
+#define ZK_NTT_WGS_PER_CU 4
+#endif
 template <class P>
-__global__ void __launch_bounds__(512, 4) k_ntt_cols(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n1, u32 n2, int C, const u32* __restrict__ plan,
+__global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n1, u32 n2, int C, const u32* __restrict__ plan,
                                                      u32 plen, const Fe<P>* __restrict__ post_, int canon) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_cols(Fe<P>* __restrict__ data_, 
 
 // "rows" pass: this workgroup owns rows [r0, r0 + R) of n2 contiguous elements each.
 template <class P>
-__global__ void __launch_bounds__(512, 4) k_ntt_rows(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n2, int R, const u32* __restrict__ plan, u32 plen,
+__global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_rows(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n2, int R, const u32* __restrict__ plan, u32 plen,
                                                      const Fe<P>* __restrict__ post_, int canon) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
