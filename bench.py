@@ -44,7 +44,7 @@ _pkg = os.environ.get("ZKHIP_PKG", "zokrates_amd")   # development hook: A/B two
 native, parallel, synth = (importlib.import_module(_pkg + "." + m) for m in ("native", "parallel", "synth"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
-SHARDED_LEG_TIMEOUT_S = 120
+SHARDED_LEG_TIMEOUT_S = int(os.environ.get("ZKHIP_BENCH_LEG_TIMEOUT_S", "120"))   # the optional latency legs, together
 PMC_TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
@@ -324,6 +324,8 @@ def main():
                                            "exchange": "all-gather of one %d-byte record per rank" % native.partial_size(ctx, curve_id)}
         except Exception as e:  # the throughput line must survive a failure of the optional leg
             out["sharded_single_proof"] = {"error": repr(e)}
+    if os.environ.get("ZKHIP_BENCH_TEST_STALL"):      # tests/test_bench_cli.py: an optional leg that never returns
+        time.sleep(3600)
     if rank == 0 and members > 1:
         out["multi_single_proof"] = multi_leg(ctx, circ, curve_id, pk_bytes, zs[0], members, gm17, prove_one)
     if world > 1:

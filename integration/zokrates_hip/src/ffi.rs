@@ -6,7 +6,7 @@ use std::os::raw::c_char;
 #[repr(C)] pub struct zkhip_pk { _p: [u8; 0] }
 #[repr(C)] pub struct zkhip_r1cs { _p: [u8; 0] }
 #[repr(C)] pub struct zkhip_multi { _p: [u8; 0] }
-/// 16 floats: h2d, matvec, ntt, msm_h, msm_z, finish, total, accum_g1, accum_g2, 7 reserved (milliseconds)
+/// 16 floats: h2d, matvec, ntt, msm_h, msm_z, finish, total, accum_g1, accum_g2, kernel_ntt, 6 reserved (milliseconds)
 #[repr(C)] #[derive(Default, Clone, Copy)] pub struct zkhip_timings { pub ms: [f32; 16] }
 
 pub const ZKHIP_CURVE_BN128: i32 = 0;

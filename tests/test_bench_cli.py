@@ -70,3 +70,15 @@ def test_two_ranks_real_bench_script(scheme, port):
     assert mm.get("identical_to_unsharded") is True and mm["members"] == 2, mm
     if scheme == "g16":                               # and its throughput mode (whole key per member, proofs dealt over the members)
         assert mm["replicas_batch"]["first_identical_to_unsharded"] is True and mm["replicas_batch"]["proofs"] == 16, mm
+
+
+def test_stalled_optional_leg_still_prints_the_line():
+    """An optional latency leg that never returns (a hung collective, an untested multi-GPU path): the watchdog prints the
+    throughput line with the leg marked as timed out and the process exits 0 — the driver's bench run must not lose its line."""
+    lines = run_bench(["--log-domain", "5", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--members", "2"],
+                      extra_env={"ZKHIP_BENCH_TEST_STALL": "1", "ZKHIP_BENCH_LEG_TIMEOUT_S": "3"}, timeout=300)
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and "timed out" in d["multi_single_proof"]["error"] and d["cpu_baseline"] is None
+    for k in REQUIRED:
+        assert k in d, k
