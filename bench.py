@@ -237,6 +237,17 @@ def main():
                    "peak_source": "tools/accum_bench.hip on MI355X (same arithmetic, synthetic sorted lists)"}
         if serial and serial[key] > 0:
             compute["frac_serial"] = madds / (serial[key] * 1e-3) / peak
+    # VALU issue occupation of the same kernel from the committed counter pass (tools/pmc_valu.py)
+    valu_path = os.path.join(ROOT, "profiles", "pmc_valu.json")
+    if compute is not None and default_workload and os.path.exists(valu_path):
+        with open(valu_path) as f:
+            pv = json.load(f)
+        ent = pv.get("G2" if "G2" in name else "G1")
+        if ent:
+            compute["valu_issue_utilisation"] = ent["issue_utilisation"]
+            compute["valu_cycles_per_instruction_per_simd"] = ent["cycles_per_valu_instruction_per_simd"]
+            compute["clock_ghz_under_load"] = ent["clock_ghz"]
+            compute["valu_source"] = "offline rocprofv3 --pmc pass of this workload, profiles/pmc_valu.json"
     roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": ("offline rocprofv3 --pmc passes of this workload, " + PMC_TRAFFIC_FILE) if traffic else None,

@@ -39,6 +39,16 @@ lines = ["| kernel | launches | avg us | VALU wave-instructions per launch | GPU
          "|---|---|---|---|---|---|---|---|"]
 for _, k, n, dur, insts, cyc, ghz, cpi, util in sorted(rows, reverse=True)[:20]:
     lines.append("| `%s` | %d | %.1f | %.3g | %.3g | %.2f | %.2f | %.0f |" % (k, n, dur, insts, cyc, ghz, cpi, util))
+import json
+js = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, ZKHIP_SERIAL=1 python bench.py --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0 (tools/gpu_pmc_valu.sh)",
+      "definition": "cycles = GRBM_GUI_ACTIVE / %d XCDs; cycles_per_valu_instruction_per_simd = cycles * %d SIMDs / SQ_INSTS_VALU; issue_utilisation = 4 / that (one wave64 VALU instruction per 4 cycles per 16-lane SIMD)" % (xcds, simds)}
+for _, k, n, dur, insts, cyc, ghz, cpi, util in rows:
+    for tag, needle in (("G1", "k_msm_accum<Fu<"), ("G2", "k_msm_accum<Fu2<"), ("NTT_cols", "k_ntt_cols"), ("NTT_rows", "k_ntt_rows")):
+        if k.startswith(needle) and "Bn254" in k:
+            js[tag] = {"launches": n, "avg_us": dur, "valu_wave_instructions_per_launch": insts, "gpu_cycles_per_launch": cyc, "clock_ghz": ghz,
+                       "cycles_per_valu_instruction_per_simd": cpi, "issue_utilisation": 4 / cpi}
+if len(sys.argv) > 2:
+    json.dump(js, open(re.sub(r"\.md$", "", sys.argv[2]) + ".json", "w"), indent=1)
 text = "\n".join(lines)
 print(text)
 open(sys.argv[2], "w").write(text + "\n")
