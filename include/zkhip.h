@@ -86,7 +86,11 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
  * _NTT_COLS: adjacent columns per workgroup of the NTT cols pass; _SLOTS: proofs in flight in the batch calls (1..4);
  * _Z_GATE: which accumulations over the assignment wait for the witness map of their proof (0 none, 1 the three G1
  * lanes — the default —, 2 the G2 lane as well); _FUSE_Z: 0 runs the three G1 MSMs over the assignment as separate
- * launches instead of one; _MSM_FUSED_WAVES: accumulation waves per SIMD of that one launch (0 = per point type). */
+ * launches instead of one; _MSM_FUSED_WAVES: accumulation waves per SIMD of that one launch (0 = per point type);
+ * _STREAM_JITTER: race-hunting mode, process-wide — before every kernel launch, copy and fill the library enqueues, a
+ * spin kernel of random length (0 .. value microseconds, value <= 5000; 0 = off) is put on the same stream with
+ * probability 1/2, so that the relative timing of the library's streams differs from call to call; an ordering that is
+ * not carried by an event then shows up as a wrong result instead of passing by luck (tests/test_stream_jitter.py). */
 #define ZKHIP_TUNE_MSM_C 1
 #define ZKHIP_TUNE_MSM_WAVES 2
 #define ZKHIP_TUNE_MSM_LANES 3
@@ -99,6 +103,7 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_Z_GATE 10
 #define ZKHIP_TUNE_FUSE_Z 11
 #define ZKHIP_TUNE_MSM_FUSED_WAVES 12
+#define ZKHIP_TUNE_STREAM_JITTER 13
 int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value);
 
 /* ---- proving key ----

@@ -16,12 +16,12 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "config", "roofline", "cpu_baseline"]
 
 
-def run_bench(args, extra_env=None, timeout=900):
+def run_bench(args, extra_env=None, timeout=900, expect_rc=0):
     emu_library()                                            # make sure the emulator build exists
     env = dict(os.environ, ZKHIP_LIBRARY=EMU_LIB)
     env.update(extra_env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == expect_rc, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     return lines
 
@@ -82,3 +82,19 @@ def test_stalled_optional_leg_still_prints_the_line():
     assert d["value"] > 0 and "timed out" in d["multi_single_proof"]["error"] and d["cpu_baseline"] is None
     for k in REQUIRED:
         assert k in d, k
+
+
+def test_measuring_process_that_dies_is_reported_and_retried():
+    """A GPU memory fault aborts the process that owns the queue (the driver's round-2 bench run: rc 134, nothing on stdout).
+    bench.py measures in a child: a child that dies once is measured again and the line carries the failed attempt; a child
+    that dies twice still leaves ONE JSON line (value null, "error", both attempts) and a non-zero exit status."""
+    args = ["--log-domain", "5", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"]
+    lines = run_bench(args, extra_env={"ZKHIP_BENCH_TEST_DIE": "0"})
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and len(d["attempts"]) == 2
+    assert d["attempts"][0]["signal"] == 6 and d["attempts"][0]["last_stage"] == "context_created" and d["attempts"][1]["exit_status"] == 0
+    lines = run_bench(args, extra_env={"ZKHIP_BENCH_TEST_DIE": "*"}, expect_rc=1)
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and "error" in d and [a["signal"] for a in d["attempts"]] == [6, 6]

@@ -55,7 +55,7 @@ struct CurveBls381 {
 // and leaving the scope — normally or through an exception — joins whatever was started.
 struct HostThreads {
     std::vector<std::thread> th;
-    HostThreads() { th.reserve(8); }
+    HostThreads() { th.reserve(64); }
     HostThreads(const HostThreads&) = delete;
     HostThreads& operator=(const HostThreads&) = delete;
     template <class Fn>
@@ -323,6 +323,7 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
     pl->R_rows = (int)R;
     const u32 ccols = (u32)ctx->ntt_cols;
     pl->C_cols = (int)std::max<u32>(1, std::min<u32>(pl->N2, std::max<u32>(ccols, 1024 / std::max<u32>(pl->N1, 1))));
+    require(pl->N2 % (u32)pl->C_cols == 0 && pl->N1 % R == 0, ZKHIP_ERR_BAD_ARG, "internal: NTT tile does not divide the domain");
     auto smem_for = [](u32 nseq, u32 n) { return (size_t)9 * nseq * ntt_seq_stride((int)n) * 4; };
     pl->smem_cols = smem_for(pl->C_cols, pl->N1);
     pl->smem_rows = smem_for(R, pl->N2);
@@ -380,6 +381,7 @@ struct MsmShape {
     u32 nkeys;      // sets * K
     u32 Lw, H;      // fold geometry: K = H rows of Lw buckets
     bool shared() const { return sets == 1 && W > 1; }
+    u32 nsums() const { return 2 * sets; }   // the fold leaves two sums per bucket set (column digit, row digit): msm_combine
 };
 static inline int env_int(const char* name, int lo, int hi, int dflt) {
     if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
@@ -463,7 +465,7 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     event_record(so.ready, s);
 }
 
-// bucket accumulation + fold for one base table; the bucket sets' weighted sums land in d_window_sums[0..sets).
+// bucket accumulation + fold for one base table; the bucket sets' weighted sums land in d_window_sums[0..nsums()), two per set.
 // Defined in group.cuh and instantiated once per (curve, group) in its own translation unit (bn254_g1.hip, ...):
 // the elliptic-curve kernels are by far the most expensive code to compile.
 // Runs on lane.stream after so.ready; lane.done is recorded behind the last kernel.
@@ -491,11 +493,11 @@ void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scal
 // the MSM's value from its bucket-set sums: the single sum of a table MSM, else the host Horner step sum_j 2^(c j) S_j
 template <class F>
 static Xyzz<F> msm_combine(const Xyzz<F>* ws, const MsmShape& sh) {
-    if (sh.sets == 1) return ws[0];
+    if (sh.sets == 1) return xyzz_add(ws[0], ws[1]);
     Xyzz<F> acc = Xyzz<F>::inf();
     for (int j = sh.W - 1; j >= 0; --j) {
         for (int i = 0; i < sh.c; ++i) acc = xyzz_dbl(acc);
-        acc = xyzz_add(acc, ws[j]);
+        acc = xyzz_add(acc, xyzz_add(ws[2 * j], ws[2 * j + 1]));
     }
     return acc;
 }
@@ -543,6 +545,10 @@ struct zkhip_pk {
     u32 rank = 0, world = 1;
     u64 z_lo = 0, z_n = 0, h_lo = 0, h_n = 0;
     int c_z = 0, c_h = 0;
+    // log2 N1 of the NTT plan the sigma order of h_sigma was made for (N = N1 * N2): a context whose plan for this domain
+    // splits differently (ZKHIP_TUNE_NTT_SINGLE_MAX_LOG changed after the key was loaded, or an image written under
+    // another setting) would pair h with the wrong bases, so the provers and zkhip_pk_import refuse the mismatch
+    int ntt_log1 = -1;
 };
 
 struct zkhip_r1cs {
@@ -650,6 +656,7 @@ struct PkLoader {
         require(m + 2 < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "too many variables");
         pk->m = m; pk->w = w; pk->l = l; pk->hlen = hl; pk->N = N; pk->logN = ilog2_floor(N);
         NttPlan<C>* plan = get_plan<C>(ctx, pk->logN);
+        pk->ntt_log1 = plan->log1;
         pk->delta_g1_canon.assign(delta_g1, delta_g1 + G1B);
 
         const u64 me = m + 2;   // extended by the (delta, r) and (delta, s) pairs — see prove()
@@ -802,6 +809,7 @@ struct Prover {
         Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
+        require(pl->log1 == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's h bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
         sl.t_start = std::chrono::steady_clock::now();
         memcpy(sl.r, r, 32);
         memcpy(sl.s, s_, 32);
@@ -824,7 +832,7 @@ struct Prover {
         // (a sharded key covers only its index range of the bases, and pairs them with the same range of the scalars)
         const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
         const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
-        const int Wmax = (int)std::max(shz.sets, shh.sets);   // bucket-set sums per MSM (1: the tables carry the window multiples)
+        const int Wmax = (int)std::max(shz.nsums(), shh.nsums());   // sums per MSM (2: the tables carry the window multiples)
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // 4 G1 MSMs + 1 G2 MSM
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
@@ -934,7 +942,7 @@ struct Prover {
         sl.busy = false;
         const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
         const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
-        const int Wmax = (int)std::max(shz.sets, shh.sets);
+        const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
         const Xyzz<Fq>* h_ws1 = (const Xyzz<Fq>*)sl.h_ws;
         const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         u32 zflag;
@@ -1125,14 +1133,21 @@ struct Prover {
         dev_h2d(ctx->cur->scalars.p, scalars, n * 32, s);
         // ad-hoc bases: no table of window multiples (building one costs ~15x the MSM itself), one bucket set per window
         const MsmShape sh = msm_shape(ctx, n, Fr::Params::BITS, false);
-        d_ws.ensure((size_t)sh.sets * sizeof(Xyzz<F>));
-        msm_prepare(ctx, s, ctx->cur->sorts[0], ptr<u32>(ctx->cur->scalars), sh, 0);
+        d_ws.ensure((size_t)sh.nsums() * sizeof(Xyzz<F>));
+        // the packed bases are written on the main stream BEFORE the sort records `ready` there: the lane stream waits on
+        // that event only, so everything the accumulation reads must precede it on the main stream
         DBuf d_packed;
         d_packed.ensure(n * packed_point_bytes<F>());
+#ifdef ZK_TEST_MSM_RACE   // round 2's ordering, kept ONLY to show that tests/test_stream_jitter.py catches it (never built into libzkhip.so)
+        msm_prepare(ctx, s, ctx->cur->sorts[0], ptr<u32>(ctx->cur->scalars), sh, 0);
         points_to_packed<F>(ctx, ptr<Aff<F>>(d_bases), d_packed.p, n);
+#else
+        points_to_packed<F>(ctx, ptr<Aff<F>>(d_bases), d_packed.p, n);
+        msm_prepare(ctx, s, ctx->cur->sorts[0], ptr<u32>(ctx->cur->scalars), sh, 0);
+#endif
         msm_run<F>(ctx, ctx->cur->lanes[0], ctx->cur->sorts[0], d_packed.p, sh, ptr<Xyzz<F>>(d_ws), nullptr, nullptr);
         stream_wait_event(s, ctx->cur->lanes[0].done);
-        std::vector<Xyzz<F>> ws(sh.sets);
+        std::vector<Xyzz<F>> ws(sh.nsums());
         dev_d2h(ws.data(), d_ws.p, ws.size() * sizeof(Xyzz<F>), s);
         stream_sync(s);
         Xyzz<F> res = msm_combine(ws.data(), sh);
@@ -1264,6 +1279,7 @@ struct CurveOps {
     u64 (*gm17_key_bytes)(u64, u64, u64);
     void (*gm17_prove_partial)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const void*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*gm17_combine)(const zkhip_pk*, u32, const uint8_t*, const uint8_t*, uint8_t*);
+    int (*ntt_log1)(zkhip_ctx*, int logN);   // log2 N1 of this context's NTT plan for a domain (what a key's h order depends on)
     size_t packed_g1_bytes;  // size of one resident G1 base (G2: twice that): lets zkhip_pk_import validate an image's shape
     int fr_bits;             // scalar width: the number of table levels follows from it and the window width
 };
@@ -1273,8 +1289,11 @@ static void field_op_dispatch(zkhip_ctx* ctx, int field, int op, u64 count, cons
     else Prover<C>::template field_op_api<typename C::Fq>(ctx, op, count, a, b, out);
 }
 template <class C>
+static int ntt_log1_of(zkhip_ctx* ctx, int logN) { return get_plan<C>(ctx, logN)->log1; }
+template <class C>
 static CurveOps make_curve_ops() {
     CurveOps o;
+    o.ntt_log1 = &ntt_log1_of<C>;
     o.pk_load = &PkLoader<C>::load;
     o.pk_table_levels = &PkLoader<C>::table_levels;
     o.r1cs_load = &Prover<C>::r1cs_load;

@@ -10,6 +10,7 @@
 // libzkhip.so, and is loaded only by tests.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <mutex>
 #include <unordered_map>
@@ -93,10 +94,45 @@ inline void* host_alloc_pinned(size_t bytes) {
 inline void host_free_pinned(void* p) {
     if (p) (void)hipHostFree(p);
 }
-inline void dev_h2d(void* d, const void* h, size_t n, Stream s) { ZK_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
-inline void dev_d2h(void* h, const void* d, size_t n, Stream s) { ZK_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
-inline void dev_d2d(void* d, const void* s_, size_t n, Stream s) { ZK_HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s)); }
-inline void dev_memset(void* d, int v, size_t n, Stream s) { ZK_HIP_CHECK(hipMemsetAsync(d, v, n, s)); }
+// Race-hunting mode (ZKHIP_TUNE_STREAM_JITTER / ZKHIP_STREAM_JITTER=<max microseconds> in the environment when the library
+// is loaded).  The library drives ~20 streams per context and orders them with events; an ordering that is missing is
+// invisible as long as the producer happens to win, and the emulator (one synchronous fibre scheduler) cannot see it at
+// all.  With jitter on, every enqueue is preceded — with probability 1/2 — by a one-wave spin kernel of random length on
+// the same stream: producers are delayed relative to consumers that do not wait for them, consumers that do wait are
+// unaffected, and a result that depended on luck changes.
+struct JitterState {
+    std::atomic<int> max_us{0};
+    std::atomic<uint64_t> rng{0x9E3779B97F4A7C15ull};
+};
+inline JitterState& jitter_state() {
+    static JitterState st;
+    static const bool init = [] {
+        if (const char* e = getenv("ZKHIP_STREAM_JITTER")) st.max_us.store(std::max(0, std::min(5000, atoi(e))));
+        return true;
+    }();
+    (void)init;
+    return st;
+}
+static __global__ void k_jitter_spin(unsigned long long ticks) {   // wall_clock64: the constant 100 MHz counter
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+inline void jitter_before(Stream s) {
+    JitterState& st = jitter_state();
+    const int max_us = st.max_us.load(std::memory_order_relaxed);
+    if (max_us <= 0) return;
+    uint64_t x = st.rng.fetch_add(0x9E3779B97F4A7C15ull, std::memory_order_relaxed);   // SplitMix64 step
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    if (x & 1) return;
+    const unsigned long long us = (x >> 8) % (uint64_t)(max_us + 1);
+    hipLaunchKernelGGL(k_jitter_spin, dim3(1), dim3(1), 0, s, us * 100ull);
+}
+inline void dev_h2d(void* d, const void* h, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
+inline void dev_d2h(void* h, const void* d, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
+inline void dev_d2d(void* d, const void* s_, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s)); }
+inline void dev_memset(void* d, int v, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemsetAsync(d, v, n, s)); }
 inline Stream stream_create() {
     Stream s;
     ZK_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -151,6 +187,7 @@ inline bool grid_nonempty(const dim3& g) { return g.x != 0 && g.y != 0 && g.z !=
     do {                                                                                  \
         if (!zk::grid_nonempty(dim3(grid))) break;                                        \
         if (zk::trace_enabled()) fprintf(stderr, "[zkhip] launch %s ...", #kernel);       \
+        zk::jitter_before(stream);                                                        \
         hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);               \
         zk::dev_check_last();                                                             \
         if (zk::trace_enabled()) {                                                        \
@@ -195,6 +232,8 @@ inline void event_sync(Event) {}
 inline void stream_wait_event(Stream, Event) {}
 inline float event_elapsed_ms(Event a, Event b) { return (float)(*b - *a); }
 inline void dev_check_last() {}
+struct JitterState { std::atomic<int> max_us{0}; };   // accepted and ignored: the emulator has one synchronous "stream"
+inline JitterState& jitter_state() { static JitterState st; return st; }
 
 #define ZK_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch(dim3(grid), dim3(block), (size_t)(smem), [&]() { kernel(__VA_ARGS__); })

@@ -141,6 +141,7 @@ struct Gm17 {
         pk->scheme = 1;
         pk->m = M; pk->w = n1; pk->l = l; pk->hlen = tl; pk->N = D; pk->logN = ilog2_floor(D);
         NttPlan<C>* plan = get_plan<C>(ctx, pk->logN);
+        pk->ntt_log1 = plan->log1;
         pk->g_gamma2_z2_canon.assign(g_gamma2_z2, g_gamma2_z2 + G1B);
 
         const u64 me = M + 2;   // extended by the (., rho) pair and one unused slot (same shape as the Groth16 key)
@@ -200,6 +201,7 @@ struct Gm17 {
         require(canon_lt_mod(dd) && canon_lt_mod(rr), ZKHIP_ERR_BAD_ARG, "d1 or r not a canonical field element");
         const Fr rho = add_mod(dd, rr);
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
+        require(pl->log1 == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's quotient bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
         sl.t_start = std::chrono::steady_clock::now();
         memcpy(sl.r, rho.v, 32);
         memset(sl.s, 0, 32);
@@ -244,7 +246,7 @@ struct Gm17 {
         // ---- the four MSMs over S = [ext_0..ext_{M-1}, rho, 0] share one digit/sort pass
         const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
         const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
-        const int Wmax = (int)std::max(shz.sets, shh.sets);
+        const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);

@@ -75,10 +75,11 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     const u32 CW = std::min<u32>(sh.Lw, 32), HG = std::max<u32>(1, std::min<u32>(8, sh.H));   // 256 work-items for big windows
     ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.sets, nt), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), sh.K,
               sh.Lw, sh.H, ptr<Xyzz<F>>(lane.cols));
-    // the scan form of the last fold step needs Lw + H points of LDS; the double-and-add form (Lw points) is the fallback
-    const unsigned TS = (sh.Lw + sh.H + 63) / 64 * 64;
-    if (ctx->fold_scan && TS <= 512 && (size_t)TS * sizeof(Xyzz<F>) <= 150 * 1024) {
-        ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.sets, nt), dim3(TS), TS * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols),
+    // the scan form of the last fold step: one workgroup of max(Lw, H) <= 256 work-items per digit; the double-and-add form
+    // (both digits in one workgroup of Lw work-items) is the fallback.  Either leaves two sums per bucket set.
+    const unsigned TS = std::max<u32>(64, std::max(sh.Lw, sh.H));
+    if (ctx->fold_scan && TS <= 256) {
+        ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.sets, nt, 2), dim3(TS), TS * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols),
                   sh.Lw, sh.H, d_window_sums, sum_stride);
     } else {
         const unsigned TF = std::max<u32>(64, sh.Lw);

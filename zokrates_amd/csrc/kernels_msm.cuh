@@ -28,8 +28,11 @@ namespace zk {
 // per point type tuning (measured on MI355X with tools/accum_bench.hip, 2^24 mixed additions on the unsaturated field:
 // G1 1.22 ms at 3 waves per SIMD; G2 3.17 ms at 2 waves per SIMD).  *_WPE = waves per SIMD the register allocator must
 // leave room for; the accumulation kernel is launched with exactly that many waves per SIMD on every CU, one slice each.
+// (G2: ONE wave per SIMD for the register allocator — 256 VGPRs + AGPRs instead of 256 VGPRs + 464 B of scratch per work-item.
+// Same speed on a fast box (profiles/r2e_g2_register_ab_runs.jsonl, variant B), and scratch is what differed between box
+// kinds; the slices stay two per SIMD lane.)
 #ifndef ZK_G2_ACCUM_WPE
-#define ZK_G2_ACCUM_WPE 2
+#define ZK_G2_ACCUM_WPE 1
 #endif
 #ifndef ZK_G2_TOUCH_PREFETCH
 #define ZK_G2_TOUCH_PREFETCH 0
@@ -44,14 +47,17 @@ template <class P_> struct MsmPrefetch<Fu2<P_>> { static constexpr bool TOUCH = 
 #define ZK_G1_SLICE_WPE 3
 #endif
 #ifndef ZK_G2_SLICE_WPE
-#define ZK_G2_SLICE_WPE ZK_G2_ACCUM_WPE
+#define ZK_G2_SLICE_WPE 2
+#endif
+#ifndef ZK_G2_COLD_WPE
+#define ZK_G2_COLD_WPE 1
 #endif
 // (ACCUM_WPE is the kernel's register budget, SLICE_WPE / FUSED_WPE how finely the sorted list is cut: slices per SIMD lane)
 template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false; };
 template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true; };
-template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = 2, FUSED_WPE = ZK_G2_ACCUM_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true; };
 template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false; };
-template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 2, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 1, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true; };
 // the base tables of the MSMs one launch serves (A, B1 and L of a proof share the sort of the assignment)
 static constexpr int MSM_MAX_TABLES = 3;
 struct MsmTables {
@@ -515,37 +521,38 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(
         for (u32 q = Lw; q > 1; q >>= 1) hi_sum = xyzz_dbl_inl(hi_sum);
         Xyzz<F> r = sh[0];
         xyzz_add_acc(r, hi_sum);
-        window_sum[j] = xyzz_to_sat<FS>(r);
+        window_sum[2 * j] = xyzz_to_sat<FS>(r);         // (a bucket set's value is the sum of its two entries: see 5c')
+        window_sum[2 * j + 1] = Xyzz<FS>::inf();
     }
 }
 
-// 5c'. the same result with a shorter dependent chain (the fold tail is pure latency: one workgroup per window).
+// 5c'. the same result with a shorter dependent chain (the fold tail is pure latency: one workgroup per digit and set).
 // Weighted sums become sums of suffix sums — sum_lo (lo+1) C_lo = sum_k S_k with S_k = sum_{lo >= k} C_lo, and
 // sum_hi hi R_hi = sum_{k >= 1} T_k with T_k = sum_{hi >= k} R_hi — so each digit costs one parallel suffix scan plus one
-// tree sum (2 log2 n full additions) instead of a double-and-add per element plus a tree sum, and the column digit
-// (work-items [0, Lw)) and the row digit (work-items [Lw, Lw + H), which also does the log2 Lw doublings) proceed side
-// by side: ~21 sequential curve operations instead of ~51.  blockDim.x >= Lw + H; dynamic LDS blockDim.x points.
+// tree sum (2 log2 n full additions) instead of a double-and-add per element plus a tree sum.  The column digit
+// (blockIdx.z = 0, Lw work-items) and the row digit (blockIdx.z = 1, H work-items, which also does the log2 Lw doublings)
+// are separate workgroups of <= 256 work-items — one wave per SIMD, the whole register file, no scratch even for G2 — and
+// each leaves its own sum: window_sum[2 j] and window_sum[2 j + 1]; the host adds the two (msm_combine).
+// blockDim.x = max(Lw, H) <= 256 (powers of two); dynamic LDS blockDim.x points.
 template <class F, class FS>
-__global__ void __launch_bounds__(512) k_msm_fold_final_scan(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final_scan(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
                                                              Xyzz<FS>* __restrict__ window_sum, u32 sum_stride) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x;
-    rows += (u64)blockIdx.y * gridDim.x * H;               // blockIdx.y: which MSM of the launch
-    cols += (u64)blockIdx.y * gridDim.x * Lw;
-    window_sum += (u64)blockIdx.y * sum_stride;
-    const bool is_col = t < Lw, live = t < Lw + H;
-    const u32 li = is_col ? t : t - Lw;                 // index inside the segment
+    const bool is_col = blockIdx.z == 0;
     const u32 seglen = is_col ? Lw : H;
+    const Xyzz<F>* src = is_col ? cols + ((u64)blockIdx.y * gridDim.x + j) * Lw     // blockIdx.y: which MSM of the launch
+                                : rows + ((u64)blockIdx.y * gridDim.x + j) * H;
+    window_sum += (u64)blockIdx.y * sum_stride;
+    const bool live = t < seglen;
     Xyzz<F> v = Xyzz<F>::inf();
-    if (is_col) v = cols[(u64)j * Lw + li];
-    else if (live) v = rows[(u64)j * H + li];
+    if (live) v = src[t];
     sh[t] = v;
     __syncthreads();
-    const u32 maxlen = Lw > H ? Lw : H;
-    for (u32 d = 1; d < maxlen; d <<= 1) {              // suffix scan inside each segment
-        const bool has = live && li + d < seglen;
+    for (u32 d = 1; d < seglen; d <<= 1) {              // suffix scan
+        const bool has = live && t + d < seglen;
         Xyzz<F> o = Xyzz<F>::inf();
         if (has) o = sh[t + d];
         __syncthreads();
@@ -555,26 +562,21 @@ __global__ void __launch_bounds__(512) k_msm_fold_final_scan(const Xyzz<F>* __re
         }
         __syncthreads();
     }
-    if (t == Lw) sh[t] = Xyzz<F>::inf();                // T_0 carries weight 0
+    if (!is_col && t == 0) sh[0] = Xyzz<F>::inf();      // T_0 carries weight 0
     __syncthreads();
-    for (u32 st = maxlen >> 1; st > 0; st >>= 1) {      // tree sum inside each segment
-        if (live && st < seglen && li < st) {
+    for (u32 st = seglen >> 1; st > 0; st >>= 1) {      // tree sum
+        if (t < st) {
             Xyzz<F> a = sh[t];
             xyzz_add_acc(a, sh[t + st]);
             sh[t] = a;
         }
         __syncthreads();
     }
-    if (t == Lw) {
-        Xyzz<F> hi_sum = sh[t];
-        for (u32 q = Lw; q > 1; q >>= 1) hi_sum = xyzz_dbl_inl(hi_sum);
-        sh[t] = hi_sum;
-    }
-    __syncthreads();
     if (t == 0) {
         Xyzz<F> r = sh[0];
-        xyzz_add_acc(r, sh[Lw]);
-        window_sum[j] = xyzz_to_sat<FS>(r);
+        if (!is_col)
+            for (u32 q = Lw; q > 1; q >>= 1) r = xyzz_dbl_inl(r);
+        window_sum[2 * j + (is_col ? 0 : 1)] = xyzz_to_sat<FS>(r);
     }
 }
 

@@ -84,6 +84,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->msm_waves = env_int("ZKHIP_MSM_WAVES", 1, 8, 0);
         ctx->ntt_single_max = env_int("ZKHIP_NTT_SINGLE_MAX_LOG", 0, NTT_MAX_SUBLOG, 10);
         ctx->ntt_cols = env_int("ZKHIP_NTT_COLS", 1, 8, 2);
+        if (ctx->ntt_cols & (ctx->ntt_cols - 1)) ctx->ntt_cols = 2;   // the cols pass has no tail handling: a power of two only
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
@@ -170,7 +171,11 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_Z_GATE: in(0, 2); ctx->z_gate = value; break;
             case ZKHIP_TUNE_FUSE_Z: in(0, 1); ctx->fuse_z = value != 0; break;
             case ZKHIP_TUNE_MSM_FUSED_WAVES: in(0, 8); ctx->msm_fused_waves = value; break;
-            case ZKHIP_TUNE_NTT_COLS: in(1, 8); dev_sync_all(); ctx->ntt_cols = value; ctx->plans.clear(); break;
+            case ZKHIP_TUNE_STREAM_JITTER: in(0, 5000); dev_sync_all(); jitter_state().max_us.store(value); break;
+            case ZKHIP_TUNE_NTT_COLS:
+                in(1, 8);
+                require((value & (value - 1)) == 0, ZKHIP_ERR_BAD_ARG, "NTT_COLS must be 1, 2, 4 or 8 (the cols pass covers N2 / cols workgroups exactly)");
+                dev_sync_all(); ctx->ntt_cols = value; ctx->plans.clear(); break;
             default: throw ApiError{ZKHIP_ERR_BAD_ARG, "unknown tunable"};
         }
     });
@@ -434,13 +439,14 @@ int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs*
 // An image holds either level 0 of the five base tables (compact: the window multiples are recomputed on the device at
 // import, ~0.1 s for a 2^20 key — less than reading the 6 GiB they occupy from any disk) or all levels
 // (ZKHIP_PK_IMAGE_FULL: import is five host-to-device copies and nothing else).
-static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '2'};
+static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '3'};
 struct PkImageHeader {
     char magic[8];
     int32_t curve, scheme;
     uint64_t m, w, l, hlen, N;
     int32_t logN, c_z, c_h, full;     // full: 0 = level 0 only, 1 = every level
     uint32_t rank, world;
+    int32_t ntt_log1, reserved;       // the NTT split h_sigma is ordered for (zkhip_pk::ntt_log1)
     uint64_t z_lo, z_n, h_lo, h_n;
     uint64_t len_delta, len_g2z2, len_buf[5];
 };
@@ -475,6 +481,7 @@ int32_t zkhip_pk_export_ex(const zkhip_pk* pk_, uint32_t flags, uint8_t* out, ui
         h.m = pk->m; h.w = pk->w; h.l = pk->l; h.hlen = pk->hlen; h.N = pk->N;
         h.logN = pk->logN; h.c_z = pk->c_z; h.c_h = pk->c_h; h.full = (flags & ZKHIP_PK_IMAGE_FULL) ? 1 : 0;
         h.rank = pk->rank; h.world = pk->world;
+        h.ntt_log1 = pk->ntt_log1;
         h.z_lo = pk->z_lo; h.z_n = pk->z_n; h.h_lo = pk->h_lo; h.h_n = pk->h_n;
         h.len_delta = pk->delta_g1_canon.size(); h.len_g2z2 = pk->g_gamma2_z2_canon.size();
         for (int k = 0; k < 5; ++k) h.len_buf[k] = pk_image_part(pk->curve, k, pk->z_n, pk->h_n, pk->c_z, pk->c_h, h.full);
@@ -518,11 +525,14 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
                         h.len_delta <= 4096 && h.len_g2z2 <= 4096;
         for (int k = 0; k < 5 && sizes_ok; ++k) sizes_ok = h.len_buf[k] == pk_image_part(h.curve, k, h.z_n, h.h_n, h.c_z, h.c_h, h.full);
         require(sizes_ok, ZKHIP_ERR_PARSE, "key image: array sizes do not match the header");
+        require(ops->ntt_log1(ctx, h.logN) == h.ntt_log1, ZKHIP_ERR_PARSE,
+                "key image: written under another NTT split (NTT_SINGLE_MAX_LOG) than this context uses; re-import the proving key");
         std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
         pk->curve = h.curve; pk->scheme = h.scheme; pk->ctx = ctx;
         pk->m = h.m; pk->w = h.w; pk->l = h.l; pk->hlen = h.hlen; pk->N = h.N; pk->logN = h.logN;
         pk->c_z = h.c_z; pk->c_h = h.c_h; pk->rank = h.rank; pk->world = h.world;
         pk->z_lo = h.z_lo; pk->z_n = h.z_n; pk->h_lo = h.h_lo; pk->h_n = h.h_n;
+        pk->ntt_log1 = h.ntt_log1;
         const uint8_t* p = bytes + sizeof(h);
         pk->delta_g1_canon.assign(p, p + h.len_delta); p += h.len_delta;
         pk->g_gamma2_z2_canon.assign(p, p + h.len_g2z2); p += h.len_g2z2;
@@ -551,7 +561,7 @@ struct zkhip_multi {
 // run fn(k) for every member — one host thread each (contexts are independent; the test emulator is single-threaded) —
 // and keep the first failure
 template <class Fn>
-static int32_t multi_each(zkhip_multi* m, Fn&& fn) {
+static int32_t multi_each(zkhip_multi* m, Fn&& fn) try {
     const size_t n = m->ctx.size();
     std::vector<int32_t> rc(n, ZKHIP_OK);
     std::vector<std::string> msg(n);
@@ -574,6 +584,16 @@ static int32_t multi_each(zkhip_multi* m, Fn&& fn) {
             return rc[k];
         }
     return ZKHIP_OK;
+} catch (const std::bad_alloc&) {   // nothing may escape through the C ABI (HostThreads joins what was started)
+    return ZKHIP_ERR_NOMEM;
+} catch (...) {
+    return ZKHIP_ERR_DEVICE;
+}
+// every member holds a constraint system and a key
+static bool multi_loaded(const zkhip_multi* m) {
+    for (auto* c : m->cs) if (!c) return false;
+    for (auto* p : m->pk) if (!p) return false;
+    return true;
 }
 extern "C" {
 static void multi_drop_keys(zkhip_multi* m) {
@@ -587,6 +607,14 @@ int32_t zkhip_ctx_create_multi(const int32_t* devices, int32_t n, zkhip_multi** 
     if (!devices || n < 1 || n > 64) { g_create_err = "device list empty or longer than 64"; return ZKHIP_ERR_BAD_ARG; }
     std::unique_ptr<zkhip_multi> m(new (std::nothrow) zkhip_multi());
     if (!m) { g_create_err = "out of host memory"; return ZKHIP_ERR_NOMEM; }
+    try {
+        m->ctx.reserve(n);
+        m->pk.assign(n, nullptr);
+        m->cs.assign(n, nullptr);
+    } catch (const std::bad_alloc&) {
+        g_create_err = "out of host memory";
+        return ZKHIP_ERR_NOMEM;
+    }
     for (int32_t k = 0; k < n; ++k) {
         zkhip_ctx* c = nullptr;
         const int32_t rc = zkhip_ctx_create(devices[k], &c);
@@ -594,10 +622,8 @@ int32_t zkhip_ctx_create_multi(const int32_t* devices, int32_t n, zkhip_multi** 
             for (auto* q : m->ctx) zkhip_ctx_free(q);
             return rc;        // message already in the per-thread create error
         }
-        m->ctx.push_back(c);
+        m->ctx.push_back(c);  // (capacity reserved above)
     }
-    m->pk.assign(n, nullptr);
-    m->cs.assign(n, nullptr);
     *out = m.release();
     return ZKHIP_OK;
 }
@@ -615,10 +641,13 @@ int32_t zkhip_multi_r1cs_load(zkhip_multi* m, int32_t curve, uint64_t n, uint64_
                               const uint8_t* val_a, const uint64_t* rowptr_b, const uint32_t* col_b, const uint8_t* val_b, const uint64_t* rowptr_c,
                               const uint32_t* col_c, const uint8_t* val_c) {
     if (!m) return ZKHIP_ERR_BAD_ARG;
-    for (auto*& c : m->cs) { zkhip_r1cs_free(c); c = nullptr; }
-    return multi_each(m, [&](size_t k) {
+    auto drop = [&] { for (auto*& c : m->cs) { zkhip_r1cs_free(c); c = nullptr; } };
+    drop();
+    const int32_t rc = multi_each(m, [&](size_t k) {
         return zkhip_r1cs_load(m->ctx[k], curve, n, l, w, rowptr_a, col_a, val_a, rowptr_b, col_b, val_b, rowptr_c, col_c, val_c, &m->cs[k]);
     });
+    if (rc != ZKHIP_OK) drop();      // all members or none: a partly loaded group must not reach the provers
+    return rc;
 }
 int32_t zkhip_multi_pk_load_g16(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len) {
     if (!m) return ZKHIP_ERR_BAD_ARG;
@@ -647,7 +676,7 @@ int32_t zkhip_multi_pk_load_g16_replicas(zkhip_multi* m, int32_t curve, const ui
 int32_t zkhip_prove_g16_multi_batch(zkhip_multi* m, uint32_t count, const uint8_t* z, const uint8_t* rs, uint8_t* proofs_out, zkhip_timings* timings) {
     if (!m) return ZKHIP_ERR_BAD_ARG;
     if ((!z || !rs || !proofs_out) && count) { m->err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
-    if (m->scheme != 0 || !m->replicas || !m->cs[0]) {
+    if (m->scheme != 0 || !m->replicas || !multi_loaded(m)) {
         m->err = "load the constraint system and zkhip_multi_pk_load_g16_replicas first";
         return ZKHIP_ERR_BAD_ARG;
     }
@@ -677,7 +706,7 @@ int32_t zkhip_prove_g16_multi_batch(zkhip_multi* m, uint32_t count, const uint8_
 static int32_t multi_prove(zkhip_multi* m, int scheme, const uint8_t* z, const uint8_t* rnd, const uint8_t* s_, uint8_t* proof_out, zkhip_timings* timings) {
     if (!m) return ZKHIP_ERR_BAD_ARG;
     if (!z || !rnd || !proof_out || (scheme == 0 && !s_)) { m->err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
-    if (m->scheme != scheme || !m->cs[0]) { m->err = "load the constraint system and a proving key of this scheme first"; return ZKHIP_ERR_BAD_ARG; }
+    if (m->scheme != scheme || !multi_loaded(m)) { m->err = "load the constraint system and a proving key of this scheme first"; return ZKHIP_ERR_BAD_ARG; }
     if (m->replicas) { m->err = "the members hold whole keys (replicas): use zkhip_prove_g16_multi_batch, or load the key sharded"; return ZKHIP_ERR_BAD_ARG; }
     const auto t0 = std::chrono::steady_clock::now();
     uint64_t rec = 0;
