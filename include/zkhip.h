@@ -328,6 +328,19 @@ int32_t zkhip_prog_matrix(const zkhip_prog* prog, int32_t which, const uint64_t*
                           const uint8_t** val);
 int32_t zkhip_prog_variable_order(const zkhip_prog* prog, const int64_t** ids);
 int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs** out);
+/* The inverse of zkhip_prog_parse: an R1CS (CSR, canonical LE values, m columns) as the bytes of a ZoKrates `out` program
+ * whose statements are exactly the constraints in row order — `ProgIterator::serialize`
+ * (/root/reference/zokrates_ast/src/ir/serialize.rs:202-279) for a program without directives.  ids[j] is the ZoKrates
+ * variable id of column j (0 = ~one, k > 0 = _{k-1}, -k = ~out_{k-1}); (arg_ids, arg_private)[n_args] is the argument
+ * list.  A reader numbers variables in first-seen order, so the columns come back in this order only if the rows
+ * mention them in it.  `out` must hold zkhip_prog_write_bound(n, nnz(A)+nnz(B)+nnz(C), n_args) bytes; *len = bytes
+ * written.  Host only. */
+int32_t zkhip_prog_write_bound(uint64_t n, uint64_t nnz, uint64_t n_args, uint64_t* bytes);
+int32_t zkhip_prog_write(int32_t curve, uint64_t n, uint64_t m, const uint64_t* rowptr_a, const uint32_t* col_a, const uint8_t* val_a,
+                         const uint64_t* rowptr_b, const uint32_t* col_b, const uint8_t* val_b, const uint64_t* rowptr_c,
+                         const uint32_t* col_c, const uint8_t* val_c, const int64_t* ids, const int64_t* arg_ids,
+                         const uint8_t* arg_private, uint64_t n_args, uint32_t return_count, uint8_t* out, uint64_t cap,
+                         uint64_t* len);
 int32_t zkhip_prog_assignment(const zkhip_prog* prog, const uint8_t* witness, size_t len, uint8_t* z_out,
                               uint8_t* inputs_out, uint64_t inputs_cap, uint64_t* n_inputs);
 

@@ -45,6 +45,11 @@ def test_single_rank_contract(args, metric):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_proof_identical"] is True
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000
+    e = d["cli_end_to_end_ms"]                         # the reference-shaped flow: files -> proof.json, one process per proof
+    assert "error" not in e, e
+    for run in ("from_proving_key", "from_key_image", "from_full_key_image"):
+        assert e[run]["proof_json_identical_to_resident_prover"] is True and e[run]["process_wall_ms"] > 0, (run, e[run])
+    assert e["from_proving_key"]["key_source"] == "proving.key" and e["from_key_image"]["key_source"] == "image"
 
 
 @pytest.mark.parametrize("scheme,port", [("g16", "29541"), ("gm17", "29543")])

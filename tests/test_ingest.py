@@ -468,3 +468,87 @@ def test_parser_survives_mutations(lib):
     with pytest.raises(native.ZkhipError) as e:
         p.assignment(struct.pack("<Q", 1) + struct.pack("<q", (1 << 31) - 2) + bytes(32))
     assert e.value.code == -2
+
+
+# ---------------------------------------------------------------- chunked / parallel decode, and the writer
+def _snapshot(p):
+    mats = p.mats()
+    return ((p.curve_id, p.n, p.l, p.w, p.return_count, p.n_public_args, p.nnz), list(p.variable_order()),
+            [(rp.tobytes(), col.tobytes(), val.tobytes()) for rp, col, val in mats])
+
+
+def test_parallel_decode_equals_sequential(lib, monkeypatch):
+    """The constraint section is decoded in chunks that start at the byte pattern of `{"Constraint":`; a cut is trusted only
+    if the chunk before it ends exactly there.  Programs with that pattern inside directive payloads, byte strings and
+    coefficients, cut every few dozen bytes, must come out exactly as from one sequential pass (variables are numbered in
+    first-seen order ACROSS chunks)."""
+    curve = BN254
+    pat = bytes([0xa1, 0x6a]) + b"Constraint"
+    rnd = random.Random(5)
+    for trial in range(5):
+        prog = random_prog(curve, rnd, n=150, n_args=3, n_out=2)
+        poison = ir.Other("Directive", {"span": None, "inputs": [], "outputs": [],
+                                        "solver": {"Zir": {"blob": pat + b"\0" * 7, "nested": {"Constraint": {"span": None, "quad": 1}}}}})
+        for pos in (5, 60, 140):
+            prog.statements.insert(pos, poison)
+        evil = int.from_bytes(pat + bytes(20), "little")            # a coefficient whose bytes start like a statement
+        prog.statements.insert(30, ir.Constraint([(7, evil)], [(8, evil), (0, 1)], [(9, 1)]))
+        data = ir.serialize_prog(prog)
+        monkeypatch.setenv("ZKHIP_INGEST_THREADS", "1")
+        want = _snapshot(native.Program(data, lib))
+        l, w, order, rows = ir.ark_order(prog)
+        assert want[1] == order
+        for threads, chunk in ((8, 64), (3, 1000), (64, 16), (5, 333)):
+            monkeypatch.setenv("ZKHIP_INGEST_THREADS", str(threads))
+            monkeypatch.setenv("ZKHIP_INGEST_MIN_CHUNK", str(chunk))
+            assert _snapshot(native.Program(data, lib)) == want, (trial, threads, chunk)
+        # errors are the sequential parser's errors: a truncated file, a flipped byte deep inside
+        for bad in (data[:len(data) * 2 // 3], data[:700] + bytes([data[700] ^ 0xff]) + data[701:]):
+            outcomes = []
+            for threads in ("1", "8"):
+                monkeypatch.setenv("ZKHIP_INGEST_THREADS", threads)
+                try:
+                    outcomes.append(_snapshot(native.Program(bad, lib)))
+                except native.ZkhipError as e:
+                    outcomes.append((e.code, str(e)))
+            assert outcomes[0] == outcomes[1]
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_program_writer_round_trip(lib, curve, monkeypatch):
+    """zkhip_prog_write (R1CS -> `out`) against the python writer byte for byte, and through the reader: the synthetic
+    benchmark circuit comes back with the same matrices in the same column order."""
+    from zokrates_amd import synth
+    circ = synth.circuit(curve.curve_id, 9, kind="sha", seed=11)
+    data = native.write_program(curve.curve_id, circ.n, circ.m, circ.mats(), args=[(1, False)], library=lib)
+    # the same program through oracle/ir.py's writer
+    stmts = []
+    rows = rows_of(circ.mats(), circ.n) if False else None
+    mats = circ.mats()
+    def row(k, i):
+        rp, col, val = mats[k]
+        return [(int(col[q]), int.from_bytes(val[32 * q:32 * q + 32].tobytes(), "little")) for q in range(int(rp[i]), int(rp[i + 1]))]
+    for i in range(circ.n):
+        stmts.append(ir.Constraint(row(0, i), row(1, i), row(2, i)))
+    prog = ir.Prog(curve, [ir.Parameter(1, False)], stmts, return_count=0)
+    assert data.tobytes() == ir.serialize_prog(prog)
+    for threads in ("1", "6"):
+        monkeypatch.setenv("ZKHIP_INGEST_THREADS", threads)
+        monkeypatch.setenv("ZKHIP_INGEST_MIN_CHUNK", "4096")
+        p = native.Program(data, lib)
+        assert (p.n, p.l, p.w) == (circ.n, circ.l, circ.w)
+        # every variable of the sha-like circuit appears, in column order, except that boolean rows mention their variable
+        # before the chain reaches it: compare as sets of rows under the returned order
+        order = list(p.variable_order())
+        assert sorted(order) == list(range(circ.m))
+        perm = {zid: j for j, zid in enumerate(order)}                  # original column -> column after the reader
+        got = rows_of(p.mats(), circ.n)
+        for k in range(3):
+            for i in range(circ.n):
+                assert got[k][i] == {perm[c]: v for c, v in row(k, i)}, (k, i)
+        z = circ.assignment(3)
+        wit = native.write_witness(np.arange(circ.m), z)
+        assert wit.tobytes() == ir.serialize_witness({j: int.from_bytes(z[32 * j:32 * j + 32].tobytes(), "little") for j in range(circ.m)})
+        zz, inputs = p.assignment(wit)
+        assert zz.reshape(-1, 32)[[perm[j] for j in range(circ.m)]].tobytes() == z.tobytes()
+        assert inputs.tobytes() == z[32:64].tobytes()

@@ -13,8 +13,13 @@ Needs a gfx950 GPU (there is no CPU fallback).
 """
 import argparse
 import hashlib
+import json
 import os
 import sys
+import threading
+import time
+
+import numpy as np
 
 from . import formats, native, rng
 
@@ -48,27 +53,39 @@ def _load_system(ctx, path):
     return native.ConstraintSystem(ctx, r1.curve_id, r1.n, r1.l, r1.w, r1.mats), None
 
 
-def _load_key(ctx, curve_id, path, scheme, cache_dir):
+def _load_key(ctx, curve_id, path, scheme, cache_dir, full_image=False):
     """`proving.key` -> resident key.  With --key-cache DIR the device-layout image (`zkhip_pk_export`) is kept next to
     it, named after (path, size, mtime, scheme) — hashing a 400 MB key would cost more than parsing it — and later runs
-    import the image (`zkhip_pk_import`: no parsing, no Montgomery conversion)."""
+    import the image (`zkhip_pk_import`: no parsing, no Montgomery conversion).  full_image: the image also holds the
+    precomputed window multiples (16x the size; import is five copies and no kernel)."""
     if cache_dir:
         st = os.stat(path)
-        tag = hashlib.sha256(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}|{scheme}|{curve_id}".encode()).hexdigest()[:32]
+        tag = hashlib.sha256(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}|{scheme}|{curve_id}|{int(full_image)}".encode()).hexdigest()[:32]
         image_path = os.path.join(cache_dir, tag + ".zkhippk")
         if os.path.exists(image_path):
             try:
-                return native.ProvingKey.from_image(ctx, curve_id, open(image_path, "rb").read(), scheme=scheme)
+                return native.ProvingKey.from_image(ctx, curve_id, np.fromfile(image_path, dtype=np.uint8), scheme=scheme), "image"
             except native.ZkhipError:
                 pass                                   # stale image of another library build: fall through and rewrite it
-    pk = native.ProvingKey(ctx, curve_id, open(path, "rb").read(), scheme=scheme)
+    pk = native.ProvingKey(ctx, curve_id, np.fromfile(path, dtype=np.uint8), scheme=scheme)
     if cache_dir:
         os.makedirs(cache_dir, exist_ok=True)
         tmp = image_path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(pk.export_image().tobytes())
+        pk.export_image(full=full_image).tofile(tmp)
         os.replace(tmp, image_path)
-    return pk
+    return pk, "proving.key"
+
+
+def _curve_of(path):
+    """Curve id from the first bytes of a program file (`out`: Field::id at offset 8; .r1cs: the prime of its header)."""
+    with open(path, "rb") as f:
+        head = f.read(4096)
+    if head[:4] == b"ZOK\0":
+        cid = {bytes.fromhex("b4f7b5bd"): 0, bytes.fromhex("40d8c1f9"): 1}.get(head[8:12])
+        if cid is None:
+            sys.exit("unknown curve identifier in the program file")
+        return cid
+    return None
 
 
 def cmd_setup(args):
@@ -89,20 +106,73 @@ def cmd_setup(args):
 
 
 def cmd_generate_proof(args):
+    """`zokrates generate-proof` (/root/reference/zokrates_cli/src/ops/generate_proof.rs:152-202): program + witness +
+    proving key -> proof.json, one proof per process.  The three inputs are independent until the proof starts, so the
+    program is read and decoded on host threads (zkhip_prog_parse: the constraint section in parallel chunks) WHILE the key
+    is uploaded and its window multiples are built on the GPU; --timings prints where the wall clock went."""
+    t_start = time.perf_counter()
+    marks = {}
+
+    def lap(name, t0):
+        marks[name] = round(1000.0 * (time.perf_counter() - t0), 3)
+
+    curve_hint = _curve_of(args.input)
+    native.default_library()                           # loaded once, before the host-side thread needs it too
+    host = {}
+
+    def load_host_side():                              # no GPU involved: runs beside the key upload
+        t0 = time.perf_counter()
+        data = np.fromfile(args.input, dtype=np.uint8)
+        wdata = np.fromfile(args.witness, dtype=np.uint8)
+        lap("read_program_and_witness_ms", t0)
+        t0 = time.perf_counter()
+        if data[:4].tobytes() == b"ZOK\0":
+            prog = native.Program(data)
+            host["prog"] = prog
+            lap("parse_program_ms", t0)
+            t0 = time.perf_counter()
+            host["z"], inp = prog.assignment(wdata)    # ark order; inputs = public_inputs_values
+            host["inputs"] = [int.from_bytes(inp[32 * i:32 * i + 32].tobytes(), "little") for i in range(inp.size // 32)]
+            lap("witness_to_assignment_ms", t0)
+        else:
+            host["r1cs"] = formats.read_r1cs(data.tobytes())
+            lap("parse_program_ms", t0)
+            t0 = time.perf_counter()
+            host["wtns"] = formats.read_wtns(wdata.tobytes())
+            lap("witness_to_assignment_ms", t0)
+
+    worker = None
+    if curve_hint is not None:                         # the key's curve is known from the header: overlap
+        worker = threading.Thread(target=load_host_side)
+        worker.start()
+    t0 = time.perf_counter()
     ctx = native.Context(args.device)
-    cs, prog = _load_system(ctx, args.input)
-    wdata = open(args.witness, "rb").read()
-    if prog is not None:
-        z, inp = prog.assignment(wdata)                # ark order; inputs = public_inputs_values
-        inputs = [int.from_bytes(inp[32 * i:32 * i + 32].tobytes(), "little") for i in range(inp.size // 32)]
+    lap("hip_init_ms", t0)
+    if worker is None:
+        load_host_side()
+        curve_hint = host["r1cs"].curve_id
+    t0 = time.perf_counter()
+    pk, key_source = _load_key(ctx, curve_hint, args.proving_key_path, args.proving_scheme, args.key_cache, args.key_cache_full)
+    lap("key_load_ms", t0)
+    if worker is not None:
+        t0 = time.perf_counter()
+        worker.join()
+        lap("wait_for_host_side_ms", t0)               # what the host side took beyond the key upload
+    t0 = time.perf_counter()
+    if "prog" in host:
+        cs = host["prog"].constraint_system(ctx)
+        z, inputs = host["z"], host["inputs"]
     else:
-        curve_w, z = formats.read_wtns(wdata)
+        r1 = host["r1cs"]
+        cs = native.ConstraintSystem(ctx, r1.curve_id, r1.n, r1.l, r1.w, r1.mats)
+        curve_w, z = host["wtns"]
         if curve_w != cs.curve_id or z.size != 32 * cs.m:
             sys.exit("witness does not match the constraint system")
         inputs = [int.from_bytes(z[32 * i:32 * i + 32].tobytes(), "little") for i in range(1, cs.l)]
-    pk = _load_key(ctx, cs.curve_id, args.proving_key_path, args.proving_scheme, args.key_cache)
+    lap("r1cs_upload_ms", t0)
     # the blinding scalars are drawn as the reference draws them: StdRng seeded from --entropy (rng.rs:5-20) or from the OS,
     # then `Fr::rand` twice (Groth16: r, s) or three times (GM17: d1, d2, r) — zokrates_amd/rng.py
+    t0 = time.perf_counter()
     gen = rng.rng_from_entropy(args.entropy) if args.entropy is not None else rng.StdRng(os.urandom(32))
     if args.proving_scheme == "gm17":
         d1, d2, r = (rng.fr_rand(gen, cs.curve_id) for _ in range(3))
@@ -110,8 +180,17 @@ def cmd_generate_proof(args):
     else:
         r, s = (rng.fr_rand(gen, cs.curve_id) for _ in range(2))
         raw = native.prove_g16(ctx, pk, cs, z, r, s)
-    open(args.proof_path, "w").write(formats.proof_json(cs.curve_id, raw, inputs, scheme=args.proving_scheme))
+    lap("prove_ms", t0)
+    t0 = time.perf_counter()
+    with open(args.proof_path, "w") as f:
+        f.write(formats.proof_json(cs.curve_id, raw, inputs, scheme=args.proving_scheme))
+    lap("proof_json_ms", t0)
+    marks["total_in_process_ms"] = round(1000.0 * (time.perf_counter() - t_start), 3)
+    marks["key_source"] = key_source
+    marks["constraints"] = cs.n
     print(f"generate-proof ({args.proving_scheme}): wrote {args.proof_path}")
+    if args.timings:
+        print("timings " + json.dumps(marks))
 
 
 def main(argv=None):
@@ -132,6 +211,8 @@ def main(argv=None):
     g.add_argument("-j", "--proof-path", default="proof.json")
     g.add_argument("-s", "--proving-scheme", default="g16", choices=["g16", "gm17"])
     g.add_argument("--key-cache", help="directory for device-layout key images (zkhip_pk_export / zkhip_pk_import)")
+    g.add_argument("--key-cache-full", action="store_true", help="cache images that include the precomputed window multiples (16x larger)")
+    g.add_argument("--timings", action="store_true", help="print the split of the wall clock as one JSON object")
     g.add_argument("--entropy")
     g.add_argument("--device", type=int, default=0)
     g.set_defaults(fn=cmd_generate_proof)

@@ -51,29 +51,6 @@ struct CurveBls381 {
     static const u32* g2_gen() { static const u32 t[] = {0xc121bdb8u, 0xd48056c8u, 0xa805bbefu, 0x0bac0326u, 0x7ae3d177u, 0xb4510b64u, 0xfa403b02u, 0xc6e47ad4u, 0x2dc51051u, 0x26080527u, 0xf08f0a91u, 0x024aa2b2u, 0x5d042b7eu, 0xe5ac7d05u, 0x13945d57u, 0x334cf112u, 0xdc7f5049u, 0xb5da61bbu, 0x9920b61au, 0x596bd0d0u, 0x88274f65u, 0x7dacd3a0u, 0x52719f60u, 0x13e02b60u, 0x08b82801u, 0xe1935486u, 0x3baca289u, 0x923ac9ccu, 0x5160d12cu, 0x6d429a69u, 0x8cbdd3a7u, 0xadfd9baau, 0xda2e351au, 0x8cc9cdc6u, 0x727d6e11u, 0x0ce5d527u, 0xf05f79beu, 0xaaa9075fu, 0x5cec1da1u, 0x3f370d27u, 0x572e99abu, 0x267492abu, 0x85a763afu, 0xcb3e287eu, 0x2bc28b99u, 0x32acd2b0u, 0x2ea734ccu, 0x0606c4a0u}; return t; }
 };
 
-// A few host threads that are always joined: if starting one fails (EAGAIN) the work runs on the calling thread instead,
-// and leaving the scope — normally or through an exception — joins whatever was started.
-struct HostThreads {
-    std::vector<std::thread> th;
-    HostThreads() { th.reserve(64); }
-    HostThreads(const HostThreads&) = delete;
-    HostThreads& operator=(const HostThreads&) = delete;
-    template <class Fn>
-    void run(Fn&& fn) {
-        try {
-            th.emplace_back(fn);
-        } catch (const std::system_error&) {
-            fn();
-        }
-    }
-    void join() {
-        for (auto& t : th)
-            if (t.joinable()) t.join();
-        th.clear();
-    }
-    ~HostThreads() { join(); }
-};
-
 struct ApiError {
     int32_t code;
     std::string msg;
@@ -558,10 +535,27 @@ struct zkhip_r1cs {
     int logN;
     DBuf rp[3], col[3], val[3];
     u64 nnz[3];
-    // host copy kept for setup (N3)
-    std::vector<u64> h_rp[3];
-    std::vector<u32> h_col[3];
-    std::vector<uint8_t> h_val[3];
+};
+// the matrices of a resident constraint system back in host memory (setup, N3: key generation walks them on the host; the
+// prover never needs them there, so zkhip_r1cs_load keeps no host copy).  Values come back as they are resident:
+// saturated Montgomery form.
+struct HostCsr {
+    std::vector<u64> rp[3];
+    std::vector<u32> col[3];
+    std::vector<uint8_t> val[3];
+    void fetch(zkhip_ctx* ctx, const zkhip_r1cs* cs) {
+        for (int k = 0; k < 3; ++k) {
+            rp[k].resize(cs->n + 1);
+            col[k].resize(cs->nnz[k]);
+            val[k].resize(cs->nnz[k] * 32);
+            dev_d2h(rp[k].data(), cs->rp[k].p, (cs->n + 1) * 8, ctx->stream);
+            if (cs->nnz[k]) {
+                dev_d2h(col[k].data(), cs->col[k].p, cs->nnz[k] * 4, ctx->stream);
+                dev_d2h(val[k].data(), cs->val[k].p, cs->nnz[k] * 32, ctx->stream);
+            }
+        }
+        stream_sync(ctx->stream);
+    }
 };
 
 // an assignment resident in HBM: (m + 2) x 32 B canonical integers; the two tail slots receive r and s
@@ -1237,9 +1231,6 @@ struct Prover {
                 dev_h2d(cs->val[k].p, val[k], nnz * 32, s);
                 ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(nnz, 256)), dim3(256), 0, s, ptr<Fr>(cs->val[k]), ptr<Fr>(cs->val[k]), nnz);
             }
-            cs->h_rp[k].assign(rp[k], rp[k] + cs->n + 1);
-            cs->h_col[k].assign(col[k], col[k] + nnz);
-            cs->h_val[k].assign(val[k], val[k] + nnz * 32);
         }
         stream_sync(s);
     }

@@ -19,6 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <system_error>
+#include <thread>
+#include <vector>
 
 #ifdef ZK_EMU
 #include "emu.h"
@@ -31,6 +34,30 @@ namespace zk {
 struct DevError {
     std::string msg;
 };
+
+// A few host threads that are always joined: if starting one fails (EAGAIN) the work runs on the calling thread instead,
+// and leaving the scope — normally or through an exception — joins whatever was started.
+struct HostThreads {
+    std::vector<std::thread> th;
+    HostThreads() { th.reserve(64); }
+    HostThreads(const HostThreads&) = delete;
+    HostThreads& operator=(const HostThreads&) = delete;
+    template <class Fn>
+    void run(Fn&& fn) {
+        try {
+            th.emplace_back(fn);
+        } catch (const std::system_error&) {
+            fn();
+        }
+    }
+    void join() {
+        for (auto& t : th)
+            if (t.joinable()) t.join();
+        th.clear();
+    }
+    ~HostThreads() { join(); }
+};
+
 
 #ifndef ZK_EMU
 #define ZK_HIP_CHECK(expr)                                                                        \

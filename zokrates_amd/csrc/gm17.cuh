@@ -431,13 +431,15 @@ struct Gm17 {
         dev_d2h(u.data(), d_u.p, D * sizeof(Fr), s);
         stream_sync(s);
         std::vector<Fr> av(M, Fr::zero()), cv(M, Fr::zero());
-        auto val_at = [&](int k, u64 q) { return fe_to_mont(fe_from_bytes_canon<Fr>(cs->h_val[k].data() + q * 32)); };
+        HostCsr hm;
+        hm.fetch(ctx, cs);
+        auto val_at = [&](int k, u64 q) { return fe_from_bytes_canon<Fr>(hm.val[k].data() + q * 32); };   // Montgomery form, as resident
         HostThreads ta;
         ta.run([&] {
             for (u64 i = 0; i < n; ++i) {
                 const Fr u_add = fe_add(u[2 * i], u[2 * i + 1]), u_sub = fe_sub(u[2 * i], u[2 * i + 1]);
-                for (u64 q = cs->h_rp[0][i]; q < cs->h_rp[0][i + 1]; ++q) { Fr& x = av[cs->h_col[0][q]]; x = fe_add(x, fe_mul(u_add, val_at(0, q))); }
-                for (u64 q = cs->h_rp[1][i]; q < cs->h_rp[1][i + 1]; ++q) { Fr& x = av[cs->h_col[1][q]]; x = fe_add(x, fe_mul(u_sub, val_at(1, q))); }
+                for (u64 q = hm.rp[0][i]; q < hm.rp[0][i + 1]; ++q) { Fr& x = av[hm.col[0][q]]; x = fe_add(x, fe_mul(u_add, val_at(0, q))); }
+                for (u64 q = hm.rp[1][i]; q < hm.rp[1][i + 1]; ++q) { Fr& x = av[hm.col[1][q]]; x = fe_add(x, fe_mul(u_sub, val_at(1, q))); }
             }
             av[0] = fe_add(av[0], u[2 * n]);
             for (u64 i = 1; i < l; ++i) {
@@ -448,7 +450,7 @@ struct Gm17 {
         });
         for (u64 i = 0; i < n; ++i) {
             const Fr u4 = fe_dbl(fe_dbl(u[2 * i]));
-            for (u64 q = cs->h_rp[2][i]; q < cs->h_rp[2][i + 1]; ++q) { Fr& x = cv[cs->h_col[2][q]]; x = fe_add(x, fe_mul(u4, val_at(2, q))); }
+            for (u64 q = hm.rp[2][i]; q < hm.rp[2][i + 1]; ++q) { Fr& x = cv[hm.col[2][q]]; x = fe_add(x, fe_mul(u4, val_at(2, q))); }
             cv[m + i] = fe_add(cv[m + i], fe_add(u[2 * i], u[2 * i + 1]));
         }
         cv[0] = fe_add(cv[0], u[2 * n]);

@@ -26,4 +26,9 @@ void prog_parse(const uint8_t* bytes, size_t len, zkhip_prog* out);
 // Witness::read + the `witness.remove(..)` walk of generate_constraints (z, m x 32 B) + public_inputs_values
 // (inputs_out, up to cap elements; *n_inputs = how many there are); throws IngestError
 void prog_assignment(const zkhip_prog* prog, const uint8_t* wit, size_t len, uint8_t* z_out, uint8_t* inputs_out, uint64_t cap, uint64_t* n_inputs);
+// R1CS -> the bytes of a ZoKrates `out` program (ProgIterator::serialize); returns the length written; throws IngestError
+uint64_t prog_write_bound(uint64_t n, uint64_t nnz, uint64_t n_args);
+uint64_t prog_write(int curve, uint64_t n, uint64_t m, const uint64_t* const rp[3], const uint32_t* const col[3], const uint8_t* const val[3],
+                    const int64_t* ids, const int64_t* arg_ids, const uint8_t* arg_private, uint64_t n_args, uint32_t return_count, uint8_t* out,
+                    uint64_t cap);
 }  // namespace zk

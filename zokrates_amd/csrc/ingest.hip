@@ -18,7 +18,12 @@
 // Pure host code: no kernel, no device memory.  This translation unit is C++ that hipcc compiles like the others.
 #include "ingest.h"
 
+#include <chrono>
+#include <climits>
 #include <cstring>
+#include <new>
+#include <system_error>
+#include <thread>
 
 #include "devrt.h"
 #include "field.cuh"
@@ -106,12 +111,16 @@ struct Cbor {
         --remaining;
         return true;
     }
-    // text key (definite length only, which is all serde_cbor writes for identifiers)
-    std::string text(const char* what) {
+    // text key (definite length only, which is all serde_cbor writes for identifiers): a view into the file
+    struct Key {
+        const uint8_t* p;
+        uint64_t n;
+        bool is(const char* s) const { const size_t l = strlen(s); return l == n && !memcmp(p, s, l); }
+    };
+    Key key(const char* what) {
         const Head h = head();
         if (h.major != 3 || h.indef) fail(ZKHIP_ERR_PARSE, std::string("text string expected for ") + what);
-        const uint8_t* q = take(h.arg);
-        return std::string((const char*)q, (size_t)h.arg);
+        return Key{take(h.arg), h.arg};
     }
     int64_t integer(const char* what) {
         const Head h = head();
@@ -156,91 +165,130 @@ struct Symbols {
         if (s == UNSEEN) s = alloc(id, id < 0);
         return s;
     }
+    uint32_t find(int64_t id) const {   // after the merge: every id of the program is bound
+        const std::vector<uint32_t>& v = id >= 0 ? pos : neg;
+        const uint64_t k = id >= 0 ? (uint64_t)id : (uint64_t)(-(id + 1));
+        return v[k];
+    }
 };
 
+// The constraint section is a plain concatenation of CBOR items, and only the ORDER in which variables are first seen
+// ties one statement to the next (ark numbers them in that order).  So the section is cut into chunks that are decoded
+// independently — each keeps raw ZoKrates ids and the list of ids in the order it first met them — and the chunks' lists,
+// walked in file order, reproduce the sequential allocation exactly.  CBOR is not self-synchronising: a chunk starts at
+// the first occurrence of the bytes every constraint statement begins with ({"Constraint": = a1 6a "Constraint") after its
+// nominal offset, and the cut is only trusted if the chunk before it ends EXACTLY there; any mismatch or error (the
+// pattern inside a field element or a directive's payload) sends the whole section through one chunk instead.
 template <class P>
 struct Builder {
     typedef Fe<P> Fr;
     struct Term {
-        uint32_t tag;
+        int64_t id;
         Fr coeff;
     };
-    Symbols sym;
-    std::vector<Term> rows[3];          // all terms, tags unresolved
-    std::vector<uint64_t> rp[3];
-    std::vector<Term> scratch;
+    struct Seen {                       // set of ids, bitmap grown on demand
+        std::vector<uint64_t> pos, neg;
+        bool test_and_set(int64_t id, uint64_t id_limit) {
+            std::vector<uint64_t>& v = id >= 0 ? pos : neg;
+            const uint64_t k = id >= 0 ? (uint64_t)id : (uint64_t)(-(id + 1));
+            if (k >= id_limit) fail(ZKHIP_ERR_PARSE, "variable id out of range");
+            if ((k >> 6) >= v.size()) v.resize(std::max<size_t>((k >> 6) + 1, v.size() * 2), 0);
+            const uint64_t bit = (uint64_t)1 << (k & 63);
+            const bool was = v[k >> 6] & bit;
+            v[k >> 6] |= bit;
+            return was;
+        }
+    };
+    struct Chunk {
+        const uint8_t *begin = nullptr, *limit = nullptr, *end_reached = nullptr;
+        std::vector<Term> terms[3];         // all rows' terms: duplicates merged, zero coefficients dropped
+        std::vector<uint32_t> count[3];     // terms per row
+        std::vector<int64_t> first_seen;    // ids in the order this chunk first met them
+        Seen seen;
+        std::vector<Term> scratch;
+        bool failed = false;
+        IngestError err{0, ""};
+        uint64_t id_limit = 0;
+        uint64_t row0 = 0, nnz0[3] = {0, 0, 0};   // where this chunk's rows / entries land in the whole program
+    };
 
     static bool canonical(const Fr& x) {
         for (int i = P::N - 1; i >= 0; --i)
             if (x.v[i] != P::mod(i)) return x.v[i] < P::mod(i);
         return false;
     }
+    static int64_t variable_id(Cbor& c) {
+        int64_t id = 0;
+        bool have_id = false;
+        uint64_t vf = c.enter(5, "a variable");
+        while (c.more(vf)) {
+            if (c.key("a Variable field").is("id")) { id = c.integer("Variable.id"); have_id = true; }
+            else c.skip();
+        }
+        if (!have_id) fail(ZKHIP_ERR_PARSE, "Variable without id");
+        return id;
+    }
     // LinComb {span, value: [[{id}, bytes], ...]} -> one matrix row: duplicates summed (ark's `acc + (coeff, var)`
     // merges equal variables), zero coefficients dropped (ark drops them when the matrices are extracted)
-    void lin_comb(Cbor& c, int which) {
+    static void lin_comb(Cbor& c, Chunk& ch, int which) {
+        std::vector<Term>& scratch = ch.scratch;
         scratch.clear();
         uint64_t nf = c.enter(5, "a linear combination");
         bool have_value = false;
         while (c.more(nf)) {
-            const std::string key = c.text("a LinComb field");
-            if (key != "value") { c.skip(); continue; }
+            if (!c.key("a LinComb field").is("value")) { c.skip(); continue; }
             have_value = true;
             uint64_t nt = c.enter(4, "LinComb.value");
             while (c.more(nt)) {
                 uint64_t pair = c.enter(4, "a (variable, coefficient) pair");
                 if (pair != 2) fail(ZKHIP_ERR_PARSE, "LinComb term is not a pair");
-                int64_t id = 0;
-                bool have_id = false;
-                uint64_t vf = c.enter(5, "a variable");
-                while (c.more(vf)) {
-                    if (c.text("a Variable field") == "id") { id = c.integer("Variable.id"); have_id = true; }
-                    else c.skip();
-                }
-                if (!have_id) fail(ZKHIP_ERR_PARSE, "Variable without id");
+                Term t;
+                t.id = variable_id(c);
                 const Cbor::Head h = c.head();
                 if (h.major != 2 || h.indef || h.arg != 32) fail(ZKHIP_ERR_PARSE, "field element is not a 32-byte string");
-                Term t;
                 memcpy(t.coeff.v, c.take(32), 32);
                 if (!canonical(t.coeff)) fail(ZKHIP_ERR_PARSE, "non-canonical field element in the program");
-                t.tag = sym.lookup(id);
+                if (!ch.seen.test_and_set(t.id, ch.id_limit)) ch.first_seen.push_back(t.id);
                 scratch.push_back(t);
             }
         }
         if (!have_value) fail(ZKHIP_ERR_PARSE, "LinComb without value");
         // merge duplicates; rows are tiny, so a quadratic pass beats sorting
+        uint32_t kept = 0;
+        constexpr int64_t GONE = INT64_MIN;
         for (size_t i = 0; i < scratch.size(); ++i) {
-            if (scratch[i].tag == UNSEEN) continue;
+            if (scratch[i].id == GONE) continue;
             for (size_t j = i + 1; j < scratch.size(); ++j)
-                if (scratch[j].tag == scratch[i].tag) {
+                if (scratch[j].id == scratch[i].id) {
                     scratch[i].coeff = fe_add(scratch[i].coeff, scratch[j].coeff);
-                    scratch[j].tag = UNSEEN;
+                    scratch[j].id = GONE;
                 }
-            if (!scratch[i].coeff.is_zero()) rows[which].push_back(scratch[i]);
+            if (!scratch[i].coeff.is_zero()) { ch.terms[which].push_back(scratch[i]); ++kept; }
         }
-        rp[which].push_back(rows[which].size());
+        ch.count[which].push_back(kept);
     }
-    void constraint(Cbor& c) {
+    static void constraint(Cbor& c, Chunk& ch) {
         uint64_t nf = c.enter(5, "a constraint statement");
         int seen = 0;
         // serde writes the fields in declaration order (span, quad, lin, error): quad before lin, which is the order
         // ark_combination is called in (left, right, lin) and hence the order variables are allocated in
         while (c.more(nf)) {
-            const std::string key = c.text("a ConstraintStatement field");
-            if (key == "quad") {
+            const Cbor::Key key = c.key("a ConstraintStatement field");
+            if (key.is("quad")) {
                 if (seen != 0) fail(ZKHIP_ERR_PARSE, "ConstraintStatement fields out of order");
                 uint64_t qf = c.enter(5, "a quadratic combination");
                 int qseen = 0;
                 while (c.more(qf)) {
-                    const std::string qk = c.text("a QuadComb field");
-                    if (qk == "left") { if (qseen != 0) fail(ZKHIP_ERR_PARSE, "QuadComb fields out of order"); lin_comb(c, 0); qseen = 1; }
-                    else if (qk == "right") { if (qseen != 1) fail(ZKHIP_ERR_PARSE, "QuadComb fields out of order"); lin_comb(c, 1); qseen = 2; }
+                    const Cbor::Key qk = c.key("a QuadComb field");
+                    if (qk.is("left")) { if (qseen != 0) fail(ZKHIP_ERR_PARSE, "QuadComb fields out of order"); lin_comb(c, ch, 0); qseen = 1; }
+                    else if (qk.is("right")) { if (qseen != 1) fail(ZKHIP_ERR_PARSE, "QuadComb fields out of order"); lin_comb(c, ch, 1); qseen = 2; }
                     else c.skip();
                 }
                 if (qseen != 2) fail(ZKHIP_ERR_PARSE, "QuadComb without left/right");
                 seen = 1;
-            } else if (key == "lin") {
+            } else if (key.is("lin")) {
                 if (seen != 1) fail(ZKHIP_ERR_PARSE, "ConstraintStatement fields out of order");
-                lin_comb(c, 2);
+                lin_comb(c, ch, 2);
                 seen = 2;
             } else {
                 c.skip();
@@ -248,8 +296,57 @@ struct Builder {
         }
         if (seen != 2) fail(ZKHIP_ERR_PARSE, "ConstraintStatement without quad/lin");
     }
+    // statements from ch.begin until the reader stands at or beyond ch.limit: a stream of CBOR items, constraints only   lib.rs:115-123
+    static void parse_chunk(Chunk& ch, const uint8_t* section_end) {
+        try {
+            Cbor c{ch.begin, section_end};
+            while (c.p < ch.limit) {
+                const uint8_t b = c.peek();
+                if ((b >> 5) == 3) { c.skip(); continue; }          // a unit variant would be a bare string: none of ours
+                uint64_t one = c.enter(5, "a statement");
+                if (one != 1) fail(ZKHIP_ERR_PARSE, "statement is not a single-entry map");
+                if (c.key("the statement variant").is("Constraint")) constraint(c, ch);
+                else c.skip();                                      // Directive, Log: witness generation only
+            }
+            ch.end_reached = c.p;
+        } catch (const IngestError& e) {
+            ch.failed = true;
+            ch.err = e;
+        } catch (const std::bad_alloc&) {
+            ch.failed = true;
+            ch.err = IngestError{ZKHIP_ERR_NOMEM, "out of host memory"};
+        }
+    }
+    static unsigned worker_count(uint64_t st_len) {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (const char* e = getenv("ZKHIP_INGEST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+        uint64_t min_chunk = (uint64_t)2 << 20;                     // at least 2 MiB of statements per worker
+        if (const char* e = getenv("ZKHIP_INGEST_MIN_CHUNK")) min_chunk = (uint64_t)std::max(16, atoi(e));   // (test hook)
+        const uint64_t by_size = st_len / min_chunk;
+        return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1, 64), by_size));
+    }
+    // chunk starts: the first {"Constraint": at or after t * len / T
+    static std::vector<const uint8_t*> cut_points(const uint8_t* b, const uint8_t* e, unsigned T) {
+        static const uint8_t PAT[12] = {0xa1, 0x6a, 'C', 'o', 'n', 's', 't', 'r', 'a', 'i', 'n', 't'};
+        std::vector<const uint8_t*> cuts{b};
+        const uint64_t len = (uint64_t)(e - b);
+        for (unsigned t = 1; t < T; ++t) {
+            const uint8_t* from = std::max(cuts.back() + 1, b + len * t / T);
+            const uint8_t* hit = nullptr;
+            for (const uint8_t* q = from; q + sizeof(PAT) <= e; ++q) {
+                q = (const uint8_t*)memchr(q, 0xa1, (size_t)(e - q) - sizeof(PAT) + 1);
+                if (!q) break;
+                if (!memcmp(q, PAT, sizeof(PAT))) { hit = q; break; }
+            }
+            if (!hit) break;
+            cuts.push_back(hit);
+        }
+        cuts.push_back(e);
+        return cuts;
+    }
+
     void run(const uint8_t* bytes, uint64_t par_off, uint64_t par_len, uint64_t st_off, uint64_t st_len, zkhip_prog* out) {
-        for (auto& r : rp) r.assign(1, 0);
+        Symbols sym;
         sym.id_limit = std::min<uint64_t>((uint64_t)1 << 31, std::max<uint64_t>((uint64_t)1 << 20, 8 * (par_len + st_len)));
         // symbols[~one] = ConstraintSystem::one()                                   lib.rs:89
         sym.slot(0) = sym.alloc(0, true);
@@ -262,14 +359,11 @@ struct Builder {
                 int64_t id = 0;
                 bool priv = false, have_id = false, have_priv = false;
                 while (c.more(nf)) {
-                    const std::string key = c.text("a Parameter field");
-                    if (key == "id") {
-                        uint64_t vf = c.enter(5, "a variable");
-                        while (c.more(vf)) {
-                            if (c.text("a Variable field") == "id") { id = c.integer("Variable.id"); have_id = true; }
-                            else c.skip();
-                        }
-                    } else if (key == "private") {
+                    const Cbor::Key key = c.key("a Parameter field");
+                    if (key.is("id")) {
+                        id = variable_id(c);
+                        have_id = true;
+                    } else if (key.is("private")) {
                         priv = c.boolean("Parameter.private");
                         have_priv = true;
                     } else {
@@ -281,49 +375,106 @@ struct Builder {
                 if (!priv) out->public_args.push_back(id);
             }
         }
-        // statements: a stream of CBOR items, constraints only                      lib.rs:115-123
-        {
-            Cbor c{bytes + st_off, bytes + st_off + st_len};
-            while (!c.at_end()) {
-                const uint8_t b = c.peek();
-                if ((b >> 5) == 3) { c.skip(); continue; }          // a unit variant would be a bare string: none of ours
-                uint64_t one = c.enter(5, "a statement");
-                if (one != 1) fail(ZKHIP_ERR_PARSE, "statement is not a single-entry map");
-                const std::string variant = c.text("the statement variant");
-                if (variant == "Constraint") constraint(c);
-                else c.skip();                                      // Directive, Log: witness generation only
+        // statements: decoded in chunks, in parallel when the section is large
+        const uint8_t *sb = bytes + st_off, *se = sb + st_len;
+        std::vector<Chunk> chunks;
+        auto decode = [&](unsigned T) {
+            const std::vector<const uint8_t*> cuts = cut_points(sb, se, T);
+            chunks.clear();
+            chunks.resize(cuts.size() - 1);
+            for (size_t t = 0; t + 1 < cuts.size(); ++t) {
+                chunks[t].begin = cuts[t];
+                chunks[t].limit = cuts[t + 1];
+                chunks[t].id_limit = sym.id_limit;
             }
+            if (chunks.size() == 1) {
+                parse_chunk(chunks[0], se);
+            } else {
+                HostThreads th;
+                for (size_t t = 1; t < chunks.size(); ++t) th.run([&, t] { parse_chunk(chunks[t], se); });
+                parse_chunk(chunks[0], se);
+                th.join();
+            }
+            for (size_t t = 0; t < chunks.size(); ++t)
+                if (chunks[t].failed || chunks[t].end_reached != chunks[t].limit) return false;
+            return true;
+        };
+        const unsigned T = worker_count(st_len);
+        const bool prof = getenv("ZKHIP_INGEST_PROFILE") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t_begin = now();
+        const bool cut_ok = decode(T);
+        const auto t_decoded = now();
+        if (prof) fprintf(stderr, "[zkhip ingest] %u worker(s) asked, %zu chunk(s), cuts %s, decode %.1f ms\n", T, chunks.size(), cut_ok ? "ok" : "REJECTED", ms(t_begin, t_decoded));
+        if (!cut_ok) {
+            if (chunks.size() > 1) decode(1);            // a cut inside an item (or a real error): one chunk decides
+            if (chunks[0].failed) throw chunks[0].err;
+            if (chunks[0].end_reached != se) fail(ZKHIP_ERR_PARSE, "program file truncated inside a CBOR item");
         }
-        const uint64_t l = sym.inst.size(), w = sym.wit.size(), n = rp[0].size() - 1;
+        // the sequential part: variables in first-seen order over the chunks in file order
+        for (Chunk& ch : chunks) {
+            for (int64_t id : ch.first_seen) sym.lookup(id);
+            std::vector<int64_t>().swap(ch.first_seen);
+            Seen().pos.swap(ch.seen.pos);
+            Seen().neg.swap(ch.seen.neg);
+        }
+        const auto t_merged = now();
+        const uint64_t l = sym.inst.size(), w = sym.wit.size();
         if (l + w + 2 >= ((uint64_t)1 << 31)) fail(ZKHIP_ERR_BAD_ARG, "too many variables");
+        uint64_t n = 0, nnz[3] = {0, 0, 0};
+        for (Chunk& ch : chunks) {
+            ch.row0 = n;
+            n += ch.count[0].size();
+            for (int k = 0; k < 3; ++k) { ch.nnz0[k] = nnz[k]; nnz[k] += ch.terms[k].size(); }
+        }
         out->n = n; out->l = l; out->w = w;
         out->order = sym.inst;
         out->order.insert(out->order.end(), sym.wit.begin(), sym.wit.end());
         for (int k = 0; k < 3; ++k) {
-            const size_t nnz = rows[k].size();
-            out->rp[k] = rp[k];
-            out->col[k].resize(nnz);
-            out->val[k].resize(nnz * 32);
-            for (size_t q = 0; q < nnz; ++q) {
-                const uint32_t t = rows[k][q].tag;
-                out->col[k][q] = (t & WIT_TAG) ? (uint32_t)(l + (t & ~WIT_TAG)) : t;
-                memcpy(&out->val[k][q * 32], rows[k][q].coeff.v, 32);
-            }
-            // ark keeps a row sorted by variable (One, Instance(i), Witness(i)): same order as the final column index
-            for (uint64_t i = 0; i < n; ++i) {
-                const uint64_t a = rp[k][i], b = rp[k][i + 1];
-                for (uint64_t x = a + 1; x < b; ++x)          // insertion sort, rows are tiny
-                    for (uint64_t y = x; y > a && out->col[k][y - 1] > out->col[k][y]; --y) {
-                        std::swap(out->col[k][y - 1], out->col[k][y]);
-                        uint8_t tmp[32];
-                        memcpy(tmp, &out->val[k][(y - 1) * 32], 32);
-                        memcpy(&out->val[k][(y - 1) * 32], &out->val[k][y * 32], 32);
-                        memcpy(&out->val[k][y * 32], tmp, 32);
-                    }
-            }
-            rows[k].clear();
-            rows[k].shrink_to_fit();
+            out->rp[k].resize(n + 1);
+            out->rp[k][n] = nnz[k];
+            out->col[k].resize(nnz[k]);
+            out->val[k].resize(nnz[k] * 32);
         }
+        // columns, values and row pointers of every chunk's rows (independent: in parallel)
+        auto emit = [&](Chunk& ch) {
+            for (int k = 0; k < 3; ++k) {
+                uint64_t q = ch.nnz0[k];
+                const Term* t = ch.terms[k].data();
+                uint32_t* col = out->col[k].data();
+                uint8_t* val = out->val[k].data();
+                for (size_t r = 0; r < ch.count[k].size(); ++r) {
+                    out->rp[k][ch.row0 + r] = q;
+                    const uint64_t a = q;
+                    for (uint32_t j = 0; j < ch.count[k][r]; ++j, ++t, ++q) {
+                        const uint32_t tag = sym.find(t->id);
+                        const uint32_t cj = (tag & WIT_TAG) ? (uint32_t)(l + (tag & ~WIT_TAG)) : tag;
+                        // ark keeps a row sorted by variable (One, Instance(i), Witness(i)): same order as the final column
+                        // index — insertion sort, rows are tiny
+                        uint64_t y = q;
+                        while (y > a && col[y - 1] > cj) {
+                            col[y] = col[y - 1];
+                            memcpy(val + y * 32, val + (y - 1) * 32, 32);
+                            --y;
+                        }
+                        col[y] = cj;
+                        memcpy(val + y * 32, t->coeff.v, 32);
+                    }
+                }
+                std::vector<Term>().swap(ch.terms[k]);
+                std::vector<uint32_t>().swap(ch.count[k]);
+            }
+        };
+        if (chunks.size() == 1) {
+            emit(chunks[0]);
+        } else {
+            HostThreads th;
+            for (size_t t = 1; t < chunks.size(); ++t) th.run([&, t] { emit(chunks[t]); });
+            emit(chunks[0]);
+            th.join();
+        }
+        if (prof) fprintf(stderr, "[zkhip ingest] first-seen merge %.1f ms, emit %.1f ms\n", ms(t_decoded, t_merged), ms(t_merged, now()));
     }
 };
 
@@ -373,6 +524,111 @@ void prog_parse(const uint8_t* bytes, size_t len, zkhip_prog* out) {
         b.run(bytes, off[0], ln[0], off[1], ln[1], out);
     }
     if (out->n != constraint_count) fail(ZKHIP_ERR_PARSE, "constraint count in the header does not match the statements");
+}
+
+// ------------------------------------------------------------------ the inverse: an R1CS as a ZoKrates `out` program
+// `ProgIterator::serialize` (/root/reference/zokrates_ast/src/ir/serialize.rs:202-279) for a program whose statements are
+// exactly the constraints A_i z * B_i z = C_i z in row order, no directives, no solvers: what `zokrates` tooling needs to
+// consume a circuit that arrived as matrices (an iden3 .r1cs file, a synthetic benchmark circuit).  ids[j] names column j
+// (0 = ~one, k > 0 = _{k-1}, -k = ~out_{k-1}); a reader allocates variables in first-seen order (zokrates_ark/src/lib.rs:
+// 80-129), so the columns come back in the caller's order only if that is the order in which the rows mention them.
+namespace {
+struct CborOut {
+    uint8_t* p;
+    uint8_t* e;
+    void need(size_t n) { if ((size_t)(e - p) < n) fail(ZKHIP_ERR_BAD_ARG, "output buffer too small (see zkhip_prog_write_bound)"); }
+    void raw(const void* b, size_t n) { need(n); memcpy(p, b, n); p += n; }
+    void byte(uint8_t b) { need(1); *p++ = b; }
+    void head(int major, uint64_t v) {
+        if (v < 24) { byte((uint8_t)(major << 5 | v)); return; }
+        const int nb = v < (1u << 8) ? 1 : v < (1u << 16) ? 2 : v < ((uint64_t)1 << 32) ? 4 : 8;
+        byte((uint8_t)(major << 5 | (nb == 1 ? 24 : nb == 2 ? 25 : nb == 4 ? 26 : 27)));
+        for (int i = nb - 1; i >= 0; --i) byte((uint8_t)(v >> (8 * i)));
+    }
+    void text(const char* t) { const size_t n = strlen(t); head(3, n); raw(t, n); }
+    void null() { byte(0xf6); }
+    void integer(int64_t v) { if (v >= 0) head(0, (uint64_t)v); else head(1, (uint64_t)(-(v + 1))); }
+    void variable(int64_t id) { head(5, 1); text("id"); integer(id); }
+};
+}  // namespace
+
+uint64_t prog_write_bound(uint64_t n, uint64_t nnz, uint64_t n_args) {
+    // header region + per argument + per statement (keys, nulls, container heads) + per term (pair, variable, 32-byte string)
+    return 120 + 16 + n_args * 48 + n * 96 + nnz * 56 + 64;
+}
+
+uint64_t prog_write(int curve, uint64_t n, uint64_t m, const uint64_t* const rp[3], const uint32_t* const col[3], const uint8_t* const val[3],
+                    const int64_t* ids, const int64_t* arg_ids, const uint8_t* arg_private, uint64_t n_args, uint32_t return_count, uint8_t* out,
+                    uint64_t cap) {
+    constexpr uint64_t HEADER_REGION = 120;   // size_of::<ProgHeader>() on x86-64; the 100 bytes the header occupies lead it
+    if (curve != ZKHIP_CURVE_BN128 && curve != ZKHIP_CURVE_BLS12_381) fail(ZKHIP_ERR_BAD_ARG, "unknown curve id");
+    if (n >= ((uint64_t)1 << 32)) fail(ZKHIP_ERR_BAD_ARG, "constraint count does not fit the header");
+    if (cap < HEADER_REGION) fail(ZKHIP_ERR_BAD_ARG, "output buffer too small (see zkhip_prog_write_bound)");
+    memset(out, 0, HEADER_REGION);
+    CborOut c{out + HEADER_REGION, out + cap};
+    uint64_t off[4], len[4];
+    // parameters: [{span, id: {id}, private}]
+    off[0] = (uint64_t)(c.p - out);
+    c.head(4, n_args);
+    for (uint64_t a = 0; a < n_args; ++a) {
+        c.head(5, 3);
+        c.text("span"); c.null();
+        c.text("id"); c.variable(arg_ids[a]);
+        c.text("private"); c.byte(arg_private[a] ? 0xf5 : 0xf4);
+    }
+    len[0] = (uint64_t)(c.p - out) - off[0];
+    // constraints: a stream of {"Constraint": {span, quad: {span, left, right}, lin, error}}
+    off[1] = (uint64_t)(c.p - out);
+    auto lin_comb = [&](int k, uint64_t i) {
+        c.head(5, 2);
+        c.text("span"); c.null();
+        c.text("value");
+        const uint64_t a = rp[k][i], b = rp[k][i + 1];
+        if (b < a) fail(ZKHIP_ERR_BAD_ARG, "rowptr not monotone");
+        c.head(4, b - a);
+        for (uint64_t q = a; q < b; ++q) {
+            if (col[k][q] >= m) fail(ZKHIP_ERR_BAD_ARG, "column index out of range");
+            c.head(4, 2);
+            c.variable(ids[col[k][q]]);
+            c.head(2, 32);
+            c.raw(val[k] + q * 32, 32);
+        }
+    };
+    for (uint64_t i = 0; i < n; ++i) {
+        c.head(5, 1);
+        c.text("Constraint");
+        c.head(5, 4);
+        c.text("span"); c.null();
+        c.text("quad");
+        c.head(5, 3);
+        c.text("span"); c.null();
+        c.text("left"); lin_comb(0, i);
+        c.text("right"); lin_comb(1, i);
+        c.text("lin"); lin_comb(2, i);
+        c.text("error"); c.null();
+    }
+    len[1] = (uint64_t)(c.p - out) - off[1];
+    off[2] = (uint64_t)(c.p - out);
+    c.head(4, 0);                                   // solvers: []
+    len[2] = 1;
+    off[3] = (uint64_t)(c.p - out);
+    c.head(5, 1); c.text("modules"); c.head(5, 0);  // module map: {modules: {}}
+    len[3] = (uint64_t)(c.p - out) - off[3];
+    // the header (ProgHeader::write, serialize.rs:133-148); the module map is tagged as a second Solvers section (:247)
+    uint8_t* h = out;
+    static const uint8_t MAGIC_VERSION[8] = {0x5a, 0x4f, 0x4b, 0, 3, 0, 0, 0};
+    memcpy(h, MAGIC_VERSION, 8);
+    memcpy(h + 8, curve == ZKHIP_CURVE_BN128 ? ID_BN128 : ID_BLS12_381, 4);
+    const uint32_t cnt = (uint32_t)n;
+    memcpy(h + 12, &cnt, 4);
+    memcpy(h + 16, &return_count, 4);
+    static const uint32_t TYPES[4] = {1, 2, 3, 3};
+    for (int s = 0; s < 4; ++s) {
+        memcpy(h + 20 + 20 * s, &TYPES[s], 4);
+        memcpy(h + 24 + 20 * s, &off[s], 8);
+        memcpy(h + 32 + 20 * s, &len[s], 8);
+    }
+    return (uint64_t)(c.p - out);
 }
 
 void prog_assignment(const zkhip_prog* prog, const uint8_t* wit, size_t len, uint8_t* z_out, uint8_t* inputs_out, uint64_t cap, uint64_t* n_inputs) {

@@ -118,18 +118,20 @@ struct Setup {
         dev_d2h(u.data(), d_u.p, N * sizeof(Fr), s);
         stream_sync(s);
         std::vector<Fr> col[3];
+        HostCsr hm;
+        hm.fetch(ctx, cs);
         {
             HostThreads th;
             for (int k = 0; k < 3; ++k)
                 th.run([&, k] {
                     std::vector<Fr>& acc = col[k];
                     acc.assign(m, Fr::zero());
-                    const u64* rp = cs->h_rp[k].data();
-                    const u32* ci = cs->h_col[k].data();
-                    const uint8_t* va = cs->h_val[k].data();
+                    const u64* rp = hm.rp[k].data();
+                    const u32* ci = hm.col[k].data();
+                    const uint8_t* va = hm.val[k].data();      // Montgomery form, as resident
                     for (u64 i = 0; i < n; ++i)
                         for (u64 q = rp[i]; q < rp[i + 1]; ++q) {
-                            Fr v = fe_to_mont(fe_from_bytes_canon<Fr>(va + q * 32));
+                            Fr v = fe_from_bytes_canon<Fr>(va + q * 32);
                             acc[ci[q]] = fe_add(acc[ci[q]], fe_mul(v, u[i]));
                         }
                     if (k == 0)

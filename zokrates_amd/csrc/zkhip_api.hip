@@ -426,6 +426,26 @@ int32_t zkhip_prog_assignment(const zkhip_prog* prog, const uint8_t* witness, si
     if (!prog || !witness) { g_create_err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
     return guarded_host([&] { prog_assignment(prog, witness, len, z_out, inputs_out, inputs_cap, n_inputs); });
 }
+int32_t zkhip_prog_write_bound(uint64_t n, uint64_t nnz, uint64_t n_args, uint64_t* bytes) {
+    if (!bytes) return ZKHIP_ERR_BAD_ARG;
+    *bytes = prog_write_bound(n, nnz, n_args);
+    return ZKHIP_OK;
+}
+int32_t zkhip_prog_write(int32_t curve, uint64_t n, uint64_t m, const uint64_t* rowptr_a, const uint32_t* col_a, const uint8_t* val_a,
+                         const uint64_t* rowptr_b, const uint32_t* col_b, const uint8_t* val_b, const uint64_t* rowptr_c, const uint32_t* col_c,
+                         const uint8_t* val_c, const int64_t* ids, const int64_t* arg_ids, const uint8_t* arg_private, uint64_t n_args,
+                         uint32_t return_count, uint8_t* out, uint64_t cap, uint64_t* len) {
+    if (!rowptr_a || !rowptr_b || !rowptr_c || !ids || !out || !len || (n_args && (!arg_ids || !arg_private))) {
+        g_create_err = "null argument";
+        return ZKHIP_ERR_BAD_ARG;
+    }
+    return guarded_host([&] {
+        const u64* rp[3] = {rowptr_a, rowptr_b, rowptr_c};
+        const u32* col[3] = {col_a, col_b, col_c};
+        const uint8_t* val[3] = {val_a, val_b, val_c};
+        *len = prog_write(curve, n, m, rp, col, val, ids, arg_ids, arg_private, n_args, return_count, out, cap);
+    });
+}
 int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs** out) {
     if (!ctx || !prog) return ZKHIP_ERR_BAD_ARG;
     return zkhip_r1cs_load(ctx, prog->curve, prog->n, prog->l, prog->w, prog->rp[0].data(), prog->col[0].data(), prog->val[0].data(),

@@ -57,7 +57,7 @@ class Library:
         "zkhip_pk_load_gm17", "zkhip_prove_gm17", "zkhip_prove_gm17_resident", "zkhip_prove_gm17_resident_batch",
         "zkhip_setup_gm17_size", "zkhip_setup_gm17", "zkhip_pk_load_gm17_shard", "zkhip_prove_gm17_partial", "zkhip_combine_gm17",
         "zkhip_prog_parse", "zkhip_prog_free", "zkhip_prog_dims", "zkhip_prog_matrix", "zkhip_prog_variable_order",
-        "zkhip_prog_r1cs_load", "zkhip_prog_assignment",
+        "zkhip_prog_r1cs_load", "zkhip_prog_assignment", "zkhip_prog_write_bound", "zkhip_prog_write",
         "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import", "zkhip_pk_export_size_ex", "zkhip_pk_export_ex",
         "zkhip_ctx_tune",
         "zkhip_ctx_create_multi", "zkhip_multi_free", "zkhip_multi_size", "zkhip_multi_ctx", "zkhip_multi_last_error", "zkhip_multi_r1cs_load",
@@ -133,6 +133,8 @@ class Library:
         L.zkhip_prog_matrix.restype = i32; L.zkhip_prog_matrix.argtypes = [vp, i32, pp, pp, pp]
         L.zkhip_prog_variable_order.restype = i32; L.zkhip_prog_variable_order.argtypes = [vp, pp]
         L.zkhip_prog_r1cs_load.restype = i32; L.zkhip_prog_r1cs_load.argtypes = [vp, vp, pp]
+        L.zkhip_prog_write_bound.restype = i32; L.zkhip_prog_write_bound.argtypes = [u64, u64, u64, vp]
+        L.zkhip_prog_write.restype = i32; L.zkhip_prog_write.argtypes = [i32, u64, u64] + [vp] * 9 + [vp, vp, vp, u64, u32, vp, u64, vp]
         L.zkhip_prog_assignment.restype = i32; L.zkhip_prog_assignment.argtypes = [vp, vp, sz, vp, vp, u64, vp]
         self.L = L
 
@@ -568,6 +570,45 @@ class Program:
             self.close()
         except Exception:
             pass
+
+
+def write_program(curve_id, n, m, mats, ids=None, args=((1, False),), return_count=0, library=None):
+    """`zkhip_prog_write`: the R1CS `mats` (as for ConstraintSystem) as the bytes of a ZoKrates `out` program.  ids[j] = the
+    ZoKrates variable id of column j (default j: column 0 = ~one, column j = _{j-1}); args = [(id, private)]."""
+    lib = library or default_library()
+    ids = np.arange(m, dtype=np.int64) if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+    if ids.size != m:
+        raise ValueError("one id per column")
+    keep, a, nnz = [], [], 0
+    for rp, col, val in mats:
+        rp = np.ascontiguousarray(rp, dtype=np.uint64); col = np.ascontiguousarray(col, dtype=np.uint32); val = _u8(val)
+        if rp.size != n + 1 or val.size != col.size * 32:
+            raise ValueError("CSR shape mismatch")
+        keep += [rp, col, val]
+        a += [_ptr(rp), _ptr(col), _ptr(val)]
+        nnz += int(col.size)
+    arg_ids = np.asarray([i for i, _ in args], dtype=np.int64)
+    arg_priv = np.asarray([1 if p else 0 for _, p in args], dtype=np.uint8)
+    bound = C.c_uint64()
+    lib.L.zkhip_prog_write_bound(n, nnz, len(args), C.byref(bound))
+    out = np.empty(bound.value, dtype=np.uint8)
+    ln = C.c_uint64()
+    rc = lib.L.zkhip_prog_write(curve_id, n, m, *a, _ptr(ids), _ptr(arg_ids), _ptr(arg_priv), len(args), return_count, _ptr(out), bound.value, C.byref(ln))
+    if rc != 0:
+        raise ZkhipError(rc, lib.L.zkhip_last_error(None).decode())
+    return out[:ln.value]
+
+
+def write_witness(ids, z):
+    """`Witness::write` (/root/reference/zokrates_ast/src/ir/witness.rs:44-53): usize count, then (isize id, 32-byte canonical
+    LE value) in ascending signed-id order (the BTreeMap's).  ids[j] names entry j of z (uint8[m*32])."""
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    z = _u8(z, ids.size * 32).reshape(-1, 32)
+    order = np.argsort(ids, kind="stable")
+    rec = np.zeros(ids.size, dtype=[("id", "<i8"), ("v", "u1", 32)])
+    rec["id"] = ids[order]
+    rec["v"] = z[order]
+    return np.concatenate([np.frombuffer(int(ids.size).to_bytes(8, "little"), dtype=np.uint8), rec.view(np.uint8).reshape(-1)])
 
 
 class Multi:
