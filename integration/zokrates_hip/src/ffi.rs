@@ -6,6 +6,7 @@ use std::os::raw::c_char;
 #[repr(C)] pub struct zkhip_pk { _p: [u8; 0] }
 #[repr(C)] pub struct zkhip_r1cs { _p: [u8; 0] }
 #[repr(C)] pub struct zkhip_multi { _p: [u8; 0] }
+#[repr(C)] pub struct zkhip_prog { _p: [u8; 0] }
 /// 16 floats: h2d, matvec, ntt, msm_h, msm_z, finish, total, accum_g1, accum_g2, kernel_ntt, 6 reserved (milliseconds)
 #[repr(C)] #[derive(Default, Clone, Copy)] pub struct zkhip_timings { pub ms: [f32; 16] }
 
@@ -28,6 +29,17 @@ extern "C" {
         r: *const u8, s: *const u8, proof_out: *mut u8, timings: *mut zkhip_timings) -> i32;
     pub fn zkhip_prove_gm17(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, cs: *const zkhip_r1cs, z: *const u8,
         d1_d2_r: *const u8, proof_out: *mut u8, timings: *mut zkhip_timings) -> i32;
+    // the files the CLI already holds: `out` -> R1CS in ark order, `witness` -> z + inputs (host only, no context)
+    pub fn zkhip_prog_parse(bytes: *const u8, len: usize, out: *mut *mut zkhip_prog) -> i32;
+    pub fn zkhip_prog_free(prog: *mut zkhip_prog);
+    pub fn zkhip_prog_dims(prog: *const zkhip_prog, out: *mut u64 /* [8] */) -> i32;
+    pub fn zkhip_prog_r1cs_load(ctx: *mut zkhip_ctx, prog: *const zkhip_prog, out: *mut *mut zkhip_r1cs) -> i32;
+    pub fn zkhip_prog_assignment(prog: *const zkhip_prog, witness: *const u8, len: usize, z_out: *mut u8,
+        inputs_out: *mut u8, inputs_cap: u64, n_inputs: *mut u64) -> i32;
+    // key cache: the resident form of a loaded key as one image
+    pub fn zkhip_pk_export_size(pk: *const zkhip_pk, bytes: *mut u64) -> i32;
+    pub fn zkhip_pk_export(pk: *const zkhip_pk, out: *mut u8, cap: u64) -> i32;
+    pub fn zkhip_pk_import(ctx: *mut zkhip_ctx, bytes: *const u8, len: usize, out: *mut *mut zkhip_pk) -> i32;
     // one proof across several GPUs of this process
     pub fn zkhip_ctx_create_multi(devices: *const i32, n: i32, out: *mut *mut zkhip_multi) -> i32;
     pub fn zkhip_multi_free(m: *mut zkhip_multi);

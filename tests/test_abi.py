@@ -44,3 +44,35 @@ def test_no_cpu_fallback(lib_path):
     with pytest.raises(native.ZkhipError) as e:
         native.Context(0, lib)
     assert e.value.code == -4
+
+
+def test_rust_bindings_and_integration_excerpt_follow_the_header():
+    """The Rust crate cannot be compiled here, so at least its `extern "C"` block is held against include/zkhip.h
+    mechanically: every function it declares exists in the header with the same number of parameters, and every function the
+    INTEGRATION.md §2 excerpt shows is declared by the crate (the two had drifted in round 2)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "zkhip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int32_t|void|const char\*|zkhip_ctx\*)\s+(zkhip_\w+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+
+    def rust_fns(text):
+        out = {}
+        for m in re.finditer(r"pub fn (zkhip_\w+)\s*\((.*?)\)\s*(?:->\s*[\w*\s]+)?;", text, flags=re.S):
+            args = re.sub(r"/\*.*?\*/", "", m.group(2), flags=re.S).strip()
+            out[m.group(1)] = 0 if not args else args.count(":")
+        return out
+
+    ffi = rust_fns(open(os.path.join(root, "integration", "zokrates_hip", "src", "ffi.rs")).read())
+    assert len(ffi) >= 25
+    for name, nargs in ffi.items():
+        assert name in protos, name + " is not in include/zkhip.h"
+        assert protos[name] == nargs, (name, protos[name], nargs)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    excerpt = rust_fns(doc[doc.index("## 2."):doc.index("## 3.")])
+    assert excerpt and set(excerpt) <= set(ffi), set(excerpt) - set(ffi)
+    for name, nargs in excerpt.items():
+        assert ffi[name] == nargs, name

@@ -155,3 +155,54 @@ def test_reference_rng_restatement():
     g = rng.rng_from_entropy("y")
     words = [g.next_u32() for _ in range(40)]
     assert words[:16] == rng.chacha_block(g.key, 0, 0, 12) and words[16:32] == rng.chacha_block(g.key, 1, 0, 12)
+
+
+def test_rng_chain_published_known_answers():
+    """The only link between `zokrates generate-proof --entropy` and this backend's bytes that the reference's tests do not
+    pin is the r, s draw: Blake2b-512 -> 32-byte seed -> rand 0.8.5 `StdRng` (= rand_chacha 0.3.1 `ChaCha12Rng`) -> ark-ff
+    0.3.0 `Fr::rand`.  Every primitive of that chain against the known answers its own specification publishes:
+      * BLAKE2b-512("abc"): RFC 7693 Appendix A;
+      * the ChaCha block function with a 256-bit all-zero key, zero IV, block 0 at 8 / 12 / 20 rounds:
+        draft-strombergson-chacha-test-vectors-01, TC1 (the 20-round words are also the expectation of rand_chacha's own
+        `test_chacha_true_values_a`: 0xade0b876, 0x903df1a0, 0xe56a5d40, 0x28bd8653, ...);
+      * RFC 7539 §2.3.2 (key 00..1f, nonce 00:00:00:09:00:00:00:4a:00:00:00:00, counter 1) for the state layout — rand_chacha
+        keeps a 64-bit block counter in words 12-13 and the stream id in 14-15, the layout the RFC vector exercises when its
+        nonce word 0 is read as the counter's high half;
+      * `next_u64` = two consecutive words, low first, across block boundaries (rand_core `BlockRng::next_u64`);
+      * ark-ff's sampler: four u64 limbs, the top REPR_SHAVE_BITS = 256 - modulus bits of the last one cleared, rejected
+        unless below the modulus, and the limbs ARE the Montgomery representation."""
+    import hashlib
+    import struct
+    from zokrates_amd import rng
+    assert hashlib.blake2b(b"abc").hexdigest() == ("ba80a53f981c4d0d6a2797b69f12f6e94c212f14685ac4b74b12bb6fdbffa2d1"
+                                                   "7d87c5392aab792dc252d5de4533cc9518d38aa8dbf1925ab92386edd4009923")
+    zero = [0] * 8
+    tc1 = {8: "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42",
+           12: "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be",
+           20: "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586"}
+    for rounds, want in tc1.items():
+        assert struct.pack("<16I", *rng.chacha_block(zero, 0, 0, rounds)).hex() == want, rounds
+    assert rng.chacha_block(zero, 0, 0, 20)[:4] == [0xade0b876, 0x903df1a0, 0xe56a5d40, 0x28bd8653]
+    # StdRng from the all-zero seed: the 12-round block, word by word, then the next block (counter 1)
+    g = rng.StdRng(bytes(32))
+    w0 = struct.unpack("<16I", bytes.fromhex(tc1[12]))
+    assert [g.next_u32() for _ in range(15)] == list(w0[:15])
+    nxt = rng.chacha_block(zero, 1, 0, 12)
+    assert g.next_u64() == w0[15] | (nxt[0] << 32)          # a u64 that straddles two blocks
+    # Fr::rand: the shave widths follow from the moduli; an out-of-range draw is rejected and the NEXT four limbs are used
+    for cid, (p, shave) in rng.FR.items():
+        assert shave == 256 - p.bit_length()
+
+    class Fixed:
+        def __init__(self, u64s):
+            self.q = list(u64s)
+
+        def next_u64(self):
+            return self.q.pop(0)
+
+    p, shave = rng.FR[0]
+    too_big = [(1 << 64) - 1] * 4                             # masked to 2^254 - 1 >= p: rejected
+    mont = 0x0123456789abcdef_0fedcba987654321_1111111122222222_0000000000000007
+    limbs = [(mont >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]
+    got = rng.fr_rand(Fixed(too_big + limbs), 0)
+    assert got == mont * pow(1 << 256, -1, p) % p and got * (1 << 256) % p == mont

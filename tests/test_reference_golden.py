@@ -1,0 +1,56 @@
+"""Byte-equality with the REAL reference backend, for whoever has a Rust toolchain: INTEGRATION.md §6 gives the four
+`zokrates` commands that produce a directory  tests/golden/reference/<name>/{out, witness, proving.key, proof.json, entropy.txt[, scheme.txt]}
+with `--backend ark`; this test feeds the same three input files and the same entropy to this backend and requires the
+same proof.json (points and inputs).  No such directory can be produced in this image (no cargo / rustc), so
+the test is skipped until one is dropped in — it is the missing pin of DESIGN.md §4 ("parity unpinned"), ready to run."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from zokrates_amd import formats, native, rng
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = sorted(d for d in glob.glob(os.path.join(ROOT, "tests", "golden", "reference", "*")) if os.path.isdir(d))
+
+
+def _prove_like_the_cli(ctx, lib, case):
+    rd = lambda name: np.fromfile(os.path.join(case, name), dtype=np.uint8)
+    scheme = open(os.path.join(case, "scheme.txt")).read().strip() if os.path.exists(os.path.join(case, "scheme.txt")) else "g16"
+    entropy = open(os.path.join(case, "entropy.txt")).read().rstrip("\n")
+    prog = native.Program(rd("out"), lib)
+    cs = prog.constraint_system(ctx)
+    z, inp = prog.assignment(rd("witness"))
+    inputs = [int.from_bytes(inp[32 * i:32 * i + 32].tobytes(), "little") for i in range(inp.size // 32)]
+    pk = native.ProvingKey(ctx, prog.curve_id, rd("proving.key"), scheme=scheme)
+    gen = rng.rng_from_entropy(entropy)
+    if scheme == "gm17":
+        raw = native.prove_gm17(ctx, pk, cs, z, *(rng.fr_rand(gen, prog.curve_id) for _ in range(3)))
+    else:
+        raw = native.prove_g16(ctx, pk, cs, z, *(rng.fr_rand(gen, prog.curve_id) for _ in range(2)))
+    return json.loads(formats.proof_json(prog.curve_id, raw, inputs, scheme=scheme))
+
+
+def _same_proof(ours, theirs):
+    return ours["proof"] == theirs["proof"] and ours["inputs"] == theirs["inputs"]
+
+
+@pytest.mark.skipif(not CASES, reason="no tests/golden/reference/<name>/ directory (needs the reference built with Rust: INTEGRATION.md §6)")
+@pytest.mark.parametrize("case", CASES, ids=os.path.basename)
+def test_reference_proof_bytes_on_emulator(case):
+    from emu_util import emu_library
+    lib = emu_library()
+    if os.path.getsize(os.path.join(case, "proving.key")) > (8 << 20):
+        pytest.skip("too large for the emulator: covered by the -m gpu variant")
+    ctx = native.Context(0, lib)
+    assert _same_proof(_prove_like_the_cli(ctx, lib, case), json.load(open(os.path.join(case, "proof.json"))))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not CASES, reason="no tests/golden/reference/<name>/ directory (needs the reference built with Rust: INTEGRATION.md §6)")
+@pytest.mark.parametrize("case", CASES, ids=os.path.basename)
+def test_reference_proof_bytes_on_gpu(case):
+    ctx = native.Context(0)
+    assert _same_proof(_prove_like_the_cli(ctx, ctx.lib, case), json.load(open(os.path.join(case, "proof.json"))))
