@@ -358,7 +358,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": workload, "curve": args.curve, "constraints": circ.n,
                    "variables": m, "domain": N, "distinct_witnesses": nw,
-                   "parallelism": f"{world} independent prover(s), full key per GPU"},
+                   "parallelism": f"{world} independent prover(s), full key per GPU",
+                   "process_group": ranks.describe()},
         "single_proof_ms": single_ms, "single_proof_from_host_ms": min(from_host), "phases_ms": avg, "phases_ms_serial": serial,
         "whole_proof_hbm": {"algorithmic_bytes": b_alg, "achieved_GBs": b_alg / (elapsed / args.steps) / 1e9,
                             "frac": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
@@ -515,6 +516,11 @@ def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one):
         ndev = ctx.lib.device_count()
         devices = [k % ndev for k in range(members)]
         multi = native.Multi(devices, ctx.lib)
+        if len(set(devices)) == len(devices):          # one GPU per member: the exchange step runs over RCCL (xGMI)
+            try:
+                multi.use_rccl(True)
+            except native.ZkhipError:
+                pass                                   # (no loadable librccl: the host exchange stays in use)
         multi.load_constraint_system(curve_id, circ.n, circ.l, circ.w, circ.mats())
         t0 = time.time()
         multi.load_proving_key(curve_id, pk_bytes, scheme="gm17" if gm17 else "g16")
@@ -537,11 +543,12 @@ def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one):
             proofs, _ = multi.prove_g16_batch(zs, rss)
             dt = time.perf_counter() - t0
             replicas = {"proofs": count, "proofs_per_s": count / dt, "first_identical_to_unsharded": bool(proofs[0] == whole)}
+        exchange = multi.exchange()
         multi.close()
         return {"ms": min(times[1:]), "members": members, "devices": devices, "distinct_gpus": len(set(devices)),
                 "identical_to_unsharded": bool(proof == whole), "key_load_ms": 1000.0 * t_load,
                 "slowest_member_phases_ms": phases, "replicas_batch": replicas,
-                "exchange": "%d-byte canonical records in host memory, combined on the calling thread" % native.partial_size(ctx, curve_id)}
+                "exchange": exchange}
     except Exception as e:   # the throughput line must survive a failure of the optional leg
         return {"error": repr(e)}
 

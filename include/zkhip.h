@@ -264,6 +264,15 @@ int32_t zkhip_ctx_create_multi(const int32_t* devices, int32_t n, zkhip_multi** 
 void zkhip_multi_free(zkhip_multi* m);
 int32_t zkhip_multi_size(const zkhip_multi* m);
 zkhip_ctx* zkhip_multi_ctx(zkhip_multi* m, int32_t member);
+/* The exchange step of zkhip_prove_*_multi over RCCL instead of host memory (BASELINE.json's "RCCL ...
+ * over xGMI"): on != 0 creates one RCCL communicator per member (ncclCommInitAll; librccl.so.1 is bound with dlopen at
+ * this call, libzkhip does not link it) and from then on every member leaves the bucket-set sums of its five partial
+ * MSMs on its device and the members ncclAllGather them (two small messages per proof, latency-bound); member 0's copy
+ * is read back and combined into the same proof bytes.  Needs distinct devices (ZKHIP_ERR_BAD_ARG otherwise: RCCL
+ * refuses two ranks on one GPU) and a loadable librccl (ZKHIP_ERR_DEVICE); on failure the host exchange stays in use.
+ * zkhip_multi_exchange describes the exchange in use (RCCL version and rank count, or the host path). */
+int32_t zkhip_multi_use_rccl(zkhip_multi* m, int32_t on);
+const char* zkhip_multi_exchange(const zkhip_multi* m);
 const char* zkhip_multi_last_error(const zkhip_multi* m);
 int32_t zkhip_multi_r1cs_load(zkhip_multi* m, int32_t curve, uint64_t n, uint64_t l, uint64_t w, const uint64_t* rowptr_a,
                               const uint32_t* col_a, const uint8_t* val_a, const uint64_t* rowptr_b, const uint32_t* col_b,

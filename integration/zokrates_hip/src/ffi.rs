@@ -44,6 +44,8 @@ extern "C" {
     pub fn zkhip_ctx_create_multi(devices: *const i32, n: i32, out: *mut *mut zkhip_multi) -> i32;
     pub fn zkhip_multi_free(m: *mut zkhip_multi);
     pub fn zkhip_multi_last_error(m: *const zkhip_multi) -> *const c_char;
+    pub fn zkhip_multi_use_rccl(m: *mut zkhip_multi, on: i32) -> i32;
+    pub fn zkhip_multi_exchange(m: *const zkhip_multi) -> *const c_char;
     pub fn zkhip_multi_r1cs_load(m: *mut zkhip_multi, curve: i32, n: u64, l: u64, w: u64,
         rp_a: *const u64, col_a: *const u32, val_a: *const u8,
         rp_b: *const u64, col_b: *const u32, val_b: *const u8,

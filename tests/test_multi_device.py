@@ -131,3 +131,88 @@ def test_gpu_config3_2e22_eight_members():
         print("config 3: 2^%d constraints, 8 members on %d GPU(s): %.1f ms per proof (slowest member phases: %s)" % (lg, ndev, tm["total_ms"], tm))
     finally:
         multi.close()
+
+
+# ---------------------------------------------------------------- the exchange step over RCCL (zkhip_multi_use_rccl)
+def _rccl_checks(lib, devices, curve, log_domain):
+    """Same proofs with the members' shares exchanged on the device (all-gather of the raw bucket-set sums) as through host
+    memory and as from one context; both schemes; switching back and forth."""
+    cid = curve.curve_id
+    circ = synth.circuit(cid, log_domain, kind="dense", seed=0xACC1 + log_domain)
+    z = circ.assignment(0x5EED + log_domain)
+    oc = cpu.Circuit.from_csr(cid, circ.n, circ.l, circ.w, circ.mats())
+    multi = native.Multi(devices, lib)
+    try:
+        multi.load_constraint_system(cid, circ.n, circ.l, circ.w, circ.mats())
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        raw = cpu.ProvingKey.setup(oc, tox).serialize()
+        multi.load_proving_key(cid, raw)
+        r, s = 0x1234567 % curve.r, 0x7654321 % curve.r
+        want = cpu.trapdoor(oc, tox, z, r, s)
+        assert "host memory" in multi.exchange()
+        assert multi.prove_g16(z, r, s) == want
+        multi.use_rccl(True)
+        desc = multi.exchange()
+        assert ("RCCL" in desc or "emulated all-gather" in desc) and "host memory" not in desc
+        for rep in range(3):
+            got, tm = multi.prove_g16(z, r + rep, s, want_timings=True)
+            assert got == cpu.trapdoor(oc, tox, z, r + rep, s) and tm["total_ms"] > 0
+        with pytest.raises(native.ZkhipError):          # a bad assignment fails on every member BEFORE anyone enters the collective
+            bad = z.copy(); bad[0] = 2
+            multi.prove_g16(bad, r, s)
+        assert multi.prove_g16(z, r, s) == want          # ... and the group is usable afterwards
+        tb17 = cpu.gm17_toxic_bytes(gm17.Toxic.from_seed(curve))
+        raw17 = cpu.Gm17ProvingKey.setup(oc, tb17).serialize()
+        multi.load_proving_key(cid, raw17, scheme="gm17")
+        assert multi.prove_gm17(z, 5, 6, 7) == cpu.gm17_trapdoor(oc, tb17, z, 5, 7)
+        multi.use_rccl(False)
+        assert "host memory" in multi.exchange()
+        assert multi.prove_gm17(z, 5, 6, 7) == cpu.gm17_trapdoor(oc, tb17, z, 5, 7)
+        return desc
+    finally:
+        multi.close()
+
+
+@pytest.mark.parametrize("curve,ndev", [(BN254, 3), (BLS12_381, 2)], ids=lambda v: getattr(v, "name", str(v)))
+def test_emu_multi_device_exchange_on_the_device(curve, ndev):
+    _rccl_checks(emu_library(), [0] * ndev, curve, 5)
+
+
+def test_libzkhip_binds_rccl_at_run_time_only():
+    """libzkhip.so must not depend on librccl at load time (the single-GPU prover and the CLI never need it); the symbols it
+    resolves with dlopen must exist in the RCCL of this image."""
+    import ctypes
+    import os
+    import subprocess
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zokrates_amd", "libzkhip.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "librccl" not in needed and "libamdhip64" in needed
+    rccl = "/opt/rocm/lib/librccl.so.1"
+    if not os.path.exists(rccl):
+        pytest.skip("no RCCL in this image")
+    syms = subprocess.run(["nm", "-D", "--defined-only", rccl], capture_output=True, text=True).stdout
+    for name in ("ncclCommInitAll", "ncclCommDestroy", "ncclAllGather", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString", "ncclGetVersion"):
+        assert (" " + name + "\n") in syms or (" " + name + "@") in syms, name
+
+
+@pytest.mark.gpu
+def test_gpu_rccl_exchange_every_gpu_one_rank_each():
+    """One member per GPU of the box with the real RCCL all-gather (a single-GPU box runs it with one rank: communicator,
+    collective call, gather buffers and the combine are the same code; the driver's 8-GPU node runs eight)."""
+    lib = native.default_library()
+    n = lib.device_count()
+    desc = _rccl_checks(lib, list(range(n)), BN254, 12)
+    assert "RCCL" in desc and ("%d rank(s)" % n) in desc, desc
+
+
+@pytest.mark.gpu
+def test_gpu_rccl_refuses_two_ranks_on_one_gpu():
+    lib = native.default_library()
+    multi = native.Multi([0, 0], lib)
+    try:
+        with pytest.raises(native.ZkhipError) as e:
+            multi.use_rccl(True)
+        assert e.value.code == -1 and "one device per member" in str(e.value)
+        assert "host memory" in multi.exchange()
+    finally:
+        multi.close()

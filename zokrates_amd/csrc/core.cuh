@@ -1040,6 +1040,49 @@ struct Prover {
         memcpy(partial_out, &g, sizeof(g));
         fill_timings(ctx->slots[0], tm, t_fin);
     }
+    // one rank's share of a proof, left ON THE DEVICE: the raw bucket-set sums of its five MSMs (ws1: 4 G1 MSMs x Wmax XYZZ
+    // sums, ws2: the G2 MSM), for an exchange that never touches host memory (zkhip_multi_use_rccl: RCCL all-gather over
+    // xGMI).  Valid until the slot's next proof.
+    static void prove_device_sums(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const uint8_t* r,
+                                  const uint8_t* s_, const void** d_ws1, size_t* b1, const void** d_ws2, size_t* b2, zkhip_timings* tm) {
+        ProofSlot& sl = ctx->slots[0];
+        enqueue(ctx, sl, pk, cs, z_host, nullptr, r, s_);
+        wait_device_sums(ctx, sl, pk, d_ws1, b1, d_ws2, b2);
+        fill_timings(sl, tm, std::chrono::steady_clock::now());
+    }
+    static void wait_device_sums(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const void** d_ws1, size_t* b1, const void** d_ws2, size_t* b2) {
+        require(sl.busy, ZKHIP_ERR_DEVICE, "internal: no proof in flight in this slot");
+        event_sync(sl.ev[3]);
+        sl.busy = false;
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
+        *b1 = (size_t)4 * Wmax * sizeof(Xyzz<Fq>);
+        *b2 = (size_t)Wmax * sizeof(Xyzz<Fq2>);
+        u32 zflag;
+        memcpy(&zflag, (const uint8_t*)sl.h_ws + *b1 + *b2, 4);
+        require_canonical(zflag);
+        *d_ws1 = sl.ws1.p;
+        *d_ws2 = sl.ws2.p;
+    }
+    // the same sums, gathered into host memory (one rank's ws1 | ws2), as a partial record for `combine` (not canonical:
+    // these never leave the process)
+    static void record_from_sums(zkhip_ctx* ctx, const zkhip_pk* pk, const uint8_t* ws1, const uint8_t* ws2, uint8_t* record_out) {
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
+        std::vector<Xyzz<Fq>> a1((size_t)4 * Wmax);
+        std::vector<Xyzz<Fq2>> a2((size_t)Wmax);
+        memcpy(a1.data(), ws1, a1.size() * sizeof(Xyzz<Fq>));
+        memcpy(a2.data(), ws2, a2.size() * sizeof(Xyzz<Fq2>));
+        Sums g;
+        g.a = msm_combine(&a1[0 * Wmax], shz);
+        g.b1 = msm_combine(&a1[1 * Wmax], shz);
+        g.l = msm_combine(&a1[2 * Wmax], shz);
+        g.h = msm_combine(&a1[3 * Wmax], shh);
+        g.b2 = msm_combine(a2.data(), shz);
+        memcpy(record_out, &g, sizeof(g));
+    }
     // sum of the ranks' partial results, then the assembly
     static void combine(const zkhip_pk* pk, u32 count, const uint8_t* partials, const uint8_t* r, const uint8_t* s_, uint8_t* out) {
         Sums t;
@@ -1254,6 +1297,11 @@ struct CurveOps {
                           zkhip_timings*);
     void (*combine)(const zkhip_pk*, u32, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*);
     size_t partial_bytes;
+    void (*prove_device_sums)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, const void**, size_t*,
+                              const void**, size_t*, zkhip_timings*);
+    void (*gm17_prove_device_sums)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const void**, size_t*, const void**,
+                                   size_t*, zkhip_timings*);
+    void (*record_from_sums)(zkhip_ctx*, const zkhip_pk*, const uint8_t*, const uint8_t*, uint8_t*);
     void (*assignment_upload)(zkhip_ctx*, zkhip_assignment*, const uint8_t*);
     void (*ntt)(zkhip_ctx*, u32, int, uint8_t*);
     void (*witness_map)(zkhip_ctx*, const zkhip_r1cs*, const uint8_t*, uint8_t*);
@@ -1294,6 +1342,9 @@ static CurveOps make_curve_ops() {
     o.prove_partial = &Prover<C>::prove_partial;
     o.combine = &Prover<C>::combine;
     o.partial_bytes = Prover<C>::PARTIAL_BYTES;
+    o.prove_device_sums = &Prover<C>::prove_device_sums;
+    o.gm17_prove_device_sums = &Gm17<C>::prove_device_sums;
+    o.record_from_sums = &Prover<C>::record_from_sums;
     o.assignment_upload = &Prover<C>::assignment_upload;
     o.ntt = &Prover<C>::ntt_api;
     o.witness_map = &Prover<C>::witness_map_api;

@@ -340,6 +340,14 @@ struct Gm17 {
         memcpy(partial_out, &g, sizeof(g));
         P::fill_timings(ctx->slots[0], tm, t_fin);
     }
+    // (as Prover<C>::prove_device_sums: the share stays on the device for the RCCL exchange)
+    static void prove_device_sums(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const uint8_t* rnd,
+                                  const void** d_ws1, size_t* b1, const void** d_ws2, size_t* b2, zkhip_timings* tm) {
+        check_d2(rnd);
+        enqueue(ctx, ctx->slots[0], pk, cs, z_host, nullptr, rnd, rnd + 64);
+        P::wait_device_sums(ctx, ctx->slots[0], pk, d_ws1, b1, d_ws2, b2);
+        P::fill_timings(ctx->slots[0], tm, std::chrono::steady_clock::now());
+    }
     static void combine(const zkhip_pk* pk, u32 count, const uint8_t* partials, const uint8_t* rnd, uint8_t* out) {
         check_d2(rnd);
         Fr dd = fe_from_bytes_canon<Fr>(rnd), rr = fe_from_bytes_canon<Fr>(rnd + 64);

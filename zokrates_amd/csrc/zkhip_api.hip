@@ -2,6 +2,10 @@
 // The drop-in boundary for `Backend<T, G16>::generate_proof` (/root/reference/zokrates_proof_systems/src/lib.rs:98-112).
 #include "core.cuh"
 #include "ingest.h"
+#ifndef ZK_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded at run time, when zkhip_multi_use_rccl asks for it
+#endif
 
 // ------------------------------------------------------------------ C ABI
 static const CurveOps* ops_for(int curve) {
@@ -576,8 +580,57 @@ struct zkhip_multi {
     int scheme = -1;                 // of the loaded key: 0 Groth16, 1 GM17
     bool replicas = false;           // every member holds the WHOLE key (throughput mode) instead of shard k of n
     std::string err;
+    // the exchange step over RCCL (zkhip_multi_use_rccl): one communicator and one pair of device buffers per member
+    bool rccl = false;
+    std::vector<void*> comm;         // ncclComm_t per member
+    std::vector<DBuf> gather1, gather2;   // all members' ws1 / ws2, rank-major, on every member's device
+    std::string rccl_desc;
 };
 }  // extern "C"
+
+// ------------------------------------------------------------------ RCCL, bound at run time
+// The data path of a sharded proof has ONE exchange: every member contributes the bucket-set sums of its five partial
+// MSMs ("ncclAllGather of a fixed-size struct").  libzkhip does not link librccl — a single-GPU prover, the
+// CLI, the tests never need it and would pay its load time — so the five entry points used are resolved with dlopen when a
+// caller asks for the RCCL exchange.  Whatever HIP runtime this process already runs is the one librccl.so.1 binds to.
+#ifndef ZK_EMU
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    std::string why;                 // why it is unavailable
+};
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            x.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.handle) break;
+        }
+        if (!x.handle) { x.why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return x; }
+        auto sym = [&](const char* n) { void* p = dlsym(x.handle, n); if (!p && x.why.empty()) x.why = std::string("librccl lacks ") + n; return p; };
+        x.CommInitAll = (decltype(x.CommInitAll))sym("ncclCommInitAll");
+        x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
+        x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
+        x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
+        x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
+        x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+        x.GetVersion = (decltype(x.GetVersion))sym("ncclGetVersion");
+        return x;
+    }();
+    return r;
+}
+void rccl_check(ncclResult_t rc, const char* what) {
+    if (rc != ncclSuccess) throw DevError{std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error")};
+}
+}  // namespace
+#endif
 // run fn(k) for every member — one host thread each (contexts are independent; the test emulator is single-threaded) —
 // and keep the first failure
 template <class Fn>
@@ -647,8 +700,82 @@ int32_t zkhip_ctx_create_multi(const int32_t* devices, int32_t n, zkhip_multi** 
     *out = m.release();
     return ZKHIP_OK;
 }
+static void multi_drop_rccl(zkhip_multi* m) {
+#ifndef ZK_EMU
+    for (size_t k = 0; k < m->comm.size(); ++k)
+        if (m->comm[k]) {
+            try { dev_set(m->ctx[k]->device); } catch (...) {}
+            (void)rccl().CommDestroy((ncclComm_t)m->comm[k]);
+        }
+#endif
+    m->comm.clear();
+    for (size_t k = 0; k < m->gather1.size(); ++k) {
+        try { dev_set(m->ctx[k]->device); } catch (...) {}
+        m->gather1[k].release();
+        m->gather2[k].release();
+    }
+    m->gather1.clear();
+    m->gather2.clear();
+    m->rccl = false;
+}
+int32_t zkhip_multi_use_rccl(zkhip_multi* m, int32_t on) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    try {
+        multi_drop_rccl(m);
+        if (!on) return ZKHIP_OK;
+        const size_t n = m->ctx.size();
+        std::vector<int> dev(n);
+        for (size_t k = 0; k < n; ++k) dev[k] = m->ctx[k]->device;
+#ifndef ZK_EMU   // (the emulator's "all-gather" is a loop of copies: its members may share the one emulated device)
+        for (size_t a = 0; a < n; ++a)
+            for (size_t b = a + 1; b < n; ++b)
+                if (dev[a] == dev[b]) {
+                    m->err = "RCCL wants one device per member (device " + std::to_string(dev[a]) + " is listed twice): the host exchange stays in use";
+                    return ZKHIP_ERR_BAD_ARG;
+                }
+#endif
+        m->gather1 = std::vector<DBuf>(n);
+        m->gather2 = std::vector<DBuf>(n);
+#ifdef ZK_EMU
+        m->rccl_desc = "emulated all-gather (TEST EMULATOR: device-to-device copies in member order)";
+#else
+        Rccl& R = rccl();
+        if (!R.why.empty()) { m->err = R.why; m->gather1.clear(); m->gather2.clear(); return ZKHIP_ERR_DEVICE; }
+        std::vector<ncclComm_t> comms(n, nullptr);
+        rccl_check(R.CommInitAll(comms.data(), (int)n, dev.data()), "ncclCommInitAll");
+        m->comm.assign(comms.begin(), comms.end());
+        int ver = 0;
+        (void)R.GetVersion(&ver);
+        m->rccl_desc = "RCCL " + std::to_string(ver) + ", " + std::to_string(n) + " rank(s), ncclAllGather of the members' bucket-set sums";
+        for (size_t a = 0; a < n; ++a)          // xGMI peer reachability, for the record (RCCL picks its own transport)
+            for (size_t b = 0; b < n; ++b) {
+                int can = 0;
+                if (a != b && hipDeviceCanAccessPeer(&can, dev[a], dev[b]) == hipSuccess && !can) m->rccl_desc += "; no peer access " + std::to_string(dev[a]) + "->" + std::to_string(dev[b]);
+            }
+#endif
+        m->rccl = true;
+        return ZKHIP_OK;
+    } catch (const DevError& e) {
+        m->err = e.msg;
+        multi_drop_rccl(m);
+        return ZKHIP_ERR_DEVICE;
+    } catch (const std::bad_alloc&) {
+        m->err = "out of host memory";
+        multi_drop_rccl(m);
+        return ZKHIP_ERR_NOMEM;
+    } catch (...) {
+        m->err = "unexpected internal error";
+        multi_drop_rccl(m);
+        return ZKHIP_ERR_DEVICE;
+    }
+}
+const char* zkhip_multi_exchange(const zkhip_multi* m) {
+    if (!m) return "";
+    return m->rccl ? m->rccl_desc.c_str() : "canonical records in host memory, combined on the calling thread";
+}
 void zkhip_multi_free(zkhip_multi* m) {
     if (!m) return;
+    multi_drop_rccl(m);
     multi_drop_keys(m);
     for (auto* c : m->cs) zkhip_r1cs_free(c);
     for (auto* c : m->ctx) zkhip_ctx_free(c);
@@ -734,11 +861,63 @@ static int32_t multi_prove(zkhip_multi* m, int scheme, const uint8_t* z, const u
     const size_t n = m->ctx.size();
     std::vector<uint8_t> records(n * rec);
     std::vector<zkhip_timings> tm(n);
-    int32_t rc = multi_each(m, [&](size_t k) {
-        return scheme == 0 ? zkhip_prove_g16_partial(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, s_, &records[k * rec], &tm[k])
-                           : zkhip_prove_gm17_partial(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, &records[k * rec], &tm[k]);
-    });
-    if (rc != ZKHIP_OK) return rc;
+    int32_t rc;
+    if (m->rccl) {
+        // every member leaves the bucket-set sums of its five partial MSMs on its device and all-gathers them (RCCL over
+        // xGMI; in the test emulator: copies in member order); member 0's gathered copy is read back and combined
+        const CurveOps* ops = ops_for(m->pk[0]->curve);
+        std::vector<const void*> d1(n), d2(n);
+        std::vector<size_t> b1(n), b2(n);
+        auto share = [&](size_t k) {
+            return guarded(m->ctx[k], [&] {
+                zkhip_ctx* c = m->ctx[k];
+                require(m->pk[k]->ctx == c && m->cs[k]->ctx == c, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
+                if (scheme == 0) ops->prove_device_sums(c, m->pk[k], m->cs[k], z, rnd, s_, &d1[k], &b1[k], &d2[k], &b2[k], &tm[k]);
+                else ops->gm17_prove_device_sums(c, m->pk[k], m->cs[k], z, rnd, &d1[k], &b1[k], &d2[k], &b2[k], &tm[k]);
+                m->gather1[k].ensure(n * b1[k]);
+                m->gather2[k].ensure(n * b2[k]);
+            });
+        };
+#ifdef ZK_EMU
+        rc = multi_each(m, share);
+        if (rc != ZKHIP_OK) return rc;
+        for (size_t k = 0; k < n; ++k) {
+            dev_d2d((uint8_t*)m->gather1[0].p + k * b1[0], d1[k], b1[0], m->ctx[0]->stream);
+            dev_d2d((uint8_t*)m->gather2[0].p + k * b2[0], d2[k], b2[0], m->ctx[0]->stream);
+        }
+#else
+        // two phases: a member enters the collective only when EVERY member has its share (one that failed alone would
+        // leave the others waiting in ncclAllGather for ever)
+        rc = multi_each(m, share);
+        if (rc != ZKHIP_OK) return rc;
+        rc = multi_each(m, [&](size_t k) {
+            return guarded(m->ctx[k], [&] {
+                Rccl& R = rccl();
+                zkhip_ctx* c = m->ctx[k];
+                rccl_check(R.GroupStart(), "ncclGroupStart");
+                rccl_check(R.AllGather(d1[k], m->gather1[k].p, b1[k], ncclUint8, (ncclComm_t)m->comm[k], c->stream), "ncclAllGather");
+                rccl_check(R.AllGather(d2[k], m->gather2[k].p, b2[k], ncclUint8, (ncclComm_t)m->comm[k], c->stream), "ncclAllGather");
+                rccl_check(R.GroupEnd(), "ncclGroupEnd");
+                stream_sync(c->stream);
+            });
+        });
+        if (rc != ZKHIP_OK) return rc;
+#endif
+        rc = guarded(m->ctx[0], [&] {
+            std::vector<uint8_t> h1(n * b1[0]), h2(n * b2[0]);
+            dev_d2h(h1.data(), m->gather1[0].p, h1.size(), m->ctx[0]->stream);
+            dev_d2h(h2.data(), m->gather2[0].p, h2.size(), m->ctx[0]->stream);
+            stream_sync(m->ctx[0]->stream);
+            for (size_t k = 0; k < n; ++k) ops->record_from_sums(m->ctx[k], m->pk[k], &h1[k * b1[0]], &h2[k * b2[0]], &records[k * rec]);
+        });
+        if (rc != ZKHIP_OK) { m->err = std::string("gather: ") + zkhip_last_error(m->ctx[0]); return rc; }
+    } else {
+        rc = multi_each(m, [&](size_t k) {
+            return scheme == 0 ? zkhip_prove_g16_partial(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, s_, &records[k * rec], &tm[k])
+                               : zkhip_prove_gm17_partial(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, &records[k * rec], &tm[k]);
+        });
+        if (rc != ZKHIP_OK) return rc;
+    }
     rc = scheme == 0 ? zkhip_combine_g16(m->ctx[0], m->pk[0], (uint32_t)n, records.data(), rnd, s_, proof_out)
                      : zkhip_combine_gm17(m->ctx[0], m->pk[0], (uint32_t)n, records.data(), rnd, proof_out);
     if (rc != ZKHIP_OK) { m->err = std::string("combine: ") + zkhip_last_error(m->ctx[0]); return rc; }

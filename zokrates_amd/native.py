@@ -62,7 +62,7 @@ class Library:
         "zkhip_ctx_tune",
         "zkhip_ctx_create_multi", "zkhip_multi_free", "zkhip_multi_size", "zkhip_multi_ctx", "zkhip_multi_last_error", "zkhip_multi_r1cs_load",
         "zkhip_multi_pk_load_g16", "zkhip_multi_pk_load_gm17", "zkhip_prove_g16_multi", "zkhip_prove_gm17_multi",
-        "zkhip_multi_pk_load_g16_replicas", "zkhip_prove_g16_multi_batch",
+        "zkhip_multi_pk_load_g16_replicas", "zkhip_prove_g16_multi_batch", "zkhip_multi_use_rccl", "zkhip_multi_exchange",
     ]
 
     def __init__(self, path=None):
@@ -82,6 +82,8 @@ class Library:
         L.zkhip_multi_size.restype = i32; L.zkhip_multi_size.argtypes = [vp]
         L.zkhip_multi_ctx.restype = vp; L.zkhip_multi_ctx.argtypes = [vp, i32]
         L.zkhip_multi_last_error.restype = C.c_char_p; L.zkhip_multi_last_error.argtypes = [vp]
+        L.zkhip_multi_use_rccl.restype = i32; L.zkhip_multi_use_rccl.argtypes = [vp, i32]
+        L.zkhip_multi_exchange.restype = C.c_char_p; L.zkhip_multi_exchange.argtypes = [vp]
         L.zkhip_multi_r1cs_load.restype = i32; L.zkhip_multi_r1cs_load.argtypes = [vp, i32, u64, u64, u64] + [vp] * 9
         L.zkhip_multi_pk_load_g16.restype = i32; L.zkhip_multi_pk_load_g16.argtypes = [vp, i32, vp, sz]
         L.zkhip_multi_pk_load_gm17.restype = i32; L.zkhip_multi_pk_load_gm17.argtypes = [vp, i32, vp, sz]
@@ -639,6 +641,13 @@ class Multi:
         ctx.h = C.c_void_p(self.lib.L.zkhip_multi_ctx(self.h, k))
         ctx.close = lambda: None
         return ctx
+
+    def use_rccl(self, on=True):
+        """`zkhip_multi_use_rccl`: exchange the members' shares with an RCCL all-gather instead of through host memory."""
+        self._check(self.lib.L.zkhip_multi_use_rccl(self.h, 1 if on else 0))
+
+    def exchange(self):
+        return self.lib.L.zkhip_multi_exchange(self.h).decode()
 
     def load_constraint_system(self, curve_id, n, l, w, mats):
         keep = []

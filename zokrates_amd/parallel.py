@@ -33,6 +33,16 @@ class Ranks:
             else:
                 dist.init_process_group(self.backend)
 
+    def describe(self):
+        """What the N ranks talk over: for the record in the bench line (the driver's scaling run can check that N RCCL ranks
+        really formed)."""
+        if self._dist is None:
+            return "single process, no process group"
+        if self.backend == "nccl":
+            ver = ".".join(str(v) for v in self._torch.cuda.nccl.version()) if hasattr(self._torch.cuda, "nccl") else "?"
+            return f"torch.distributed nccl (= RCCL {ver}), {self._dist.get_world_size()} rank(s), one GPU each"
+        return f"torch.distributed {self.backend}, {self._dist.get_world_size()} rank(s)"
+
     def barrier(self):
         """Barrier + device synchronisation (libzkhip calls return only after their streams have drained; the explicit
         torch.cuda.synchronize covers the collective itself)."""
