@@ -55,9 +55,9 @@ def supervise():
         sys.stderr.flush()
         out_lines = proc.stdout.decode(errors="replace").splitlines()
         json_lines = [l for l in out_lines if l.startswith("{")]
-        for l in out_lines:
+        for l in out_lines:                      # (anything else the child or a library wrote to stdout: kept, but off the JSON channel)
             if not l.startswith("{"):
-                print(l)
+                print(l, file=sys.stderr)
         stages = [l for l in etxt.splitlines() if l.startswith("[bench]")]
         other = "\n".join(l for l in etxt.splitlines() if not l.startswith("[bench]"))
         rec = {"exit_status": proc.returncode, "signal": -proc.returncode if proc.returncode < 0 else None,
@@ -379,7 +379,7 @@ def main():
             note = {"error": "timed out after %d s" % SHARDED_LEG_TIMEOUT_S}
             if world > 1:
                 out.setdefault("sharded_single_proof", note)
-            if members > 1:
+            if members >= 1:
                 out.setdefault("multi_single_proof", note)
             out["cpu_baseline"] = None
             print(json.dumps(out), flush=True)
@@ -387,7 +387,7 @@ def main():
 
     watchdog = threading.Timer(SHARDED_LEG_TIMEOUT_S, give_up)
     watchdog.daemon = True
-    if world > 1 or members > 1:
+    if world > 1 or members >= 1:
         watchdog.start()
     if world > 1:
         # ONE proof sharded over all ranks (1/world of the bases per GPU, RCCL all-gather of the partial records);
@@ -409,7 +409,7 @@ def main():
             out["sharded_single_proof"] = {"error": repr(e)}
     if os.environ.get("ZKHIP_BENCH_TEST_STALL"):      # tests/test_bench_cli.py: an optional leg that never returns
         time.sleep(3600)
-    if rank == 0 and members > 1:
+    if rank == 0 and members >= 1:
         out["multi_single_proof"] = multi_leg(ctx, circ, curve_id, pk_bytes, zs[0], members, gm17, prove_one)
     if world > 1:
         barrier_sync()      # the other ranks idle while rank 0 drives every GPU through the library

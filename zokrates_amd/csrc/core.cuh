@@ -902,10 +902,10 @@ struct Prover {
             sl.h_ws = host_alloc_pinned(b1 + b2 + 4);
             sl.h_ws_cap = b1 + b2 + 4;
         }
-        dev_d2h(sl.h_ws, ws1, b1, so);
-        dev_d2h((uint8_t*)sl.h_ws + b1, sl.ws2.p, b2, so);
+        dev_d2h_pinned(sl.h_ws, ws1, b1, so);                         // (h_ws is the slot's own pinned buffer: truly asynchronous)
+        dev_d2h_pinned((uint8_t*)sl.h_ws + b1, sl.ws2.p, b2, so);
         sl.zflag.ensure(4);
-        dev_d2h((uint8_t*)sl.h_ws + b1 + b2, sl.zflag.p, 4, so);   // written on the main stream before ev[0], which every lane waits for
+        dev_d2h_pinned((uint8_t*)sl.h_ws + b1 + b2, sl.zflag.p, 4, so);   // written on the main stream before ev[0], which every lane waits for
         event_record(sl.ev[3], so);
         sl.busy = true;
     }

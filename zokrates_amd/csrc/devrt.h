@@ -156,8 +156,114 @@ inline void jitter_before(Stream s) {
     const unsigned long long us = (x >> 8) % (uint64_t)(max_us + 1);
     hipLaunchKernelGGL(k_jitter_spin, dim3(1), dim3(1), 0, s, us * 100ull);
 }
-inline void dev_h2d(void* d, const void* h, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
-inline void dev_d2h(void* h, const void* d, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
+// Copies between the device and host memory THE CALLER OWNS (pageable: numpy arrays, std::vector, stack).  The HIP runtime
+// accepts such pointers in hipMemcpyAsync by pinning the user's pages behind the caller's back for the duration of the
+// transfer; on this stack that path faults now and then when several transfers and kernels are queued without a host
+// synchronisation between them (round 2's driver run died that way, and removing an unrelated 40 ms host loop between the
+// three uploads of zkhip_r1cs_load made it die every time: profiles/r3c_pageable_copy_fault.md).  So the library never
+// hands a pointer it does not own to an asynchronous copy: pageable data goes through a pinned staging ring that belongs to
+// the library, in chunks — host memcpy into the ring, asynchronous copy out of it, an event per chunk before its reuse.
+// dev_h2d / dev_d2h are therefore safe for ANY host pointer; dev_h2d_pinned / dev_d2h_pinned are the raw asynchronous copies
+// for memory the library allocated with host_alloc_pinned.
+inline int& copy_mode() {
+    static int mode = getenv("ZKHIP_COPY_MODE") ? atoi(getenv("ZKHIP_COPY_MODE")) : 2;   // 0: raw async (the runtime pins), 1: hipMemcpy, 2: staged
+    return mode;
+}
+struct StagingRing {
+    static constexpr size_t CHUNK = (size_t)8 << 20;
+    static constexpr int SLOTS = 4;
+    void* buf[SLOTS] = {};
+    hipEvent_t ev[SLOTS] = {};
+    bool used[SLOTS] = {};
+    int next = 0;
+    int device = -1;
+    std::mutex mu;
+    void init() {
+        if (buf[0]) return;
+        for (int i = 0; i < SLOTS; ++i) {
+            ZK_HIP_CHECK(hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault));
+            ZK_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+    }
+    // a slot whose previous transfer has completed
+    int acquire() {
+        const int i = next;
+        next = (next + 1) % SLOTS;
+        if (used[i]) ZK_HIP_CHECK(hipEventSynchronize(ev[i]));
+        used[i] = false;
+        return i;
+    }
+};
+// one ring per device (contexts on one device share it under its mutex; the copies of one call are issued under the lock)
+inline StagingRing& staging_ring() {
+    static StagingRing rings[64];
+    int d = 0;
+    (void)hipGetDevice(&d);
+    StagingRing& r = rings[d & 63];
+    return r;
+}
+inline void dev_h2d_pinned(void* d, const void* h, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
+inline void dev_d2h_pinned(void* h, const void* d, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
+inline void dev_h2d(void* d, const void* h, size_t n, Stream s) {
+    if (!n) return;
+    const int mode = copy_mode();
+    if (mode == 0) { dev_h2d_pinned(d, h, n, s); return; }
+    if (mode == 1) {   // the synchronous API: ordered after what the stream already holds, complete when it returns
+        ZK_HIP_CHECK(hipStreamSynchronize(s));
+        ZK_HIP_CHECK(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+        return;
+    }
+    StagingRing& r = staging_ring();
+    std::lock_guard<std::mutex> lock(r.mu);
+    r.init();
+    for (size_t off = 0; off < n; off += StagingRing::CHUNK) {
+        const size_t len = std::min(StagingRing::CHUNK, n - off);
+        const int i = r.acquire();
+        memcpy(r.buf[i], (const char*)h + off, len);
+        jitter_before(s);
+        ZK_HIP_CHECK(hipMemcpyAsync((char*)d + off, r.buf[i], len, hipMemcpyHostToDevice, s));
+        ZK_HIP_CHECK(hipEventRecord(r.ev[i], s));
+        r.used[i] = true;
+    }
+}
+// (the host needs the bytes, so this one returns when they are there: every caller synchronised right after it anyway)
+inline void dev_d2h(void* h, const void* d, size_t n, Stream s) {
+    if (!n) return;
+    const int mode = copy_mode();
+    if (mode == 0) { dev_d2h_pinned(h, d, n, s); return; }
+    if (mode == 1) {
+        ZK_HIP_CHECK(hipStreamSynchronize(s));
+        ZK_HIP_CHECK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+        return;
+    }
+    StagingRing& r = staging_ring();
+    std::lock_guard<std::mutex> lock(r.mu);
+    r.init();
+    // two chunks in flight: while one is copied out of the ring on the host, the next one arrives
+    int pending[2] = {-1, -1};
+    size_t pend_off[2] = {0, 0}, pend_len[2] = {0, 0};
+    int q = 0;
+    auto drain = [&](int k) {
+        if (pending[k] < 0) return;
+        ZK_HIP_CHECK(hipEventSynchronize(r.ev[pending[k]]));
+        memcpy((char*)h + pend_off[k], r.buf[pending[k]], pend_len[k]);
+        r.used[pending[k]] = false;
+        pending[k] = -1;
+    };
+    for (size_t off = 0; off < n; off += StagingRing::CHUNK) {
+        const size_t len = std::min(StagingRing::CHUNK, n - off);
+        drain(q);
+        const int i = r.acquire();
+        jitter_before(s);
+        ZK_HIP_CHECK(hipMemcpyAsync(r.buf[i], (const char*)d + off, len, hipMemcpyDeviceToHost, s));
+        ZK_HIP_CHECK(hipEventRecord(r.ev[i], s));
+        r.used[i] = true;
+        pending[q] = i; pend_off[q] = off; pend_len[q] = len;
+        q ^= 1;
+    }
+    drain(q);
+    drain(q ^ 1);
+}
 inline void dev_d2d(void* d, const void* s_, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s)); }
 inline void dev_memset(void* d, int v, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemsetAsync(d, v, n, s)); }
 inline Stream stream_create() {
@@ -245,6 +351,8 @@ inline void* host_alloc_pinned(size_t bytes) { return dev_alloc(bytes); }
 inline void host_free_pinned(void* p) { free(p); }
 inline void dev_h2d(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }
 inline void dev_d2h(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n); }
+inline void dev_h2d_pinned(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }
+inline void dev_d2h_pinned(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n); }
 inline void dev_d2d(void* d, const void* s_, size_t n, Stream) { memcpy(d, s_, n); }
 inline void dev_memset(void* d, int v, size_t n, Stream) { memset(d, v, n); }
 inline Stream stream_create() { return 0; }
