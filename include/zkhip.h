@@ -104,6 +104,9 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_FUSE_Z 11
 #define ZKHIP_TUNE_MSM_FUSED_WAVES 12
 #define ZKHIP_TUNE_STREAM_JITTER 13
+#define ZKHIP_TUNE_SORT_KH_LOG 14  /* log2 of the buckets one LDS histogram of the sort holds (2..15; default 15): windows with more
+                                    * buckets are sorted in two passes — a test hook to reach that path with small windows          */
+#define ZKHIP_TUNE_FOLD3_MIN_H 15  /* bucket sets with at least this many rows of 256 buckets fold in three digits (default 512)  */
 int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value);
 
 /* ---- proving key ----
