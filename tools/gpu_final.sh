@@ -8,25 +8,27 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd "$root"
 git rev-parse HEAD > "$out/head.txt" 2>/dev/null || true
-timeout 240 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1 || { echo "SMOKE FAILED: giving the box back"; tail -5 "$out/smoke.log"; exit 0; }
-if [ -z "${SKIP_SUITE:-}" ]; then timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"; fi
+# the driver's own sequence first, on the cold box: the suite, smoke(), the bench command with the driver's flags
+if [ -z "${SKIP_SUITE:-}" ]; then timeout 1500 python -m pytest tests/ -x -q -m gpu > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"; fi
+timeout 240 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1 || { echo "SMOKE FAILED"; tail -5 "$out/smoke.log"; }
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_command.json" 2> "$out/bench_driver_command.err"
 timeout 600 python bench.py > "$out/bench_default.json" 2> "$out/bench.err"
-timeout 600 python bench.py --scheme gm17 > "$out/bench_gm17.json" 2>> "$out/bench.err"
-timeout 600 python bench.py --curve bls12_381 --log-domain 18 --kind poseidon > "$out/bench_poseidon_bls12_381_2e18.json" 2>> "$out/bench.err"
-timeout 600 python bench.py --kind sha --cpu-seconds 0 > "$out/bench_sha_like.json" 2>> "$out/bench.err"
-timeout 600 python bench.py --cpu-seconds 0 --constraints 1048576 --steps 16 > "$out/bench_n2e20_literal_domain2e21.json" 2>> "$out/bench.err"
-timeout 900 python bench.py --cpu-seconds 0 --log-domain 22 --steps 8 --members 8 > "$out/bench_config3_2e22_members8.json" 2>> "$out/bench.err"
-timeout 600 python bench.py --cpu-seconds 0 --members 8 --steps 16 > "$out/bench_2e20_members8.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --scheme gm17 --e2e 0 > "$out/bench_gm17.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --curve bls12_381 --log-domain 18 --kind poseidon --e2e 0 > "$out/bench_poseidon_bls12_381_2e18.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --kind sha --cpu-seconds 0 --e2e 0 > "$out/bench_sha_like.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --cpu-seconds 0 --constraints 1048576 --steps 16 --e2e 0 > "$out/bench_n2e20_literal_domain2e21.json" 2>> "$out/bench.err"
+timeout 900 python bench.py --cpu-seconds 0 --log-domain 22 --steps 8 --members 8 --e2e 0 > "$out/bench_config3_2e22_members8.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --cpu-seconds 0 --members 8 --steps 16 --e2e 0 > "$out/bench_2e20_members8.json" 2>> "$out/bench.err"
 # the N > 1 code path of bench.py on real hardware: two ranks sharing this box's one GPU (gloo instead of RCCL, which wants
 # one device per rank); rank 0 also drives the in-library multi leg
 ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 \
-  bench.py --gpus 2 --steps 8 --warmup 2 > "$out/bench_two_ranks_one_gpu.json" 2>> "$out/bench.err"
+  bench.py --gpus 2 --steps 8 --warmup 2 --e2e 0 > "$out/bench_two_ranks_one_gpu.json" 2>> "$out/bench.err"
 # HBM traffic of the accumulation / transform kernels -> profiles/pmc_traffic.json (what the NEXT bench lines report as
 # roofline.traffic): two PMC passes (their own runs, kernel trace only), one stream; a pass that does not finish in 200 s is
 # given up.  Last, so that a profiler pass that hangs (one did: 900 s) cannot cost the bench lines.
-[ -z "${SKIP_PMC:-}" ] && ( cd /tmp && export TMPDIR=/tmp
+[ -z "${SKIP_PMC:-}" ] && ( cd /tmp && export TMPDIR=/tmp ZKHIP_BENCH_CHILD=1
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    ZKHIP_SERIAL=1 timeout 200 rocprofv3 --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 > "$out/prof_pmc_$ctr.log" 2>&1
+    ZKHIP_SERIAL=1 timeout 200 rocprofv3 --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0 > "$out/prof_pmc_$ctr.log" 2>&1
     db=$(find "$out/prof_pmc_$ctr" -name "*.db" 2>/dev/null | head -1)
     [ -n "$db" ] && python "$root/tools/pmc_stats.py" "$db" "$out/${tag}_pmc_$ctr.md" > /dev/null
   done
