@@ -216,3 +216,32 @@ def test_gpu_rccl_refuses_two_ranks_on_one_gpu():
         assert "host memory" in multi.exchange()
     finally:
         multi.close()
+
+
+@pytest.mark.gpu
+def test_gpu_context_churn_with_host_transfers():
+    """Contexts created and destroyed in turn, each moving caller-owned host memory both ways (the library's pinned staging
+    ring outlives a context: it must not hold events of streams that are gone), alone and with two contexts alive at once."""
+    lib = native.default_library()
+    circ = synth.circuit(0, 11, kind="dense", seed=0xC0DE)
+    z = circ.assignment(5)
+    oc = cpu.Circuit.from_csr(0, circ.n, circ.l, circ.w, circ.mats())
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(BN254))
+    raw = cpu.ProvingKey.setup(oc, tox).serialize()
+    want = cpu.trapdoor(oc, tox, z, 3, 4)
+    keep = None
+    for rep in range(8):
+        ctx = native.Context(0, lib)
+        cs = native.ConstraintSystem(ctx, 0, circ.n, circ.l, circ.w, circ.mats())
+        pk = native.ProvingKey(ctx, 0, raw)
+        assert native.prove_g16(ctx, pk, cs, z, 3, 4) == want, rep
+        assert cs.witness_map(z).size == 32 * 2048
+        if rep % 3 == 0 and keep is None:
+            keep = (ctx, cs, pk)                       # stays alive across the next iterations
+            continue
+        pk.close(); cs.close(); ctx.close()
+        if keep is not None and rep % 3 == 2:
+            kctx, kcs, kpk = keep
+            assert native.prove_g16(kctx, kpk, kcs, z, 3, 4) == want
+            kpk.close(); kcs.close(); kctx.close()
+            keep = None

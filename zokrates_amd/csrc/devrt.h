@@ -202,6 +202,19 @@ inline StagingRing& staging_ring() {
     StagingRing& r = rings[d & 63];
     return r;
 }
+// Before a context destroys its streams: wait for every transfer the ring still tracks and forget it.  An event keeps a
+// reference to the stream it was last recorded on; synchronising on it after that stream is gone is undefined (HIP answered
+// "operation not permitted on an event last recorded in a capturing stream" once: freed stream memory read as a capture flag).
+inline void staging_drain() {
+    StagingRing& r = staging_ring();
+    std::lock_guard<std::mutex> lock(r.mu);
+    if (!r.buf[0]) return;
+    for (int i = 0; i < StagingRing::SLOTS; ++i)
+        if (r.used[i]) {
+            (void)hipEventSynchronize(r.ev[i]);
+            r.used[i] = false;
+        }
+}
 inline void dev_h2d_pinned(void* d, const void* h, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
 inline void dev_d2h_pinned(void* h, const void* d, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
 inline void dev_h2d(void* d, const void* h, size_t n, Stream s) {
@@ -351,6 +364,7 @@ inline void* host_alloc_pinned(size_t bytes) { return dev_alloc(bytes); }
 inline void host_free_pinned(void* p) { free(p); }
 inline void dev_h2d(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }
 inline void dev_d2h(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n); }
+inline void staging_drain() {}
 inline void dev_h2d_pinned(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }
 inline void dev_d2h_pinned(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n); }
 inline void dev_d2d(void* d, const void* s_, size_t n, Stream) { memcpy(d, s_, n); }

@@ -140,6 +140,7 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
     } catch (...) {
     }
     dev_sync_all();
+    staging_drain();          // (the device's staging ring may still track transfers recorded on this context's streams)
     for (auto& sl : ctx->slots) {
         for (auto& so : sl.sorts) event_destroy(so.ready);
         for (int k = 0; k < ZK_NLANES; ++k) {
