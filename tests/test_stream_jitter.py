@@ -140,3 +140,25 @@ def test_members_sharing_the_gpu(ctx):
                 assert multi.prove_g16(z, 4242, 777) == want, (members, rep)
         finally:
             multi.close()
+
+
+def test_full_pipeline_at_2e18_same_bytes_with_and_without_jitter(ctx):
+    """All proof slots in flight at a size where every kernel fills the machine: 16 pipelined proofs under jitter must be the
+    bytes the same library produces one proof at a time without it (and the oracle's, for the first)."""
+    cid = 0
+    circ, cs, pk_bytes, oc, opk, _ = _keyed(ctx, cid, 18, 0xBEEF)
+    pk = native.ProvingKey(ctx, cid, pk_bytes)
+    zs = [circ.assignment(500 + i) for i in range(3)]
+    res = [native.Assignment(ctx, cs, z) for z in zs]
+    rs = [(0x3333 * (i + 1), 0x5555 * (i + 2)) for i in range(3)]
+    ctx.tune("stream_jitter", 0)
+    try:
+        calm = [native.prove_g16_resident(ctx, pk, cs, res[i], *rs[i]) for i in range(3)]
+    finally:
+        ctx.tune("stream_jitter", JITTER_US)
+    assert calm[0] == cpu.prove(oc, opk, zs[0], *rs[0])[0]
+    order = [k % 3 for k in range(16)]
+    proofs, _ = native.prove_g16_resident_batch(ctx, pk, cs, [res[i] for i in order], [rs[i] for i in order])
+    assert proofs == [calm[i] for i in order]
+    for i in range(3):
+        assert native.prove_g16(ctx, pk, cs, zs[i], *rs[i]) == calm[i]

@@ -457,10 +457,10 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
         lds_opt_in(ctx, (const void*)k_msm_count);
         lds_opt_in(ctx, (const void*)k_msm_place);
         const u32 key_stride = sh.sets == 1 ? 0 : sh.K;
-        ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride, kh,
+        ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride, kh,
                   ptr<u32>(so.cnt));
         scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
-        ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride, kh,
+        ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride, kh,
                   level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
     } else {
         // wider than one LDS histogram (shared buckets only): sort on the low bits, stable partition on the high bits
@@ -475,9 +475,9 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
         dev_memset(so.cursor.p, 0, (size_t)kh * 4, s);
         lds_opt_in(ctx, (const void*)k_msm_count_lo);
         lds_opt_in(ctx, (const void*)k_msm_place_lo);
-        ZK_LAUNCH(k_msm_count_lo, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, chunk, kh, ptr<u32>(so.cnt));
+        ZK_LAUNCH(k_msm_count_lo, dim3((unsigned)sort_chunks, sh.W), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, chunk, kh, ptr<u32>(so.cnt));
         scan_u32(s, so.cnt, so.off1, kh, so.chunk_sum, so.grand);                  // so.grand = length of the list
-        ZK_LAUNCH(k_msm_place_lo, dim3((unsigned)sort_chunks, sh.W), dim3(512), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, chunk, kh, level_stride,
+        ZK_LAUNCH(k_msm_place_lo, dim3((unsigned)sort_chunks, sh.W), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, chunk, kh, level_stride,
                   ptr<u32>(so.off1), ptr<u32>(so.cursor), ptr<u32>(so.keys1), ptr<u32>(so.ent1));
         const u32 nchunks2 = (u32)((max_total + PART_CHUNK - 1) / PART_CHUNK);
         const int kh_log = ilog2_floor(kh);

@@ -113,6 +113,11 @@ __global__ void k_points_to_packed(const Aff<FS>* __restrict__ in, AffPacked<U>*
 }
 
 static constexpr u32 MSM_NO_DIGIT = 0xffffffffu;
+// work-items of a sort workgroup (one workgroup per CU: its histogram takes up to 128 KiB of LDS): the scattered 4-byte
+// stores of the place pass are latency-bound, so the more waves a CU holds the better
+#ifndef ZK_SORT_THREADS
+#define ZK_SORT_THREADS 1024
+#endif
 static constexpr u32 MSM_HEAVY = 16;  // a bucket spread over more slices than this is reduced by a whole workgroup (a value repeated
                                       // across a witness — the constant in every first S-box of a Poseidon chain, the ones of a
                                       // boolean-heavy assignment — would otherwise be summed serially by one work-item of the fold)
@@ -160,7 +165,7 @@ static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ w
 // grid (nchunks, W, K / kh); dynamic LDS kh x 4 B.  cnt[key] += number of digits with that key in this chunk.
 // A workgroup histograms the buckets [z * kh, (z + 1) * kh) of its window (kh = min(K, 2^15): the histogram fits LDS up to
 // c = 16; wider windows split their buckets over blockIdx.z and every split rescans the chunk's digits).
-static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
+static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
                                                         u32* __restrict__ cnt) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
@@ -183,7 +188,7 @@ static __global__ void __launch_bounds__(512) k_msm_count(const u32* __restrict_
 }
 // same geometry; after the scan: reserve this workgroup's run inside every bucket it touches (one global atomic per
 // bucket), then place the entries with LDS atomics.
-static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
+static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
                                                         u64 idx_stride, const u32* __restrict__ off, u32* __restrict__ cursor,
                                                         u32* __restrict__ sorted) {
     ZK_PRIO_HIGH();
@@ -226,7 +231,7 @@ static __global__ void __launch_bounds__(512) k_msm_place(const u32* __restrict_
 // bits.  Pass 2 is a STABLE partition of that list by the high bits (K / kh <= 16 classes): inside a class the pairs keep
 // the order pass 1 gave them, i.e. they are ordered by the low bits, so the result is ordered by the whole bucket index.
 // Then off[b] = the first position whose bucket is >= b (binary search; the keys are read once more from L2).
-static __global__ void __launch_bounds__(512) k_msm_count_lo(const u32* __restrict__ wm, u64 n, int c, u64 chunk, u32 kh, u32* __restrict__ cnt) {
+static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count_lo(const u32* __restrict__ wm, u64 n, int c, u64 chunk, u32 kh, u32* __restrict__ cnt) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
@@ -244,7 +249,7 @@ static __global__ void __launch_bounds__(512) k_msm_count_lo(const u32* __restri
     for (u32 b = threadIdx.x; b < kh; b += blockDim.x)
         if (hist[b]) atomicAdd(&cnt[b], hist[b]);
 }
-static __global__ void __launch_bounds__(512) k_msm_place_lo(const u32* __restrict__ wm, u64 n, int c, u64 chunk, u32 kh, u64 idx_stride,
+static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place_lo(const u32* __restrict__ wm, u64 n, int c, u64 chunk, u32 kh, u64 idx_stride,
                                                            const u32* __restrict__ off, u32* __restrict__ cursor, u32* __restrict__ keys1,
                                                            u32* __restrict__ ent1) {
     ZK_PRIO_HIGH();
