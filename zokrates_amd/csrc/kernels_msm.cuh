@@ -113,10 +113,10 @@ __global__ void k_points_to_packed(const Aff<FS>* __restrict__ in, AffPacked<U>*
 }
 
 static constexpr u32 MSM_NO_DIGIT = 0xffffffffu;
-// work-items of a sort workgroup (one workgroup per CU: its histogram takes up to 128 KiB of LDS): the scattered 4-byte
-// stores of the place pass are latency-bound, so the more waves a CU holds the better
+// work-items of a sort workgroup (one workgroup per CU: its histogram takes up to 128 KiB of LDS); 1024 measured the same as
+// 512 (profiles/r3e_sort_workgroup_ab.txt)
 #ifndef ZK_SORT_THREADS
-#define ZK_SORT_THREADS 1024
+#define ZK_SORT_THREADS 512
 #endif
 static constexpr u32 MSM_HEAVY = 16;  // a bucket spread over more slices than this is reduced by a whole workgroup (a value repeated
                                       // across a witness — the constant in every first S-box of a Poseidon chain, the ones of a
