@@ -300,7 +300,7 @@ def main():
     # kernel on synthetic data (tools/accum_bench.hip); one mixed addition per non-zero signed digit, W digits per scalar
     W = (synth.FR_BITS[curve_id] + 1 + 15) // 16 if args.log_domain >= 15 else None
     compute = None
-    if W and args.curve == "bn128":
+    if W and args.curve == "bn128" and args.kind == "dense":   # (sparse / boolean witnesses drop their zero digits: no fixed addition count)
         madds = (((m + 2) if "G2" in name else (3 * (m + 2) + N)) * W)
         peak = 5.29e9 if "G2" in name else 13.75e9
         compute = {"unit": "mixed additions/s", "achieved": madds / (ms * 1e-3), "peak": peak, "frac": madds / (ms * 1e-3) / peak,
@@ -317,7 +317,7 @@ def main():
             compute["valu_issue_utilisation"] = ent["issue_utilisation"]
             compute["valu_cycles_per_instruction_per_simd"] = ent["cycles_per_valu_instruction_per_simd"]
             compute["clock_ghz_under_load"] = ent["clock_ghz"]
-            compute["valu_source"] = "offline rocprofv3 --pmc pass of this workload, profiles/pmc_valu.json"
+            compute["valu_source"] = "OFFLINE: rocprofv3 --pmc pass of this workload on this build, profiles/pmc_valu.json (not measured in this run)"
     roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": ("offline rocprofv3 --pmc passes of this workload, " + PMC_TRAFFIC_FILE) if traffic else None,
@@ -350,7 +350,9 @@ def main():
                 f"5 NTTs + 5 MSMs per proof") if gm17 else (
         (f"Poseidon hash chain depth {circ.depth} (t = 3, 243 constraints per hash), n = {circ.n} constraints (QAP domain 2^{args.log_domain}), "
          if args.kind == "poseidon" else
-         f"synthetic R1CS {args.kind}, n = {circ.n} constraints (QAP domain 2^{args.log_domain}), ")
+         f"synthetic R1CS {args.kind}, n = {circ.n} constraints (QAP domain 2^{args.log_domain})"
+         + (" [stand-in for BASELINE configs[0], stdlib sha256/512bitPacked.zok: the ZoKrates compiler cannot run here, so the wire "
+            "statistics of a SHA-256 circuit (90 % boolean) are generated directly], " if args.kind == "sha" else ", "))
         + f"{args.curve} Groth16, 7 NTTs + 5 MSMs per proof")
     out = {
         "metric": "gm17_proofs_per_sec" if gm17 else "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",

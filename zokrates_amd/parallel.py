@@ -39,7 +39,10 @@ class Ranks:
         if self._dist is None:
             return "single process, no process group"
         if self.backend == "nccl":
-            ver = ".".join(str(v) for v in self._torch.cuda.nccl.version()) if hasattr(self._torch.cuda, "nccl") else "?"
+            try:
+                ver = ".".join(str(v) for v in self._torch.cuda.nccl.version())
+            except Exception:      # (a torch build without the query: the rank count is what matters)
+                ver = "?"
             return f"torch.distributed nccl (= RCCL {ver}), {self._dist.get_world_size()} rank(s), one GPU each"
         return f"torch.distributed {self.backend}, {self._dist.get_world_size()} rank(s)"
 
