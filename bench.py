@@ -473,11 +473,17 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
         inputs = [int.from_bytes(z[32 * j:32 * j + 32].tobytes(), "little") for j in range(1, circ.l)]
         want = formats.proof_json(curve_id, raw, inputs, scheme=scheme)
 
-        def run(name, extra):
+        # the native executable of the compiled host layer (csrc/host: C++ over the C ABI), and the Python shim
+        native_exe = os.path.join(ROOT, _pkg, "zkhip-cli")
+        if os.environ.get("ZKHIP_LIBRARY", "").endswith("libzkhip_emu.so"):      # (tests: the emulator build of the same executable)
+            native_exe = os.path.join(ROOT, "tests", "_emu", "zkhip-cli-emu")
+
+        def run(name, extra, exe=None):
             if os.path.exists(paths["proof.json"]):
                 os.remove(paths["proof.json"])
-            cmd = [sys.executable, "-m", _pkg + ".cli", "generate-proof", "-i", paths["out"], "-w", paths["witness"], "-p", paths["proving.key"],
-                   "-j", paths["proof.json"], "-s", scheme, "--entropy", "bench", "--timings"] + extra
+            cmd = ([exe] if exe else [sys.executable, "-m", _pkg + ".cli"]) + [
+                "generate-proof", "-i", paths["out"], "-w", paths["witness"], "-p", paths["proving.key"],
+                "-j", paths["proof.json"], "-s", scheme, "--entropy", "bench", "--timings"] + extra
             t0 = time.perf_counter()
             p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
             wall = 1000.0 * (time.perf_counter() - t0)
@@ -491,6 +497,11 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
                 rec["proof_json_identical_to_resident_prover"] = open(paths["proof.json"]).read() == want
             res[name] = rec
 
+        if os.access(native_exe, os.X_OK):
+            paths["cache_native"] = os.path.join(d, "cache_native")
+            run("native_from_proving_key", [], native_exe)
+            run("native_first_run_with_key_cache", ["--key-cache", paths["cache_native"]], native_exe)
+            run("native_from_key_image", ["--key-cache", paths["cache_native"]], native_exe)
         run("from_proving_key", [])
         run("first_run_with_key_cache", ["--key-cache", paths["cache"]])
         run("from_key_image", ["--key-cache", paths["cache"]])

@@ -11,3 +11,5 @@ for f in curve_bn254 curve_bls381 bn254_g1 bn254_g2 bls381_g1 bls381_g2 zkhip_ap
 done
 wait
 g++ -shared -o "$HERE/libzkhip_emu.so" "$HERE"/obj/*.o
+# the compiled host side (csrc/host) against the emulator library: the same executable the product ships, for CPU tests
+g++ -O2 -std=c++17 -Wall -pthread "$SRC/host/backend.cpp" "$SRC/host/cli_main.cpp" -L"$HERE" -lzkhip_emu -Wl,-rpath,'$ORIGIN' -o "$HERE/zkhip-cli-emu"

@@ -47,7 +47,7 @@ def test_single_rank_contract(args, metric):
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000
     e = d["cli_end_to_end_ms"]                         # the reference-shaped flow: files -> proof.json, one process per proof
     assert "error" not in e, e
-    for run in ("from_proving_key", "from_key_image", "from_full_key_image"):
+    for run in ("native_from_proving_key", "native_from_key_image", "from_proving_key", "from_key_image", "from_full_key_image"):
         assert e[run]["proof_json_identical_to_resident_prover"] is True and e[run]["process_wall_ms"] > 0, (run, e[run])
     assert e["from_proving_key"]["key_source"] == "proving.key" and e["from_key_image"]["key_source"] == "image"
 

@@ -59,7 +59,25 @@ def build_lib(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_cli(force, verbose)
     return LIB
+
+
+CLI = os.path.join(HERE, "zkhip-cli")
+
+
+def build_cli(force=False, verbose=False):
+    """The compiled host side (include/zkhip_backend.hpp, csrc/host/backend.cpp) and its `generate-proof` executable: plain C++17
+    over the C ABI, linked against the in-tree libzkhip.so (found next to the executable through $ORIGIN)."""
+    srcs = [os.path.join(CSRC, "host", f) for f in ("backend.cpp", "cli_main.cpp")]
+    deps = srcs + [os.path.join(HERE, "..", "include", h) for h in ("zkhip.h", "zkhip_backend.hpp")] + [LIB]
+    if not force and not _newer(CLI, deps):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread"] + srcs + ["-L" + HERE, "-lzkhip", "-Wl,-rpath,$ORIGIN", "-Wl,--allow-shlib-undefined", "-o", CLI]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":

@@ -1,0 +1,178 @@
+// zkhip-cli — `zokrates generate-proof` for the hip backend, as a native executable over zkhip_backend.hpp.
+//
+//   zkhip-cli generate-proof -i out -w witness -p proving.key -j proof.json [-s g16|gm17] [--entropy TEXT]
+//                            [--key-cache DIR] [--device N] [--timings]
+//
+// Mirrors /root/reference/zokrates_cli/src/ops/generate_proof.rs:95-202: the compiled program (`out`), the witness and the
+// proving key are read from files, the proof is written as JSON, one proof per process; `--entropy` seeds the RNG as
+// `get_rng_from_entropy` does, otherwise the OS does (`StdRng::from_entropy`).  Failures print the message and exit 1 (the
+// reference's panic hook and `exit(1)`: zokrates_cli/src/bin.rs:18-25,90-105).
+// The three inputs are independent until the proof starts: the program is read and decoded on host threads (zkhip_prog_parse
+// cuts the constraint section into parallel chunks) WHILE the key is uploaded and its window multiples are built on the GPU.
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <thread>
+
+#include "../../../include/zkhip_backend.hpp"
+
+using namespace zokrates_hip;
+
+namespace {
+std::vector<uint8_t> read_file(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw Error(ZKHIP_ERR_BAD_ARG, "cannot open " + path);
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0) { fclose(f); throw Error(ZKHIP_ERR_BAD_ARG, "cannot stat " + path); }
+    std::vector<uint8_t> buf((size_t)st.st_size);
+    const size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    if (got != buf.size()) throw Error(ZKHIP_ERR_BAD_ARG, "short read on " + path);
+    return buf;
+}
+double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+int usage() {
+    fprintf(stderr, "usage: zkhip-cli generate-proof -i <out> -w <witness> -p <proving.key> -j <proof.json> [-s g16|gm17] [--entropy TEXT] "
+                    "[--key-cache DIR] [--device N] [--timings]\n");
+    return 2;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2 || strcmp(argv[1], "generate-proof") != 0) return usage();
+    std::string input = "out", witness_path = "witness", pk_path = "proving.key", proof_path = "proof.json", scheme_s = "g16", entropy, cache_dir;
+    bool have_entropy = false, timings = false;
+    int device = 0;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
+        if (a == "-i" || a == "--input") input = val();
+        else if (a == "-w" || a == "--witness") witness_path = val();
+        else if (a == "-p" || a == "--proving-key-path") pk_path = val();
+        else if (a == "-j" || a == "--proof-path") proof_path = val();
+        else if (a == "-s" || a == "--proving-scheme") scheme_s = val();
+        else if (a == "--entropy") { entropy = val(); have_entropy = true; }
+        else if (a == "--key-cache") cache_dir = val();
+        else if (a == "--device") device = atoi(val().c_str());
+        else if (a == "--timings") timings = true;
+        else return usage();
+    }
+    if (scheme_s != "g16" && scheme_s != "gm17") return usage();
+    const Scheme scheme = scheme_s == "gm17" ? Scheme::GM17 : Scheme::G16;
+    const auto t_start = std::chrono::steady_clock::now();
+    try {
+        // host side, beside the key upload: read + decode the program, read the witness
+        std::unique_ptr<Program> program;
+        std::vector<uint8_t> witness;
+        std::string host_error;
+        int32_t host_code = 0;
+        double ms_read = 0, ms_parse = 0;
+        std::thread host([&] {
+            try {
+                auto t0 = std::chrono::steady_clock::now();
+                const std::vector<uint8_t> prog_bytes = read_file(input);
+                witness = read_file(witness_path);
+                ms_read = ms_since(t0);
+                t0 = std::chrono::steady_clock::now();
+                program.reset(new Program(prog_bytes.data(), prog_bytes.size()));
+                ms_parse = ms_since(t0);
+            } catch (const Error& e) {
+                host_error = e.what();
+                host_code = e.code;
+            } catch (const std::exception& e) {
+                host_error = e.what();
+                host_code = ZKHIP_ERR_NOMEM;
+            }
+        });
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{host};
+        // the curve of the key: bytes 8..12 of the program file (Field::id)
+        int32_t curve = -1;
+        {
+            FILE* f = fopen(input.c_str(), "rb");
+            uint8_t head[12] = {0};
+            if (!f || fread(head, 1, 12, f) != 12) { if (f) fclose(f); throw Error(ZKHIP_ERR_PARSE, "Invalid header"); }
+            fclose(f);
+            static const uint8_t BN[4] = {0xb4, 0xf7, 0xb5, 0xbd}, BLS[4] = {0x40, 0xd8, 0xc1, 0xf9};
+            curve = !memcmp(head + 8, BN, 4) ? ZKHIP_CURVE_BN128 : !memcmp(head + 8, BLS, 4) ? ZKHIP_CURVE_BLS12_381 : -1;
+            if (memcmp(head, "ZOK\0", 4) != 0 || curve < 0) throw Error(ZKHIP_ERR_PARSE, "not a ZoKrates program for bn128 / bls12_381");
+        }
+        auto t0 = std::chrono::steady_clock::now();
+        Hip hip(device);
+        const double ms_init = ms_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        Key key;
+        std::string key_source = "proving.key", image_path;
+        if (!cache_dir.empty()) {
+            struct stat st;
+            if (stat(pk_path.c_str(), &st) != 0) throw Error(ZKHIP_ERR_BAD_ARG, "cannot stat " + pk_path);
+            char tag[64];
+            snprintf(tag, sizeof(tag), "%016llx", (unsigned long long)fnv1a(pk_path + "|" + std::to_string((long long)st.st_size) + "|" +
+                                                                           std::to_string((long long)st.st_mtime) + "|" + scheme_s + "|" + std::to_string(curve)));
+            image_path = cache_dir + "/" + tag + ".zkhippk";
+            struct stat ist;
+            if (stat(image_path.c_str(), &ist) == 0) {
+                try {
+                    const std::vector<uint8_t> img = read_file(image_path);
+                    key = hip.import_key_image(img.data(), img.size());
+                    key_source = "image";
+                } catch (const Error&) {
+                    // a stale image of another library build: fall through and rewrite it
+                }
+            }
+        }
+        if (!key) {
+            const std::vector<uint8_t> pk = read_file(pk_path);
+            key = hip.load_proving_key(scheme, curve, pk.data(), pk.size());
+            if (!image_path.empty()) {
+                mkdir(cache_dir.c_str(), 0777);
+                const std::vector<uint8_t> img = hip.export_key_image(key);
+                const std::string tmp = image_path + ".tmp" + std::to_string((long long)getpid());
+                std::ofstream o(tmp, std::ios::binary);
+                o.write((const char*)img.data(), (std::streamsize)img.size());
+                o.close();
+                rename(tmp.c_str(), image_path.c_str());
+            }
+        }
+        const double ms_key = ms_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        host.join();
+        const double ms_wait = ms_since(t0);
+        if (!program) throw Error(host_code ? host_code : ZKHIP_ERR_PARSE, host_error);
+        StdRng rng = have_entropy ? get_rng_from_entropy(entropy) : StdRng::from_os_entropy();
+        Timings tm;
+        const Proof proof = hip.prove(scheme, *program, witness.data(), witness.size(), key, rng, &tm);
+        t0 = std::chrono::steady_clock::now();
+        {
+            std::ofstream o(proof_path);
+            if (!o) throw Error(ZKHIP_ERR_BAD_ARG, "cannot write " + proof_path);
+            o << proof.to_json();
+        }
+        const double ms_json = ms_since(t0);
+        printf("generate-proof (%s): wrote %s\n", scheme_s.c_str(), proof_path.c_str());
+        if (timings)
+            printf("timings {\"read_program_and_witness_ms\": %.3f, \"parse_program_ms\": %.3f, \"hip_init_ms\": %.3f, \"key_load_ms\": %.3f, "
+                   "\"wait_for_host_side_ms\": %.3f, \"witness_to_assignment_ms\": %.3f, \"r1cs_upload_ms\": %.3f, \"prove_ms\": %.3f, "
+                   "\"proof_json_ms\": %.3f, \"total_in_process_ms\": %.3f, \"key_source\": \"%s\", \"constraints\": %llu}\n",
+                   ms_read, ms_parse, ms_init, ms_key, ms_wait, tm.witness_to_assignment, tm.r1cs_upload, tm.prove, ms_json, ms_since(t_start),
+                   key_source.c_str(), (unsigned long long)program->constraints());
+        return 0;
+    } catch (const Error& e) {
+        fprintf(stderr, "zkhip-cli: %s\n", e.what());
+        return 1;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "zkhip-cli: %s\n", e.what());
+        return 1;
+    }
+}
