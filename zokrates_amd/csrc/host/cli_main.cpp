@@ -9,6 +9,8 @@
 // reference's panic hook and `exit(1)`: zokrates_cli/src/bin.rs:18-25,90-105).
 // The three inputs are independent until the proof starts: the program is read and decoded on host threads (zkhip_prog_parse
 // cuts the constraint section into parallel chunks) WHILE the key is uploaded and its window multiples are built on the GPU.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -24,17 +26,30 @@
 using namespace zokrates_hip;
 
 namespace {
-std::vector<uint8_t> read_file(const std::string& path) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) throw Error(ZKHIP_ERR_BAD_ARG, "cannot open " + path);
-    struct stat st;
-    if (fstat(fileno(f), &st) != 0) { fclose(f); throw Error(ZKHIP_ERR_BAD_ARG, "cannot stat " + path); }
-    std::vector<uint8_t> buf((size_t)st.st_size);
-    const size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
-    fclose(f);
-    if (got != buf.size()) throw Error(ZKHIP_ERR_BAD_ARG, "short read on " + path);
-    return buf;
-}
+// a file mapped read-only (the page cache is the buffer: nothing is copied, nothing is zero-filled first)
+struct Mapped {
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    Mapped() = default;
+    explicit Mapped(const std::string& path) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw Error(ZKHIP_ERR_BAD_ARG, "cannot open " + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); throw Error(ZKHIP_ERR_BAD_ARG, "cannot stat " + path); }
+        size = (size_t)st.st_size;
+        if (size) {
+            void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (p == MAP_FAILED) { close(fd); throw Error(ZKHIP_ERR_NOMEM, "cannot map " + path); }
+            data = (const uint8_t*)p;
+        }
+        close(fd);
+    }
+    Mapped(Mapped&& o) noexcept : data(o.data), size(o.size) { o.data = nullptr; o.size = 0; }
+    Mapped& operator=(Mapped&& o) noexcept { std::swap(data, o.data); std::swap(size, o.size); return *this; }
+    Mapped(const Mapped&) = delete;
+    Mapped& operator=(const Mapped&) = delete;
+    ~Mapped() { if (data) munmap((void*)data, size); }
+};
 double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -75,18 +90,18 @@ int main(int argc, char** argv) {
     try {
         // host side, beside the key upload: read + decode the program, read the witness
         std::unique_ptr<Program> program;
-        std::vector<uint8_t> witness;
+        Mapped witness;
         std::string host_error;
         int32_t host_code = 0;
         double ms_read = 0, ms_parse = 0;
         std::thread host([&] {
             try {
                 auto t0 = std::chrono::steady_clock::now();
-                const std::vector<uint8_t> prog_bytes = read_file(input);
-                witness = read_file(witness_path);
+                const Mapped prog_bytes(input);
+                witness = Mapped(witness_path);
                 ms_read = ms_since(t0);
                 t0 = std::chrono::steady_clock::now();
-                program.reset(new Program(prog_bytes.data(), prog_bytes.size()));
+                program.reset(new Program(prog_bytes.data, prog_bytes.size));
                 ms_parse = ms_since(t0);
             } catch (const Error& e) {
                 host_error = e.what();
@@ -96,7 +111,8 @@ int main(int argc, char** argv) {
                 host_code = ZKHIP_ERR_NOMEM;
             }
         });
-        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{host};
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } };
+        Joiner joiner{host};
         // the curve of the key: bytes 8..12 of the program file (Field::id)
         int32_t curve = -1;
         {
@@ -108,12 +124,10 @@ int main(int argc, char** argv) {
             curve = !memcmp(head + 8, BN, 4) ? ZKHIP_CURVE_BN128 : !memcmp(head + 8, BLS, 4) ? ZKHIP_CURVE_BLS12_381 : -1;
             if (memcmp(head, "ZOK\0", 4) != 0 || curve < 0) throw Error(ZKHIP_ERR_PARSE, "not a ZoKrates program for bn128 / bls12_381");
         }
-        auto t0 = std::chrono::steady_clock::now();
-        Hip hip(device);
-        const double ms_init = ms_since(t0);
-        t0 = std::chrono::steady_clock::now();
-        Key key;
+        // which bytes hold the key (the image of an earlier run, if --key-cache has one): mapped on a second thread while the
+        // HIP runtime starts
         std::string key_source = "proving.key", image_path;
+        bool try_image = false;
         if (!cache_dir.empty()) {
             struct stat st;
             if (stat(pk_path.c_str(), &st) != 0) throw Error(ZKHIP_ERR_BAD_ARG, "cannot stat " + pk_path);
@@ -122,19 +136,35 @@ int main(int argc, char** argv) {
                                                                            std::to_string((long long)st.st_mtime) + "|" + scheme_s + "|" + std::to_string(curve)));
             image_path = cache_dir + "/" + tag + ".zkhippk";
             struct stat ist;
-            if (stat(image_path.c_str(), &ist) == 0) {
-                try {
-                    const std::vector<uint8_t> img = read_file(image_path);
-                    key = hip.import_key_image(img.data(), img.size());
-                    key_source = "image";
-                } catch (const Error&) {
-                    // a stale image of another library build: fall through and rewrite it
-                }
+            try_image = stat(image_path.c_str(), &ist) == 0;
+        }
+        Mapped key_bytes;
+        std::string key_error;
+        std::thread key_reader([&] {
+            try {
+                key_bytes = Mapped(try_image ? image_path : pk_path);
+            } catch (const std::exception& e) {
+                key_error = e.what();
+            }
+        });
+        Joiner key_joiner{key_reader};
+        auto t0 = std::chrono::steady_clock::now();
+        Hip hip(device);
+        const double ms_init = ms_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        key_reader.join();
+        if (!key_error.empty()) throw Error(ZKHIP_ERR_BAD_ARG, key_error);
+        Key key;
+        if (try_image) {
+            try {
+                key = hip.import_key_image(key_bytes.data, key_bytes.size);
+                key_source = "image";
+            } catch (const Error&) {
+                key_bytes = Mapped(pk_path);                  // a stale image of another library build: rewrite it below
             }
         }
         if (!key) {
-            const std::vector<uint8_t> pk = read_file(pk_path);
-            key = hip.load_proving_key(scheme, curve, pk.data(), pk.size());
+            key = hip.load_proving_key(scheme, curve, key_bytes.data, key_bytes.size);
             if (!image_path.empty()) {
                 mkdir(cache_dir.c_str(), 0777);
                 const std::vector<uint8_t> img = hip.export_key_image(key);
@@ -152,7 +182,7 @@ int main(int argc, char** argv) {
         if (!program) throw Error(host_code ? host_code : ZKHIP_ERR_PARSE, host_error);
         StdRng rng = have_entropy ? get_rng_from_entropy(entropy) : StdRng::from_os_entropy();
         Timings tm;
-        const Proof proof = hip.prove(scheme, *program, witness.data(), witness.size(), key, rng, &tm);
+        const Proof proof = hip.prove(scheme, *program, witness.data, witness.size, key, rng, &tm);
         t0 = std::chrono::steady_clock::now();
         {
             std::ofstream o(proof_path);
@@ -167,7 +197,9 @@ int main(int argc, char** argv) {
                    "\"proof_json_ms\": %.3f, \"total_in_process_ms\": %.3f, \"key_source\": \"%s\", \"constraints\": %llu}\n",
                    ms_read, ms_parse, ms_init, ms_key, ms_wait, tm.witness_to_assignment, tm.r1cs_upload, tm.prove, ms_json, ms_since(t_start),
                    key_source.c_str(), (unsigned long long)program->constraints());
-        return 0;
+        // one proof per process: the proof is on disk, so leave without tearing down 6 GiB of tables and the HIP runtime
+        fflush(stdout);
+        _exit(0);
     } catch (const Error& e) {
         fprintf(stderr, "zkhip-cli: %s\n", e.what());
         return 1;
