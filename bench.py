@@ -478,14 +478,19 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
         if os.environ.get("ZKHIP_LIBRARY", "").endswith("libzkhip_emu.so"):      # (tests: the emulator build of the same executable)
             native_exe = os.path.join(ROOT, "tests", "_emu", "zkhip-cli-emu")
 
+        t_leg = time.perf_counter()
+
         def run(name, extra, exe=None):
+            if time.perf_counter() - t_leg > 150:          # the leg must never hold the throughput line back for long
+                res[name] = {"skipped": "time budget of this leg (150 s) spent"}
+                return
             if os.path.exists(paths["proof.json"]):
                 os.remove(paths["proof.json"])
             cmd = ([exe] if exe else [sys.executable, "-m", _pkg + ".cli"]) + [
                 "generate-proof", "-i", paths["out"], "-w", paths["witness"], "-p", paths["proving.key"],
                 "-j", paths["proof.json"], "-s", scheme, "--entropy", "bench", "--timings"] + extra
             t0 = time.perf_counter()
-            p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
+            p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=120)
             wall = 1000.0 * (time.perf_counter() - t0)
             rec = {"process_wall_ms": wall}
             if p.returncode != 0:
