@@ -119,6 +119,7 @@ struct ProofSlot {
     Event ev[4] = {nullptr, nullptr, nullptr, nullptr};   // staged, MSMs over z issued, h ready, all done (copied out)
     Event acc_b[ZK_NLANES] = {}, acc_e[ZK_NLANES] = {};   // around each accumulation kernel
     Event ntt_b = nullptr, ntt_e = nullptr;               // around the transforms (7 for Groth16: 6 batched launches + 2; 5 for GM17)
+    bool ready = false;        // streams and events exist (slot_init)
     // the proof currently in flight in this slot
     bool busy = false;
     uint8_t r[32], s[32];
@@ -132,7 +133,7 @@ struct zkhip_ctx {
                               // the next proof's staging and z-sort (what its four big MSMs wait for) do not queue behind it
     Stream ws = 0;            // the stream the mat-vec / NTT helpers launch on right now (ntt_stream inside a proof, else `stream`)
     bool serial = false;      // ZKHIP_SERIAL=1: every MSM on the main stream (debugging / per-kernel timing)
-    bool shared_lane_streams = false;   // lane k of every slot on one stream (the round-1 schedule; measurement hook)
+    bool g2_first = true;     // the G2 lane's stream at high priority (see slot_init)
     int cus = 256;            // compute units of the device: sizes the accumulation launch (one slice per resident work-item)
     // tunables (zkhip_ctx_tune; the environment variables ZKHIP_SERIAL, ZKHIP_MSM_C, ZKHIP_MSM_WAVES and
     // ZKHIP_NTT_SINGLE_MAX_LOG give their initial values, read ONCE when the context is created)
@@ -161,6 +162,23 @@ struct zkhip_ctx {
     // process would leave the second GPU of a process at the 64 KiB default)
     std::unordered_set<const void*> lds_opted;
 };
+// streams and events of one proof slot, made the first time the slot is used
+static inline void slot_init(zkhip_ctx* ctx, ProofSlot& sl) {
+    if (sl.ready) return;
+    for (auto& so : sl.sorts) so.ready = event_create();
+    for (int k = 0; k < ZK_NLANES; ++k) {
+        // lane 3 is the G2 MSM: the longest accumulation AND the longest fold tail of a proof; at high priority its
+        // workgroups are dispatched first, it finishes early and its tail hides under the G1 accumulations
+        sl.lanes[k].stream = (k == 3 && ctx->g2_first) ? stream_create_high_priority() : stream_create();
+        sl.lanes[k].done = event_create();
+        sl.acc_b[k] = event_create();
+        sl.acc_e[k] = event_create();
+    }
+    for (auto& e : sl.ev) e = event_create();
+    sl.ntt_b = event_create();
+    sl.ntt_e = event_create();
+    sl.ready = true;
+}
 // gfx950 has 160 KiB of LDS per CU; anything above the 64 KiB default must be opted into, per kernel and per device
 // the z-lane gate of the proof being enqueued (see Prover::enqueue)
 static inline int z_gate(const zkhip_ctx* ctx) { return ctx->serial ? 0 : ctx->z_gate; }
@@ -854,6 +872,7 @@ struct Prover {
         require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
                 "proving key does not match the constraint system (m, w or domain size)");
         require(!sl.busy, ZKHIP_ERR_DEVICE, "internal: proof slot still in flight");
+        slot_init(ctx, sl);
         const u64 m = pk->m, N = pk->N;
         Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");

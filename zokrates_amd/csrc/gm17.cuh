@@ -196,6 +196,7 @@ struct Gm17 {
                         const uint8_t* d1, const uint8_t* r) {
         check_match(pk, cs);
         require(!sl.busy, ZKHIP_ERR_DEVICE, "internal: proof slot still in flight");
+        slot_init(ctx, sl);
         const u64 m = cs->l + cs->w, n = cs->n, l = cs->l, M = pk->m, D = pk->N;
         Fr dd = fe_from_bytes_canon<Fr>(d1), rr = fe_from_bytes_canon<Fr>(r);
         require(canon_lt_mod(dd) && canon_lt_mod(rr), ZKHIP_ERR_BAD_ARG, "d1 or r not a canonical field element");

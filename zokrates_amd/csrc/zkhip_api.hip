@@ -98,27 +98,11 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->sort_wgs = (u32)env_int("ZKHIP_SORT_WGS", 16, 4096, 256);
         // every (slot, lane) has a stream of its own: with one stream per lane shared by the slots, the accumulation of
         // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
-        // fold workgroup holding the machine 16 % of the time); ZKHIP_SHARED_LANE_STREAMS=1 restores that schedule
-        const bool shared_lanes = env_int("ZKHIP_SHARED_LANE_STREAMS", 0, 1, 0) != 0;
-        const bool g2_first = env_int("ZKHIP_G2_PRIORITY", 0, 1, 1) != 0;
-        Stream lane_streams[ZK_NLANES];
-        if (shared_lanes)
-            for (auto& st : lane_streams) st = stream_create();
-        ctx->shared_lane_streams = shared_lanes;
-        for (auto& sl : ctx->slots) {
-            for (auto& so : sl.sorts) so.ready = event_create();
-            for (int k = 0; k < ZK_NLANES; ++k) {
-                // lane 3 is the G2 MSM: the longest accumulation AND the longest fold tail of a proof; at high priority its
-                // workgroups are dispatched first, it finishes early and its tail hides under the G1 accumulations
-                sl.lanes[k].stream = shared_lanes ? lane_streams[k] : (k == 3 && g2_first ? stream_create_high_priority() : stream_create());
-                sl.lanes[k].done = event_create();
-                sl.acc_b[k] = event_create();
-                sl.acc_e[k] = event_create();
-            }
-            for (auto& e : sl.ev) e = event_create();
-            sl.ntt_b = event_create();
-            sl.ntt_e = event_create();
-        }
+        // fold workgroup holding the machine 16 % of the time).  Slot 0 — the one single proofs and the primitives use — is
+        // made now, the others when a batch call first needs them (slot_init: 20 ms of stream and event creation each, which a
+        // one-proof process never spends).
+        ctx->g2_first = env_int("ZKHIP_G2_PRIORITY", 0, 1, 1) != 0;
+        slot_init(ctx.get(), ctx->slots[0]);
 #ifdef ZK_EMU
         ctx->desc = "zkhip TEST EMULATOR (not a product build)";
 #else
@@ -142,19 +126,19 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
     dev_sync_all();
     staging_drain();          // (the device's staging ring may still track transfers recorded on this context's streams)
     for (auto& sl : ctx->slots) {
+        if (!sl.ready) continue;
         for (auto& so : sl.sorts) event_destroy(so.ready);
         for (int k = 0; k < ZK_NLANES; ++k) {
             event_destroy(sl.lanes[k].done);
             event_destroy(sl.acc_b[k]);
             event_destroy(sl.acc_e[k]);
+            stream_destroy(sl.lanes[k].stream);
         }
         for (auto& e : sl.ev) event_destroy(e);
         event_destroy(sl.ntt_b);
         event_destroy(sl.ntt_e);
         host_free_pinned(sl.h_ws);
     }
-    for (int q = 0; q < (ctx->shared_lane_streams ? 1 : ZK_NSLOTS); ++q)
-        for (int k = 0; k < ZK_NLANES; ++k) stream_destroy(ctx->slots[q].lanes[k].stream);
     stream_destroy(ctx->out_stream);
     stream_destroy(ctx->ntt_stream);
     stream_destroy(ctx->stream);
