@@ -451,6 +451,31 @@ template <class P> ZK_HD_CALL Fu2<P> fu2_sqr_call(const Fu2<P> a) { return fu2_s
 template <class P> ZK_HD Fu2<P> ec_mul(const Fu2<P>& a, const Fu2<P>& b) { return UCfg<P>::FQ2_INLINE ? fu2_mul_inl(a, b) : fu2_mul_call(a, b); }
 template <class P> ZK_HD Fu2<P> ec_sqr(const Fu2<P>& a) { return UCfg<P>::FQ2_INLINE ? fu2_sqr_inl(a) : fu2_sqr_call(a); }
 
+// ---- inversion (Fermat) on the unsaturated form: x^(p-2), one squaring per exponent bit and a product per set bit ----
+// For the kernels that invert once per work-item (the window-multiple tables at key load): 254 + ~127 Comba products
+// instead of the same count of saturated CIOS products behind an out-of-line call (field.cuh's fe_inv: half the rate and a
+// scratch frame).  x: TIGHT, value < 8p, non-zero mod p; the result is TIGHT, < 2p.
+template <class P>
+ZK_HD Fu<P> fu_inv(const Fu<P>& x) {
+    Fu<P> r = Fu<P>::one();
+    u32 borrow = 2;                                  // the exponent p - 2, word by word
+    u32 e[P::N];
+    ZK_UNROLL for (int i = 0; i < P::N; ++i) {
+        const u64 t = (u64)P::mod(i) - borrow;
+        e[i] = (u32)t;
+        borrow = (u32)(t >> 63);
+    }
+    for (int w = P::N - 1; w >= 0; --w) {
+        const u32 word = e[w];
+        for (int b = 31; b >= 0; --b) {
+            r = fu_sqr_inl(r);
+            if ((word >> b) & 1) r = fu_mul_inl(r, x);
+        }
+    }
+    return r;
+}
+template <class P> ZK_HD Fu<P> ec_inv(const Fu<P>& x) { return fu_inv(x); }
+
 // ---- conversions at the MSM boundary ----
 // saturated Montgomery (x * 2^(32W) mod p, canonical) -> unsaturated Montgomery (x * R'), TIGHT, value < 2p
 template <class P>
@@ -537,6 +562,12 @@ template <class P> struct FuUnpack<Fu2<P>> { ZK_HD static Fu2<P> get(const u32* 
 
 template <class P> ZK_HD Fu2<P> fu_from_fe(const Fe2<P>& a) { return {fu_from_fe(a.c0), fu_from_fe(a.c1)}; }
 template <class P> ZK_HD Fe2<P> fu_to_fe(const Fu2<P>& a) { return {fu_to_fe(a.c0), fu_to_fe(a.c1)}; }
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)
+template <class P>
+ZK_HD Fu2<P> ec_inv(const Fu2<P>& a) {
+    const Fu<P> n = fu_inv(fe_add(fu_sqr_inl(a.c0), fu_sqr_inl(a.c1)));
+    return {fu_mul_inl(a.c0, n), fu_mul_inl(fe_sub_k<8>(Fu<P>::zero(), a.c1), n)};
+}
 
 // type map: saturated field of a group -> its unsaturated working type
 template <class F> struct Unsat;

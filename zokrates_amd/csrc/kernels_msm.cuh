@@ -743,14 +743,14 @@ __global__ void __launch_bounds__(256) k_msm_table_levels(AffPacked<F>* __restri
     Xyzz<F> P = Xyzz<F>::from_affine(aff_unpack<F>(w));
     F acc = F::one();
     for (int j = 1; j < W; ++j) {
-        for (int b = 0; b < c; ++b) P = xyzz_dbl(P);
+        for (int b = 0; b < c; ++b) P = xyzz_dbl_inl(P);
         tmp[(u64)(j - 1) * cnt + i] = P;
         if (!P.is_inf()) {
             pre[(u64)(j - 1) * cnt + i] = acc;
             acc = ec_mul(acc, P.zzz);
         }
     }
-    F inv = fu_from_fe(fe_inv(fu_to_fe(acc)));   // acc is a product of non-zero ZZZ values
+    F inv = ec_inv(acc);                         // acc is a product of non-zero ZZZ values
     for (int j = W - 1; j >= 1; --j) {
         const Xyzz<F> Q = tmp[(u64)(j - 1) * cnt + i];
         Aff<F> a = Aff<F>::inf();
