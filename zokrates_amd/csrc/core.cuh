@@ -730,30 +730,30 @@ struct PkLoader {
         std::vector<uint8_t> host;
         // A_ext = [a_query..., delta_1, inf]          (+ alpha_1 folded into entry 0)
         host.assign(me * G1B, 0);
-        for (u64 i = 0; i < m; ++i) decode_point<FQB, 2>(a_q + i * G1B, &host[i * G1B]);
+        host_parallel_for(m, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) decode_point<FQB, 2>(a_q + i * G1B, &host[i * G1B]); });
         decode_point<FQB, 2>(delta_g1, &host[m * G1B]);
         upload_points(ctx, pk->a_ext, host, me * 2);
         stream_sync(ctx->stream);
         // B1_ext = [b_g1_query..., inf, delta_1]      (+ beta_1 folded into entry 0)
         host.assign(me * G1B, 0);
-        for (u64 i = 0; i < m; ++i) decode_point<FQB, 2>(b1_q + i * G1B, &host[i * G1B]);
+        host_parallel_for(m, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) decode_point<FQB, 2>(b1_q + i * G1B, &host[i * G1B]); });
         decode_point<FQB, 2>(delta_g1, &host[(m + 1) * G1B]);
         upload_points(ctx, pk->b1_ext, host, me * 2);
         stream_sync(ctx->stream);
         // L_ext = [inf x l, l_query..., inf, inf]
         host.assign(me * G1B, 0);
-        for (u64 j = 0; j < w; ++j) decode_point<FQB, 2>(l_q + j * G1B, &host[(l + j) * G1B]);
+        host_parallel_for(w, [&](u64 lo, u64 hi) { for (u64 j = lo; j < hi; ++j) decode_point<FQB, 2>(l_q + j * G1B, &host[(l + j) * G1B]); });
         upload_points(ctx, pk->l_ext, host, me * 2);
         stream_sync(ctx->stream);
         // B2_ext = [b_g2_query..., inf, delta_2]      (+ beta_2 folded into entry 0)
         host.assign(me * G2B, 0);
-        for (u64 i = 0; i < m; ++i) decode_point<FQB, 4>(b2_q + i * G2B, &host[i * G2B]);
+        host_parallel_for(m, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) decode_point<FQB, 4>(b2_q + i * G2B, &host[i * G2B]); });
         decode_point<FQB, 4>(delta_g2, &host[(m + 1) * G2B]);
         upload_points(ctx, pk->b2_ext, host, me * 4);
         stream_sync(ctx->stream);
         // h_query, permuted into the sigma order the NTT pipeline leaves h in, padded with infinity
         host.assign(hl * G1B, 0);
-        for (u64 i = 0; i < hl; ++i) decode_point<FQB, 2>(h_q + i * G1B, &host[i * G1B]);
+        host_parallel_for(hl, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) decode_point<FQB, 2>(h_q + i * G1B, &host[i * G1B]); });
         ctx->tmp.ensure(std::max<size_t>(host.size(), 16));
         dev_h2d(ctx->tmp.p, host.data(), host.size(), ctx->stream);
         ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(hl * 2, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(ctx->tmp), ptr<Fq>(ctx->tmp), hl * 2);

@@ -59,6 +59,18 @@ struct HostThreads {
 };
 
 
+// [0, n) cut into a few contiguous ranges, one host thread each (memory-bound host loops: key decoding)
+template <class Fn>
+inline void host_parallel_for(uint64_t n, Fn&& fn, unsigned max_threads = 8) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1, max_threads), n / 65536));
+    if (T <= 1) { fn((uint64_t)0, n); return; }
+    HostThreads th;
+    for (unsigned t = 1; t < T; ++t) th.run([&fn, n, t, T] { fn(n * t / T, n * (t + 1) / T); });
+    fn((uint64_t)0, n / T);
+    th.join();
+}
+
 #ifndef ZK_EMU
 #define ZK_HIP_CHECK(expr)                                                                        \
     do {                                                                                          \
