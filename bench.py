@@ -328,9 +328,10 @@ def main():
                 "note": "bucket accumulation is bound by integer-multiply issue (Montgomery products), not by HBM; `frac` uses HIP-event "
                         "intervals on the MSM streams inside the timed region (five MSMs and two proofs overlap), `frac_serial` the same "
                         "kernels alone on one stream after it"}
-    # the NTT passes: 2 * N * 32 B per pass and vector; Groth16 runs 14 pass-vectors per proof (7 transforms
+    # the NTT passes: 2 * N * 32 B per pass and vector; Groth16 runs 12 pass-vectors per proof (6 transforms: c
+    # needs only its coefficients; the reference runs 7), GM17 8 (4 transforms; the reference 5) — (formerly: 7 transforms
     # x 2 passes; a, b, c share launches), GM17 10 over its domain; the interval also holds the pointwise quotient kernel
-    passes = 10 if gm17 else 14
+    passes = 8 if gm17 else 12
     if N <= 1 << 10:
         passes //= 2
     ntt_bytes = passes * 2 * N * 32
@@ -347,13 +348,13 @@ def main():
         roofline_ntt["us_per_pass_serial"] = 1000.0 * serial["kernel_ntt_ms"] / passes
     b_alg = gm17_algorithmic_bytes(circ, fq, m, N) if gm17 else proof_algorithmic_bytes(circ, fq)
     workload = (f"synthetic R1CS {args.kind}, n = 2^{args.log_domain} - 2 constraints, {args.curve} GM17 (SAP: {m} variables, domain {N}), "
-                f"5 NTTs + 5 MSMs per proof") if gm17 else (
+                f"4 NTTs + 5 MSMs per proof") if gm17 else (
         (f"Poseidon hash chain depth {circ.depth} (t = 3, 243 constraints per hash), n = {circ.n} constraints (QAP domain 2^{args.log_domain}), "
          if args.kind == "poseidon" else
          f"synthetic R1CS {args.kind}, n = {circ.n} constraints (QAP domain 2^{args.log_domain})"
          + (" [stand-in for BASELINE configs[0], stdlib sha256/512bitPacked.zok: the ZoKrates compiler cannot run here, so the wire "
             "statistics of a SHA-256 circuit (90 % boolean) are generated directly], " if args.kind == "sha" else ", "))
-        + f"{args.curve} Groth16, 7 NTTs + 5 MSMs per proof")
+        + f"{args.curve} Groth16, 6 NTTs + 5 MSMs per proof")
     out = {
         "metric": "gm17_proofs_per_sec" if gm17 else "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
@@ -615,7 +616,7 @@ def proof_algorithmic_bytes(circ, fq):
     F, n, m, N, w, l = 32, circ.n, circ.m, circ.N, circ.w, circ.l
     nnz = sum(int(mat[0][-1]) for mat in circ.mats())
     matvec = nnz * (F + 4) + 3 * (n + 1) * 8 + m * F + 3 * N * F
-    transforms = 7 * 2 * N * F
+    transforms = 6 * 2 * N * F          # (the reference's witness_map runs 7; this one needs 6)
     bases = (N - 1) * 2 * fq + w * 2 * fq + 2 * m * 2 * fq + m * 4 * fq
     scalars = N * F + w * F + 3 * m * F
     return matvec + transforms + bases + scalars
@@ -627,7 +628,7 @@ def gm17_algorithmic_bytes(circ, fq, M, D):
     F, n, m = 32, circ.n, circ.m
     nnz = sum(int(mat[0][-1]) for mat in circ.mats())
     rows = nnz * (F + 4) + 3 * (n + 1) * 8 + m * F + 2 * D * F + (M - m) * F
-    transforms = 5 * 2 * D * F
+    transforms = 4 * 2 * D * F          # (ark-gm17 runs 5)
     bases = 3 * M * 2 * fq + M * 4 * fq + D * 2 * fq
     scalars = 4 * M * F + D * F
     return rows + transforms + bases + scalars

@@ -205,6 +205,8 @@ struct NttPlan : NttPlanBase {
     // roots: 9-limb R'-form; tw (inter-pass twiddles, the inverse ones times 1/N... see get_plan), s_coset (g^i / N, sigma
     // order), s_cosetinv_canon (g^-i / N as plain integers: the Montgomery exit): packed, N entries each
     DBuf roots_fwd, roots_inv, tw_fwd, tw_inv, s_coset, s_cosetinv_canon;
+    DBuf s_cexit;            // zinv / N as plain integers, N entries: exit factor of the transform that turns c's evaluations into
+                             // its share zinv * c_i of the quotient's coefficients (canonical integers)
     DBuf plan1[2], plan2[2];   // twiddle plans of the N1- and N2-point sub-NTTs, [0] forward, [1] inverse (kernels_ntt.cuh)
     u32 plen1 = 0, plen2 = 0;
     Fr omega, omega_inv, n_inv, g, g_inv, zinv;   // saturated Montgomery form (host code, setup)
@@ -314,6 +316,9 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
     // plain integers: multiplying an R'-form value by them (R' Montgomery product) leaves the plain value
     ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->s_cosetinv_canon), pl->g_inv, fe_from_mont(pl->n_inv), pl->N,
               pl->N1, pl->N2, 2);
+    pl->s_cexit.ensure(pl->N * sizeof(Fr));
+    ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->s_cexit), Fr::one(), fe_from_mont(fe_mul(pl->n_inv, pl->zinv)), pl->N,
+              0u, 0u, 0);
     // launch geometry.  A workgroup stages `tile` elements as nine limb planes (36 B + padding per element): tiles of
     // 1024 elements (38 KiB) let four workgroups share a CU, so that one loads while another computes; a cols tile
     // needs >= 2 columns for 64-byte rows in HBM.
@@ -338,25 +343,25 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
 // `nvec` vectors of N elements, vec_stride elements apart, go through one launch (grid.y)
 template <class C>
 static void ntt_cols(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, int nvec = 1, u64 vec_stride = 0,
-                     int canon = 0) {
+                     int canon = 0, const typename C::Fr* minus = nullptr) {
     typedef typename C::Fr Fr;
     ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3(pl->N2 / pl->C_cols, nvec), dim3(pl->threads_cols), pl->smem_cols, ctx->ws, data, vec_stride,
-              pl->log1, pl->N2, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon);
+              pl->log1, pl->N2, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon, minus);
 }
 template <class C>
 static void ntt_rows(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, int nvec = 1, u64 vec_stride = 0,
-                     int canon = 0) {
+                     int canon = 0, const typename C::Fr* minus = nullptr) {
     typedef typename C::Fr Fr;
     ZK_LAUNCH((k_ntt_rows<typename Fr::Params>), dim3(pl->N1 / pl->R_rows, nvec), dim3(pl->threads_rows), pl->smem_rows, ctx->ws, data, vec_stride,
-              pl->log2, pl->R_rows, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, canon);
+              pl->log2, pl->R_rows, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, canon, minus);
 }
 // natural order in -> sigma order out
 template <class C>
 static void ntt_kind_a(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* final_post, int nvec = 1,
-                       u64 vec_stride = 0, int canon = 0) {
+                       u64 vec_stride = 0, int canon = 0, const typename C::Fr* final_minus = nullptr) {
     typedef typename C::Fr Fr;
     if (pl->log1 > 0) ntt_cols<C>(ctx, pl, data, inverse, inverse ? ptr<Fr>(pl->tw_inv) : ptr<Fr>(pl->tw_fwd), nvec, vec_stride);
-    ntt_rows<C>(ctx, pl, data, inverse, final_post, nvec, vec_stride, canon);
+    ntt_rows<C>(ctx, pl, data, inverse, final_post, nvec, vec_stride, canon, final_minus);
 }
 // sigma order in -> natural order out
 template <class C>
@@ -831,10 +836,15 @@ struct Prover {
         Fr *a = ptr<Fr>(ctx->cur->va), *b = a + N, *c = b + N;
         matvec(ctx, cs, ptr<Fr>(ctx->cur->zmont), a, b, c, cs->n, cs->l, N);
         event_record(ctx->cur->ntt_b, s);
-        ntt_kind_a<C>(ctx, pl, a, true, ptr<Fr>(pl->s_coset), 3, N);   // ifft, then * g^i   (coset shift)
-        ntt_kind_b<C>(ctx, pl, a, false, nullptr, 3, N);                // evaluations on g<w>
-        ZK_LAUNCH((k_quotient<typename Fr::Params>), dim3(blocks_for(N, 256)), dim3(256), 0, s, a, b, c, pl->zinv_rp, a, N);
-        ntt_kind_a<C>(ctx, pl, a, true, ptr<Fr>(pl->s_cosetinv_canon), 1, 0, 1);   // coset_ifft, leaving canonical integers
+        // SIX transforms (the reference's witness_map runs seven): a and b go to the coset and back as a product; c only needs
+        // its coefficients — ((ab - c)/Z)'s coefficients are coset_ifft(ab / Z) - c_coeffs / Z, because the coset transform pair is
+        // the identity on the c term — so c takes ONE inverse transform whose exit factor carries 1/(N Z) and leaves canonical
+        // integers, and the last transform subtracts them where it stores h.  Same h, bit for bit.
+        ntt_kind_a<C>(ctx, pl, a, true, ptr<Fr>(pl->s_coset), 2, N);    // a, b: ifft, then * g^i   (coset shift)
+        ntt_kind_a<C>(ctx, pl, c, true, ptr<Fr>(pl->s_cexit), 1, 0, 1);  // c: ifft * 1/(N Z), canonical integers, sigma order
+        ntt_kind_b<C>(ctx, pl, a, false, nullptr, 2, N);                 // a, b: evaluations on g<w>
+        ZK_LAUNCH((k_quotient<typename Fr::Params>), dim3(blocks_for(N, 256)), dim3(256), 0, s, a, b, pl->zinv_rp, a, N);
+        ntt_kind_a<C>(ctx, pl, a, true, ptr<Fr>(pl->s_cosetinv_canon), 1, 0, 1, c);   // coset_ifft, canonical, minus c's share
         event_record(ctx->cur->ntt_e, s);
     }
 

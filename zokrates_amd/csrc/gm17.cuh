@@ -64,14 +64,15 @@ __global__ void k_sap_rows(const Fe<P>* __restrict__ ra, const Fe<P>* __restrict
         ext[m + n - 1 + j] = rp_to_plain(f);
     }
 }
-// quotient evaluations on the coset: out = (a^2 - c) * zinv     (R'-form operands < 2^256, canonical R'-form out)
+// quotient evaluations on the coset, square part: out = a^2 * zinv     (R'-form operand < 2^256, canonical R'-form out); the
+// `- c` is subtracted in coefficient form by the last transform (see k_quotient)
 template <class P>
-__global__ void k_sap_quotient(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ c, Fe<P> zinv, Fe<P>* __restrict__ out, u64 n) {
+__global__ void k_sap_quotient(const Fe<P>* __restrict__ a, Fe<P> zinv, Fe<P>* __restrict__ out, u64 n) {
     ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Fu<P> aa = fu_sqr_inl(fu_unpack<P>(a[i].v));
-    out[i] = rp_canon(fu_mul_inl(fe_sub_k<8>(aa, fu_unpack<P>(c[i].v)), fu_unpack<P>(zinv.v)));
+    out[i] = rp_canon(fu_mul_inl(aa, fu_unpack<P>(zinv.v)));
 }
 // setup: the per-variable key scalars (canonical) from u_i(t) = a[i], w_i(t) = c[i]
 //   aq = gamma a;  c1 = gamma^2 c + (alpha+beta) gamma a;  c2 = 2 gamma^2 Z a;  vq = gamma c + (alpha+beta) a
@@ -260,16 +261,18 @@ struct Gm17 {
                 msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
         }
 
-        // ---- quotient h0 = (U^2 - W)/Z: 2 iNTT, 2 coset NTT, pointwise, coset iNTT (sigma order, canonical)
+        // ---- quotient h0 = (U^2 - W)/Z: iNTT + coset NTT of U, pointwise square, coset iNTT minus W's coefficients / Z (sigma order, canonical)
         // the transforms and the h-sort run on the NTT stream (the SAP rows above feed the z-sort and stay on the main one)
         Stream wn = ctx->serial ? st : ctx->ntt_stream;
         stream_wait_event(wn, sl.ev[1]);
         ctx->ws = wn;
         event_record(sl.ntt_b, wn);
-        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_coset), 2, D);
-        ntt_kind_b<C>(ctx, pl, sa, false, nullptr, 2, D);
-        ZK_LAUNCH((k_sap_quotient<typename Fr::Params>), dim3(blocks_for(D, 256)), dim3(256), 0, wn, sa, sc, pl->zinv_rp, sa, D);
-        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_cosetinv_canon), 1, 0, 1);
+        // four transforms (ark-gm17's witness_map runs five): W only needs its coefficients, as c in the Groth16 prover
+        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_coset), 1, 0);
+        ntt_kind_a<C>(ctx, pl, sc, true, ptr<Fr>(pl->s_cexit), 1, 0, 1);
+        ntt_kind_b<C>(ctx, pl, sa, false, nullptr, 1, 0);
+        ZK_LAUNCH((k_sap_quotient<typename Fr::Params>), dim3(blocks_for(D, 256)), dim3(256), 0, wn, sa, pl->zinv_rp, sa, D);
+        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_cosetinv_canon), 1, 0, 1, sc);
         ctx->ws = ctx->stream;
         event_record(sl.ntt_e, wn);
         event_record(sl.ev[2], wn);

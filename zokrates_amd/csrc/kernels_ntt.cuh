@@ -127,17 +127,17 @@ __global__ void k_sigma_permute(const F* __restrict__ in, F* __restrict__ out, u
     if (dir == 0) out[p] = in[nat];
     else out[nat] = in[p];
 }
-// quotient evaluations: out = (a*b - c) * zinv        (App. A.3: division by the constant Z(g) on the coset); R'-form
-// operands (any packed value < 2^256), zinv in R'-form, canonical R'-form out
+// quotient evaluations, product part: out = a*b * zinv   (App. A.3: division by the constant Z(g) on the coset); R'-form
+// operands (any packed value < 2^256), zinv in R'-form, canonical R'-form out.  The `- c` of (a*b - c)/Z never visits the
+// coset: the coset transform pair is the identity on it, so its share of the quotient's coefficients is zinv * c's own
+// coefficients, subtracted where the last transform stores h (ntt_store's `minus`) — 6 transforms per proof, not 7.
 template <class P>
-__global__ void k_quotient(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ b, const Fe<P>* __restrict__ c, Fe<P> zinv, Fe<P>* __restrict__ out,
-                           u64 n) {
+__global__ void k_quotient(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ b, Fe<P> zinv, Fe<P>* __restrict__ out, u64 n) {
     ZK_PRIO_HIGH();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Fu<P> ab = fu_mul_inl(fu_unpack<P>(a[i].v), fu_unpack<P>(b[i].v));          // < 2p
-    const Fu<P> d = fe_sub_k<8>(ab, fu_unpack<P>(c[i].v));                              // c < 2^256 < 8p
-    out[i] = rp_canon(fu_mul_inl(d, fu_unpack<P>(zinv.v)));
+    out[i] = rp_canon(fu_mul_inl(ab, fu_unpack<P>(zinv.v)));
 }
 
 // ---------------- K1: sparse mat-vec ----------------
@@ -318,7 +318,8 @@ __device__ __forceinline__ Fu<P> ntt_load(const uint4* __restrict__ data, size_t
 // x: TIGHT, value < 32p.  With a post factor the product is < 2p; without one fe_relax leaves < 2p; `canon` adds the
 // final conditional subtraction (the Montgomery exit of the last transform must leave canonical integers: MSM digits).
 template <class P>
-__device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu<P> x, const uint4* __restrict__ post, int canon) {
+__device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu<P> x, const uint4* __restrict__ post, int canon,
+                                          const uint4* __restrict__ minus = nullptr) {
     if (post) {
         const uint4 lo = post[2 * g], hi = post[2 * g + 1];
         const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -329,6 +330,12 @@ __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu
     Fe<P> o;
     fu_pack(x, o.v);
     if (canon) fe_reduce_once(o);
+    if (minus) {            // canonical exit only: o - minus[g] mod p, both canonical integers (the c term of the quotient)
+        const uint4 lo = minus[2 * g], hi = minus[2 * g + 1];
+        Fe<P> m;
+        m.v[0] = lo.x; m.v[1] = lo.y; m.v[2] = lo.z; m.v[3] = lo.w; m.v[4] = hi.x; m.v[5] = hi.y; m.v[6] = hi.z; m.v[7] = hi.w;
+        o = fe_sub(o, m);
+    }
     data[2 * g] = make_uint4(o.v[0], o.v[1], o.v[2], o.v[3]);
     data[2 * g + 1] = make_uint4(o.v[4], o.v[5], o.v[6], o.v[7]);
 }
@@ -341,7 +348,7 @@ __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu
 #endif
 template <class P>
 __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n1, u32 n2, int C, const u32* __restrict__ plan,
-                                                     u32 plen, const Fe<P>* __restrict__ post_, int canon) {
+                                                     u32 plen, const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     static_assert(P::N == 8, "Fr is 8 x 32-bit words");
@@ -360,14 +367,14 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __re
     lds_ntt_dif4<P>(lds, PL, SS, log_n1, C, plan, plen);
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int k = e / C, j = e - k * C;
-        ntt_store<P>(data, (size_t)k * n2 + c0 + j, lds_get_u<P>(lds, PL, j * SS + ntt_slot(bitrev_n(k, log_n1))), post, canon);
+        ntt_store<P>(data, (size_t)k * n2 + c0 + j, lds_get_u<P>(lds, PL, j * SS + ntt_slot(bitrev_n(k, log_n1))), post, canon, (const uint4*)minus_);
     }
 }
 
 // "rows" pass: this workgroup owns rows [r0, r0 + R) of n2 contiguous elements each.
 template <class P>
 __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_rows(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n2, int R, const u32* __restrict__ plan, u32 plen,
-                                                     const Fe<P>* __restrict__ post_, int canon) {
+                                                     const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     u32* lds = (u32*)smem;
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_rows(Fe<P>* __re
     lds_ntt_dif4<P>(lds, PL, SS, log_n2, R, plan, plen);
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int r = e >> log_n2, k = e & (n2 - 1);
-        ntt_store<P>(data, base + e, lds_get_u<P>(lds, PL, r * SS + ntt_slot(bitrev_n(k, log_n2))), post, canon);
+        ntt_store<P>(data, base + e, lds_get_u<P>(lds, PL, r * SS + ntt_slot(bitrev_n(k, log_n2))), post, canon, (const uint4*)minus_);
     }
 }
 
