@@ -102,6 +102,13 @@ class Program {
     uint64_t n_ = 0, l_ = 0, w_ = 0;
 };
 
+// NonUniversalBackend::setup's result (zokrates_proof_systems/src/lib.rs:59-65,113-118): the verification key as the text of
+// `verification.key` (scheme/groth16.rs:18-25, scheme/gm17.rs:19-27) and the proving key in ark's serialize_unchecked bytes
+struct SetupKeypair {
+    std::string vk;
+    std::vector<uint8_t> pk;
+};
+
 // where the wall clock of one proof went (milliseconds)
 struct Timings {
     double witness_to_assignment = 0, r1cs_upload = 0, prove = 0;
@@ -126,6 +133,10 @@ class Hip {
     std::vector<uint8_t> export_key_image(const Key& key) const;      // zkhip_pk_export (compact: level 0 of the tables)
     Proof prove(Scheme scheme, const Program& program, const uint8_t* witness, size_t witness_len, const Key& key, StdRng& rng,
                 Timings* timings = nullptr);
+    // NonUniversalBackend<T, S>::setup(program, rng) -> SetupKeypair: toxic waste = five non-zero `Fr::rand` draws (alpha, beta,
+    // gamma, delta, tau; GM17: gamma = 1 as in ark-gm17), standard group generators (ark samples random ones from the RNG: a
+    // key made here is valid, not byte-equal to `zokrates setup --entropy`'s), key generation on the GPU (zkhip_setup_*)
+    SetupKeypair setup(Scheme scheme, const Program& program, StdRng& rng);
     std::string describe() const;
 
   private:

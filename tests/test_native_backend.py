@@ -81,6 +81,16 @@ def _both_clis(paths, scheme, exe, env):
         if "--timings" in extra:
             tm = json.loads([l for l in cpp.stdout.splitlines() if l.startswith("timings ")][0][8:])
             assert tm["key_source"] == "image" and tm["constraints"] == 3
+    # setup: both host layers draw the toxic waste the same way -> the same proving.key and verification.key, byte for byte
+    outs = {}
+    for who, cmd in (("py", [os.sys.executable, "-m", "zokrates_amd.cli", "setup"]), ("cpp", [exe, "setup"])):
+        pkp, vkp = paths["proving.key"] + "." + who, paths["proving.key"] + ".vk." + who
+        r = subprocess.run(cmd + ["-i", paths["out"], "-p", pkp, "-v", vkp, "-s", scheme, "--entropy", "setup entropy"], capture_output=True, text=True,
+                           cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[who] = (open(pkp, "rb").read(), open(vkp).read())
+    assert outs["py"][0] == outs["cpp"][0] and outs["py"][1] == outs["cpp"][1]
+    assert json.loads(outs["cpp"][1])["scheme"] == scheme
     doc = json.load(open(paths["proof_cpp.json"]))
     assert doc["scheme"] == scheme and len(doc["inputs"]) == 3 and doc["inputs"][0] == "0x" + (9).to_bytes(32, "big").hex()
     # failures: message on stderr, exit status 1 (the reference's panic hook + exit(1))

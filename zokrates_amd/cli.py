@@ -24,23 +24,19 @@ import numpy as np
 from . import formats, native, rng
 
 
-def _field_elems(curve_id, seed, count):
-    """`count` non-zero Fr elements from a seed (SHAKE-256 stream, rejection sampling) — setup toxic waste.  (The
-    reference's setup also samples random group generators from its RNG; a key made here is a valid key, not the key
-    `zokrates setup --entropy` would make.  Proof randomness, in contrast, follows the reference: see rng.py.)"""
-    p = formats.FR_MODULUS[curve_id]
-    stream = hashlib.shake_256(seed).digest(64 * (count + 8))
-    out, pos = [], 0
-    while len(out) < count:
-        v = int.from_bytes(stream[pos:pos + 32], "little") & ((1 << p.bit_length()) - 1)
-        pos += 32
-        if 0 < v < p:
+def _toxic_waste(curve_id, entropy):
+    """(alpha, beta, gamma, delta, tau) for setup: five `Fr::rand` draws from the RNG the reference would use — `StdRng` seeded
+    from --entropy (rng.rs:5-20) or from the OS —, redrawn while zero.  ark's `generate_random_parameters` starts with the same
+    four draws (alpha, beta, gamma, delta) but then samples random group generators from the RNG, which this setup replaces by
+    the standard generators: a key made here is a valid key, not the key `zokrates setup --entropy` would make.  The same
+    recipe, draw for draw, is in the compiled host layer (csrc/host/backend.cpp): both CLIs write the same key."""
+    gen = rng.rng_from_entropy(entropy) if entropy is not None else rng.StdRng(os.urandom(32))
+    out = []
+    while len(out) < 5:
+        v = rng.fr_rand(gen, curve_id)
+        if v:
             out.append(v)
     return out
-
-
-def _seed(entropy):
-    return entropy.encode() if entropy is not None else os.urandom(32)
 
 
 def _load_system(ctx, path):
@@ -91,7 +87,7 @@ def _curve_of(path):
 def cmd_setup(args):
     ctx = native.Context(args.device)
     cs, _ = _load_system(ctx, args.input)
-    toxic = _field_elems(cs.curve_id, b"zkhip-setup" + _seed(args.entropy), 5)
+    toxic = _toxic_waste(cs.curve_id, args.entropy)
     if args.proving_scheme == "gm17":
         toxic[2] = 1                                   # ark's generate_random_parameters: gamma = 1
         pk = native.setup_gm17(ctx, cs, (toxic[0], toxic[1], toxic[2], toxic[4]))

@@ -292,6 +292,90 @@ Proof Hip::prove(Scheme scheme, const Program& program, const uint8_t* witness, 
     return p;
 }
 
+// ------------------------------------------------------------------ setup
+namespace {
+std::string json_g1(const uint8_t* p, size_t fq, const std::string& ind) {
+    std::vector<uint8_t> t(p, p + 2 * fq);
+    t[2 * fq - 1] &= 0x3f;                                   // ark's flag bits live in the last byte
+    return "[\n" + ind + "  \"" + hex_be(&t[0], fq) + "\",\n" + ind + "  \"" + hex_be(&t[fq], fq) + "\"\n" + ind + "]";
+}
+std::string json_g2(const uint8_t* p, size_t fq, const std::string& ind) {
+    std::vector<uint8_t> t(p, p + 4 * fq);
+    t[4 * fq - 1] &= 0x3f;
+    auto pair = [&](size_t k) {
+        return "[\n" + ind + "    \"" + hex_be(&t[k * fq], fq) + "\",\n" + ind + "    \"" + hex_be(&t[(k + 1) * fq], fq) + "\"\n" + ind + "  ]";
+    };
+    return "[\n" + ind + "  " + pair(0) + ",\n" + ind + "  " + pair(2) + "\n" + ind + "]";
+}
+std::string json_g1_list(const uint8_t* p, uint64_t count, size_t fq) {
+    if (!count) return "[]";
+    std::string s = "[\n";
+    for (uint64_t i = 0; i < count; ++i) s += "    " + json_g1(p + i * 2 * fq, fq, "    ") + (i + 1 < count ? ",\n" : "\n");
+    return s + "  ]";
+}
+}  // namespace
+
+SetupKeypair Hip::setup(Scheme scheme, const Program& program, StdRng& rng) {
+    const int32_t curve = program.curve();
+    const size_t fq = curve == ZKHIP_CURVE_BN128 ? 32 : 48, g1 = 2 * fq, g2 = 4 * fq;
+    std::array<uint8_t, 32> tox[5];
+    for (int k = 0; k < 5;) {                                   // alpha, beta, gamma, delta, tau: redrawn while zero
+        tox[k] = fr_rand(rng, curve);
+        bool zero = true;
+        for (uint8_t b : tox[k]) zero = zero && b == 0;
+        if (!zero) ++k;
+    }
+    zkhip_r1cs* cs = nullptr;
+    check(zkhip_prog_r1cs_load(ctx_, program.get(), &cs));
+    SetupKeypair kp;
+    uint64_t size = 0;
+    int32_t rc;
+    if (scheme == Scheme::GM17) {
+        uint8_t t4[128];
+        memcpy(t4, tox[0].data(), 32); memcpy(t4 + 32, tox[1].data(), 32);
+        memset(t4 + 64, 0, 32); t4[64] = 1;                     // ark-gm17's generate_random_parameters: gamma = 1
+        memcpy(t4 + 96, tox[4].data(), 32);
+        zkhip_setup_gm17_size(cs, &size);
+        kp.pk.resize(size);
+        rc = zkhip_setup_gm17(ctx_, cs, t4, nullptr, nullptr, kp.pk.data(), size);
+    } else {
+        uint8_t t5[160];
+        for (int k = 0; k < 5; ++k) memcpy(t5 + 32 * k, tox[k].data(), 32);
+        zkhip_setup_g16_size(cs, &size);
+        kp.pk.resize(size);
+        rc = zkhip_setup_g16(ctx_, cs, t5, nullptr, nullptr, kp.pk.data(), size);
+    }
+    zkhip_r1cs_free(cs);
+    check(rc);
+    const uint8_t* pk = kp.pk.data();
+    const std::string cname = curve == ZKHIP_CURVE_BN128 ? "bn128" : "bls12_381";
+    std::string s = "{\n";
+    if (scheme == Scheme::GM17) {      // vk = h_g2, g_alpha_g1, h_beta_g2, g_gamma_g1, h_gamma_g2, query[]   (scheme/gm17.rs:19-27)
+        size_t pos = 0;
+        const uint8_t *h = pk; pos += g2;
+        const uint8_t* g_alpha = pk + pos; pos += g1;
+        const uint8_t* h_beta = pk + pos; pos += g2;
+        const uint8_t* g_gamma = pk + pos; pos += g1;
+        const uint8_t* h_gamma = pk + pos; pos += g2;
+        uint64_t nq;
+        memcpy(&nq, pk + pos, 8);
+        s += "  \"scheme\": \"gm17\",\n  \"curve\": \"" + cname + "\",\n";
+        s += "  \"h\": " + json_g2(h, fq, "  ") + ",\n  \"g_alpha\": " + json_g1(g_alpha, fq, "  ") + ",\n  \"h_beta\": " + json_g2(h_beta, fq, "  ") + ",\n";
+        s += "  \"g_gamma\": " + json_g1(g_gamma, fq, "  ") + ",\n  \"h_gamma\": " + json_g2(h_gamma, fq, "  ") + ",\n";
+        s += "  \"query\": " + json_g1_list(pk + pos + 8, nq, fq) + "\n}";
+    } else {                           // vk = alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1[]            (scheme/groth16.rs:18-25)
+        const size_t off = g1 + 3 * g2;
+        uint64_t n_abc;
+        memcpy(&n_abc, pk + off, 8);
+        s += "  \"scheme\": \"g16\",\n  \"curve\": \"" + cname + "\",\n";
+        s += "  \"alpha\": " + json_g1(pk, fq, "  ") + ",\n  \"beta\": " + json_g2(pk + g1, fq, "  ") + ",\n";
+        s += "  \"gamma\": " + json_g2(pk + g1 + g2, fq, "  ") + ",\n  \"delta\": " + json_g2(pk + g1 + 2 * g2, fq, "  ") + ",\n";
+        s += "  \"gamma_abc\": " + json_g1_list(pk + off + 8, n_abc, fq) + "\n}";
+    }
+    kp.vk = s;
+    return kp;
+}
+
 Proof Hip::generate_proof(Scheme scheme, const uint8_t* program, size_t program_len, const uint8_t* witness, size_t witness_len,
                           const uint8_t* proving_key, size_t proving_key_len, StdRng& rng) {
     Program prog(program, program_len);

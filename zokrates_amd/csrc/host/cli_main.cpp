@@ -60,12 +60,52 @@ uint64_t fnv1a(const std::string& s) {
 }
 int usage() {
     fprintf(stderr, "usage: zkhip-cli generate-proof -i <out> -w <witness> -p <proving.key> -j <proof.json> [-s g16|gm17] [--entropy TEXT] "
-                    "[--key-cache DIR] [--device N] [--timings]\n");
+                    "[--key-cache DIR] [--device N] [--timings]\n"
+                    "       zkhip-cli setup -i <out> -p <proving.key> -v <verification.key> [-s g16|gm17] [--entropy TEXT] [--device N]\n");
     return 2;
 }
 }  // namespace
 
+// zkhip-cli setup -i out -p proving.key -v verification.key [-s g16|gm17] [--entropy TEXT] [--device N]
+// (/root/reference/zokrates_cli/src/ops/setup.rs: program in, proving.key + verification.key out)
+int cmd_setup(int argc, char** argv) {
+    std::string input = "out", pk_path = "proving.key", vk_path = "verification.key", scheme_s = "g16", entropy;
+    bool have_entropy = false;
+    int device = 0;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
+        if (a == "-i" || a == "--input") input = val();
+        else if (a == "-p" || a == "--proving-key-path") pk_path = val();
+        else if (a == "-v" || a == "--verification-key-path") vk_path = val();
+        else if (a == "-s" || a == "--proving-scheme") scheme_s = val();
+        else if (a == "--entropy") { entropy = val(); have_entropy = true; }
+        else if (a == "--device") device = atoi(val().c_str());
+        else return usage();
+    }
+    if (scheme_s != "g16" && scheme_s != "gm17") return usage();
+    try {
+        const Mapped prog_bytes(input);
+        const Program program(prog_bytes.data, prog_bytes.size);
+        Hip hip(device);
+        StdRng rng = have_entropy ? get_rng_from_entropy(entropy) : StdRng::from_os_entropy();
+        const SetupKeypair kp = hip.setup(scheme_s == "gm17" ? Scheme::GM17 : Scheme::G16, program, rng);
+        std::ofstream o(pk_path, std::ios::binary);
+        o.write((const char*)kp.pk.data(), (std::streamsize)kp.pk.size());
+        std::ofstream v(vk_path);
+        v << kp.vk;
+        if (!o || !v) throw Error(ZKHIP_ERR_BAD_ARG, "cannot write the key files");
+        printf("setup (%s): %llu constraints, %llu variables; wrote %s, %s\n", scheme_s.c_str(), (unsigned long long)program.constraints(),
+               (unsigned long long)program.variables(), pk_path.c_str(), vk_path.c_str());
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "zkhip-cli: %s\n", e.what());
+        return 1;
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && strcmp(argv[1], "setup") == 0) return cmd_setup(argc, argv);
     if (argc < 2 || strcmp(argv[1], "generate-proof") != 0) return usage();
     std::string input = "out", witness_path = "witness", pk_path = "proving.key", proof_path = "proof.json", scheme_s = "g16", entropy, cache_dir;
     bool have_entropy = false, timings = false;
