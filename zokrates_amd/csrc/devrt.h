@@ -241,46 +241,12 @@ inline void dev_h2d(void* d, const void* h, size_t n, Stream s) {
     StagingRing& r = staging_ring();
     std::lock_guard<std::mutex> lock(r.mu);
     r.init();
-    const size_t nchunks = (n + StagingRing::CHUNK - 1) / StagingRing::CHUNK;
-    if (nchunks >= 2) {
-        // several chunks: one host thread per ring slot, each copying its share of the chunks into ITS slot and enqueueing it —
-        // the host memcpy (the slow half of a staged transfer) runs SLOTS-wide; the copies land in disjoint ranges, so their
-        // order on the stream does not matter, and all of them are enqueued when this returns
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const int T = (int)std::min<size_t>(StagingRing::SLOTS, nchunks);
-        std::string err[StagingRing::SLOTS];
-        auto work = [&](int t) {
-            try {
-                ZK_HIP_CHECK(hipSetDevice(dev));
-                for (size_t c = (size_t)t; c < nchunks; c += (size_t)T) {
-                    const size_t off = c * StagingRing::CHUNK, len = std::min(StagingRing::CHUNK, n - off);
-                    if (r.used[t]) ZK_HIP_CHECK(hipEventSynchronize(r.ev[t]));
-                    memcpy(r.buf[t], (const char*)h + off, len);
-                    ZK_HIP_CHECK(hipMemcpyAsync((char*)d + off, r.buf[t], len, hipMemcpyHostToDevice, s));
-                    ZK_HIP_CHECK(hipEventRecord(r.ev[t], s));
-                    r.used[t] = true;
-                }
-            } catch (const DevError& e) {
-                err[t] = e.msg;
-            }
-        };
-        jitter_before(s);
-        {
-            HostThreads th;
-            for (int t = 1; t < T; ++t) th.run([&work, t] { work(t); });
-            work(0);
-        }
-        r.next = 0;
-        for (int t = 0; t < T; ++t)
-            if (!err[t].empty()) throw DevError{err[t]};
-        return;
-    }
-    {
+    for (size_t off = 0; off < n; off += StagingRing::CHUNK) {
+        const size_t len = std::min(StagingRing::CHUNK, n - off);
         const int i = r.acquire();
-        memcpy(r.buf[i], h, n);
+        memcpy(r.buf[i], (const char*)h + off, len);
         jitter_before(s);
-        ZK_HIP_CHECK(hipMemcpyAsync(d, r.buf[i], n, hipMemcpyHostToDevice, s));
+        ZK_HIP_CHECK(hipMemcpyAsync((char*)d + off, r.buf[i], len, hipMemcpyHostToDevice, s));
         ZK_HIP_CHECK(hipEventRecord(r.ev[i], s));
         r.used[i] = true;
     }
