@@ -495,7 +495,6 @@ ZK_HD Fu<P> fu_from_fe(const Fe<P>& a) {
 // unsaturated Montgomery, TIGHT, value < 8p -> saturated Montgomery, canonical
 template <class P>
 ZK_HD Fe<P> fu_to_fe(const Fu<P>& a) {
-    typedef UConst<P> C;
     constexpr int N = Fu<P>::N, B = Fu<P>::B, W = P::N;
     Fu<P> unit = Fu<P>::zero();
     unit.v[0] = 1;
