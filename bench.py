@@ -3,11 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log-domain 20] [--curve bn128] [--kind dense] [--scheme g16]
 
-A "step" is one Groth16 proof (sparse mat-vec, 7 NTTs, 5 MSMs, assembly) of the synthetic 2^20-constraint BN254
+A "step" is one Groth16 proof (sparse mat-vec, 6 NTTs, 5 MSMs, assembly) of the synthetic 2^20-constraint BN254
 circuit of BASELINE.json configs[1].  The proving key, the constraint system and the assignments are
 resident in HBM when the timed region starts; EVERY step proves a different witness (--witnesses defaults to --steps,
 all resident: 32 x 32 MiB) with its own (r, s).  The timed region is ONE call of `zkhip_prove_g16_resident_batch` over
-the K steps — the library keeps two proofs in flight (steady-state proofs/sec, the headline metric).
+the K steps — the library keeps three proofs in flight (steady-state proofs/sec, the headline metric); the measurement runs
+in a child process that a parent supervises (a GPU fault kills the process that owns the queue: see supervise()).
 `single_proof_ms` is the latency of an isolated proof of a resident assignment, `single_proof_from_host_ms` the same
 from an assignment in host memory to the proof bytes in host memory (SURVEY.md §8d's definition; the PCIe leg is
 never part of `value`).  With N > 1 every rank proves its own K proofs on its own GPU with a full copy of the key
@@ -329,8 +330,8 @@ def main():
                         "intervals on the MSM streams inside the timed region (five MSMs and two proofs overlap), `frac_serial` the same "
                         "kernels alone on one stream after it"}
     # the NTT passes: 2 * N * 32 B per pass and vector; Groth16 runs 12 pass-vectors per proof (6 transforms: c
-    # needs only its coefficients; the reference runs 7), GM17 8 (4 transforms; the reference 5) — (formerly: 7 transforms
-    # x 2 passes; a, b, c share launches), GM17 10 over its domain; the interval also holds the pointwise quotient kernel
+    # needs only its coefficients; the reference runs 7), GM17 8 (4 transforms; the reference 5); the interval also
+    # holds the pointwise quotient kernel
     passes = 8 if gm17 else 12
     if N <= 1 << 10:
         passes //= 2
@@ -612,7 +613,7 @@ def rocm_smi():
 
 def proof_algorithmic_bytes(circ, fq):
     """Compulsory HBM traffic of one proof: every input read once, every output written once per logical stage
-    (SURVEY.md §8d): mat-vec, 7 transforms, MSM bases, MSM scalars."""
+    (SURVEY.md §8d): mat-vec, the transforms (6 here, 7 in the reference), MSM bases, MSM scalars."""
     F, n, m, N, w, l = 32, circ.n, circ.m, circ.N, circ.w, circ.l
     nnz = sum(int(mat[0][-1]) for mat in circ.mats())
     matvec = nnz * (F + 4) + 3 * (n + 1) * 8 + m * F + 3 * N * F
