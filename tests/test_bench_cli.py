@@ -32,7 +32,8 @@ def run_bench(args, extra_env=None, timeout=900, expect_rc=0):
     (["--log-domain", "9", "--kind", "poseidon", "--curve", "bls12_381"], "groth16_proofs_per_sec"),
 ])
 def test_single_rank_contract(args, metric):
-    lines = run_bench(args + ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
+    with_cli_leg = "--scheme" not in args and "--kind" not in args      # the CLI-shaped leg (eleven subprocesses) once is enough
+    lines = run_bench(args + ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"] + ([] if with_cli_leg else ["--e2e", "0"]))
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in REQUIRED:
@@ -45,6 +46,8 @@ def test_single_rank_contract(args, metric):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_proof_identical"] is True
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000
+    if not with_cli_leg:
+        return
     e = d["cli_end_to_end_ms"]                         # the reference-shaped flow: files -> proof.json, one process per proof
     assert "error" not in e, e
     for run in ("native_from_proving_key", "native_from_key_image", "from_proving_key", "from_key_image", "from_full_key_image"):
