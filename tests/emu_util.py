@@ -14,6 +14,8 @@ _lib = None
 
 def emu_library():
     global _lib
+    if _lib is None and os.environ.get("ZKHIP_EMU_LIBRARY"):      # another build of the emulator (e.g. -DZK_CHECKED: index assertions)
+        _lib = native.Library(os.environ["ZKHIP_EMU_LIBRARY"])
     if _lib is None:
         srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "zkhip.h")]
         if not os.path.exists(EMU_LIB) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):

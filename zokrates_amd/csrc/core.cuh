@@ -823,7 +823,7 @@ struct Prover {
         int g[3];
         for (int k = 0; k < 3; ++k) g[k] = matvec_group(cs->nnz[k], cs->n);
         ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), 3), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
-                  l, N, g[0], g[1], g[2]);
+                  l, N, g[0], g[1], g[2], cs->l + cs->w);
     }
     static unsigned gmax_rows(const int g[3]) { return (unsigned)std::max(g[0], std::max(g[1], g[2])); }
 

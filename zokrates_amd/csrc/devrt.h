@@ -363,6 +363,15 @@ inline bool grid_nonempty(const dim3& g) { return g.x != 0 && g.y != 0 && g.z !=
 #define ZK_WAVE_PRIO 3
 #endif
 #define ZK_PRIO_HIGH() __builtin_amdgcn_s_setprio(ZK_WAVE_PRIO)
+// -DZK_CHECKED: a debugging build whose kernels check every index they compute from data another kernel produced (sorted
+// entries, bucket offsets, partial slots, matrix columns) and trap instead of touching memory outside their buffers; with
+// ZKHIP_TRACE=1 (synchronise after every launch) the launch that trapped is the last one named on stderr.
+// tools/build_variant.sh checked -DZK_CHECKED; the parity suite must run clean on it (profiles/r3k_checked_build.log).
+#ifdef ZK_CHECKED
+#define ZK_ASSERT_IDX(cond) do { if (!(cond)) __builtin_trap(); } while (0)
+#else
+#define ZK_ASSERT_IDX(cond) ((void)0)
+#endif
 
 #else  // ---------------------------- emulator ----------------------------
 
@@ -400,6 +409,11 @@ inline JitterState& jitter_state() { static JitterState st; return st; }
     emu::launch(dim3(grid), dim3(block), (size_t)(smem), [&]() { kernel(__VA_ARGS__); })
 #define ZK_DYN_SMEM(name) unsigned char* name = emu::dyn_smem()
 #define ZK_PRIO_HIGH() ((void)0)
+#ifdef ZK_CHECKED
+#define ZK_ASSERT_IDX(cond) do { if (!(cond)) { fprintf(stderr, "ZK_ASSERT_IDX failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); abort(); } } while (0)
+#else
+#define ZK_ASSERT_IDX(cond) ((void)0)
+#endif
 
 #endif
 

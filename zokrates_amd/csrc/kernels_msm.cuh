@@ -221,6 +221,7 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32*
         const u32 b = (d & 0x7fffffffu) - b0;
         if (b >= kh) continue;
         const u32 pos = atomicAdd(&hist[b], 1u);
+        ZK_ASSERT_IDX(pos >= off[(u64)j * key_stride + b0 + b] && pos < off[(u64)j * key_stride + b0 + b + 1]);
         sorted[pos] = (level + (u32)i) | (d & 0x80000000u);
     }
 }
@@ -278,6 +279,7 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place_lo(const u
         if (d == MSM_NO_DIGIT) continue;
         const u32 b = d & 0x7fffffffu;
         const u32 pos = atomicAdd(&hist[b & (kh - 1)], 1u);
+        ZK_ASSERT_IDX(pos >= off[b & (kh - 1)] && pos < off[(b & (kh - 1)) + 1]);
         keys1[pos] = b;
         ent1[pos] = (level + (u32)i) | (d & 0x80000000u);
     }
@@ -329,6 +331,7 @@ static __global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const u32*
     ZK_UNROLL for (int q = 0; q < PART_PER_THREAD; ++q) {
         if (key[q] == 0xffffffffu) continue;
         const u32 dst = cnt[key[q] >> kh_log][t]++;
+        ZK_ASSERT_IDX(dst < total && (key[q] >> kh_log) < nclass);
         keys2[dst] = key[q];
         sorted[dst] = ent1[base + q];
     }
@@ -412,7 +415,7 @@ static __global__ void k_scan_add(u32* __restrict__ off, const u32* __restrict__
 // The list (length total = off[nkeys], known only on the device) is cut into nlanes slices of P = max(ceil(total / nlanes),
 // min_slice) entries: with nlanes = the number of work-items the machine holds, every work-item of the accumulation
 // kernel does the same number of additions in ONE round of workgroups, whatever the scalars look like.
-struct MsmCut { u32 nlanes, min_slice; };
+struct MsmCut { u32 nlanes, min_slice; u32 table_len; };   // table_len: entries of a base table (levels x points), for the checked build
 static __device__ __forceinline__ u32 msm_slice_len(const u32* __restrict__ off, u32 nkeys, MsmCut cut) {
     const u32 total = off[nkeys];
     const u32 P = (total + cut.nlanes - 1) / cut.nlanes;
@@ -465,8 +468,10 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
     const u64 p0 = (u64)g * P;
     const u64 p1 = p0 + P < total ? p0 + P : total;
     u32 end = off[cur + 1];
+    ZK_ASSERT_IDX(p0 < total && off[cur] <= p0 && p0 < end && (u64)nkeys + cut.nlanes <= partial_stride);
     Xyzz<F> acc = Xyzz<F>::inf();
     u32 e = sorted[p0];
+    ZK_ASSERT_IDX((e & 0x7fffffffu) < cut.table_len);
     if (MsmPrefetch<F>::TOUCH) {
         // register-starved point types: the next base is only TOUCHED one entry ahead (one word: the line travels to the
         // cache) and loaded when it is used, instead of being held in 32-48 registers through a whole addition
@@ -501,12 +506,13 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
         ZK_UNROLL for (int q = 0; q < NW2; ++q) w_next[q] = w[q];
         if (pos + 1 < p1) {            // fetch the next base while this one is being added
             e_next = sorted[pos + 1];
+            ZK_ASSERT_IDX((e_next & 0x7fffffffu) < cut.table_len);
             aff_load_words<F>(bases, e_next & 0x7fffffffu, w_next);
         }
         if (pos == end) {
             partial[(u64)cur + g] = acc;
             acc = Xyzz<F>::inf();
-            do { ++cur; end = off[cur + 1]; } while (end <= pos);
+            do { ++cur; ZK_ASSERT_IDX(cur < nkeys); end = off[cur + 1]; } while (end <= pos);
         }
         Aff<F> pt = aff_unpack<F>(w);
         if (e & 0x80000000u) pt.y = fe_neg(pt.y);
@@ -521,6 +527,7 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
 template <class F>
 __device__ __forceinline__ Xyzz<F> msm_bucket_sum(const Xyzz<F>* partial, const u32* __restrict__ off, u32 key, u32 P) {
     const u32 b = off[key], e = off[key + 1];
+    ZK_ASSERT_IDX(b <= e);
     if (e <= b) return Xyzz<F>::inf();
     const u32 g0 = b / P, g1 = (e - 1) / P;
     Xyzz<F> s = partial[(u64)key + g0];
@@ -591,6 +598,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(X
         __syncthreads();
     }
     const u32 key = row0 + lo;
+    ZK_ASSERT_IDX(key < nkeys && (u64)key + (off[key + 1] ? (off[key + 1] - 1) / P : 0) < partial_stride);
     Xyzz<F> v = msm_bucket_sum<F>(partial, off, key, P);
     bucket[key] = v;
     sh[lo] = v;

@@ -154,7 +154,7 @@ struct CsrDev {
 // partial sums meet in an LDS tree.  G = 1 is the plain one-row-per-work-item kernel.
 template <class F>
 __global__ void __launch_bounds__(256) k_matvec(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ oa, F* __restrict__ ob,
-                                                F* __restrict__ oc, u64 n, u64 l, u64 N, int gA, int gB, int gC) {
+                                                F* __restrict__ oc, u64 n, u64 l, u64 N, int gA, int gB, int gC, u64 m_vars) {
     ZK_PRIO_HIGH();
     __shared__ F sh[256];
     const int which = blockIdx.y;
@@ -169,7 +169,10 @@ __global__ void __launch_bounds__(256) k_matvec(CsrDev A, CsrDev B, CsrDev C, co
     if (i < n) {
         const F* val = (const F*)M.val;
         const u64 e = M.rowptr[i + 1];
-        for (u64 k = M.rowptr[i] + lane; k < e; k += (u32)G) acc = fe_add(acc, fe_mul(val[k], z[M.col[k]]));
+        for (u64 k = M.rowptr[i] + lane; k < e; k += (u32)G) {
+            ZK_ASSERT_IDX(M.col[k] < m_vars);
+            acc = fe_add(acc, fe_mul(val[k], z[M.col[k]]));
+        }
     } else if (which == 0 && i < n + l && lane == 0) {
         acc = z[i - n];
     }
