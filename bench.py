@@ -127,24 +127,47 @@ def cpu_baseline(circ, pk_bytes, z, budget_s, gm17=False):
             "ms_per_proof": 1000.0 * el / done}, proofs[0]
 
 
-_CIRC = None
-
-
-def _assignment(seed):
-    return _CIRC.assignment(seed)
-
-
 def make_witnesses(circ, seeds):
-    """Distinct satisfying assignments (host, pure Python: a 2^20-step multiplication chain each), generated by a pool
-    of forked workers BEFORE the HIP runtime and torch.distributed start."""
-    global _CIRC
-    _CIRC = circ
+    """Distinct satisfying assignments (host, pure Python: a 2^20-step multiplication chain each), generated by forked
+    workers BEFORE the HIP runtime and torch.distributed start.  The workers are plain os.fork children that answer over a
+    pipe and leave with os._exit: no SIGTERM (multiprocessing.Pool ends its workers with one) and no exit handlers — under
+    `rocprofv3 --pmc` the profiler's handler for either in a forked child never returned and the parent waited in wait4
+    until the pass's timeout (gpurun_out r3y: two 900 s passes lost that way)."""
     workers = min(len(seeds), os.cpu_count() or 1, 32)
     if workers <= 1:
         return [circ.assignment(s) for s in seeds]
-    import multiprocessing
-    with multiprocessing.get_context("fork").Pool(workers) as pool:
-        return pool.map(_assignment, seeds)
+    import pickle
+    jobs = []
+    for k in range(workers):
+        mine = list(range(k, len(seeds), workers))
+        rd, wr = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            status = 1
+            try:
+                os.close(rd)
+                blob = pickle.dumps([circ.assignment(seeds[i]) for i in mine], protocol=pickle.HIGHEST_PROTOCOL)
+                with os.fdopen(wr, "wb") as f:
+                    f.write(blob)
+                status = 0
+            finally:
+                os._exit(status)
+        os.close(wr)
+        jobs.append((pid, rd, mine))
+    out = [None] * len(seeds)
+    failed = []
+    for pid, rd, mine in jobs:
+        with os.fdopen(rd, "rb") as f:
+            blob = f.read()
+        _, st = os.waitpid(pid, 0)
+        if st != 0 or not blob:
+            failed.append((pid, st))
+            continue
+        for i, z in zip(mine, pickle.loads(blob)):
+            out[i] = z
+    if failed:
+        raise RuntimeError(f"witness workers failed: {failed}")
+    return out
 
 
 def main():

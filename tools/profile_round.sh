@@ -15,7 +15,7 @@ export ZKHIP_BENCH_CHILD=1     # bench.py measures in this very process (no supe
 run() {     # run <name> <rocprof args> -- <bench args>; env taken from the caller
   name=$1; shift
   rm -rf "$out/prof_$name"
-  timeout 900 rocprofv3 "$@" > "$out/prof_$name.log" 2>&1
+  timeout ${PROF_TIMEOUT:-420} rocprofv3 "$@" > "$out/prof_$name.log" 2>&1
 }
 # 1. pipelined
 run pipelined --kernel-trace --stats -d "$out/prof_pipelined" -o pipelined -- python "$root/bench.py" --cpu-seconds 0 --serial-proofs 0 --e2e 0
