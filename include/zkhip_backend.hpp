@@ -10,6 +10,7 @@
 //   Backend::generate_proof(program, witness, pk, rng)     Hip::generate_proof(scheme, program, witness, pk, rng)
 //   Proof { proof: ProofPoints { a, b, c }, inputs }       Proof / ProofPoints / G1Affine / G2Affine   (lib.rs:33-96, scheme/groth16.rs:8-16)
 //   TaggedProof -> serde_json::to_string_pretty            Proof::to_json()                            (tagged.rs:14-37)
+//   Backend::verify(vk, proof) -> bool                     verify(VerificationKey, Proof) -> bool      (groth16.rs:55-87, gm17.rs:69-110; host CPU)
 //   get_rng_from_entropy(&str) -> StdRng                   get_rng_from_entropy(std::string) -> StdRng (rng.rs:5-20)
 //   StdRng::from_entropy()                                 StdRng::from_os_entropy()
 //   panic!(..) on any failure (groth16.rs:41-44 unwrap)    throws zokrates_hip::Error (code = ZKHIP_ERR_*, message of the library)
@@ -21,6 +22,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -45,7 +47,29 @@ struct Proof {
     ProofPoints proof;
     std::vector<std::string> inputs;      // public_inputs_values as 32-byte big-endian hex (parse_fr, lib.rs:220-226)
     std::string to_json() const;          // serde_json::to_string_pretty of the tagged proof: the text of proof.json
+    static Proof from_json(const std::string& text);      // serde_json::from_value::<Proof<T, S>> (ops/verify.rs:181-182); Error on a malformed file
+    // `zokrates print-proof --format json|remix` (ops/print_proof.rs:85-114): the line to paste into the Solidity verifier; bn128 only
+    std::string print(const std::string& format) const;
 };
+
+// `verification.key` (scheme/groth16.rs:18-25: alpha, beta, gamma, delta, gamma_abc; scheme/gm17.rs:19-27: h, g_alpha, h_beta,
+// g_gamma, h_gamma, query), points as in the file, looked up by the file's field names
+struct VerificationKey {
+    std::string scheme, curve;
+    std::map<std::string, G1Affine> g1;
+    std::map<std::string, G2Affine> g2;
+    std::vector<G1Affine> query;          // gamma_abc (g16) / query (gm17)
+    static VerificationKey from_json(const std::string& text);
+};
+
+// Backend<T, S>::verify(vk, proof) -> bool (zokrates_ark/src/groth16.rs:55-87, gm17.rs:69-110): the pairing check, on the host
+// CPU as in the reference (no GPU, no context; csrc/host/verify.cpp).  bn128 and bls12_381, g16 and gm17.  false: the equation
+// does not hold, or a point is off its curve / outside the r-torsion.  Error: curve or scheme of the two files differ (the CLI's
+// messages, ops/verify.rs:95-107), a coordinate or input is not canonical, the input count does not fit the key (the reference
+// panics through `unwrap` there).
+bool verify(const VerificationKey& vk, const Proof& proof);
+// prod_i e(g1_i, g2_i) == 1 in the target group (the Solidity verifier's `pairing` precompile call, solidity.rs:  pairingProd*)
+bool pairing_product_is_one(const std::string& curve, const std::vector<std::pair<G1Affine, G2Affine>>& pairs);
 
 // rand 0.8.5 `StdRng` (= rand_chacha 0.3.1 ChaCha12Rng): key = seed, 64-bit block counter, words of a block in order
 class StdRng {

@@ -12,4 +12,4 @@ done
 wait
 g++ -shared -o "$HERE/libzkhip_emu.so" "$HERE"/obj/*.o
 # the compiled host side (csrc/host) against the emulator library: the same executable the product ships, for CPU tests
-g++ -O2 -std=c++17 -Wall -pthread "$SRC/host/backend.cpp" "$SRC/host/cli_main.cpp" -L"$HERE" -lzkhip_emu -Wl,-rpath,'$ORIGIN' -o "$HERE/zkhip-cli-emu"
+g++ -O2 -std=c++17 -Wall -pthread "$SRC/host/backend.cpp" "$SRC/host/verify.cpp" "$SRC/host/cli_main.cpp" -L"$HERE" -lzkhip_emu -Wl,-rpath,'$ORIGIN' -o "$HERE/zkhip-cli-emu"

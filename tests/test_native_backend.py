@@ -91,6 +91,19 @@ def _both_clis(paths, scheme, exe, env):
         outs[who] = (open(pkp, "rb").read(), open(vkp).read())
     assert outs["py"][0] == outs["cpp"][0] and outs["py"][1] == outs["cpp"][1]
     assert json.loads(outs["cpp"][1])["scheme"] == scheme
+    # the whole trait in one chain: setup -> generate-proof -> verify (csrc/host/verify.cpp, no GPU in that step) says PASSED,
+    # and FAILED once a public input is changed
+    chain = paths["proof_cpp.json"] + ".chain"
+    r = subprocess.run([exe, "generate-proof", "-i", paths["out"], "-w", paths["witness"], "-p", paths["proving.key"] + ".cpp", "-j", chain, "-s", scheme],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "verify", "-v", paths["proving.key"] + ".vk.cpp", "-j", chain], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.split()[-1] == "PASSED", (r.stdout, r.stderr)
+    forged = json.load(open(chain))
+    forged["inputs"][-1] = "0x" + (int(forged["inputs"][-1], 16) ^ 1).to_bytes(32, "big").hex()
+    json.dump(forged, open(chain, "w"))
+    r = subprocess.run([exe, "verify", "-v", paths["proving.key"] + ".vk.cpp", "-j", chain], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.split()[-1] == "FAILED", (r.stdout, r.stderr)
     doc = json.load(open(paths["proof_cpp.json"]))
     assert doc["scheme"] == scheme and len(doc["inputs"]) == 3 and doc["inputs"][0] == "0x" + (9).to_bytes(32, "big").hex()
     # failures: message on stderr, exit status 1 (the reference's panic hook + exit(1))

@@ -69,8 +69,8 @@ CLI = os.path.join(HERE, "zkhip-cli")
 def build_cli(force=False, verbose=False):
     """The compiled host side (include/zkhip_backend.hpp, csrc/host/backend.cpp) and its `generate-proof` executable: plain C++17
     over the C ABI, linked against the in-tree libzkhip.so (found next to the executable through $ORIGIN)."""
-    srcs = [os.path.join(CSRC, "host", f) for f in ("backend.cpp", "cli_main.cpp")]
-    deps = srcs + [os.path.join(HERE, "..", "include", h) for h in ("zkhip.h", "zkhip_backend.hpp")] + [LIB]
+    srcs = [os.path.join(CSRC, "host", f) for f in ("backend.cpp", "verify.cpp", "cli_main.cpp")]
+    deps = srcs + [os.path.join(HERE, "..", "include", h) for h in ("zkhip.h", "zkhip_backend.hpp")] + [os.path.join(CSRC, h) for h in ("field.cuh", "fieldu.cuh", "ec.cuh")] + [LIB]
     if not force and not _newer(CLI, deps):
         return CLI
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread"] + srcs + ["-L" + HERE, "-lzkhip", "-Wl,-rpath,$ORIGIN", "-Wl,--allow-shlib-undefined", "-o", CLI]

@@ -10,6 +10,8 @@ Needs a gfx950 GPU (there is no CPU fallback).
 
     python -m zokrates_amd.cli setup          -i circuit.r1cs|out -p proving.key -v verification.key [-s g16|gm17] [--entropy TEXT]
     python -m zokrates_amd.cli generate-proof -i circuit.r1cs|out -w witness.wtns|witness -p proving.key -j proof.json [-s g16|gm17]
+    python -m zokrates_amd.cli verify         -v verification.key -j proof.json        (the compiled verifier: no GPU needed)
+    python -m zokrates_amd.cli print-proof    -j proof.json -f remix|json
 """
 import argparse
 import hashlib
@@ -189,7 +191,21 @@ def cmd_generate_proof(args):
         print("timings " + json.dumps(marks))
 
 
+def cmd_native(args):
+    """`verify` / `print-proof`: the pairing check and the proof printer live in the compiled host layer (csrc/host/verify.cpp,
+    /root/reference/zokrates_cli/src/ops/{verify,print_proof}.rs); this shim hands the command to the executable next to the
+    library and leaves with its exit status."""
+    exe = os.environ.get("ZKHIP_CLI") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "zkhip-cli")
+    if not os.access(exe, os.X_OK):
+        raise SystemExit(f"{exe} is missing: python -m zokrates_amd.build builds it next to libzkhip.so")
+    sys.stdout.flush()
+    os.execv(exe, [exe, args.cmd] + args.rest)
+
+
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if argv and argv[0] in ("verify", "print-proof"):
+        return cmd_native(argparse.Namespace(cmd=argv[0], rest=argv[1:]))
     ap = argparse.ArgumentParser(prog="zokrates_amd.cli")
     sub = ap.add_subparsers(dest="cmd", required=True)
     s = sub.add_parser("setup")

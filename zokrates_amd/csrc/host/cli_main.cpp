@@ -61,7 +61,9 @@ uint64_t fnv1a(const std::string& s) {
 int usage() {
     fprintf(stderr, "usage: zkhip-cli generate-proof -i <out> -w <witness> -p <proving.key> -j <proof.json> [-s g16|gm17] [--entropy TEXT] "
                     "[--key-cache DIR] [--device N] [--timings]\n"
-                    "       zkhip-cli setup -i <out> -p <proving.key> -v <verification.key> [-s g16|gm17] [--entropy TEXT] [--device N]\n");
+                    "       zkhip-cli setup -i <out> -p <proving.key> -v <verification.key> [-s g16|gm17] [--entropy TEXT] [--device N]\n"
+                    "       zkhip-cli verify [-v <verification.key>] [-j <proof.json>]\n"
+                    "       zkhip-cli print-proof [-j <proof.json>] [-f remix|json]\n");
     return 2;
 }
 }  // namespace
@@ -104,8 +106,78 @@ int cmd_setup(int argc, char** argv) {
     }
 }
 
+static std::string slurp(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error(ZKHIP_ERR_BAD_ARG, "Could not open " + path);
+    return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+// zkhip-cli verify -v verification.key -j proof.json      (/root/reference/zokrates_cli/src/ops/verify.rs:49-195: curve and scheme
+// come from the two files and must agree; "Performing verification..." then PASSED or FAILED, exit status 0 for both; no GPU)
+int cmd_verify(int argc, char** argv) {
+    std::string vk_path = "verification.key", proof_path = "proof.json";
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
+        if (a == "-v" || a == "--verification-key-path") vk_path = val();
+        else if (a == "-j" || a == "--proof-path") proof_path = val();
+        else if (a == "-b" || a == "--backend") val();          // accepted and ignored: there is one verifier here
+        else return usage();
+    }
+    try {
+        const VerificationKey vk = VerificationKey::from_json(slurp(vk_path));
+        const Proof proof = Proof::from_json(slurp(proof_path));
+        printf("Performing verification...\n");
+        printf("%s\n", verify(vk, proof) ? "PASSED" : "FAILED");
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+}
+
+// zkhip-cli print-proof -j proof.json -f remix|json       (zokrates_cli/src/ops/print_proof.rs)
+int cmd_print_proof(int argc, char** argv) {
+    std::string proof_path = "proof.json", format = "remix";
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
+        if (a == "-j" || a == "--proof-path") proof_path = val();
+        else if (a == "-f" || a == "--format") format = val();
+        else return usage();
+    }
+    try {
+        fputs(Proof::from_json(slurp(proof_path)).print(format).c_str(), stdout);
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+}
+
+// zkhip-cli pairing-check <curve> <file>: the file holds lines "g1x g1y g2x0 g2x1 g2y0 g2y1" (hex as in proof.json); prints ONE or
+// NOT-ONE for the product of the pairings (a test hook for the pairing itself: bilinearity on the reference's MPC fixture points)
+int cmd_pairing_check(int argc, char** argv) {
+    if (argc != 4) return usage();
+    try {
+        std::ifstream f(argv[3]);
+        if (!f) throw Error(ZKHIP_ERR_BAD_ARG, std::string("Could not open ") + argv[3]);
+        std::vector<std::pair<G1Affine, G2Affine>> pairs;
+        std::string w[6];
+        while (f >> w[0] >> w[1] >> w[2] >> w[3] >> w[4] >> w[5]) pairs.push_back({G1Affine{w[0], w[1]}, G2Affine{{w[2], w[3]}, {w[4], w[5]}}});
+        printf("%s\n", pairing_product_is_one(argv[2], pairs) ? "ONE" : "NOT-ONE");
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "setup") == 0) return cmd_setup(argc, argv);
+    if (argc >= 2 && strcmp(argv[1], "verify") == 0) return cmd_verify(argc, argv);
+    if (argc >= 2 && strcmp(argv[1], "print-proof") == 0) return cmd_print_proof(argc, argv);
+    if (argc >= 2 && strcmp(argv[1], "pairing-check") == 0) return cmd_pairing_check(argc, argv);
     if (argc < 2 || strcmp(argv[1], "generate-proof") != 0) return usage();
     std::string input = "out", witness_path = "witness", pk_path = "proving.key", proof_path = "proof.json", scheme_s = "g16", entropy, cache_dir;
     bool have_entropy = false, timings = false;
