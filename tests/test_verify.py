@@ -264,3 +264,21 @@ def test_proof_json_round_trip_through_the_cpp_reader(tmp_path):
     for name in ("compact.json", "spaced.json"):
         r = _run(["verify", "-v", p("vk_compact.key"), "-j", p(name)], env)
         assert r.returncode == 0 and r.stdout.split()[-1] == "PASSED", (name, r.stderr)
+
+
+def test_mutated_files_never_crash_the_verifier(tmp_path):
+    """tests/host/verify_fuzz.cpp under ASan + UBSan: 600 byte-level mutations of a (verification key, proof) pair; a verdict or an
+    Error every time, and PASSED only when the parsed values are the original ones."""
+    env = _env()
+    d = str(tmp_path)
+    _program_files(d, BN254)
+    p = lambda name: os.path.join(d, name)
+    assert _run(["setup", "-i", p("out"), "-p", p("proving.key"), "-v", p("verification.key"), "--entropy", "fz"], env).returncode == 0
+    assert _run(["generate-proof", "-i", p("out"), "-w", p("witness"), "-p", p("proving.key"), "-j", p("proof.json"), "--entropy", "fz"], env).returncode == 0
+    exe = p("verify_fuzz")
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17",
+                           os.path.join(HERE, "host", "verify_fuzz.cpp"), os.path.join(root, "zokrates_amd", "csrc", "host", "verify.cpp"), "-o", exe])
+    r = subprocess.run([exe, p("verification.key"), p("proof.json"), "600", "11"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.startswith("verified ") and "errors" in r.stdout
