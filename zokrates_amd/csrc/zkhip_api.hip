@@ -102,6 +102,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         // made now, the others when a batch call first needs them (slot_init: 20 ms of stream and event creation each, which a
         // one-proof process never spends).
         ctx->g2_first = env_int("ZKHIP_G2_PRIORITY", 0, 1, 1) != 0;
+        ctx->fold3_min_h = (u32)env_int("ZKHIP_FOLD3_MIN_H", 4, 1 << 20, 512);
         slot_init(ctx.get(), ctx->slots[0]);
 #ifdef ZK_EMU
         ctx->desc = "zkhip TEST EMULATOR (not a product build)";
