@@ -68,6 +68,8 @@ struct VerificationKey {
 // messages, ops/verify.rs:95-107), a coordinate or input is not canonical, the input count does not fit the key (the reference
 // panics through `unwrap` there).
 bool verify(const VerificationKey& vk, const Proof& proof);
+// the text of `verification.key` for the key at the head of an ark proving key (ProvingKey { vk, .. }); Error if the bytes are too short
+std::string verification_key_json(Scheme scheme, int32_t curve, const uint8_t* proving_key, size_t len);
 // prod_i e(g1_i, g2_i) == 1 in the target group (the Solidity verifier's `pairing` precompile call, solidity.rs:  pairingProd*)
 bool pairing_product_is_one(const std::string& curve, const std::vector<std::pair<G1Affine, G2Affine>>& pairs);
 

@@ -282,3 +282,28 @@ def test_mutated_files_never_crash_the_verifier(tmp_path):
     r = subprocess.run([exe, p("verification.key"), p("proof.json"), "600", "11"], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert r.stdout.startswith("verified ") and "errors" in r.stdout
+
+
+@pytest.mark.parametrize("scheme", ["g16", "gm17"])
+def test_generate_proof_with_self_check(tmp_path, scheme):
+    """`zkhip-cli generate-proof --verify`: the proof is checked against the verification key at the head of the proving key before
+    the process reports success; an assignment that does not satisfy the program yields no proof.json and exit status 1."""
+    env = _env()
+    d = str(tmp_path)
+    _program_files(d, BN254)
+    p = lambda name: os.path.join(d, name)
+    assert _run(["setup", "-i", p("out"), "-p", p("proving.key"), "-v", p("verification.key"), "-s", scheme, "--entropy", "sc"], env).returncode == 0
+    r = _run(["generate-proof", "-i", p("out"), "-w", p("witness"), "-p", p("proving.key"), "-j", p("proof.json"), "-s", scheme, "--verify", "--timings"], env)
+    assert r.returncode == 0 and "verified against the verification key" in r.stdout, (r.stdout, r.stderr)
+    tm = json.loads([l for l in r.stdout.splitlines() if l.startswith("timings ")][0][8:])
+    assert tm["verify_ms"] > 0
+    # the key's own verification key is the one `setup` wrote
+    assert _run(["verify", "-v", p("verification.key"), "-j", p("proof.json")], env).stdout.split()[-1] == "PASSED"
+    a, b = 7, 9
+    open(p("bad_witness"), "wb").write(ir.serialize_witness({0: 1, 1: a, 2: b, 3: a * b + 1, -1: a * b, -2: a * b + b}))
+    r = _run(["generate-proof", "-i", p("out"), "-w", p("bad_witness"), "-p", p("proving.key"), "-j", p("bad_proof.json"), "-s", scheme, "--verify"], env)
+    assert r.returncode == 1 and "does not verify" in r.stderr and not os.path.exists(p("bad_proof.json")), (r.stdout, r.stderr)
+    # without the self check the same run writes a proof — which `verify` then refuses
+    r = _run(["generate-proof", "-i", p("out"), "-w", p("bad_witness"), "-p", p("proving.key"), "-j", p("bad_proof.json"), "-s", scheme], env)
+    assert r.returncode == 0
+    assert _run(["verify", "-v", p("verification.key"), "-j", p("bad_proof.json")], env).stdout.split()[-1] == "FAILED"

@@ -317,7 +317,6 @@ std::string json_g1_list(const uint8_t* p, uint64_t count, size_t fq) {
 
 SetupKeypair Hip::setup(Scheme scheme, const Program& program, StdRng& rng) {
     const int32_t curve = program.curve();
-    const size_t fq = curve == ZKHIP_CURVE_BN128 ? 32 : 48, g1 = 2 * fq, g2 = 4 * fq;
     std::array<uint8_t, 32> tox[5];
     for (int k = 0; k < 5;) {                                   // alpha, beta, gamma, delta, tau: redrawn while zero
         tox[k] = fr_rand(rng, curve);
@@ -347,34 +346,42 @@ SetupKeypair Hip::setup(Scheme scheme, const Program& program, StdRng& rng) {
     }
     zkhip_r1cs_free(cs);
     check(rc);
-    const uint8_t* pk = kp.pk.data();
+    kp.vk = verification_key_json(scheme, curve, kp.pk.data(), kp.pk.size());
+    return kp;
+}
+
+// The verification key sits at the head of ark's proving key (ProvingKey { vk, .. }: serialize_unchecked writes it first):
+// g16: alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1[]; gm17: h_g2, g_alpha_g1, h_beta_g2, g_gamma_g1, h_gamma_g2, query[].
+std::string verification_key_json(Scheme scheme, int32_t curve, const uint8_t* pk, size_t len) {
+    if (curve != ZKHIP_CURVE_BN128 && curve != ZKHIP_CURVE_BLS12_381) throw Error(ZKHIP_ERR_BAD_ARG, "verification_key_json: unsupported curve");
+    const size_t fq = curve == ZKHIP_CURVE_BN128 ? 32 : 48, g1 = 2 * fq, g2 = 4 * fq;
+    const size_t fixed = scheme == Scheme::GM17 ? 2 * g1 + 3 * g2 : g1 + 3 * g2;
+    if (!pk || len < fixed + 8) throw Error(ZKHIP_ERR_PARSE, "proving key too short for its verification key");
+    uint64_t count;
+    memcpy(&count, pk + fixed, 8);
+    if (count > (len - fixed - 8) / g1) throw Error(ZKHIP_ERR_PARSE, "proving key too short for its verification key");
     const std::string cname = curve == ZKHIP_CURVE_BN128 ? "bn128" : "bls12_381";
     std::string s = "{\n";
-    if (scheme == Scheme::GM17) {      // vk = h_g2, g_alpha_g1, h_beta_g2, g_gamma_g1, h_gamma_g2, query[]   (scheme/gm17.rs:19-27)
+    if (scheme == Scheme::GM17) {      // (scheme/gm17.rs:19-27)
         size_t pos = 0;
         const uint8_t *h = pk; pos += g2;
         const uint8_t* g_alpha = pk + pos; pos += g1;
         const uint8_t* h_beta = pk + pos; pos += g2;
         const uint8_t* g_gamma = pk + pos; pos += g1;
         const uint8_t* h_gamma = pk + pos; pos += g2;
-        uint64_t nq;
-        memcpy(&nq, pk + pos, 8);
         s += "  \"scheme\": \"gm17\",\n  \"curve\": \"" + cname + "\",\n";
         s += "  \"h\": " + json_g2(h, fq, "  ") + ",\n  \"g_alpha\": " + json_g1(g_alpha, fq, "  ") + ",\n  \"h_beta\": " + json_g2(h_beta, fq, "  ") + ",\n";
         s += "  \"g_gamma\": " + json_g1(g_gamma, fq, "  ") + ",\n  \"h_gamma\": " + json_g2(h_gamma, fq, "  ") + ",\n";
-        s += "  \"query\": " + json_g1_list(pk + pos + 8, nq, fq) + "\n}";
-    } else {                           // vk = alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1[]            (scheme/groth16.rs:18-25)
-        const size_t off = g1 + 3 * g2;
-        uint64_t n_abc;
-        memcpy(&n_abc, pk + off, 8);
+        s += "  \"query\": " + json_g1_list(pk + pos + 8, count, fq) + "\n}";
+    } else {                           // (scheme/groth16.rs:18-25)
         s += "  \"scheme\": \"g16\",\n  \"curve\": \"" + cname + "\",\n";
         s += "  \"alpha\": " + json_g1(pk, fq, "  ") + ",\n  \"beta\": " + json_g2(pk + g1, fq, "  ") + ",\n";
         s += "  \"gamma\": " + json_g2(pk + g1 + g2, fq, "  ") + ",\n  \"delta\": " + json_g2(pk + g1 + 2 * g2, fq, "  ") + ",\n";
-        s += "  \"gamma_abc\": " + json_g1_list(pk + off + 8, n_abc, fq) + "\n}";
+        s += "  \"gamma_abc\": " + json_g1_list(pk + fixed + 8, count, fq) + "\n}";
     }
-    kp.vk = s;
-    return kp;
+    return s;
 }
+
 
 Proof Hip::generate_proof(Scheme scheme, const uint8_t* program, size_t program_len, const uint8_t* witness, size_t witness_len,
                           const uint8_t* proving_key, size_t proving_key_len, StdRng& rng) {

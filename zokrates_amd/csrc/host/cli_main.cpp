@@ -1,7 +1,7 @@
 // zkhip-cli — `zokrates generate-proof` for the hip backend, as a native executable over zkhip_backend.hpp.
 //
 //   zkhip-cli generate-proof -i out -w witness -p proving.key -j proof.json [-s g16|gm17] [--entropy TEXT]
-//                            [--key-cache DIR] [--device N] [--timings]
+//                            [--key-cache DIR] [--device N] [--timings] [--verify]
 //
 // Mirrors /root/reference/zokrates_cli/src/ops/generate_proof.rs:95-202: the compiled program (`out`), the witness and the
 // proving key are read from files, the proof is written as JSON, one proof per process; `--entropy` seeds the RNG as
@@ -60,7 +60,7 @@ uint64_t fnv1a(const std::string& s) {
 }
 int usage() {
     fprintf(stderr, "usage: zkhip-cli generate-proof -i <out> -w <witness> -p <proving.key> -j <proof.json> [-s g16|gm17] [--entropy TEXT] "
-                    "[--key-cache DIR] [--device N] [--timings]\n"
+                    "[--key-cache DIR] [--device N] [--timings] [--verify]\n"
                     "       zkhip-cli setup -i <out> -p <proving.key> -v <verification.key> [-s g16|gm17] [--entropy TEXT] [--device N]\n"
                     "       zkhip-cli verify [-v <verification.key>] [-j <proof.json>]\n"
                     "       zkhip-cli print-proof [-j <proof.json>] [-f remix|json]\n");
@@ -180,12 +180,13 @@ int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "pairing-check") == 0) return cmd_pairing_check(argc, argv);
     if (argc < 2 || strcmp(argv[1], "generate-proof") != 0) return usage();
     std::string input = "out", witness_path = "witness", pk_path = "proving.key", proof_path = "proof.json", scheme_s = "g16", entropy, cache_dir;
-    bool have_entropy = false, timings = false;
+    bool have_entropy = false, timings = false, self_check = false;
     int device = 0;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
         if (a == "-i" || a == "--input") input = val();
+        else if (a == "--verify") self_check = true;
         else if (a == "-w" || a == "--witness") witness_path = val();
         else if (a == "-p" || a == "--proving-key-path") pk_path = val();
         else if (a == "-j" || a == "--proof-path") proof_path = val();
@@ -302,12 +303,35 @@ int main(int argc, char** argv) {
             o << proof.to_json();
         }
         const double ms_json = ms_since(t0);
+        // --verify: the proof just written against the verification key at the head of the proving key, on the host CPU
+        // (csrc/host/verify.cpp; ~40 ms on bn128) — a proof the pairing check refuses is an error, not an output
+        double ms_verify = 0;
+        if (self_check) {
+            t0 = std::chrono::steady_clock::now();
+            // only the head of the key file is read: the fixed points, the count, then that many G1 points
+            const size_t fq = curve == ZKHIP_CURVE_BN128 ? 32 : 48, fixed = scheme == Scheme::GM17 ? 16 * fq : 14 * fq;
+            std::vector<uint8_t> head(fixed + 8);
+            std::ifstream kf(pk_path, std::ios::binary);
+            if (!kf.read((char*)head.data(), (std::streamsize)head.size())) throw Error(ZKHIP_ERR_PARSE, "proving key too short for its verification key");
+            uint64_t count;
+            memcpy(&count, head.data() + fixed, 8);
+            if (count > (1u << 24)) throw Error(ZKHIP_ERR_PARSE, "proving key: implausible number of public inputs");
+            head.resize(fixed + 8 + count * 2 * fq);
+            if (count && !kf.read((char*)head.data() + fixed + 8, (std::streamsize)(count * 2 * fq))) throw Error(ZKHIP_ERR_PARSE, "proving key too short for its verification key");
+            const VerificationKey vk = VerificationKey::from_json(verification_key_json(scheme, curve, head.data(), head.size()));
+            if (!verify(vk, proof)) {
+                remove(proof_path.c_str());
+                throw Error(ZKHIP_ERR_UNSATISFIED, "the proof does not verify against the key of " + pk_path + " (witness not satisfying the program, or a key for another program)");
+            }
+            ms_verify = ms_since(t0);
+            printf("verified against the verification key of %s\n", pk_path.c_str());
+        }
         printf("generate-proof (%s): wrote %s\n", scheme_s.c_str(), proof_path.c_str());
         if (timings)
             printf("timings {\"read_program_and_witness_ms\": %.3f, \"parse_program_ms\": %.3f, \"hip_init_ms\": %.3f, \"key_load_ms\": %.3f, "
                    "\"wait_for_host_side_ms\": %.3f, \"witness_to_assignment_ms\": %.3f, \"r1cs_upload_ms\": %.3f, \"prove_ms\": %.3f, "
-                   "\"proof_json_ms\": %.3f, \"total_in_process_ms\": %.3f, \"key_source\": \"%s\", \"constraints\": %llu}\n",
-                   ms_read, ms_parse, ms_init, ms_key, ms_wait, tm.witness_to_assignment, tm.r1cs_upload, tm.prove, ms_json, ms_since(t_start),
+                   "\"proof_json_ms\": %.3f, \"verify_ms\": %.3f, \"total_in_process_ms\": %.3f, \"key_source\": \"%s\", \"constraints\": %llu}\n",
+                   ms_read, ms_parse, ms_init, ms_key, ms_wait, tm.witness_to_assignment, tm.r1cs_upload, tm.prove, ms_json, ms_verify, ms_since(t_start),
                    key_source.c_str(), (unsigned long long)program->constraints());
         // one proof per process: the proof is on disk, so leave without tearing down 6 GiB of tables and the HIP runtime
         fflush(stdout);
