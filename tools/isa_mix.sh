@@ -6,7 +6,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -Wno-unused-variable --cuda-device-only -S \
-  $ISA_FLAGS "$root/zokrates_amd/csrc/bn254_g1.hip" -o "$tmp/g1.s" 2>/dev/null
+  ${ISA_FLAGS:-} "$root/zokrates_amd/csrc/bn254_g1.hip" -o "$tmp/g1.s" 2>/dev/null
 python3 - "$tmp/g1.s" <<'PY' | tee "${1:-/dev/stdout}"
 import re, sys, collections
 src = open(sys.argv[1]).read().split("\n")
