@@ -63,7 +63,8 @@ struct VerificationKey {
 };
 
 // Backend<T, S>::verify(vk, proof) -> bool (zokrates_ark/src/groth16.rs:55-87, gm17.rs:69-110): the pairing check, on the host
-// CPU as in the reference (no GPU, no context; csrc/host/verify.cpp).  bn128 and bls12_381, g16 and gm17.  false: the equation
+// CPU as in the reference (no GPU, no context; csrc/host/verify.cpp).  bn128, bls12_381 and — for the reference's own golden proofs —
+// bls12_377; g16 and gm17.  false: the equation
 // does not hold, or a point is off its curve / outside the r-torsion.  Error: curve or scheme of the two files differ (the CLI's
 // messages, ops/verify.rs:95-107), a coordinate or input is not canonical, the input count does not fit the key (the reference
 // panics through `unwrap` there).

@@ -8,6 +8,10 @@ What pins it:
     leg) PASS, the mutations the reference tests reject (to_token.rs:68-71: a.x overwritten; a valid but different point; a
     different public input) FAIL, and the oracle's independent pairing (oracle/pairing.py, oracle/gm17.py: flat degree-12
     arithmetic, Miller loop in Fq12) gives the same verdict on the same files;
+  * THE REFERENCE'S OWN PROOFS: the four GM17 artefacts the reference ships — zokrates_stdlib/tests/tests/snark/gm17.json and
+    zokrates_core_test/tests/tests/snark/snark_verify_bls12_377_{1,2,5}.json, made by `zokrates setup / generate-proof -b ark -s gm17`
+    over BLS12-377 (tests/golden/gm17_bls12_377_*.json) — PASS, and fail once an input is changed: the compiled verifier knows
+    that curve for exactly this purpose;
   * bilinearity on BLS12-381 with oracle-made multiples of the generators;
   * the CLI's messages and exit codes (ops/verify.rs:95-107,181-195) and `print-proof` (ops/print_proof.rs:85-114)."""
 import json
@@ -307,3 +311,41 @@ def test_generate_proof_with_self_check(tmp_path, scheme):
     r = _run(["generate-proof", "-i", p("out"), "-w", p("bad_witness"), "-p", p("proving.key"), "-j", p("bad_proof.json"), "-s", scheme], env)
     assert r.returncode == 0
     assert _run(["verify", "-v", p("verification.key"), "-j", p("bad_proof.json")], env).stdout.split()[-1] == "FAILED"
+
+
+def test_reference_gm17_artefacts_over_bls12_377(tmp_path, golden_dir):
+    """Proofs the reference itself generated (ark backend, GM17, BLS12-377) through the compiled verifier: PASSED as they are,
+    FAILED with a changed input, FAILED with the two halves of B's coordinates swapped ([c1, c0] is not the encoding)."""
+    p = lambda name: os.path.join(str(tmp_path), name)
+    cases = []
+    d = json.load(open(os.path.join(golden_dir, "gm17_bls12_377_triple.json")))
+    assert d["curve"] == "bls12_377" and d["expected"] is True
+    cases.append(("stdlib_gm17", dict(d["vk"]), d["proof"], d["inputs"]))
+    e = json.load(open(os.path.join(golden_dir, "gm17_bls12_377_embed_triples.json")))
+    assert e["curve"] == "bls12_377" and len(e["triples"]) == 3
+    h48 = lambda v: _hex(int(v), 48)
+    g1 = lambda a, i: [h48(a[i]), h48(a[i + 1])]
+    g2 = lambda a, i: [[h48(a[i]), h48(a[i + 1])], [h48(a[i + 2]), h48(a[i + 3])]]
+    for k, t in enumerate(e["triples"]):
+        pr, v = t["proof"], t["vk"]
+        n_in = len(t["inputs"])
+        vk = {"h": g2(v, 0), "g_alpha": g1(v, 4), "h_beta": g2(v, 6), "g_gamma": g1(v, 10), "h_gamma": g2(v, 12),
+              "query": [g1(v, 16 + 2 * i) for i in range(n_in + 1)]}
+        cases.append(("core_test_%d" % k, vk, {"a": g1(pr, 0), "b": g2(pr, 2), "c": g1(pr, 6)}, [_hex(int(x), 32) for x in t["inputs"]]))
+    env = _env()
+    for name, vk, pts, inputs in cases:
+        vk = dict(vk, scheme="gm17", curve="bls12_377")
+        json.dump(vk, open(p(name + ".key"), "w"))
+
+        def verdict(points, ins):
+            json.dump({"scheme": "gm17", "curve": "bls12_377", "proof": points, "inputs": ins}, open(p(name + ".json"), "w"))
+            r = _run(["verify", "-v", p(name + ".key"), "-j", p(name + ".json")], env)
+            assert r.returncode == 0, (name, r.stderr)
+            return r.stdout.split()[-1]
+
+        assert verdict(pts, inputs) == "PASSED", name
+        changed = list(inputs)
+        changed[-1] = _hex(int(changed[-1], 16) + 1, 32)
+        assert verdict(pts, changed) == "FAILED", name
+        swapped = dict(pts, b=[pts["b"][0][::-1], pts["b"][1][::-1]])
+        assert verdict(swapped, inputs) == "FAILED", name

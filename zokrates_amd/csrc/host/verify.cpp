@@ -10,6 +10,7 @@
 // (scheme/gm17.rs:170-195).  This is SURVEY.md §8 row N4: it stays on the CPU; it exists here so that the compiled host layer
 // holds the whole trait (generate_proof, setup, verify) and `zkhip-cli verify` can say PASSED / FAILED as
 // zokrates_cli/src/ops/verify.rs:188-195 does.  Product code: it shares nothing with oracle/pairing.py (the tests compare them).
+// Known answers: the reference's own GM17 proofs (made by its ark backend over BLS12-377, tests/golden/gm17_bls12_377_*.json) verify here.
 //
 // How: the Miller loop runs on the TWIST in affine Fq2 coordinates and multiplies sparse line values into one Fq12
 // accumulator for all pairs (one squaring per loop bit whatever the number of pairs).  Fq12 = Fq2[w] / (w^6 - xi) as six
@@ -26,6 +27,69 @@
 
 #include "../ec.cuh"
 #include "../../../include/zkhip_backend.hpp"
+
+namespace zk {
+// BLS12-377 is not a curve libzkhip proves over; the verifier knows it so that it can be held against the reference's own GM17
+// artefacts, all of which are over this curve (zokrates_stdlib/tests/tests/snark/gm17.json and zokrates_core_test/tests/tests/
+// snark/snark_verify_bls12_377_{1,2,5}.json: proofs made by `zokrates generate-proof -b ark -s gm17`).  [UPSTREAM] ark-bls12-377
+// 0.3.0: q (377 bits), r (253 bits), y^2 = x^3 + 1, Fq2 = Fq[u]/(u^2 + 5), Fq6 = Fq2[v]/(v^3 - u), twist y^2 = x^3 + 1/u (type D),
+// x = 0x8508c00000000001.  Montgomery constants as field.cuh defines them (R = 2^384).
+struct Bls377Fr {
+    static constexpr int N = 8;
+    static constexpr int BITS = 253;
+    ZK_TABLE(mod, 8, 0x00000001u, 0x0a118000u, 0xd0000001u, 0x59aa76feu, 0x5c37b001u, 0x60b44d1eu, 0x9a2ca556u, 0x12ab655eu)
+};
+struct Bls377Fq {
+    static constexpr int N = 12;
+    static constexpr int BITS = 377;
+    static constexpr u32 INV = 0xffffffffu;
+    ZK_TABLE(mod, 12, 0x00000001u, 0x8508c000u, 0x30000000u, 0x170b5d44u, 0xba094800u, 0x1ef3622fu, 0x00f5138fu, 0x1a22d9f3u, 0x6ca1493bu,
+             0xc63b05c0u, 0x17c510eau, 0x01ae3a46u)
+    ZK_TABLE(r1, 12, 0xffffff68u, 0x02cdffffu, 0x7fffffb1u, 0x51409f83u, 0x8a7d3ff2u, 0x9f7db3a9u, 0x6e7c6305u, 0x7b4e97b7u, 0x803c84e8u,
+             0x4cf495bfu, 0xe2fdf49au, 0x008d6661u)
+    ZK_TABLE(r2, 12, 0x9400cd22u, 0xb786686cu, 0xb00431b1u, 0x0329fcaau, 0x62d6b46du, 0x22a5f111u, 0x827dc3acu, 0xbfdf7d03u, 0x41790bf9u,
+             0x837e92f0u, 0x1e914b88u, 0x006dfccbu)
+};
+
+// Fq2 = Fq[u] / (u^2 + BETA) for the verifier: BETA = 1 for BN254 and BLS12-381 (field.cuh's Fe2), 5 for BLS12-377.  With the
+// overloads below the group law of ec.cuh (Xyzz<F>) works over it unchanged.
+template <class P> struct QBeta { static constexpr u32 value = 1; };
+template <> struct QBeta<Bls377Fq> { static constexpr u32 value = 5; };
+template <class P>
+struct Q2 {
+    typedef P Params;
+    Fe<P> c0, c1;
+    static Q2 zero() { return {Fe<P>::zero(), Fe<P>::zero()}; }
+    static Q2 one() { return {Fe<P>::one(), Fe<P>::zero()}; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    bool equals(const Q2& o) const { return c0.equals(o.c0) && c1.equals(o.c1); }
+};
+template <class P> inline Fe<P> q2_times_beta(const Fe<P>& x) {
+    if (QBeta<P>::value == 1) return x;
+    Fe<P> r = Fe<P>::zero(), t = x;
+    for (u32 k = QBeta<P>::value; k; k >>= 1, t = fe_dbl(t))
+        if (k & 1) r = fe_add(r, t);
+    return r;
+}
+template <class P> inline Q2<P> fe_add(const Q2<P>& a, const Q2<P>& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
+template <class P> inline Q2<P> fe_sub(const Q2<P>& a, const Q2<P>& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
+template <class P> inline Q2<P> fe_neg(const Q2<P>& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
+template <class P> inline Q2<P> fe_dbl(const Q2<P>& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
+template <class P> inline Q2<P> fe_mul(const Q2<P>& a, const Q2<P>& b) {      // Karatsuba: (a0 b0 - beta a1 b1) + ((a0 + a1)(b0 + b1) - a0 b0 - a1 b1) u
+    const Fe<P> v0 = fe_mul(a.c0, b.c0), v1 = fe_mul(a.c1, b.c1), s = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
+    return {fe_sub(v0, q2_times_beta(v1)), fe_sub(fe_sub(s, v0), v1)};
+}
+template <class P> inline Q2<P> fe_sqr(const Q2<P>& a) { return fe_mul(a, a); }
+template <class P> inline Q2<P> fe_inv(const Q2<P>& a) {                        // (a0 - a1 u) / (a0^2 + beta a1^2)
+    const Fe<P> n = fe_inv(fe_add(fe_sqr(a.c0), q2_times_beta(fe_sqr(a.c1))));
+    return {fe_mul(a.c0, n), fe_neg(fe_mul(a.c1, n))};
+}
+template <class P> inline Q2<P> ec_mul(const Q2<P>& a, const Q2<P>& b) { return fe_mul(a, b); }
+template <class P> inline Q2<P> ec_sqr(const Q2<P>& a) { return fe_sqr(a); }
+template <int K, class P> inline Q2<P> fe_sub_k(const Q2<P>& a, const Q2<P>& b) { return fe_sub(a, b); }
+template <class P> inline Q2<P> fe_relax(const Q2<P>& a) { return a; }
+template <class P> inline bool fe_is_zero_modp(const Q2<P>& a) { return a.is_zero(); }
+}  // namespace zk
 
 namespace zokrates_hip {
 namespace {
@@ -94,18 +158,24 @@ Big big_divmod(const Big& a, const Big& b, Big* rem) {
 }
 
 // ---------------- per-curve facts ----------------
-template <class P> struct PairingCfg;
+template <class P> struct PairingCfg;      // XI0: xi = XI0 + u; LOOP: the ate loop count t - 1 (0: p - r, the BN case)
 template <> struct PairingCfg<Bn254Fq> {     // y^2 = x^3 + 3; twist y^2 = x^3 + 3 / xi (type D), xi = 9 + u
     typedef Bn254Fr Fr;
     static constexpr u32 XI0 = 9, B = 3;
     static constexpr bool D_TWIST = true;
-    static constexpr const char* NAME = "bn128";
+    static constexpr u64 LOOP = 0;
 };
-template <> struct PairingCfg<Bls381Fq> {    // y^2 = x^3 + 4; twist y^2 = x^3 + 4 xi (type M), xi = 1 + u
+template <> struct PairingCfg<Bls381Fq> {    // y^2 = x^3 + 4; twist y^2 = x^3 + 4 xi (type M), xi = 1 + u; |x| = 0xd201000000010000
     typedef Bls381Fr Fr;
     static constexpr u32 XI0 = 1, B = 4;
     static constexpr bool D_TWIST = false;
-    static constexpr const char* NAME = "bls12_381";
+    static constexpr u64 LOOP = 0xd201000000010000ull;
+};
+template <> struct PairingCfg<Bls377Fq> {    // y^2 = x^3 + 1; twist y^2 = x^3 + 1 / xi (type D), xi = u (u^2 = -5); x = 0x8508c00000000001
+    typedef Bls377Fr Fr;
+    static constexpr u32 XI0 = 0, B = 1;
+    static constexpr bool D_TWIST = true;
+    static constexpr u64 LOOP = 0x8508c00000000001ull;
 };
 
 template <class P> Big modulus_of() { u32 w[P::N]; for (int i = 0; i < P::N; ++i) w[i] = P::mod(i); return big_from(w, P::N); }
@@ -114,7 +184,7 @@ template <class P>
 struct Pairing {
     typedef PairingCfg<P> Cfg;
     typedef Fe<P> Fq;
-    typedef Fe2<P> Fq2;
+    typedef Q2<P> Fq2;
     struct F12 { Fq2 c[6]; };                 // sum c[i] w^i, w^6 = xi
 
     Big p, r, loop, hard;                     // loop = t - 1 (ate), hard = (p^4 - p^2 + 1) / r
@@ -129,10 +199,10 @@ struct Pairing {
             if (k & 1) r = fe_add(r, t);
         return r;
     }
-    // xi * a = (xi0 a0 - a1) + (a0 + xi0 a1) u
+    // xi * a = (xi0 a0 - beta a1) + (a0 + xi0 a1) u
     static Fq2 mul_xi(const Fq2& a) {
         const Fq2 k = mul_small(a, Cfg::XI0);
-        return {fe_sub(k.c0, a.c1), fe_add(a.c0, k.c1)};
+        return {fe_sub(k.c0, q2_times_beta(a.c1)), fe_add(a.c0, k.c1)};
     }
     static Fq2 pow2(const Fq2& a, const Big& e) {
         Fq2 r = Fq2::one();
@@ -146,7 +216,7 @@ struct Pairing {
     Pairing() {
         p = modulus_of<P>();
         r = modulus_of<typename Cfg::Fr>();
-        loop = Cfg::D_TWIST ? big_sub(p, r) : big_small(0xd201000000010000ull);
+        loop = Cfg::LOOP ? big_small(Cfg::LOOP) : big_sub(p, r);
         const Big p2 = big_mul(p, p), p4 = big_mul(p2, p2);
         Big rem;
         hard = big_divmod(big_add(big_sub(p4, p2), big_small(1)), r, &rem);
@@ -573,7 +643,8 @@ bool verify(const VerificationKey& vk, const Proof& proof) {
     if (vk.scheme != "g16" && vk.scheme != "gm17") throw Error(ZKHIP_ERR_BAD_ARG, "verify: scheme " + vk.scheme + " is not supported (g16, gm17)");
     if (vk.curve == "bn128") return verify_curve<Bn254Fq>(vk, proof);
     if (vk.curve == "bls12_381") return verify_curve<Bls381Fq>(vk, proof);
-    throw Error(ZKHIP_ERR_BAD_ARG, "verify: curve " + vk.curve + " is not supported (bn128, bls12_381)");
+    if (vk.curve == "bls12_377") return verify_curve<Bls377Fq>(vk, proof);
+    throw Error(ZKHIP_ERR_BAD_ARG, "verify: curve " + vk.curve + " is not supported (bn128, bls12_381, bls12_377)");
 }
 
 bool pairing_product_is_one(const std::string& curve, const std::vector<std::pair<G1Affine, G2Affine>>& pairs) {
@@ -590,7 +661,8 @@ bool pairing_product_is_one(const std::string& curve, const std::vector<std::pai
     };
     if (curve == "bn128") return run(Bn254Fq{});
     if (curve == "bls12_381") return run(Bls381Fq{});
-    throw Error(ZKHIP_ERR_BAD_ARG, "pairing: curve " + curve + " is not supported (bn128, bls12_381)");
+    if (curve == "bls12_377") return run(Bls377Fq{});
+    throw Error(ZKHIP_ERR_BAD_ARG, "pairing: curve " + curve + " is not supported (bn128, bls12_381, bls12_377)");
 }
 
 // `zokrates print-proof --format json|remix` (zokrates_cli/src/ops/print_proof.rs:85-114): the points as serde_json prints a
