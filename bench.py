@@ -525,6 +525,8 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
                     if line.startswith("timings "):
                         rec.update(json.loads(line[8:]))
                 rec["proof_json_identical_to_resident_prover"] = open(paths["proof.json"]).read() == want
+                if "--verify" in extra:
+                    rec["verified"] = "verified against the verification key" in p.stdout
             res[name] = rec
 
         if os.access(native_exe, os.X_OK):
@@ -532,6 +534,9 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
             run("native_from_proving_key", [], native_exe)
             run("native_first_run_with_key_cache", ["--key-cache", paths["cache_native"]], native_exe)
             run("native_from_key_image", ["--key-cache", paths["cache_native"]], native_exe)
+            # the same once more with the self check: the proof of the 2^20 circuit against the verification key at the head of its
+            # proving key, by the compiled verifier on the host CPU (csrc/host/verify.cpp) — "verify_ms" and "verified" in the record
+            run("native_from_key_image_with_verify", ["--key-cache", paths["cache_native"], "--verify"], native_exe)
         run("from_proving_key", [])
         run("first_run_with_key_cache", ["--key-cache", paths["cache"]])
         run("from_key_image", ["--key-cache", paths["cache"]])

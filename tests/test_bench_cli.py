@@ -53,6 +53,8 @@ def test_single_rank_contract(args, metric):
     for run in ("native_from_proving_key", "native_from_key_image", "from_proving_key", "from_key_image", "from_full_key_image"):
         assert e[run]["proof_json_identical_to_resident_prover"] is True and e[run]["process_wall_ms"] > 0, (run, e[run])
     assert e["from_proving_key"]["key_source"] == "proving.key" and e["from_key_image"]["key_source"] == "image"
+    chk = e["native_from_key_image_with_verify"]         # the proof of the run checked by the compiled verifier before the process reports success
+    assert chk["verified"] is True and chk["verify_ms"] > 0 and chk["proof_json_identical_to_resident_prover"] is True, chk
 
 
 @pytest.mark.parametrize("scheme,port", [("g16", "29541"), ("gm17", "29543")])
