@@ -229,7 +229,7 @@ def test_prove_with_wide_windows():
         c2.close()
 
 
-@pytest.mark.parametrize("c,kh_log,fold3_min_h", [(12, 7, 4), (9, 4, 512), (13, 9, 8)])
+@pytest.mark.parametrize("c,kh_log,fold3_min_h", [(12, 7, 4), (9, 4, 512)])
 def test_two_pass_sort_and_three_digit_fold_at_small_sizes(c, kh_log, fold3_min_h):
     """The wide-window machinery with its thresholds pulled down (ZKHIP_TUNE_SORT_KH_LOG, ZKHIP_TUNE_FOLD3_MIN_H) so that a
     circuit of a few hundred constraints fills every class of the second sort pass and every digit of the fold; dense and
