@@ -342,6 +342,8 @@ def main():
             compute["valu_cycles_per_instruction_per_simd"] = ent["cycles_per_valu_instruction_per_simd"]
             compute["clock_ghz_under_load"] = ent["clock_ghz"]
             compute["valu_source"] = "OFFLINE: rocprofv3 --pmc pass of this workload on this build, profiles/pmc_valu.json (not measured in this run)"
+    if compute is not None and "valu_issue_utilisation" in compute and world == 1 and not gm17:
+        compute["pipeline_issue_bound"] = pipeline_issue_bound(pv, 1000.0 * elapsed / args.steps)
     roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": ("offline rocprofv3 --pmc passes of this workload, " + PMC_TRAFFIC_FILE) if traffic else None,
@@ -599,6 +601,24 @@ def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one):
                 "exchange": exchange}
     except Exception as e:   # the throughput line must survive a failure of the optional leg
         return {"error": repr(e)}
+
+
+def pipeline_issue_bound(pv, ms_per_step):
+    """The proof rate against the issue limit of the pipeline's own instruction stream: the VALU wavefront instructions the
+    committed counter pass (profiles/pmc_valu.json) counted for the kernels that fill the machine — two G1 accumulation launches,
+    one G2, four column and four row transform launches per Groth16 proof; sort, fold and mat-vec add < 3 % —, divided by what
+    1024 SIMDs issue at one instruction per 4 cycles at the clock the chip held during that pass.  OFFLINE instruction counts,
+    this run's time.  None if the file does not hold what is needed."""
+    try:
+        per_proof = {"G1": 2, "G2": 1, "NTT_cols": 4, "NTT_rows": 4}
+        instr = sum(n * pv[k]["valu_wave_instructions_per_launch"] for k, n in per_proof.items())
+        clock = pv["G1"]["clock_ghz"]
+        ms = instr / (1024 * clock * 1e9 / 4) * 1e3
+        return {"valu_wave_instructions_per_proof": instr, "clock_ghz_under_load": clock, "ms_per_proof_at_issue_limit": ms,
+                "frac_of_ms_per_step": ms / ms_per_step if ms_per_step > 0 else None,
+                "source": "OFFLINE instruction counts (profiles/pmc_valu.json), this run's ms_per_step"}
+    except Exception:
+        return None
 
 
 def box_probe():

@@ -108,3 +108,24 @@ def test_measuring_process_that_dies_is_reported_and_retried():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["value"] is None and "error" in d and [a["signal"] for a in d["attempts"]] == [6, 6]
+
+
+def test_pipeline_issue_bound_from_the_committed_counter_file():
+    """bench.pipeline_issue_bound: the committed VALU counter pass turned into the issue-limited time of one proof."""
+    import importlib.util
+    env_before = os.environ.get("ZKHIP_BENCH_CHILD")
+    os.environ["ZKHIP_BENCH_CHILD"] = "1"           # importing bench.py must not start its supervising parent
+    try:
+        spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+    finally:
+        if env_before is None:
+            del os.environ["ZKHIP_BENCH_CHILD"]
+        else:
+            os.environ["ZKHIP_BENCH_CHILD"] = env_before
+    pv = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
+    b = bench.pipeline_issue_bound(pv, 10.57)
+    assert 4.0e9 < b["valu_wave_instructions_per_proof"] < 6.0e9 and 8.0 < b["ms_per_proof_at_issue_limit"] < 11.0
+    assert abs(b["frac_of_ms_per_step"] - b["ms_per_proof_at_issue_limit"] / 10.57) < 1e-12
+    assert bench.pipeline_issue_bound({}, 10.0) is None and bench.pipeline_issue_bound({"G1": {}}, 10.0) is None
