@@ -14,6 +14,12 @@ from an assignment in host memory to the proof bytes in host memory (SURVEY.md Â
 never part of `value`).  With N > 1 every rank proves its own K proofs on its own GPU with a full copy of the key
 (independent proofs: no data-path collective; "weak" scaling) and `value` is N*K / max-over-ranks time.
 
+Launch contract.  `python bench.py --gpus N` on its own starts the N ranks itself (one process per GPU, `nccl` = RCCL,
+rendezvous on 127.0.0.1) and relays rank 0's line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N` it is one of the ranks the launcher started (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+`n_gpus` is the number of ranks that RAN; fewer visible GPUs than N, or --gpus disagreeing with WORLD_SIZE, is an error
+(a JSON line with "error", non-zero exit status), never a silently smaller measurement.
+
 `--scheme gm17` runs BASELINE.json configs[4] instead (the same circuit through the GM17 prover: R1CS -> SAP on the
 device, 5 NTTs over the twice-larger domain, 5 MSMs over the extended assignment); the default line is Groth16.
 
@@ -75,9 +81,123 @@ def supervise():
     return 1
 
 
-if __name__ == "__main__" and not os.environ.get("ZKHIP_BENCH_CHILD") and int(os.environ.get("WORLD_SIZE", "1")) == 1 \
-        and not any(a in ("-h", "--help") for a in sys.argv[1:]):
-    sys.exit(supervise())
+def requested_gpus(argv):
+    """--gpus N as given on the command line (both `--gpus N` and `--gpus=N`); 1 when absent."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n
+
+
+def visible_gpus():
+    """GPUs the library sees, counted in a throw-away process (the launching parent never loads the HIP runtime)."""
+    import subprocess
+    code = ("import importlib, os, sys; sys.path.insert(0, %r); "
+            "print(importlib.import_module(os.environ.get('ZKHIP_PKG', 'zokrates_amd') + '.native').default_library().device_count())"
+            % os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    if p.returncode != 0:
+        raise RuntimeError("cannot count the GPUs: " + (p.stderr or p.stdout)[-400:])
+    return int(p.stdout.strip().splitlines()[-1])
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here â€” one process per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set as `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N` would set them, `nccl` (= RCCL) underneath â€” relay rank 0's JSON line and fail loudly (one JSON line
+    with "error", exit status 1) when the box has fewer than N GPUs or a rank dies.  `n_gpus` of the line is the number of ranks
+    that ran, never the number asked for."""
+    import socket
+    import subprocess
+    import tempfile
+
+    def fail(msg, extra=None):
+        doc = {"metric": "groth16_proofs_per_sec", "value": None, "unit": "proofs/s", "n_gpus": 0, "requested_gpus": n,
+               "higher_is_better": True, "error": msg}
+        doc.update(extra or {})
+        print(json.dumps(doc), flush=True)
+        print("bench.py: " + msg, file=sys.stderr, flush=True)
+        return 1
+
+    if not os.environ.get("ZKHIP_BENCH_DEVICE"):          # (test hook: every rank on the one device of the emulator build)
+        try:
+            have = visible_gpus()
+        except Exception as e:
+            return fail(str(e))
+        if have < n:
+            return fail("--gpus %d asked for, %d GPU(s) visible: refusing to measure fewer GPUs than the line would claim" % (n, have),
+                        {"visible_gpus": have})
+    with socket.socket() as sk:                            # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs, errs = [], []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ZKHIP_BENCH_LAUNCHED="self")
+        err = tempfile.TemporaryFile()
+        errs.append(err)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=err))
+    # a rank that dies before the rendezvous would leave the others waiting in it: watch all of them, end all on the first failure
+    budget = float(os.environ.get("ZKHIP_BENCH_LAUNCH_TIMEOUT_S", "1800"))
+    t0, failed = time.time(), None
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with status %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > budget:
+            failed = "ranks still running after %.0f s" % budget
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    tails = []
+    for rank, err in enumerate(errs):
+        err.seek(0)
+        txt = err.read().decode(errors="replace")
+        err.close()
+        sys.stderr.write(txt)
+        tails.append(txt[-600:])
+    sys.stderr.flush()
+    lines = [l for l in (out0[0].decode(errors="replace") if out0 else "").splitlines() if l.startswith("{")]
+    if failed or not lines:
+        return fail(failed or "rank 0 printed no result line", {"stderr_tails": tails})
+    print(lines[-1], flush=True)
+    return 0
+
+
+if __name__ == "__main__" and not any(a in ("-h", "--help") for a in sys.argv[1:]):
+    _want = requested_gpus(sys.argv[1:])
+    _world_env = os.environ.get("WORLD_SIZE")
+    _explicit = any(a == "--gpus" or a.startswith("--gpus=") for a in sys.argv[1:])
+    if _want < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if _world_env is not None and _explicit and _want != int(_world_env):
+        # under a launcher (torch.distributed.run) the ranks exist already: a line that would claim another number of GPUs than
+        # the launcher started is refused, not silently re-labelled
+        print("bench.py: --gpus %d but WORLD_SIZE=%s: start as many ranks as --gpus says" % (_want, _world_env), file=sys.stderr)
+        sys.exit(2)
+    if _world_env is None and _want > 1:
+        sys.exit(launch_ranks(_want))
+    if int(_world_env or "1") == 1 and not os.environ.get("ZKHIP_BENCH_CHILD"):
+        sys.exit(supervise())
 
 import numpy as np
 
@@ -224,7 +344,16 @@ def main():
     # the rank's GPU: LOCAL_RANK, unless the launcher already narrowed this process's view to one device
     # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) â€” ZKHIP_BENCH_DEVICE: test hook (all ranks on one GPU)
     ndev = native.default_library().device_count()
-    ctx = native.Context(int(os.environ.get("ZKHIP_BENCH_DEVICE", local_rank if local_rank < ndev else 0)))
+    if os.environ.get("ZKHIP_BENCH_DEVICE") is not None:
+        device = int(os.environ["ZKHIP_BENCH_DEVICE"])
+    elif local_rank < ndev:
+        device = local_rank
+    elif ndev == 1 and (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")):
+        device = 0                   # the launcher gave this rank a view of exactly one GPU
+    else:
+        raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own: %d visible â€” one GPU per rank, or fewer ranks"
+                         % (ranks.rank, local_rank, ndev))
+    ctx = native.Context(device)
     mark("context_created")
     if os.environ.get("ZKHIP_BENCH_TEST_DIE") in (os.environ.get("ZKHIP_BENCH_ATTEMPT", "-"), "*"):
         os.abort()      # tests/test_bench_cli.py: what a GPU memory fault does to the measuring process
@@ -388,7 +517,9 @@ def main():
         "config": {"workload": workload, "curve": args.curve, "constraints": circ.n,
                    "variables": m, "domain": N, "distinct_witnesses": nw,
                    "parallelism": f"{world} independent prover(s), full key per GPU",
-                   "process_group": ranks.describe()},
+                   "process_group": ranks.describe(),
+                   "launcher": ("bench.py --gpus N started the ranks itself" if os.environ.get("ZKHIP_BENCH_LAUNCHED") == "self" else
+                                "external launcher (torch.distributed.run)" if world > 1 else "single process")},
         "single_proof_ms": single_ms, "single_proof_from_host_ms": min(from_host), "phases_ms": avg, "phases_ms_serial": serial,
         "whole_proof_hbm": {"algorithmic_bytes": b_alg, "achieved_GBs": b_alg / (elapsed / args.steps) / 1e9,
                             "frac": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
@@ -441,7 +572,8 @@ def main():
     if rank == 0 and members >= 1:
         out["multi_single_proof"] = multi_leg(ctx, circ, curve_id, pk_bytes, zs[0], members, gm17, prove_one)
     if world > 1:
-        barrier_sync()      # the other ranks idle while rank 0 drives every GPU through the library
+        ranks.host_barrier()      # the other ranks idle (on the host: no collective kernel parked on their GPUs) while rank 0
+                                  # drives every GPU through the library
     watchdog.cancel()
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         base, cpu_proof = cpu_baseline(circ, pk_bytes, zs[0], args.cpu_seconds, gm17)

@@ -82,6 +82,39 @@ def test_two_ranks_real_bench_script(scheme, port):
         assert mm["replicas_batch"]["first_identical_to_unsharded"] is True and mm["replicas_batch"]["proofs"] == 16, mm
 
 
+def test_gpus_flag_alone_starts_the_ranks():
+    """`python bench.py --gpus 2` with NO rank environment (the shape of the driver's N = 1 command): bench.py
+    starts the two ranks itself and the line says n_gpus = 2 — here over gloo on the emulator, both ranks on its one device."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ZKHIP_LIBRARY=EMU_LIB, ZKHIP_DIST_BACKEND="gloo", ZKHIP_BENCH_DEVICE="0")
+    emu_library()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-domain", "5", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "2 rank(s)" in d["config"]["process_group"] and "itself" in d["config"]["launcher"]
+    assert d["sharded_single_proof"]["identical_to_unsharded"] is True and d["multi_single_proof"]["identical_to_unsharded"] is True
+    for k in REQUIRED:
+        assert k in d, k
+
+
+def test_more_gpus_asked_for_than_visible_fails_loudly():
+    """--gpus 3 on a box with one device: an error line and exit status 1, not a one-GPU measurement labelled 3 (or 1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ZKHIP_BENCH_DEVICE")}
+    env.update(ZKHIP_LIBRARY=EMU_LIB)
+    emu_library()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--log-domain", "5"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value"] is None and d["n_gpus"] == 0 and d["requested_gpus"] == 3 and d["visible_gpus"] == 1 and "refusing" in d["error"]
+    # and under a launcher: --gpus must agree with the ranks that exist
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=60)
+    assert p.returncode == 2 and "WORLD_SIZE=2" in p.stderr and not p.stdout.strip()
+
+
 def test_stalled_optional_leg_still_prints_the_line():
     """An optional latency leg that never returns (a hung collective, an untested multi-GPU path): the watchdog prints the
     throughput line with the leg marked as timed out and the process exits 0 — the driver's bench run must not lose its line."""

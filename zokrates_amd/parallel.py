@@ -17,6 +17,7 @@ class Ranks:
         self.backend = None
         self._dist = None
         self._torch = None
+        self._cpu_group = None
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -26,10 +27,18 @@ class Ranks:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if self.backend == "nccl":
-                # LOCAL_RANK, unless the launcher narrowed this process's view to one device
-                dev = self.local_rank if self.local_rank < torch.cuda.device_count() else 0
+                # LOCAL_RANK, unless the launcher narrowed this process's view to exactly one device; RCCL wants one GPU per
+                # rank, so a rank without a GPU of its own is an error, never a silent second tenant of GPU 0
+                ndev = torch.cuda.device_count()
+                narrowed = ndev == 1 and (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"))
+                if self.local_rank >= ndev and not narrowed:
+                    raise RuntimeError(f"rank {self.rank} (LOCAL_RANK {self.local_rank}) has no GPU of its own: {ndev} visible")
+                dev = self.local_rank if self.local_rank < ndev else 0
                 torch.cuda.set_device(dev)
                 dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+                # a host-side group beside it: ranks that only WAIT (rank 0 drives every GPU through the library's own
+                # multi-GPU path after the timed region) must not park a spinning collective kernel on their GPU meanwhile
+                self._cpu_group = dist.new_group(backend="gloo")
             else:
                 dist.init_process_group(self.backend)
 
@@ -53,6 +62,11 @@ class Ranks:
             self._dist.barrier()
             if self.backend == "nccl":
                 self._torch.cuda.synchronize()
+
+    def host_barrier(self):
+        """Barrier on the host only (gloo beside nccl): for waits of unknown length during which the GPUs belong to someone else."""
+        if self._dist is not None:
+            self._dist.barrier(group=self._cpu_group) if self._cpu_group is not None else self._dist.barrier()
 
     def max_over_ranks(self, value):
         if self._dist is None:
