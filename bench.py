@@ -601,7 +601,7 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
     key from files and writes proof.json, ONE proof per process (/root/reference/zokrates_cli/src/ops/generate_proof.rs:152-202).
     Here: the same three files for the benchmark circuit (ZoKrates' `out` / `witness` formats, ark's proving.key) in a RAM-backed
     directory, `python -m zokrates_amd.cli generate-proof` as a fresh process per run — from the proving.key, and from the
-    device-layout key image a first run leaves behind (compact: level 0 of the base tables; full: every window multiple) —
+    device-layout key image a first run leaves behind (level 0 of the base tables) —
     wall clock of the process and the split it reports (the program is decoded on host threads while the key is uploaded).
     The steady-state numbers above are what a resident prover service gets; this is what the CLI user gets."""
     import shutil
@@ -615,7 +615,7 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
         t0 = time.perf_counter()
         ids = np.arange(circ.m, dtype=np.int64)
         prog_bytes = native.write_program(curve_id, circ.n, circ.m, circ.mats(), ids=ids, args=[(j, False) for j in range(1, circ.l)])
-        paths = {k: os.path.join(d, k) for k in ("out", "witness", "proving.key", "proof.json", "cache", "cache_full")}
+        paths = {k: os.path.join(d, k) for k in ("out", "witness", "proving.key", "proof.json", "cache")}
         prog_bytes.tofile(paths["out"])
         native.write_witness(ids, z).tofile(paths["witness"])
         np.asarray(pk_bytes, dtype=np.uint8).tofile(paths["proving.key"])
@@ -674,11 +674,6 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
         run("from_proving_key", [])
         run("first_run_with_key_cache", ["--key-cache", paths["cache"]])
         run("from_key_image", ["--key-cache", paths["cache"]])
-        free = shutil.disk_usage(d).free
-        if free > 24 * len(pk_bytes):                     # the full image is ~16x the key
-            run("first_run_with_full_key_cache", ["--key-cache", paths["cache_full"], "--key-cache-full"])
-            run("from_full_key_image", ["--key-cache", paths["cache_full"], "--key-cache-full"])
-            res["file_bytes"]["full_key_image"] = sum(os.path.getsize(os.path.join(paths["cache_full"], f)) for f in os.listdir(paths["cache_full"]))
         res["file_bytes"]["key_image"] = sum(os.path.getsize(os.path.join(paths["cache"], f)) for f in os.listdir(paths["cache"]))
         ing = res["from_proving_key"].get("parse_program_ms")
         if ing:

@@ -107,6 +107,12 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_SORT_KH_LOG 14  /* log2 of the buckets one LDS histogram of the sort holds (2..15; default 15): windows with more
                                     * buckets are sorted in two passes — a test hook to reach that path with small windows          */
 #define ZKHIP_TUNE_FOLD3_MIN_H 15  /* bucket sets with at least this many rows of 256 buckets fold in three digits (default 512)  */
+#define ZKHIP_TUNE_MSM_SETS 17        /* bucket sets of the MSM tables built by later key loads: 1 = every window multiple of every base
+                                      * (one bucket set per MSM), 2 = every second multiple (two sets) ...; 0 = automatic: 1 while the
+                                      * tables fit the device, else the smallest power of two that does (keys above 2^24 constraints) */
+#define ZKHIP_TUNE_NTT_MAX_SUBLOG 16 /* log2 of the longest sub-transform of an NTT pass (2..11; default 11): domains above 2^(2 x this)
+                                      * take three passes instead of two — a test hook to reach the three-pass path (domains above
+                                      * 2^22) with small domains.  Keys loaded before a change must be reloaded (their h order)        */
 int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value);
 
 /* ---- proving key ----
@@ -300,18 +306,15 @@ int32_t zkhip_prove_g16_multi_batch(zkhip_multi* m, uint32_t count, const uint8_
  * zkhip_pk_import brings such an image back with five host-to-device copies and no parsing or conversion, taking
  * `ProvingKey::deserialize_unchecked` (/root/reference/zokrates_ark/src/groth16.rs:40-42; one Fq multiplication per
  * coordinate and a single-threaded read in the reference) off the per-invocation path.
- * A resident key is a set of five MSM tables: level 0 = the key's points, levels 1 .. W-1 their precomputed window
- * multiples 2^(c j) P.  The default image carries level 0 only and the import recomputes the other
- * levels on the device (~0.1 s for a 2^20-constraint key, less than reading them from a disk); with
- * ZKHIP_PK_IMAGE_FULL the image carries every level (16x the size) and the import is copies only.
+ * A resident key is a set of five MSM tables: level 0 = the key's points, the further levels their precomputed window
+ * multiples.  The image carries level 0 only and the import recomputes the other levels on the device
+ * (~0.1 s for a 2^20-constraint key — less than reading them from a disk would take: an image that carried every level was
+ * measured 2x slower end to end in round 3 and has been removed).
  * The library does no file I/O: the caller stores the image wherever it likes, keyed e.g. by the SHA-256 of the
- * `proving.key` it came from (`python -m zokrates_amd.cli generate-proof --key-cache DIR` does exactly that).  An image
+ * `proving.key` it came from (`zkhip-cli generate-proof --key-cache DIR` does exactly that).  An image
  * is tied to the library build that wrote it (magic + layout version); a foreign image is rejected with ZKHIP_ERR_PARSE. */
-#define ZKHIP_PK_IMAGE_FULL 1u
 int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes);
 int32_t zkhip_pk_export(const zkhip_pk* pk, uint8_t* out, uint64_t cap);
-int32_t zkhip_pk_export_size_ex(const zkhip_pk* pk, uint32_t flags, uint64_t* bytes);
-int32_t zkhip_pk_export_ex(const zkhip_pk* pk, uint32_t flags, uint8_t* out, uint64_t cap);
 int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk** out);
 
 /* ---- "next" row N1: ZoKrates' own input files (host only: no context, no device work) ----

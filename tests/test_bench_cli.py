@@ -32,7 +32,7 @@ def run_bench(args, extra_env=None, timeout=900, expect_rc=0):
     (["--log-domain", "9", "--kind", "poseidon", "--curve", "bls12_381"], "groth16_proofs_per_sec"),
 ])
 def test_single_rank_contract(args, metric):
-    with_cli_leg = "--scheme" not in args and "--kind" not in args      # the CLI-shaped leg (eleven subprocesses) once is enough
+    with_cli_leg = "--scheme" not in args and "--kind" not in args      # the CLI-shaped leg (seven subprocesses) once is enough
     lines = run_bench(args + ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"] + ([] if with_cli_leg else ["--e2e", "0"]))
     assert len(lines) == 1
     d = json.loads(lines[0])
@@ -50,7 +50,7 @@ def test_single_rank_contract(args, metric):
         return
     e = d["cli_end_to_end_ms"]                         # the reference-shaped flow: files -> proof.json, one process per proof
     assert "error" not in e, e
-    for run in ("native_from_proving_key", "native_from_key_image", "from_proving_key", "from_key_image", "from_full_key_image"):
+    for run in ("native_from_proving_key", "native_from_key_image", "from_proving_key", "from_key_image"):
         assert e[run]["proof_json_identical_to_resident_prover"] is True and e[run]["process_wall_ms"] > 0, (run, e[run])
     assert e["from_proving_key"]["key_source"] == "proving.key" and e["from_key_image"]["key_source"] == "image"
     chk = e["native_from_key_image_with_verify"]         # the proof of the run checked by the compiled verifier before the process reports success

@@ -223,8 +223,43 @@ def test_prove_with_wide_windows():
             c2.tune("msm_c", c)
             pk = native.ProvingKey(c2, 0, raw)
             assert native.prove_g16(c2, pk, cs, z, 11, 13) == want, c
-            img = pk.export_image(full=(c == 4))
+            img = pk.export_image()
             assert native.prove_g16(c2, native.ProvingKey.from_image(c2, 0, img), cs, z, 11, 13) == want, c
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_prove_with_thinned_tables(curve):
+    """Keys too large for every window multiple of every base (domains above 2^24: the tables of a 2^26 key would take 384 GiB)
+    keep every 2nd / 4th / ... multiple and fold as many bucket sets (ZKHIP_TUNE_MSM_SETS; automatic by device memory otherwise);
+    sets >= windows is the table-less limit.  Same proofs — Groth16, GM17, a sharded key, a key image — at every setting."""
+    c2 = native.Context(0, emu_library())
+    try:
+        oc = cpu.Circuit.synth(curve.curve_id, 40, 7)
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        raw = cpu.ProvingKey.setup(oc, tox).serialize()
+        tb17 = tox[:96] + tox[128:160]
+        raw17 = cpu.Gm17ProvingKey.setup(oc, tb17).serialize()
+        cs = native.ConstraintSystem(c2, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+        z = oc.assignment()
+        want, want17 = cpu.trapdoor(oc, tox, z, 11, 13), cpu.gm17_trapdoor(oc, tb17, z, 21, 23)
+        for sets, c in ((2, 0), (3, 0), (4, 5), (64, 0)):
+            c2.tune("msm_sets", sets)
+            c2.tune("msm_c", c)
+            pk = native.ProvingKey(c2, curve.curve_id, raw)
+            assert native.prove_g16(c2, pk, cs, z, 11, 13) == want, sets
+            assert native.prove_g16(c2, native.ProvingKey.from_image(c2, curve.curve_id, pk.export_image()), cs, z, 11, 13) == want, sets
+            pk17 = native.ProvingKey(c2, curve.curve_id, raw17, scheme="gm17")
+            assert native.prove_gm17(c2, pk17, cs, z, 21, 7, 23) == want17, sets
+            shards = [native.ProvingKey(c2, curve.curve_id, raw, rank=k, world=3) for k in range(3)]
+            parts = [native.prove_g16_partial(c2, sh, cs, z, 11, 13) for sh in shards]
+            assert native.combine_g16(c2, shards[0], parts, 11, 13) == want, sets
+        # an image written with thinned tables names them in its header: imported under other defaults it keeps its own shape
+        c2.tune("msm_sets", 2)
+        img = native.ProvingKey(c2, curve.curve_id, raw).export_image()
+        c2.tune("msm_sets", 0)
+        assert native.prove_g16(c2, native.ProvingKey.from_image(c2, curve.curve_id, img), cs, z, 11, 13) == want
     finally:
         c2.close()
 
@@ -280,6 +315,59 @@ def test_two_pass_prove(ctx):
         assert native.prove_g16(c2, pk, cs, z, 11, 13) == cpu.trapdoor(oc, tox, z, 11, 13)
     finally:
         os.environ.pop("ZKHIP_NTT_SINGLE_MAX_LOG")
+        c2.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("sub", [2, 3])
+def test_ntt_three_passes(curve, sub):
+    """Domains above 2^22 take three passes (N = N1 * N2 * N3, sigma order with three digits).  ZKHIP_TUNE_NTT_MAX_SUBLOG pulls the
+    threshold down so that the same launchers and kernels run here on 2^5 .. 2^9 points: every split shape (equal factors, a short
+    first one, odd sub-lengths) against the oracle's radix-2 transform."""
+    c2 = native.Context(0, emu_library())
+    c2.tune("ntt_max_sublog", sub)
+    rnd = random.Random(60 + sub)
+    try:
+        for logn in range(2 * sub + 1, 3 * sub + 1):
+            a = le([rnd.randrange(curve.r) for _ in range(1 << logn)])
+            for d in ("fft", "ifft", "coset_fft", "coset_ifft"):
+                assert c2.ntt(curve.curve_id, a, d).tobytes() == cpu.ntt(curve.curve_id, a, d).tobytes(), (logn, d)
+        with pytest.raises(native.ZkhipError):                  # beyond three sub-transforms of the (test-sized) length
+            c2.ntt(curve.curve_id, le([1] * (1 << (3 * sub + 1))), "fft")
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize("logn,sub", [(5, 2), (6, 2), (7, 3), (8, 3)])
+def test_three_pass_prove(logn, sub):
+    """The whole prover over a three-pass domain: the witness map's kind-b transforms (sigma order in, natural out), h left in the
+    three-digit sigma order and paired with the h bases the key load permuted the same way — Groth16 and GM17."""
+    c2 = native.Context(0, emu_library())
+    c2.tune("ntt_max_sublog", sub)
+    try:
+        curve = BN254
+        oc = cpu.Circuit.synth(0, (1 << logn) - 2, 0x5EED0030 + logn)
+        assert oc.N == 1 << logn
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        opk = cpu.ProvingKey.setup(oc, tox)
+        z = oc.assignment()
+        cs = native.ConstraintSystem(c2, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+        pk = native.ProvingKey(c2, 0, opk.serialize())
+        assert cs.witness_map(z).tobytes() == cpu.witness_map(oc, z).tobytes()
+        assert native.prove_g16(c2, pk, cs, z, 11, 13) == cpu.trapdoor(oc, tox, z, 11, 13)
+        proofs, _ = native.prove_g16_batch(c2, pk, cs, np.concatenate([z, z]), [(3, 4), (5, 6)])
+        assert proofs == [cpu.trapdoor(oc, tox, z, 3, 4), cpu.trapdoor(oc, tox, z, 5, 6)]
+        if logn + 1 <= 3 * sub:                                 # GM17: SAP domain 2^(logn + 1) must fit three (test-sized) passes
+            t4 = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+            tb17 = t4[:96] + t4[128:160]                        # alpha, beta, gamma, t
+            opk17 = cpu.Gm17ProvingKey.setup(oc, tb17)
+            pk17 = native.ProvingKey(c2, 0, opk17.serialize(), scheme="gm17")
+            assert native.prove_gm17(c2, pk17, cs, z, 21, 7, 23) == cpu.gm17_trapdoor(oc, tb17, z, 21, 23)
+        # a key ordered for this split is refused once the split changes (its h bases would pair with the wrong coefficients)
+        c2.tune("ntt_max_sublog", 11)
+        with pytest.raises(native.ZkhipError):
+            native.prove_g16(c2, pk, cs, z, 11, 13)
+    finally:
         c2.close()
 
 

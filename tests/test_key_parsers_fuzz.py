@@ -80,12 +80,11 @@ def test_proving_key_loader_survives_mutations(ctx, curve):
         native.ProvingKey(ctx, curve.curve_id, np.frombuffer(graw, dtype=np.uint8))
 
 
-@pytest.mark.parametrize("full", [False, True], ids=["level0", "full"])
-def test_key_image_importer_survives_mutations(ctx, full):
+def test_key_image_importer_survives_mutations(ctx):
     curve = BN254
     oc, raw, _ = _keys(curve)
     pk = native.ProvingKey(ctx, curve.curve_id, np.frombuffer(raw, dtype=np.uint8))
-    img = pk.export_image(full=full).tobytes()
+    img = pk.export_image().tobytes()
     pk.close()
     cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
     z = oc.assignment()

@@ -51,14 +51,13 @@ def _load_system(ctx, path):
     return native.ConstraintSystem(ctx, r1.curve_id, r1.n, r1.l, r1.w, r1.mats), None
 
 
-def _load_key(ctx, curve_id, path, scheme, cache_dir, full_image=False):
+def _load_key(ctx, curve_id, path, scheme, cache_dir):
     """`proving.key` -> resident key.  With --key-cache DIR the device-layout image (`zkhip_pk_export`) is kept next to
     it, named after (path, size, mtime, scheme) — hashing a 400 MB key would cost more than parsing it — and later runs
-    import the image (`zkhip_pk_import`: no parsing, no Montgomery conversion).  full_image: the image also holds the
-    precomputed window multiples (16x the size; import is five copies and no kernel)."""
+    import the image (`zkhip_pk_import`: no parsing, no Montgomery conversion; the window multiples are recomputed on the device)."""
     if cache_dir:
         st = os.stat(path)
-        tag = hashlib.sha256(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}|{scheme}|{curve_id}|{int(full_image)}".encode()).hexdigest()[:32]
+        tag = hashlib.sha256(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}|{scheme}|{curve_id}".encode()).hexdigest()[:32]
         image_path = os.path.join(cache_dir, tag + ".zkhippk")
         if os.path.exists(image_path):
             try:
@@ -69,7 +68,7 @@ def _load_key(ctx, curve_id, path, scheme, cache_dir, full_image=False):
     if cache_dir:
         os.makedirs(cache_dir, exist_ok=True)
         tmp = image_path + ".tmp%d" % os.getpid()
-        pk.export_image(full=full_image).tofile(tmp)
+        pk.export_image().tofile(tmp)
         os.replace(tmp, image_path)
     return pk, "proving.key"
 
@@ -139,9 +138,15 @@ def cmd_generate_proof(args):
             host["wtns"] = formats.read_wtns(wdata.tobytes())
             lap("witness_to_assignment_ms", t0)
 
+    def load_host_side_guarded():                      # an error in the worker is the run's error: kept, raised by the main thread
+        try:
+            load_host_side()
+        except BaseException as e:                     # noqa: B902 — whatever it is, the main thread must see it
+            host["error"] = e
+
     worker = None
     if curve_hint is not None:                         # the key's curve is known from the header: overlap
-        worker = threading.Thread(target=load_host_side)
+        worker = threading.Thread(target=load_host_side_guarded)
         worker.start()
     t0 = time.perf_counter()
     ctx = native.Context(args.device)
@@ -150,12 +155,14 @@ def cmd_generate_proof(args):
         load_host_side()
         curve_hint = host["r1cs"].curve_id
     t0 = time.perf_counter()
-    pk, key_source = _load_key(ctx, curve_hint, args.proving_key_path, args.proving_scheme, args.key_cache, args.key_cache_full)
+    pk, key_source = _load_key(ctx, curve_hint, args.proving_key_path, args.proving_scheme, args.key_cache)
     lap("key_load_ms", t0)
     if worker is not None:
         t0 = time.perf_counter()
         worker.join()
         lap("wait_for_host_side_ms", t0)               # what the host side took beyond the key upload
+        if "error" in host:                            # a bad program / witness file: its own message, not a KeyError further down
+            raise host["error"]
     t0 = time.perf_counter()
     if "prog" in host:
         cs = host["prog"].constraint_system(ctx)
@@ -223,7 +230,6 @@ def main(argv=None):
     g.add_argument("-j", "--proof-path", default="proof.json")
     g.add_argument("-s", "--proving-scheme", default="g16", choices=["g16", "gm17"])
     g.add_argument("--key-cache", help="directory for device-layout key images (zkhip_pk_export / zkhip_pk_import)")
-    g.add_argument("--key-cache-full", action="store_true", help="cache images that include the precomputed window multiples (16x larger)")
     g.add_argument("--timings", action="store_true", help="print the split of the wall clock as one JSON object")
     g.add_argument("--entropy")
     g.add_argument("--device", type=int, default=0)

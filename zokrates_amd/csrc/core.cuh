@@ -138,6 +138,7 @@ struct zkhip_ctx {
     // tunables (zkhip_ctx_tune; the environment variables ZKHIP_SERIAL, ZKHIP_MSM_C, ZKHIP_MSM_WAVES and
     // ZKHIP_NTT_SINGLE_MAX_LOG give their initial values, read ONCE when the context is created)
     int msm_c_env = 0;        // window width of the tables built / ad-hoc MSMs run from now on (0 = automatic)
+    int msm_sets = 0;         // bucket sets of the tables built from now on: 1 = every window multiple, 2 = every second ... (0 = what fits the device)
     int msm_waves = 0;        // accumulation waves per SIMD (0 = per point type)
     u32 msm_lanes = 0;        // slices of the sorted list (0 = one per resident work-item)
     u32 msm_min_slice = 8;    // finest cut of the sorted list
@@ -147,6 +148,7 @@ struct zkhip_ctx {
     int msm_g1_waves = 0, msm_g2_waves = 0;   // slices per SIMD lane of a single-table G1 / G2 accumulation (0 = per point type)
     int z_gate = 1;           // which accumulations over z wait for the witness map of their proof: 0 none, 1 the G1 lanes, 2 all
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
+    int ntt_max_sublog = 11;  // largest sub-transform of a pass (2^11 elements staged per sequence); domains above twice this take three passes
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
     int sort_kh_log = 15;     // log2 of the buckets one LDS histogram of the sort holds (windows with more buckets sort in two passes)
     u32 fold3_min_h = 512;    // bucket sets with at least this many rows of 256 buckets fold in three digits instead of two
@@ -199,21 +201,26 @@ template <class C>
 struct NttPlan : NttPlanBase {
     typedef typename C::Fr Fr;
     typedef Fu<typename Fr::Params> FrU;   // the passes' working form (kernels_ntt.cuh)
-    int log1, log2;          // N = N1 * N2, cols pass over N1, rows pass over N2
+    int log1, log2, log3;    // N = N1 * N2 * N3: cols pass over N1, (three passes, log3 > 0: cols pass over N2 inside every N2 x N3 block,) rows pass over the last factor
     u64 N;
-    u32 N1, N2, M;           // M = max(N1, N2): root tables hold w_M^j, j < M
+    u32 N1, N2, N3, M;       // M = max(N1, N2, N3): root tables hold w_M^j, j < M; N3 = 1 for one or two passes
+    u64 Nb;                  // N2 * N3: the block of one outer index
+    int split() const { return log1 | (log3 << 8); }   // what the sigma order depends on besides N (zkhip_pk::ntt_log1, key images)
     // roots: 9-limb R'-form; tw (inter-pass twiddles, the inverse ones times 1/N... see get_plan), s_coset (g^i / N, sigma
     // order), s_cosetinv_canon (g^-i / N as plain integers: the Montgomery exit): packed, N entries each
     DBuf roots_fwd, roots_inv, tw_fwd, tw_inv, s_coset, s_cosetinv_canon;
     DBuf s_cexit;            // zinv / N as plain integers, N entries: exit factor of the transform that turns c's evaluations into
                              // its share zinv * c_i of the quotient's coefficients (canonical integers)
-    DBuf plan1[2], plan2[2];   // twiddle plans of the N1- and N2-point sub-NTTs, [0] forward, [1] inverse (kernels_ntt.cuh)
-    u32 plen1 = 0, plen2 = 0;
+    DBuf tw2_fwd, tw2_inv;   // three passes: the twiddles inside a block, w_Nb^(k2 * j3), Nb entries
+    DBuf plan1[2], plan2[2], plan3[2];   // twiddle plans of the N1-, N2- and N3-point sub-NTTs, [0] forward, [1] inverse (kernels_ntt.cuh)
+    u32 plen1 = 0, plen2 = 0, plen3 = 0;
     Fr omega, omega_inv, n_inv, g, g_inv, zinv;   // saturated Montgomery form (host code, setup)
     Fr zinv_rp;                                   // zinv in R'-form (k_quotient)
     Fr k_to_rp, k_mont_to_rp;                     // canonical integer -> R'-form, saturated Montgomery -> R'-form (fe_mul by these)
     int C_cols, R_rows, threads_cols, threads_rows;
     size_t smem_cols, smem_rows;
+    int C_mid = 1, threads_mid = 64;   // the middle pass of three: columns per workgroup, work-items
+    size_t smem_mid = 0;
 };
 
 template <class Fr>
@@ -240,18 +247,24 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
     typedef typename C::Fr Fr;
     for (auto& p : ctx->plans)
         if (p->curve == C::ID && p->logN == logN) return (NttPlan<C>*)p.get();
-    require(logN >= 0 && logN <= 2 * NTT_MAX_SUBLOG && logN <= C::TWO_ADICITY, ZKHIP_ERR_BAD_ARG,
-            "domain size unsupported (log2 N must be <= 22)");
+    const int sub = ctx->ntt_max_sublog;
+    require(logN >= 0 && logN <= 3 * sub && logN <= C::TWO_ADICITY, ZKHIP_ERR_BAD_ARG,
+            "domain size unsupported (log2 N must not exceed the field's two-adicity: 28 for bn128, 32 for bls12_381)");
     auto* pl = new NttPlan<C>();
     ctx->plans.emplace_back(pl);
     pl->curve = C::ID;
     pl->logN = logN;
     pl->N = (u64)1 << logN;
-    pl->log1 = logN <= ctx->ntt_single_max ? 0 : logN / 2;
-    pl->log2 = logN - pl->log1;
+    // one pass up to 2^ntt_single_max, two passes (N1 x N2) up to 2^(2 sub), three (N1 x N2 x N3) beyond: the reference's
+    // radix-2 domain goes up to the field's two-adicity (ark-poly Radix2EvaluationDomain), so does this one
+    if (logN <= ctx->ntt_single_max && logN <= sub) { pl->log1 = 0; pl->log2 = logN; pl->log3 = 0; }
+    else if (logN <= 2 * sub) { pl->log1 = logN / 2; pl->log2 = logN - pl->log1; pl->log3 = 0; }
+    else { pl->log1 = logN / 3; pl->log2 = (logN - pl->log1) / 2; pl->log3 = logN - pl->log1 - pl->log2; }
     pl->N1 = 1u << pl->log1;
     pl->N2 = 1u << pl->log2;
-    pl->M = std::max(pl->N1, pl->N2);
+    pl->N3 = 1u << pl->log3;
+    pl->Nb = (u64)pl->N2 * pl->N3;
+    pl->M = std::max(pl->N1, std::max(pl->N2, pl->N3));
     pl->omega = host_root_of_unity<Fr>(C::TWO_ADICITY, C::GENERATOR, logN);
     pl->omega_inv = fe_inv(pl->omega);
     pl->n_inv = fe_inv(fe_from_u64<typename Fr::Params>(pl->N));
@@ -277,7 +290,7 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
     for (int inv = 0; inv < 2; ++inv) {
         DBuf& dst = inv ? pl->roots_inv : pl->roots_fwd;
         dst.ensure(nroots * sizeof(FrU));
-        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(nroots, T)), dim3(T), 0, s, ptr<Fr>(ctx->tmp), inv ? fe_inv(wM) : wM, Fr::one(), nroots, 0u, 0u, 0);
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(nroots, T)), dim3(T), 0, s, ptr<Fr>(ctx->tmp), inv ? fe_inv(wM) : wM, Fr::one(), nroots, 0u, 0u, 0, 1u);
         to_rp(ctx->tmp, nroots);
         ZK_LAUNCH((k_unpack_table<typename Fr::Params>), dim3(blocks_for(nroots, T)), dim3(T), 0, s, ptr<Fr>(ctx->tmp), ptr<FrU>(dst), nroots);
     }
@@ -285,15 +298,16 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
     {
         std::vector<u32> src;
         DBuf d_src;
-        for (int which = 0; which < 2; ++which) {
-            const int lg = which ? pl->log2 : pl->log1;
+        for (int which = 0; which < 3; ++which) {
+            if (which == 2 && pl->log3 == 0) break;
+            const int lg = which == 0 ? pl->log1 : which == 1 ? pl->log2 : pl->log3;
             const u32 plen = ntt_plan_len(lg);
-            (which ? pl->plen2 : pl->plen1) = plen;
+            (which == 0 ? pl->plen1 : which == 1 ? pl->plen2 : pl->plen3) = plen;
             ntt_plan_exponents(lg, src);
             d_src.ensure(src.size() * 4);
             dev_h2d(d_src.p, src.data(), src.size() * 4, s);
             for (int inv = 0; inv < 2; ++inv) {
-                DBuf& dst = which ? pl->plan2[inv] : pl->plan1[inv];
+                DBuf& dst = which == 0 ? pl->plan1[inv] : which == 1 ? pl->plan2[inv] : pl->plan3[inv];
                 dst.ensure((size_t)plen * Fu<typename Fr::Params>::N * 4);
                 ZK_LAUNCH((k_ntt_plan_gather<typename Fr::Params>), dim3(blocks_for(plen, T)), dim3(T), 0, s, ptr<FrU>(inv ? pl->roots_inv : pl->roots_fwd),
                           (int)(pl->M >> lg), ptr<u32>(d_src), plen, ptr<u32>(dst));
@@ -302,38 +316,59 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
         }
     }
     if (pl->log1 > 0) {
+        // between the pass over N1 and what follows: w_N^(k1 * j), j < Nb the position inside the block of k1
         pl->tw_fwd.ensure(pl->N * sizeof(Fr));
         pl->tw_inv.ensure(pl->N * sizeof(Fr));
-        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->tw_fwd), pl->omega, Fr::one(), pl->N, pl->N1, pl->N2, 1);
-        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->tw_inv), pl->omega_inv, Fr::one(), pl->N, pl->N1, pl->N2, 1);
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->tw_fwd), pl->omega, Fr::one(), pl->N, pl->N1, (u32)pl->Nb, 1, 1u);
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->tw_inv), pl->omega_inv, Fr::one(), pl->N, pl->N1, (u32)pl->Nb, 1, 1u);
         to_rp(pl->tw_fwd, pl->N);
         to_rp(pl->tw_inv, pl->N);
     }
+    if (pl->log3 > 0) {
+        // inside a block: w_Nb^(k2 * j3), the two-pass rule once more (w_Nb = w_N^N1)
+        const Fr wb = fe_pow_u64(pl->omega, pl->N1), wb_inv = fe_pow_u64(pl->omega_inv, pl->N1);
+        pl->tw2_fwd.ensure(pl->Nb * sizeof(Fr));
+        pl->tw2_inv.ensure(pl->Nb * sizeof(Fr));
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->Nb, T)), dim3(T), 0, s, ptr<Fr>(pl->tw2_fwd), wb, Fr::one(), pl->Nb, pl->N2, pl->N3, 1, 1u);
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->Nb, T)), dim3(T), 0, s, ptr<Fr>(pl->tw2_inv), wb_inv, Fr::one(), pl->Nb, pl->N2, pl->N3, 1, 1u);
+        to_rp(pl->tw2_fwd, pl->Nb);
+        to_rp(pl->tw2_inv, pl->Nb);
+    }
     pl->s_coset.ensure(pl->N * sizeof(Fr));
     pl->s_cosetinv_canon.ensure(pl->N * sizeof(Fr));
-    ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->s_coset), pl->g, pl->n_inv, pl->N, pl->N1, pl->N2, 2);
+    ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->s_coset), pl->g, pl->n_inv, pl->N, pl->N1, pl->N2, 2, pl->N3);
     to_rp(pl->s_coset, pl->N);
     // plain integers: multiplying an R'-form value by them (R' Montgomery product) leaves the plain value
     ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->s_cosetinv_canon), pl->g_inv, fe_from_mont(pl->n_inv), pl->N,
-              pl->N1, pl->N2, 2);
+              pl->N1, pl->N2, 2, pl->N3);
     pl->s_cexit.ensure(pl->N * sizeof(Fr));
     ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(pl->N, T)), dim3(T), 0, s, ptr<Fr>(pl->s_cexit), Fr::one(), fe_from_mont(fe_mul(pl->n_inv, pl->zinv)), pl->N,
-              0u, 0u, 0);
+              0u, 0u, 0, 1u);
     // launch geometry.  A workgroup stages `tile` elements as nine limb planes (36 B + padding per element): tiles of
     // 1024 elements (38 KiB) let four workgroups share a CU, so that one loads while another computes; a cols tile
     // needs >= 2 columns for 64-byte rows in HBM.
-    const u32 tile_rows = std::max<u32>(pl->N2, std::min<u32>((u32)pl->N, 1024));
-    u32 R = pl->log1 == 0 ? 1 : std::max<u32>(1, std::min<u32>(pl->N1, tile_rows / pl->N2));
+    const u32 last = pl->log3 > 0 ? pl->N3 : pl->N2;                        // length of the rows pass's sequences
+    const u64 nrows = pl->N / last;
+    const u32 tile_rows = std::max<u32>(last, (u32)std::min<u64>(pl->N, 1024));
+    u32 R = pl->log1 == 0 ? 1 : (u32)std::max<u64>(1, std::min<u64>(nrows, tile_rows / last));
     pl->R_rows = (int)R;
     const u32 ccols = (u32)ctx->ntt_cols;
-    pl->C_cols = (int)std::max<u32>(1, std::min<u32>(pl->N2, std::max<u32>(ccols, 1024 / std::max<u32>(pl->N1, 1))));
-    require(pl->N2 % (u32)pl->C_cols == 0 && pl->N1 % R == 0, ZKHIP_ERR_BAD_ARG, "internal: NTT tile does not divide the domain");
+    auto cols_per_wg = [&](u64 ncols, u32 n) { return (int)std::max<u64>(1, std::min<u64>(ncols, std::max<u32>(ccols, 1024 / std::max<u32>(n, 1)))); };
+    pl->C_cols = cols_per_wg(pl->Nb, pl->N1);
+    require(pl->Nb % (u64)pl->C_cols == 0 && nrows % R == 0, ZKHIP_ERR_BAD_ARG, "internal: NTT tile does not divide the domain");
     auto smem_for = [](u32 nseq, u32 n) { return (size_t)9 * nseq * ntt_seq_stride((int)n) * 4; };
     pl->smem_cols = smem_for(pl->C_cols, pl->N1);
-    pl->smem_rows = smem_for(R, pl->N2);
+    pl->smem_rows = smem_for(R, last);
     auto pick_threads = [](u64 butterflies) { return (int)std::min<u64>(512, std::max<u64>(64, (butterflies + 63) / 64 * 64)); };
     pl->threads_cols = pick_threads((u64)pl->C_cols * pl->N1 / 4);
-    pl->threads_rows = pick_threads((u64)R * pl->N2 / 4);
+    pl->threads_rows = pick_threads((u64)R * last / 4);
+    if (pl->log3 > 0) {
+        pl->C_mid = cols_per_wg(pl->N3, pl->N2);
+        require(pl->N3 % (u32)pl->C_mid == 0, ZKHIP_ERR_BAD_ARG, "internal: NTT tile does not divide the domain");
+        pl->smem_mid = smem_for(pl->C_mid, pl->N2);
+        pl->threads_mid = pick_threads((u64)pl->C_mid * pl->N2 / 4);
+        require(pl->N1 <= 65535, ZKHIP_ERR_BAD_ARG, "internal: NTT batch exceeds the grid");
+    }
     lds_opt_in(ctx, (const void*)k_ntt_cols<typename Fr::Params>);
     lds_opt_in(ctx, (const void*)k_ntt_rows<typename Fr::Params>);
     stream_sync(s);
@@ -341,19 +376,31 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
 }
 
 // `nvec` vectors of N elements, vec_stride elements apart, go through one launch (grid.y)
+// the pass over N1: columns of the N1 x Nb matrix
 template <class C>
 static void ntt_cols(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, int nvec = 1, u64 vec_stride = 0,
                      int canon = 0, const typename C::Fr* minus = nullptr) {
     typedef typename C::Fr Fr;
-    ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3(pl->N2 / pl->C_cols, nvec), dim3(pl->threads_cols), pl->smem_cols, ctx->ws, data, vec_stride,
-              pl->log1, pl->N2, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon, minus);
+    ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3((unsigned)(pl->Nb / pl->C_cols), nvec), dim3(pl->threads_cols), pl->smem_cols, ctx->ws, data, vec_stride,
+              pl->log1, (u32)pl->Nb, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon, minus, (u64)0, ~(u64)0);
 }
+// three passes only — the pass over N2: columns of the N2 x N3 matrix of every outer index (grid.z).  `post_mask`: Nb - 1 for
+// the per-block twiddles, all ones for a table as long as the vector.
+template <class C>
+static void ntt_mid(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, u64 post_mask, int nvec, u64 vec_stride) {
+    typedef typename C::Fr Fr;
+    ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3(pl->N3 / pl->C_mid, nvec, pl->N1), dim3(pl->threads_mid), pl->smem_mid, ctx->ws, data, vec_stride,
+              pl->log2, pl->N3, pl->C_mid, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, 0, (const Fr*)nullptr, pl->Nb, post_mask);
+}
+// the pass over the last factor: contiguous sequences
 template <class C>
 static void ntt_rows(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, int nvec = 1, u64 vec_stride = 0,
-                     int canon = 0, const typename C::Fr* minus = nullptr) {
+                     int canon = 0, const typename C::Fr* minus = nullptr, u64 post_mask = ~(u64)0) {
     typedef typename C::Fr Fr;
-    ZK_LAUNCH((k_ntt_rows<typename Fr::Params>), dim3(pl->N1 / pl->R_rows, nvec), dim3(pl->threads_rows), pl->smem_rows, ctx->ws, data, vec_stride,
-              pl->log2, pl->R_rows, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, canon, minus);
+    const bool three = pl->log3 > 0;
+    const int lg = three ? pl->log3 : pl->log2;
+    ZK_LAUNCH((k_ntt_rows<typename Fr::Params>), dim3((unsigned)((pl->N >> lg) / pl->R_rows), nvec), dim3(pl->threads_rows), pl->smem_rows, ctx->ws, data, vec_stride,
+              lg, pl->R_rows, ptr<u32>((three ? pl->plan3 : pl->plan2)[inverse ? 1 : 0]), three ? pl->plen3 : pl->plen2, post, canon, minus, post_mask);
 }
 // natural order in -> sigma order out
 template <class C>
@@ -361,6 +408,7 @@ static void ntt_kind_a(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, boo
                        u64 vec_stride = 0, int canon = 0, const typename C::Fr* final_minus = nullptr) {
     typedef typename C::Fr Fr;
     if (pl->log1 > 0) ntt_cols<C>(ctx, pl, data, inverse, inverse ? ptr<Fr>(pl->tw_inv) : ptr<Fr>(pl->tw_fwd), nvec, vec_stride);
+    if (pl->log3 > 0) ntt_mid<C>(ctx, pl, data, inverse, inverse ? ptr<Fr>(pl->tw2_inv) : ptr<Fr>(pl->tw2_fwd), pl->Nb - 1, nvec, vec_stride);
     ntt_rows<C>(ctx, pl, data, inverse, final_post, nvec, vec_stride, canon, final_minus);
 }
 // sigma order in -> natural order out
@@ -368,7 +416,11 @@ template <class C>
 static void ntt_kind_b(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* final_post, int nvec = 1,
                        u64 vec_stride = 0, int canon = 0) {
     typedef typename C::Fr Fr;
-    if (pl->log1 > 0) {
+    if (pl->log3 > 0) {
+        ntt_rows<C>(ctx, pl, data, inverse, inverse ? ptr<Fr>(pl->tw2_inv) : ptr<Fr>(pl->tw2_fwd), nvec, vec_stride, 0, nullptr, pl->Nb - 1);
+        ntt_mid<C>(ctx, pl, data, inverse, inverse ? ptr<Fr>(pl->tw_inv) : ptr<Fr>(pl->tw_fwd), ~(u64)0, nvec, vec_stride);
+        ntt_cols<C>(ctx, pl, data, inverse, final_post, nvec, vec_stride, canon);
+    } else if (pl->log1 > 0) {
         ntt_rows<C>(ctx, pl, data, inverse, inverse ? ptr<Fr>(pl->tw_inv) : ptr<Fr>(pl->tw_fwd), nvec, vec_stride);
         ntt_cols<C>(ctx, pl, data, inverse, final_post, nvec, vec_stride, canon);
     } else {
@@ -381,13 +433,15 @@ struct MsmShape {
     u64 n;
     int c, W;
     u32 K;          // buckets per set = 2^(c-1)
-    u32 sets;       // bucket sets: 1 when the bases carry precomputed window multiples (all windows share one set), else W
+    u32 sets;       // bucket sets: 1 when the bases carry every window multiple (all windows share one set), W without a table, in
+                    // between for keys too large for W levels (window j: bucket set j % sets, table level j / sets)
+    u32 levels;     // table levels the sorted entries refer to: ceil(W / sets) (1 without a table)
     u32 nkeys;      // sets * K
     u32 Lw, H;      // fold geometry: K = H rows of Lw buckets
     u32 ndig;       // digits of the fold: 2 (column, row), or 3 for wide windows (column, row = g * I + i: i, g)
     u32 I, G;       // three-digit fold: H = G groups of I rows
     u32 kh, nhi;    // sort: K = nhi classes of kh buckets (kh = what one LDS histogram holds); nhi > 1: two passes
-    bool shared() const { return sets == 1 && W > 1; }
+    int level_bits() const { return c * (int)sets; }   // level t of a table holds 2^(level_bits t) P
     u32 nsums() const { return ndig * sets; }   // the fold leaves one sum per digit and bucket set: msm_combine adds them
 };
 static inline int env_int(const char* name, int lo, int hi, int dflt) {
@@ -397,7 +451,7 @@ static inline int env_int(const char* name, int lo, int hi, int dflt) {
 static constexpr int MSM_MAX_C = 20;   // widest window: the sort's LDS histogram holds 2^15 counters and its second pass splits 16 ways
 static constexpr int MSM_AUTO_MAX_C = 16;   // widest window chosen automatically
 // `table`: the bases carry precomputed window multiples 2^(c j) P (resident keys); otherwise one bucket set per window.
-static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, bool table, int force_c = 0) {
+static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, bool table, int force_c = 0, int force_sets = 0) {
     MsmShape s;
     s.n = n;
     const int lg = ilog2_floor(std::max<u64>(n, 1));
@@ -429,14 +483,15 @@ static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, b
     s.c = std::min(s.c, kh_log + 1 + 4);             // the second sort pass splits at most 16 ways
     s.W = (scalar_bits + 1 + s.c - 1) / s.c;
     s.K = 1u << (s.c - 1);
-    s.sets = table ? 1 : (u32)s.W;
+    s.sets = table ? (u32)std::max(1, std::min(force_sets ? force_sets : 1, s.W)) : (u32)s.W;
+    s.levels = ((u32)s.W + s.sets - 1) / s.sets;
     s.nkeys = s.sets * s.K;
     s.Lw = std::min<u32>(s.K, 256);
     s.H = s.K / s.Lw;
     s.kh = std::min<u32>(s.K, 1u << kh_log);
     s.nhi = s.K / s.kh;
     s.ndig = 2; s.I = s.G = 0;
-    if (table && s.H >= (ctx ? ctx->fold3_min_h : 512u) && s.H >= 4) {
+    if (table && s.sets == 1 && s.H >= (ctx ? ctx->fold3_min_h : 512u) && s.H >= 4) {
         s.ndig = 3;
         s.I = std::min<u32>(64, s.H / 2);
         s.G = s.H / s.I;
@@ -459,7 +514,7 @@ static inline void scan_u32(Stream s, const DBuf& cnt, DBuf& off, u64 nk, DBuf& 
 static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32* d_scalars, const MsmShape& sh, u64 level_stride) {
     const u64 nk = sh.nkeys;
     require(sh.n * (u64)sh.W < ((u64)1 << 32) - sh.nkeys, ZKHIP_ERR_BAD_ARG, "MSM too large for 32-bit sort offsets");
-    require(level_stride * (u64)sh.W < ((u64)1 << 31) && sh.n < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "MSM too large for 31-bit table indices");
+    require(level_stride * (u64)sh.levels < ((u64)1 << 31) && sh.n < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "MSM too large for 31-bit table indices");
     so.wm.ensure(sh.n * 32);
     so.sorted.ensure(sh.n * sh.W * 4);
     const unsigned T = 256;
@@ -479,11 +534,10 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
         dev_memset(so.cursor.p, 0, nk * 4, s);
         lds_opt_in(ctx, (const void*)k_msm_count);
         lds_opt_in(ctx, (const void*)k_msm_place);
-        const u32 key_stride = sh.sets == 1 ? 0 : sh.K;
-        ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride, kh,
+        ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, sh.sets, kh,
                   ptr<u32>(so.cnt));
         scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
-        ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, key_stride, kh,
+        ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, sh.sets, kh,
                   level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
     } else {
         // wider than one LDS histogram (shared buckets only): sort on the low bits, stable partition on the high bits
@@ -530,9 +584,9 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
 // affine points, saturated Montgomery form -> packed working form of the MSM kernels (level 0 of a table); on ctx->stream
 template <class F>
 void points_to_packed(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
-// levels 1 .. W-1 (2^(c j) P) behind a level 0 of `count` points; synchronises ctx->stream
+// levels 1 .. L-1 (2^(bits j) P) behind a level 0 of `count` points; synchronises ctx->stream
 template <class F>
-void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int c, int W);
+void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int bits, int L);
 template <class F> static constexpr size_t packed_point_bytes() { return sizeof(AffPacked<typename Unsat<F>::type>); }
 // fixed-base tables / multiplications for setup (N3); also per-group code
 template <class F>
@@ -550,7 +604,7 @@ static Xyzz<F> msm_combine(const Xyzz<F>* ws, const MsmShape& sh) {
     };
     if (sh.sets == 1) return set_sum(0);
     Xyzz<F> acc = Xyzz<F>::inf();
-    for (int j = sh.W - 1; j >= 0; --j) {
+    for (int j = (int)sh.sets - 1; j >= 0; --j) {
         for (int i = 0; i < sh.c; ++i) acc = xyzz_dbl(acc);
         acc = xyzz_add(acc, set_sum(j));
     }
@@ -600,6 +654,7 @@ struct zkhip_pk {
     u32 rank = 0, world = 1;
     u64 z_lo = 0, z_n = 0, h_lo = 0, h_n = 0;
     int c_z = 0, c_h = 0;
+    int s_z = 1, s_h = 1;     // bucket sets of the MSMs over z / over h = every s-th window multiple is in the tables (MsmShape::sets)
     // log2 N1 of the NTT plan the sigma order of h_sigma was made for (N = N1 * N2): a context whose plan for this domain
     // splits differently (ZKHIP_TUNE_NTT_SINGLE_MAX_LOG changed after the key was loaded, or an image written under
     // another setting) would pair h with the wrong bases, so the provers and zkhip_pk_import refuse the mismatch
@@ -728,7 +783,7 @@ struct PkLoader {
         require(m + 2 < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "too many variables");
         pk->m = m; pk->w = w; pk->l = l; pk->hlen = hl; pk->N = N; pk->logN = ilog2_floor(N);
         NttPlan<C>* plan = get_plan<C>(ctx, pk->logN);
-        pk->ntt_log1 = plan->log1;
+        pk->ntt_log1 = plan->split();
         pk->delta_g1_canon.assign(delta_g1, delta_g1 + G1B);
 
         const u64 me = m + 2;   // extended by the (delta, r) and (delta, s) pairs — see prove()
@@ -764,7 +819,7 @@ struct PkLoader {
         ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(hl * 2, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(ctx->tmp), ptr<Fq>(ctx->tmp), hl * 2);
         pk->h_sigma.ensure(N * G1B);
         ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(N, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(ctx->tmp),
-                  ptr<Aff<Fq>>(pk->h_sigma), N, hl, plan->N1, plan->N2);
+                  ptr<Aff<Fq>>(pk->h_sigma), N, hl, plan->N1, plan->N2, plan->N3);
         stream_sync(ctx->stream);
         // constant terms: z_0 = 1, so alpha/beta ride on entry 0 of their query vectors
         add_into<Fq, 2>(ctx, pk->a_ext, 0, alpha_g1);
@@ -778,9 +833,30 @@ struct PkLoader {
         u64 nominal_z, nominal_h;
         range_of(me, pk->rank, pk->world, pk->z_lo, pk->z_n, nominal_z);
         range_of(hdom, pk->rank, pk->world, pk->h_lo, pk->h_n, nominal_h);
-        const MsmShape shz = msm_shape(ctx, nominal_z, C::Fr::Params::BITS, true), shh = msm_shape(ctx, nominal_h, C::Fr::Params::BITS, true);
+        MsmShape shz = msm_shape(ctx, nominal_z, C::Fr::Params::BITS, true), shh = msm_shape(ctx, nominal_h, C::Fr::Params::BITS, true);
+        // Every window multiple of every base (one bucket set, one fold per MSM) while that fits the device: a 2^20 key is 6 GiB,
+        // 2^24 96 GiB.  Beyond — or when ZKHIP_TUNE_MSM_SETS says so — the tables keep every 2nd, 4th, ... multiple and the MSMs
+        // fold as many bucket sets (the reference has no size limit below the field's two-adicity; this is how it is met).
+        int sets = ctx->msm_sets;
+        if (!sets) {
+            size_t free_b = 0, total_b = 0;
+            dev_mem_info(&free_b, &total_b);
+            const u64 budget = (u64)(0.6 * (double)free_b);
+            const u64 g1 = packed_point_bytes<Fq>(), g2 = packed_point_bytes<Fq2>();
+            sets = 1;
+            for (;;) {
+                const MsmShape a = msm_shape(ctx, nominal_z, C::Fr::Params::BITS, true, 0, sets), b = msm_shape(ctx, nominal_h, C::Fr::Params::BITS, true, 0, sets);
+                const u64 need = pk->z_n * (3 * g1 + g2) * a.levels + pk->h_n * g1 * b.levels;
+                if (need <= budget || (int)a.sets < sets) break;      // (a.sets < sets: already one bucket set per window)
+                sets *= 2;
+            }
+        }
+        shz = msm_shape(ctx, nominal_z, C::Fr::Params::BITS, true, 0, sets);
+        shh = msm_shape(ctx, nominal_h, C::Fr::Params::BITS, true, 0, sets);
         pk->c_z = shz.c;
         pk->c_h = shh.c;
+        pk->s_z = (int)shz.sets;
+        pk->s_h = (int)shh.sets;
         to_table<Fq>(ctx, pk->a_ext, pk->z_lo, pk->z_n, shz);
         to_table<Fq>(ctx, pk->b1_ext, pk->z_lo, pk->z_n, shz);
         to_table<Fq>(ctx, pk->l_ext, pk->z_lo, pk->z_n, shz);
@@ -789,22 +865,22 @@ struct PkLoader {
     }
     // levels 1 .. W-1 of the five tables of a key whose level 0 is in place (zkhip_pk_import of a compact image)
     static void table_levels(zkhip_ctx* ctx, zkhip_pk* pk) {
-        const MsmShape shz = msm_shape(ctx, pk->z_n, C::Fr::Params::BITS, true, pk->c_z), shh = msm_shape(ctx, pk->h_n, C::Fr::Params::BITS, true, pk->c_h);
-        msm_table_levels<Fq>(ctx, pk->a_ext.p, pk->z_n, shz.c, shz.W);
-        msm_table_levels<Fq>(ctx, pk->b1_ext.p, pk->z_n, shz.c, shz.W);
-        msm_table_levels<Fq>(ctx, pk->l_ext.p, pk->z_n, shz.c, shz.W);
-        msm_table_levels<Fq2>(ctx, pk->b2_ext.p, pk->z_n, shz.c, shz.W);
-        msm_table_levels<Fq>(ctx, pk->h_sigma.p, pk->h_n, shh.c, shh.W);
+        const MsmShape shz = msm_shape(ctx, pk->z_n, C::Fr::Params::BITS, true, pk->c_z, pk->s_z), shh = msm_shape(ctx, pk->h_n, C::Fr::Params::BITS, true, pk->c_h, pk->s_h);
+        msm_table_levels<Fq>(ctx, pk->a_ext.p, pk->z_n, shz.level_bits(), (int)shz.levels);
+        msm_table_levels<Fq>(ctx, pk->b1_ext.p, pk->z_n, shz.level_bits(), (int)shz.levels);
+        msm_table_levels<Fq>(ctx, pk->l_ext.p, pk->z_n, shz.level_bits(), (int)shz.levels);
+        msm_table_levels<Fq2>(ctx, pk->b2_ext.p, pk->z_n, shz.level_bits(), (int)shz.levels);
+        msm_table_levels<Fq>(ctx, pk->h_sigma.p, pk->h_n, shh.level_bits(), (int)shh.levels);
     }
     template <class F>
     static void to_table(zkhip_ctx* ctx, DBuf& buf, u64 lo, u64 count, const MsmShape& sh) {
         DBuf out;
-        out.ensure(std::max<u64>(count, 1) * (u64)sh.W * packed_point_bytes<F>());
+        out.ensure(std::max<u64>(count, 1) * (u64)sh.levels * packed_point_bytes<F>());
         if (count) points_to_packed<F>(ctx, ptr<Aff<F>>(buf) + lo, out.p, count);
         stream_sync(ctx->stream);
         buf.swap(out);
         out.release();                        // the saturated copy goes before the levels' workspace is allocated
-        msm_table_levels<F>(ctx, buf.p, count, sh.c, sh.W);
+        msm_table_levels<F>(ctx, buf.p, count, sh.level_bits(), (int)sh.levels);
     }
 };
 
@@ -887,7 +963,7 @@ struct Prover {
         Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
-        require(pl->log1 == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's h bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
+        require(pl->split() == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's h bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
         sl.t_start = std::chrono::steady_clock::now();
         memcpy(sl.r, r, 32);
         memcpy(sl.s, s_, 32);
@@ -908,8 +984,12 @@ struct Prover {
 
         // ---- MSMs over S = [z_0..z_{m-1}, r, s]: A, B1, L in G1 and B2 in G2 share one digit/sort pass
         // (a sharded key covers only its index range of the bases, and pairs them with the same range of the scalars)
-        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
-        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
+        // (a knob that narrows the sort after the key was loaded — SORT_KH_LOG — must not silently pair the sort of one window
+        // width with tables built for another)
+        require(shz.c == pk->c_z && shh.c == pk->c_h && (int)shz.sets == pk->s_z && (int)shh.sets == pk->s_h, ZKHIP_ERR_BAD_ARG,
+                "the key's tables were built for another window width than this context's sort settings allow (SORT_KH_LOG changed): reload the key");
         const int Wmax = (int)std::max(shz.nsums(), shh.nsums());   // sums per MSM (2: the tables carry the window multiples)
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // 4 G1 MSMs + 1 G2 MSM
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
@@ -1018,8 +1098,8 @@ struct Prover {
         require(sl.busy, ZKHIP_ERR_DEVICE, "internal: no proof in flight in this slot");
         event_sync(sl.ev[3]);
         sl.busy = false;
-        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
-        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
         const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
         const Xyzz<Fq>* h_ws1 = (const Xyzz<Fq>*)sl.h_ws;
         const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
@@ -1138,8 +1218,8 @@ struct Prover {
         require(sl.busy, ZKHIP_ERR_DEVICE, "internal: no proof in flight in this slot");
         event_sync(sl.ev[3]);
         sl.busy = false;
-        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
-        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
         const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
         *b1 = (size_t)4 * Wmax * sizeof(Xyzz<Fq>);
         *b2 = (size_t)Wmax * sizeof(Xyzz<Fq2>);
@@ -1152,8 +1232,8 @@ struct Prover {
     // the same sums, gathered into host memory (one rank's ws1 | ws2), as a partial record for `combine` (not canonical:
     // these never leave the process)
     static void record_from_sums(zkhip_ctx* ctx, const zkhip_pk* pk, const uint8_t* ws1, const uint8_t* ws2, uint8_t* record_out) {
-        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
-        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
         const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
         std::vector<Xyzz<Fq>> a1((size_t)4 * Wmax);
         std::vector<Xyzz<Fq2>> a2((size_t)Wmax);
@@ -1300,7 +1380,7 @@ struct Prover {
             ZK_LAUNCH((k_mul_table<Fr>), dim3(B), dim3(T), 0, s, a, t, a, N);
         }
         ntt_kind_a<C>(ctx, pl, a, inverse, nullptr, 1, 0, 1);
-        ZK_LAUNCH((k_sigma_permute<Fr>), dim3(B), dim3(T), 0, s, a, b, N, pl->N1, pl->N2, 1);
+        ZK_LAUNCH((k_sigma_permute<Fr>), dim3(B), dim3(T), 0, s, a, b, N, pl->N1, pl->N2, 1, pl->N3);
         if (inverse) {    // * 1/N (and g^-i for coset_ifft)
             ZK_LAUNCH((k_pow_table<Fr>), dim3(B), dim3(T), 0, s, t, dir == 3 ? pl->g_inv : Fr::one(), pl->n_inv, N, 0u, 0u, 0);
             ZK_LAUNCH((k_mul_table<Fr>), dim3(B), dim3(T), 0, s, b, t, b, N);
@@ -1320,7 +1400,7 @@ struct Prover {
         witness_map(ctx, cs, pl);
         ctx->cur->vb.ensure(pl->N * sizeof(Fr));
         ZK_LAUNCH((k_sigma_permute<Fr>), dim3(blocks_for(pl->N, 256)), dim3(256), 0, ctx->stream, ptr<Fr>(ctx->cur->va), ptr<Fr>(ctx->cur->vb), pl->N,
-                  pl->N1, pl->N2, 1);
+                  pl->N1, pl->N2, 1, pl->N3);
         dev_d2h(h_out, ctx->cur->vb.p, pl->N * 32, ctx->stream);
         stream_sync(ctx->stream);
     }
@@ -1402,7 +1482,8 @@ struct CurveOps {
     u64 (*gm17_key_bytes)(u64, u64, u64);
     void (*gm17_prove_partial)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const void*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*gm17_combine)(const zkhip_pk*, u32, const uint8_t*, const uint8_t*, uint8_t*);
-    int (*ntt_log1)(zkhip_ctx*, int logN);   // log2 N1 of this context's NTT plan for a domain (what a key's h order depends on)
+    int (*ntt_log1)(zkhip_ctx*, int logN);   // the split of this context's NTT plan for a domain (what a key's h order depends on)
+    bool (*msm_shape_ok)(const zkhip_ctx*, u64 n, int c, int sets);   // (c, sets) of a key usable as they are under this context's settings
     size_t packed_g1_bytes;  // size of one resident G1 base (G2: twice that): lets zkhip_pk_import validate an image's shape
     int fr_bits;             // scalar width: the number of table levels follows from it and the window width
 };
@@ -1412,10 +1493,16 @@ static void field_op_dispatch(zkhip_ctx* ctx, int field, int op, u64 count, cons
     else Prover<C>::template field_op_api<typename C::Fq>(ctx, op, count, a, b, out);
 }
 template <class C>
-static int ntt_log1_of(zkhip_ctx* ctx, int logN) { return get_plan<C>(ctx, logN)->log1; }
+static int ntt_log1_of(zkhip_ctx* ctx, int logN) { return get_plan<C>(ctx, logN)->split(); }
+template <class C>
+static bool msm_shape_ok_of(const zkhip_ctx* ctx, u64 n, int c, int sets) {
+    const MsmShape sh = msm_shape(ctx, n, C::Fr::Params::BITS, true, c, sets);
+    return sh.c == c && (int)sh.sets == sets;
+}
 template <class C>
 static CurveOps make_curve_ops() {
     CurveOps o;
+    o.msm_shape_ok = &msm_shape_ok_of<C>;
     o.ntt_log1 = &ntt_log1_of<C>;
     o.pk_load = &PkLoader<C>::load;
     o.pk_table_levels = &PkLoader<C>::table_levels;

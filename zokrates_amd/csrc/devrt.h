@@ -308,6 +308,8 @@ inline Stream stream_create_high_priority() {
 inline void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
 inline void stream_sync(Stream s) { ZK_HIP_CHECK(hipStreamSynchronize(s)); }
 inline void dev_sync_all() { (void)hipDeviceSynchronize(); }
+// free / total bytes of the current device
+inline void dev_mem_info(size_t* free_b, size_t* total_b) { ZK_HIP_CHECK(hipMemGetInfo(free_b, total_b)); }
 inline Event event_create() {
     Event e;
     ZK_HIP_CHECK(hipEventCreate(&e));
@@ -395,6 +397,7 @@ inline Stream stream_create_high_priority() { return 0; }
 inline void stream_destroy(Stream) {}
 inline void stream_sync(Stream) {}
 inline void dev_sync_all() {}
+inline void dev_mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)1 << 40; }
 inline Event event_create() { return new double(0); }
 inline void event_destroy(Event e) { delete e; }
 inline void event_record(Event e, Stream) { *e = emu::now_ms(); }

@@ -28,6 +28,17 @@ namespace zk {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+// The order a transform leaves its output in ("sigma order"; kernels_ntt.cuh).  Two passes, N = n1 * n2 (n3 = 1): position
+// k1 * n2 + k2 holds the element of natural index k1 + n1 * k2.  Three passes, N = n1 * n2 * n3 (domains above 2^22): position
+// (k1 * n2 + k2) * n3 + k3 holds natural index k1 + n1 * (k2 + n2 * k3) — the same rule applied again inside the n2 * n3 block
+// of every k1.  The h bases of a key are stored in this order (k_sigma_gather_points), so the prover never permutes.
+ZK_HD u64 sigma_nat(u64 p, u32 n1, u32 n2, u32 n3) {
+    const u64 m = (u64)n2 * n3;
+    const u64 k1 = p / m, rem = p % m;
+    const u64 k2 = rem / n3, k3 = rem % n3;
+    return k1 + (u64)n1 * (k2 + (u64)n2 * k3);
+}
+
 // ---- field parameter packs (constexpr tables readable from host and device code) ----
 #define ZK_TABLE(name, n, ...) \
     ZK_HD static constexpr u32 name(int i) { constexpr u32 t[n] = {__VA_ARGS__}; return t[i]; }

@@ -142,7 +142,7 @@ struct Gm17 {
         pk->scheme = 1;
         pk->m = M; pk->w = n1; pk->l = l; pk->hlen = tl; pk->N = D; pk->logN = ilog2_floor(D);
         NttPlan<C>* plan = get_plan<C>(ctx, pk->logN);
-        pk->ntt_log1 = plan->log1;
+        pk->ntt_log1 = plan->split();
         pk->g_gamma2_z2_canon.assign(g_gamma2_z2, g_gamma2_z2 + G1B);
 
         const u64 me = M + 2;   // extended by the (., rho) pair and one unused slot (same shape as the Groth16 key)
@@ -175,7 +175,7 @@ struct Gm17 {
         ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(D * 2, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(ctx->tmp), ptr<Fq>(ctx->tmp), D * 2);
         pk->h_sigma.ensure(D * G1B);
         ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(D, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(ctx->tmp),
-                  ptr<Aff<Fq>>(pk->h_sigma), D, D, plan->N1, plan->N2);
+                  ptr<Aff<Fq>>(pk->h_sigma), D, D, plan->N1, plan->N2, plan->N3);
         stream_sync(ctx->stream);
         L::finish_tables(ctx, pk, me, D);
     }
@@ -203,7 +203,7 @@ struct Gm17 {
         require(canon_lt_mod(dd) && canon_lt_mod(rr), ZKHIP_ERR_BAD_ARG, "d1 or r not a canonical field element");
         const Fr rho = add_mod(dd, rr);
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
-        require(pl->log1 == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's quotient bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
+        require(pl->split() == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's quotient bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
         sl.t_start = std::chrono::steady_clock::now();
         memcpy(sl.r, rho.v, 32);
         memset(sl.s, 0, 32);
@@ -246,8 +246,10 @@ struct Gm17 {
         event_record(sl.ev[1], st);
 
         // ---- the four MSMs over S = [ext_0..ext_{M-1}, rho, 0] share one digit/sort pass
-        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z);
-        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h);
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
+        require(shz.c == pk->c_z && shh.c == pk->c_h && (int)shz.sets == pk->s_z && (int)shh.sets == pk->s_h, ZKHIP_ERR_BAD_ARG,
+                "the key's tables were built for another window width than this context's sort settings allow (SORT_KH_LOG changed): reload the key");
         const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));

@@ -48,7 +48,7 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     const int wpe = ctx->msm_waves ? ctx->msm_waves : (nt > 1 ? std::max(1, (ctx->msm_fused_waves ? ctx->msm_fused_waves : MsmTuning<F>::FUSED_WPE)) : single);
     const u64 machine = ctx->msm_lanes ? (u64)ctx->msm_lanes : (u64)ctx->cus * 4 * 64 * wpe / (nt > 1 && !ctx->msm_waves ? nt : 1);
     const u32 nlanes = (u32)std::max<u64>(1, std::min<u64>(machine, (sh.n * (u64)sh.W + ctx->msm_min_slice - 1) / ctx->msm_min_slice));
-    const MsmCut cut{nlanes, ctx->msm_min_slice, (u32)std::min<u64>(sh.n * (u64)(sh.shared() ? sh.W : 1), 0x7fffffffu)};
+    const MsmCut cut{nlanes, ctx->msm_min_slice, (u32)std::min<u64>(sh.n * (u64)sh.levels, 0x7fffffffu)};
     const u64 partial_stride = (u64)sh.nkeys + nlanes;
     lane.heavy.ensure(((size_t)sh.nkeys + 1) * 4);            // [0] = count, [1..] = keys
     lane.lane_key.ensure((size_t)nlanes * 4);

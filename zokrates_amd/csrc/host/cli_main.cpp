@@ -96,6 +96,8 @@ int cmd_setup(int argc, char** argv) {
         o.write((const char*)kp.pk.data(), (std::streamsize)kp.pk.size());
         std::ofstream v(vk_path);
         v << kp.vk;
+        o.close();                      // (the stream state is only final once the buffers have been flushed)
+        v.close();
         if (!o || !v) throw Error(ZKHIP_ERR_BAD_ARG, "cannot write the key files");
         printf("setup (%s): %llu constraints, %llu variables; wrote %s, %s\n", scheme_s.c_str(), (unsigned long long)program.constraints(),
                (unsigned long long)program.variables(), pk_path.c_str(), vk_path.c_str());
@@ -246,7 +248,8 @@ int main(int argc, char** argv) {
             if (stat(pk_path.c_str(), &st) != 0) throw Error(ZKHIP_ERR_BAD_ARG, "cannot stat " + pk_path);
             char tag[64];
             snprintf(tag, sizeof(tag), "%016llx", (unsigned long long)fnv1a(pk_path + "|" + std::to_string((long long)st.st_size) + "|" +
-                                                                           std::to_string((long long)st.st_mtime) + "|" + scheme_s + "|" + std::to_string(curve)));
+                                                                           std::to_string((long long)st.st_mtim.tv_sec) + "." + std::to_string((long long)st.st_mtim.tv_nsec) + "|" +
+                                                                           std::to_string((unsigned long long)st.st_ino) + "|" + scheme_s + "|" + std::to_string(curve)));
             image_path = cache_dir + "/" + tag + ".zkhippk";
             struct stat ist;
             try_image = stat(image_path.c_str(), &ist) == 0;
@@ -285,7 +288,11 @@ int main(int argc, char** argv) {
                 std::ofstream o(tmp, std::ios::binary);
                 o.write((const char*)img.data(), (std::streamsize)img.size());
                 o.close();
-                rename(tmp.c_str(), image_path.c_str());
+                // only a completely written image enters the cache (ENOSPC, I/O error: the run goes on without one)
+                if (!o || rename(tmp.c_str(), image_path.c_str()) != 0) {
+                    unlink(tmp.c_str());
+                    fprintf(stderr, "warning: key image not cached (%s could not be written)\n", image_path.c_str());
+                }
             }
         }
         const double ms_key = ms_since(t0);
@@ -301,6 +308,8 @@ int main(int argc, char** argv) {
             std::ofstream o(proof_path);
             if (!o) throw Error(ZKHIP_ERR_BAD_ARG, "cannot write " + proof_path);
             o << proof.to_json();
+            o.close();
+            if (!o) throw Error(ZKHIP_ERR_BAD_ARG, "error while writing " + proof_path);
         }
         const double ms_json = ms_since(t0);
         // --verify: the proof just written against the verification key at the head of the proving key, on the host CPU

@@ -417,7 +417,7 @@ struct Pairing {
         Xyzz<Fq> acc = Xyzz<Fq>::inf();
         for (size_t i = 0; i < base.size(); ++i) {
             const Aff<Fq> b = g1(base[i]);
-            if (!on_curve_g1(b)) { *ok = false; return Aff<Fq>::inf(); }
+            if (!good(b)) { *ok = false; return Aff<Fq>::inf(); }       // on the curve AND in the r-torsion, like every other vk / proof point
             if (i == 0) { acc = Xyzz<Fq>::from_affine(b); continue; }
             const Big k = scalar(inputs[i - 1]);
             if (!k.empty()) acc = xyzz_add(acc, xyzz_mul_limbs(Xyzz<Fq>::from_affine(b), k.data(), (int)k.size()));

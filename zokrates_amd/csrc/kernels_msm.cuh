@@ -127,8 +127,10 @@ static constexpr u32 MSM_HEAVY = 16;  // a bucket spread over more slices than t
 // pass at 2^20).  Here a workgroup owns ONE window of a chunk of scalars, so all its keys fall into one set of K buckets:
 // the histogram lives in LDS (K x 4 B <= 128 KB) and only one global atomic per touched (workgroup, bucket) remains.
 // Scalars are first transposed to word-major order so that a window reads the two 32-bit words it needs with unit stride.
-// key = j * key_stride + bucket (key_stride = K: one bucket set per window; 0: all windows share one set);
-// sorted entry = (j * idx_stride + i) | sign << 31 (idx_stride = table level stride, 0 without a table).
+// Window j belongs to bucket set j % sets and pairs with table level j / sets (level t holds 2^(c sets t) P): sets = 1 — every
+// window multiple precomputed, ONE bucket set; sets = W — no table, a bucket set per window; in between, keys too large for
+// W levels of every base (domains above 2^24) keep every sets-th multiple and fold `sets` bucket sets.
+// key = (j % sets) * K + bucket;  sorted entry = ((j / sets) * idx_stride + i) | sign << 31 (idx_stride = table level stride).
 static __global__ void k_scalars_to_word_major(const u32* __restrict__ scalars, u64 n, u32* __restrict__ wm) {
     ZK_PRIO_HIGH();
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,7 +167,7 @@ static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ w
 // grid (nchunks, W, K / kh); dynamic LDS kh x 4 B.  cnt[key] += number of digits with that key in this chunk.
 // A workgroup histograms the buckets [z * kh, (z + 1) * kh) of its window (kh = min(K, 2^15): the histogram fits LDS up to
 // c = 16; wider windows split their buckets over blockIdx.z and every split rescans the chunk's digits).
-static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
+static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
                                                         u32* __restrict__ cnt) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
@@ -184,11 +186,11 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32*
     }
     __syncthreads();
     for (u32 b = threadIdx.x; b < kh; b += blockDim.x)
-        if (hist[b]) atomicAdd(&cnt[(u64)j * key_stride + b0 + b], hist[b]);
+        if (hist[b]) atomicAdd(&cnt[(u64)((u32)j % sets) * K + b0 + b], hist[b]);
 }
 // same geometry; after the scan: reserve this workgroup's run inside every bucket it touches (one global atomic per
 // bucket), then place the entries with LDS atomics.
-static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 key_stride, u32 kh,
+static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
                                                         u64 idx_stride, const u32* __restrict__ off, u32* __restrict__ cursor,
                                                         u32* __restrict__ sorted) {
     ZK_PRIO_HIGH();
@@ -210,18 +212,18 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32*
     for (u32 b = threadIdx.x; b < kh; b += blockDim.x) {
         const u32 have = hist[b];
         if (!have) continue;
-        const u64 key = (u64)j * key_stride + b0 + b;
+        const u64 key = (u64)((u32)j % sets) * K + b0 + b;
         hist[b] = off[key] + atomicAdd(&cursor[key], have);   // global position of this workgroup's first entry
     }
     __syncthreads();
-    const u32 level = (u32)((u64)j * idx_stride);
+    const u32 level = (u32)((u64)((u32)j / sets) * idx_stride);
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
         const u32 b = (d & 0x7fffffffu) - b0;
         if (b >= kh) continue;
         const u32 pos = atomicAdd(&hist[b], 1u);
-        ZK_ASSERT_IDX(pos >= off[(u64)j * key_stride + b0 + b] && pos < off[(u64)j * key_stride + b0 + b + 1]);
+        ZK_ASSERT_IDX(pos >= off[(u64)((u32)j % sets) * K + b0 + b] && pos < off[(u64)((u32)j % sets) * K + b0 + b + 1]);
         sorted[pos] = (level + (u32)i) | (d & 0x80000000u);
     }
 }
@@ -738,7 +740,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final_
 }
 
 // ---- precomputed window multiples (key load) ----
-// tbl[j * stride + i] = 2^(c j) * tbl[i] for j = 1 .. W-1 and i in [i0, i0 + cnt): one work-item per base walks the
+// tbl[j * stride + i] = 2^(c j) * tbl[i] for j = 1 .. W-1 and i in [i0, i0 + cnt) (c: bits between two levels, W: levels): one work-item per base walks the
 // doublings (XYZZ, kept in `tmp`), then turns its W-1 points back into affine form with ONE field inversion (Montgomery's
 // trick over its own ZZZ values, prefix products in `pre`) and packs them.  tmp / pre: (W-1) x cnt entries, level-major.
 template <class F, class FS>
@@ -776,10 +778,10 @@ __global__ void __launch_bounds__(256) k_msm_table_levels(AffPacked<F>* __restri
 // ---- key preparation ----
 // out[p] = (idx < n_src) ? in[idx] : infinity, idx = natural index of sigma position p (h_query layout)
 template <class PT>
-__global__ void k_sigma_gather_points(const PT* __restrict__ in, PT* __restrict__ out, u64 n, u64 n_src, u32 n1, u32 n2) {
+__global__ void k_sigma_gather_points(const PT* __restrict__ in, PT* __restrict__ out, u64 n, u64 n_src, u32 n1, u32 n2, u32 n3) {
     u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    u64 nat = (p / n2) + (u64)n1 * (p % n2);
+    u64 nat = sigma_nat(p, n1, n2, n3);
     out[p] = nat < n_src ? in[nat] : PT::inf();
 }
 

@@ -106,24 +106,24 @@ __global__ void k_mul_table(const F* __restrict__ in, const F* __restrict__ tbl,
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fe_mul(in[i], tbl[i]);
 }
-// out[i] = scale * base^e(i); mode 0: e = i; mode 1: e = (i / n2) * (i % n2)  (2-D twiddle);
-// mode 2: e = natural index of sigma position i, i.e. k1 + n1*k2 with k1 = i / n2, k2 = i % n2
+// out[i] = scale * base^e(i); mode 0: e = i; mode 1: e = (i / n2) * (i % n2)  (the twiddles between two passes: rows x n2
+// columns); mode 2: e = natural index of sigma position i (sigma_nat, field.cuh)
 template <class F>
-__global__ void k_pow_table(F* __restrict__ out, F base, F scale, u64 n, u32 n1, u32 n2, int mode) {
+__global__ void k_pow_table(F* __restrict__ out, F base, F scale, u64 n, u32 n1, u32 n2, int mode, u32 n3 = 1) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 e = i;
     if (mode == 1) e = (i / n2) * (i % n2);
-    else if (mode == 2) e = (i / n2) + (u64)n1 * (i % n2);
+    else if (mode == 2) e = sigma_nat(i, n1, n2, n3);
     out[i] = fe_mul(scale, fe_pow_u64(base, e));
 }
 // out[p] = in[sigma(p)] : gather between natural and sigma order (sigma is its own inverse only when n1 == n2,
-// so both directions are provided): dir 0: out[k1*n2+k2] = in[k1 + n1*k2]; dir 1: out[k1 + n1*k2] = in[k1*n2+k2]
+// so both directions are provided): dir 0: out[p] = in[sigma_nat(p)]; dir 1: out[sigma_nat(p)] = in[p]
 template <class F>
-__global__ void k_sigma_permute(const F* __restrict__ in, F* __restrict__ out, u64 n, u32 n1, u32 n2, int dir) {
+__global__ void k_sigma_permute(const F* __restrict__ in, F* __restrict__ out, u64 n, u32 n1, u32 n2, int dir, u32 n3 = 1) {
     u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    u64 nat = (p / n2) + (u64)n1 * (p % n2);
+    u64 nat = sigma_nat(p, n1, n2, n3);
     if (dir == 0) out[p] = in[nat];
     else out[nat] = in[p];
 }
@@ -320,11 +320,13 @@ __device__ __forceinline__ Fu<P> ntt_load(const uint4* __restrict__ data, size_t
 }
 // x: TIGHT, value < 32p.  With a post factor the product is < 2p; without one fe_relax leaves < 2p; `canon` adds the
 // final conditional subtraction (the Montgomery exit of the last transform must leave canonical integers: MSM digits).
+// `pg`: index of this position's factor in `post` (and of its subtrahend in `minus`): the position counted from the start of the
+// vector, masked for per-block tables — `g` counts from wherever `data` points.
 template <class P>
 __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu<P> x, const uint4* __restrict__ post, int canon,
-                                          const uint4* __restrict__ minus = nullptr) {
+                                          const uint4* __restrict__ minus, size_t pg) {
     if (post) {
-        const uint4 lo = post[2 * g], hi = post[2 * g + 1];
+        const uint4 lo = post[2 * pg], hi = post[2 * pg + 1];
         const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         x = fu_mul_inl(x, fu_unpack<P>(w));
     } else {
@@ -334,7 +336,7 @@ __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu
     fu_pack(x, o.v);
     if (canon) fe_reduce_once(o);
     if (minus) {            // canonical exit only: o - minus[g] mod p, both canonical integers (the c term of the quotient)
-        const uint4 lo = minus[2 * g], hi = minus[2 * g + 1];
+        const uint4 lo = minus[2 * pg], hi = minus[2 * pg + 1];
         Fe<P> m;
         m.v[0] = lo.x; m.v[1] = lo.y; m.v[2] = lo.z; m.v[3] = lo.w; m.v[4] = hi.x; m.v[5] = hi.y; m.v[6] = hi.z; m.v[7] = hi.w;
         o = fe_sub(o, m);
@@ -349,14 +351,19 @@ __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu
 #ifndef ZK_NTT_WGS_PER_CU
 #define ZK_NTT_WGS_PER_CU 4
 #endif
+// blockIdx.z = batch: `data` advances by batch_stride elements per batch (the middle pass of a three-pass transform runs the
+// n1 x n2 sub-matrix of every outer index as one batch entry).  The element-wise factor of position g (counted from the start
+// of the vector) is post[g & post_mask]: all ones for a table as long as the vector, block length - 1 for a table per block.
 template <class P>
 __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n1, u32 n2, int C, const u32* __restrict__ plan,
-                                                     u32 plen, const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr) {
+                                                     u32 plen, const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr,
+                                                     u64 batch_stride = 0, u64 post_mask = ~(u64)0) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     static_assert(P::N == 8, "Fr is 8 x 32-bit words");
     u32* lds = (u32*)smem;
-    uint4* data = (uint4*)(data_ + (size_t)blockIdx.y * vec_stride);
+    const size_t boff = (size_t)blockIdx.z * batch_stride;
+    uint4* data = (uint4*)(data_ + (size_t)blockIdx.y * vec_stride + boff);
     const uint4* post = (const uint4*)post_;
     const int n1 = 1 << log_n1;
     const int SS = n1 + (n1 >> 5) + 1, PL = C * SS;
@@ -370,14 +377,16 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __re
     lds_ntt_dif4<P>(lds, PL, SS, log_n1, C, plan, plen);
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int k = e / C, j = e - k * C;
-        ntt_store<P>(data, (size_t)k * n2 + c0 + j, lds_get_u<P>(lds, PL, j * SS + ntt_slot(bitrev_n(k, log_n1))), post, canon, (const uint4*)minus_);
+        const size_t g = (size_t)k * n2 + c0 + j;
+        ntt_store<P>(data, g, lds_get_u<P>(lds, PL, j * SS + ntt_slot(bitrev_n(k, log_n1))), post, canon, (const uint4*)minus_, (boff + g) & post_mask);
     }
 }
 
 // "rows" pass: this workgroup owns rows [r0, r0 + R) of n2 contiguous elements each.
 template <class P>
 __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_rows(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n2, int R, const u32* __restrict__ plan, u32 plen,
-                                                     const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr) {
+                                                     const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr,
+                                                     u64 post_mask = ~(u64)0) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     u32* lds = (u32*)smem;
@@ -395,7 +404,7 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_rows(Fe<P>* __re
     lds_ntt_dif4<P>(lds, PL, SS, log_n2, R, plan, plen);
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int r = e >> log_n2, k = e & (n2 - 1);
-        ntt_store<P>(data, base + e, lds_get_u<P>(lds, PL, r * SS + ntt_slot(bitrev_n(k, log_n2))), post, canon, (const uint4*)minus_);
+        ntt_store<P>(data, base + e, lds_get_u<P>(lds, PL, r * SS + ntt_slot(bitrev_n(k, log_n2))), post, canon, (const uint4*)minus_, (base + e) & post_mask);
     }
 }
 

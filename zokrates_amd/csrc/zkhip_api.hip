@@ -85,8 +85,10 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->ws = ctx->stream;
         ctx->serial = getenv("ZKHIP_SERIAL") != nullptr;
         ctx->msm_c_env = env_int("ZKHIP_MSM_C", 2, MSM_MAX_C, 0);
+        ctx->msm_sets = env_int("ZKHIP_MSM_SETS", 1, 64, 0);
         ctx->msm_waves = env_int("ZKHIP_MSM_WAVES", 1, 8, 0);
         ctx->ntt_single_max = env_int("ZKHIP_NTT_SINGLE_MAX_LOG", 0, NTT_MAX_SUBLOG, 10);
+        ctx->ntt_max_sublog = env_int("ZKHIP_NTT_MAX_SUBLOG", 2, NTT_MAX_SUBLOG, NTT_MAX_SUBLOG);
         ctx->ntt_cols = env_int("ZKHIP_NTT_COLS", 1, 8, 2);
         if (ctx->ntt_cols & (ctx->ntt_cols - 1)) ctx->ntt_cols = 2;   // the cols pass has no tail handling: a power of two only
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
@@ -151,12 +153,14 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
         auto in = [&](int lo, int hi) { require(value >= lo && value <= hi, ZKHIP_ERR_BAD_ARG, "tunable value out of range"); };
         switch (which) {
             case ZKHIP_TUNE_MSM_C: if (value) in(2, MSM_MAX_C); ctx->msm_c_env = value; break;
+            case ZKHIP_TUNE_MSM_SETS: in(0, 64); ctx->msm_sets = value; break;
             case ZKHIP_TUNE_MSM_WAVES: in(0, 8); ctx->msm_waves = value; break;
             case ZKHIP_TUNE_MSM_LANES: in(0, 1 << 24); ctx->msm_lanes = (u32)value; break;
             case ZKHIP_TUNE_MSM_MIN_SLICE: in(1, 1 << 20); ctx->msm_min_slice = (u32)value; break;
             case ZKHIP_TUNE_FOLD_SCAN: in(0, 1); ctx->fold_scan = value != 0; break;
             case ZKHIP_TUNE_SERIAL: in(0, 1); dev_sync_all(); ctx->serial = value != 0; break;
             case ZKHIP_TUNE_NTT_SINGLE_MAX_LOG: in(0, NTT_MAX_SUBLOG); dev_sync_all(); ctx->ntt_single_max = value; ctx->plans.clear(); break;
+            case ZKHIP_TUNE_NTT_MAX_SUBLOG: in(2, NTT_MAX_SUBLOG); dev_sync_all(); ctx->ntt_max_sublog = value; ctx->plans.clear(); break;
             case ZKHIP_TUNE_SLOTS: in(1, ZK_NSLOTS); dev_sync_all(); ctx->nslots = value; break;
             case ZKHIP_TUNE_Z_GATE: in(0, 2); ctx->z_gate = value; break;
             case ZKHIP_TUNE_FUSE_Z: in(0, 1); ctx->fuse_z = value != 0; break;
@@ -448,55 +452,57 @@ int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs*
 // ------------------------------------------------------------------ N2: device-layout image of a loaded key
 // "ZKHIPPK" + layout version; bump the version whenever the resident layout (packed points, sigma order, the extended base
 // vectors, table levels) changes: an image is only meaningful to the library build that wrote it.
-// An image holds either level 0 of the five base tables (compact: the window multiples are recomputed on the device at
-// import, ~0.1 s for a 2^20 key — less than reading the 6 GiB they occupy from any disk) or all levels
-// (ZKHIP_PK_IMAGE_FULL: import is five host-to-device copies and nothing else).
-static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '3'};
+// An image holds level 0 of the five base tables; the window multiples are recomputed on the device at import (~0.1 s for a
+// 2^20 key — less than reading the 6 GiB they occupy from any disk: measured in round 3, which is why the image that carried
+// every level is gone).
+static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '4'};
 struct PkImageHeader {
     char magic[8];
     int32_t curve, scheme;
     uint64_t m, w, l, hlen, N;
-    int32_t logN, c_z, c_h, full;     // full: 0 = level 0 only, 1 = every level
+    int32_t logN, c_z, c_h, sets;     // sets: s_z | s_h << 8 — which window multiples the tables hold (MsmShape::sets)
     uint32_t rank, world;
-    int32_t ntt_log1, reserved;       // the NTT split h_sigma is ordered for (zkhip_pk::ntt_log1)
+    int32_t ntt_split, reserved;      // the NTT split h_sigma is ordered for (zkhip_pk::ntt_log1 = NttPlan::split())
     uint64_t z_lo, z_n, h_lo, h_n;
     uint64_t len_delta, len_g2z2, len_buf[5];
 };
 static DBuf* pk_bufs(zkhip_pk* pk, int k) { DBuf* b[5] = {&pk->a_ext, &pk->b1_ext, &pk->l_ext, &pk->b2_ext, &pk->h_sigma}; return b[k]; }
-static int pk_levels(int curve, int c) { const int bits = ops_for(curve)->fr_bits; return (bits + 1 + c - 1) / c; }
-// bytes of table k of this key in an image: count x (1 | levels) x point size
-static uint64_t pk_image_part(int curve, int k, uint64_t z_n, uint64_t h_n, int c_z, int c_h, bool full) {
+static int pk_levels(int curve, int c, int sets) {
+    const int bits = ops_for(curve)->fr_bits, W = (bits + 1 + c - 1) / c;
+    return (W + sets - 1) / sets;
+}
+// bytes of table k of this key: count x levels x point size (levels = 1: what an image holds)
+static uint64_t pk_table_bytes(int curve, int k, uint64_t z_n, uint64_t h_n, int levels) {
     const uint64_t g1b = ops_for(curve)->packed_g1_bytes;
     const uint64_t count = std::max<uint64_t>(k == 4 ? h_n : z_n, 1), pt = k == 3 ? 2 * g1b : g1b;
-    return count * pt * (full ? (uint64_t)pk_levels(curve, k == 4 ? c_h : c_z) : 1);
+    return count * pt * (uint64_t)levels;
 }
-int32_t zkhip_pk_export_size_ex(const zkhip_pk* pk, uint32_t flags, uint64_t* bytes) {
-    if (!pk || !bytes || (flags & ~(uint32_t)ZKHIP_PK_IMAGE_FULL)) return ZKHIP_ERR_BAD_ARG;
+int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes) {
+    if (!pk || !bytes) return ZKHIP_ERR_BAD_ARG;
     uint64_t t = sizeof(PkImageHeader) + pk->delta_g1_canon.size() + pk->g_gamma2_z2_canon.size();
-    for (int k = 0; k < 5; ++k) t += pk_image_part(pk->curve, k, pk->z_n, pk->h_n, pk->c_z, pk->c_h, flags & ZKHIP_PK_IMAGE_FULL);
+    for (int k = 0; k < 5; ++k) t += pk_table_bytes(pk->curve, k, pk->z_n, pk->h_n, 1);
     *bytes = t;
     return ZKHIP_OK;
 }
-int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes) { return zkhip_pk_export_size_ex(pk, 0, bytes); }
-int32_t zkhip_pk_export_ex(const zkhip_pk* pk_, uint32_t flags, uint8_t* out, uint64_t cap) {
-    if (!pk_ || !out || (flags & ~(uint32_t)ZKHIP_PK_IMAGE_FULL)) return ZKHIP_ERR_BAD_ARG;
+int32_t zkhip_pk_export(const zkhip_pk* pk_, uint8_t* out, uint64_t cap) {
+    if (!pk_ || !out) return ZKHIP_ERR_BAD_ARG;
     zkhip_pk* pk = const_cast<zkhip_pk*>(pk_);
     zkhip_ctx* ctx = pk->ctx;
     return guarded(ctx, [&] {
         uint64_t need = 0;
-        zkhip_pk_export_size_ex(pk, flags, &need);
+        zkhip_pk_export_size(pk, &need);
         require(cap >= need, ZKHIP_ERR_BAD_ARG, "output buffer too small (see zkhip_pk_export_size)");
         PkImageHeader h;
         memset(&h, 0, sizeof(h));
         memcpy(h.magic, PK_IMAGE_MAGIC, 8);
         h.curve = pk->curve; h.scheme = pk->scheme;
         h.m = pk->m; h.w = pk->w; h.l = pk->l; h.hlen = pk->hlen; h.N = pk->N;
-        h.logN = pk->logN; h.c_z = pk->c_z; h.c_h = pk->c_h; h.full = (flags & ZKHIP_PK_IMAGE_FULL) ? 1 : 0;
+        h.logN = pk->logN; h.c_z = pk->c_z; h.c_h = pk->c_h; h.sets = pk->s_z | (pk->s_h << 8);
         h.rank = pk->rank; h.world = pk->world;
-        h.ntt_log1 = pk->ntt_log1;
+        h.ntt_split = pk->ntt_log1;
         h.z_lo = pk->z_lo; h.z_n = pk->z_n; h.h_lo = pk->h_lo; h.h_n = pk->h_n;
         h.len_delta = pk->delta_g1_canon.size(); h.len_g2z2 = pk->g_gamma2_z2_canon.size();
-        for (int k = 0; k < 5; ++k) h.len_buf[k] = pk_image_part(pk->curve, k, pk->z_n, pk->h_n, pk->c_z, pk->c_h, h.full);
+        for (int k = 0; k < 5; ++k) h.len_buf[k] = pk_table_bytes(pk->curve, k, pk->z_n, pk->h_n, 1);
         uint8_t* p = out;
         memcpy(p, &h, sizeof(h)); p += sizeof(h);
         memcpy(p, pk->delta_g1_canon.data(), h.len_delta); p += h.len_delta;
@@ -508,7 +514,6 @@ int32_t zkhip_pk_export_ex(const zkhip_pk* pk_, uint32_t flags, uint8_t* out, ui
         stream_sync(ctx->stream);
     });
 }
-int32_t zkhip_pk_export(const zkhip_pk* pk, uint8_t* out, uint64_t cap) { return zkhip_pk_export_ex(pk, 0, out, cap); }
 int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk** out) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
@@ -528,34 +533,38 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
             total += part;
         }
         require(total == len, ZKHIP_ERR_PARSE, "trailing bytes after key image");
-        require(h.world >= 1 && h.rank < h.world && h.logN >= 0 && h.logN <= 2 * NTT_MAX_SUBLOG && h.N == ((uint64_t)1 << h.logN) && h.z_n <= h.m + 2 &&
-                    h.h_n <= h.N && h.c_z >= 2 && h.c_z <= MSM_MAX_C && h.c_h >= 2 && h.c_h <= MSM_MAX_C && (h.full == 0 || h.full == 1),
+        const int s_z = h.sets & 0xff, s_h = (h.sets >> 8) & 0xff;
+        require(h.world >= 1 && h.rank < h.world && h.logN >= 0 && h.logN <= 3 * NTT_MAX_SUBLOG && h.N == ((uint64_t)1 << h.logN) && h.z_n <= h.m + 2 &&
+                    h.h_n <= h.N && h.c_z >= 2 && h.c_z <= MSM_MAX_C && h.c_h >= 2 && h.c_h <= MSM_MAX_C && s_z >= 1 && s_h >= 1 && (h.sets >> 16) == 0,
                 ZKHIP_ERR_PARSE, "key image: inconsistent header");
         // the index ranges must lie inside the key and the five base arrays must have exactly the size the ranges imply:
         // the kernels trust these numbers
         bool sizes_ok = h.m + 2 < ((uint64_t)1 << 31) && h.z_lo <= h.m + 2 && h.z_n <= h.m + 2 - h.z_lo && h.h_lo <= h.N && h.h_n <= h.N - h.h_lo &&
                         h.len_delta <= 4096 && h.len_g2z2 <= 4096;
-        for (int k = 0; k < 5 && sizes_ok; ++k) sizes_ok = h.len_buf[k] == pk_image_part(h.curve, k, h.z_n, h.h_n, h.c_z, h.c_h, h.full);
+        for (int k = 0; k < 5 && sizes_ok; ++k) sizes_ok = h.len_buf[k] == pk_table_bytes(h.curve, k, h.z_n, h.h_n, 1);
         require(sizes_ok, ZKHIP_ERR_PARSE, "key image: array sizes do not match the header");
-        require(ops->ntt_log1(ctx, h.logN) == h.ntt_log1, ZKHIP_ERR_PARSE,
-                "key image: written under another NTT split (NTT_SINGLE_MAX_LOG) than this context uses; re-import the proving key");
+        require(ops->ntt_log1(ctx, h.logN) == h.ntt_split, ZKHIP_ERR_PARSE,
+                "key image: written under another NTT split (NTT_SINGLE_MAX_LOG / NTT_MAX_SUBLOG) than this context uses; re-import the proving key");
+        // (c, sets) must be a shape this context's sort can run (SORT_KH_LOG may have changed since the image was written)
+        require(ops->msm_shape_ok(ctx, h.z_n, h.c_z, s_z) && ops->msm_shape_ok(ctx, h.h_n, h.c_h, s_h), ZKHIP_ERR_PARSE,
+                "key image: window width / bucket sets not usable under this context's settings; re-import the proving key");
         std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
         pk->curve = h.curve; pk->scheme = h.scheme; pk->ctx = ctx;
         pk->m = h.m; pk->w = h.w; pk->l = h.l; pk->hlen = h.hlen; pk->N = h.N; pk->logN = h.logN;
-        pk->c_z = h.c_z; pk->c_h = h.c_h; pk->rank = h.rank; pk->world = h.world;
+        pk->c_z = h.c_z; pk->c_h = h.c_h; pk->s_z = s_z; pk->s_h = s_h; pk->rank = h.rank; pk->world = h.world;
         pk->z_lo = h.z_lo; pk->z_n = h.z_n; pk->h_lo = h.h_lo; pk->h_n = h.h_n;
-        pk->ntt_log1 = h.ntt_log1;
+        pk->ntt_log1 = h.ntt_split;
         const uint8_t* p = bytes + sizeof(h);
         pk->delta_g1_canon.assign(p, p + h.len_delta); p += h.len_delta;
         pk->g_gamma2_z2_canon.assign(p, p + h.len_g2z2); p += h.len_g2z2;
         for (int k = 0; k < 5; ++k) {
             DBuf* b = pk_bufs(pk.get(), k);
-            b->ensure(pk_image_part(h.curve, k, h.z_n, h.h_n, h.c_z, h.c_h, true));
+            b->ensure(pk_table_bytes(h.curve, k, h.z_n, h.h_n, k == 4 ? pk_levels(h.curve, h.c_h, s_h) : pk_levels(h.curve, h.c_z, s_z)));
             dev_h2d(b->p, p, h.len_buf[k], ctx->stream);
             p += h.len_buf[k];
         }
         stream_sync(ctx->stream);
-        if (!h.full) ops->pk_table_levels(ctx, pk.get());       // recompute the window multiples behind level 0
+        ops->pk_table_levels(ctx, pk.get());       // recompute the window multiples behind level 0
         *out = pk.release();
     });
 }

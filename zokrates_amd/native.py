@@ -58,7 +58,7 @@ class Library:
         "zkhip_setup_gm17_size", "zkhip_setup_gm17", "zkhip_pk_load_gm17_shard", "zkhip_prove_gm17_partial", "zkhip_combine_gm17",
         "zkhip_prog_parse", "zkhip_prog_free", "zkhip_prog_dims", "zkhip_prog_matrix", "zkhip_prog_variable_order",
         "zkhip_prog_r1cs_load", "zkhip_prog_assignment", "zkhip_prog_write_bound", "zkhip_prog_write",
-        "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import", "zkhip_pk_export_size_ex", "zkhip_pk_export_ex",
+        "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import",
         "zkhip_ctx_tune",
         "zkhip_ctx_create_multi", "zkhip_multi_free", "zkhip_multi_size", "zkhip_multi_ctx", "zkhip_multi_last_error", "zkhip_multi_r1cs_load",
         "zkhip_multi_pk_load_g16", "zkhip_multi_pk_load_gm17", "zkhip_prove_g16_multi", "zkhip_prove_gm17_multi",
@@ -126,8 +126,6 @@ class Library:
         L.zkhip_setup_gm17.restype = i32; L.zkhip_setup_gm17.argtypes = [vp, vp, vp, vp, vp, vp, u64]
         L.zkhip_pk_export_size.restype = i32; L.zkhip_pk_export_size.argtypes = [vp, vp]
         L.zkhip_pk_export.restype = i32; L.zkhip_pk_export.argtypes = [vp, vp, u64]
-        L.zkhip_pk_export_size_ex.restype = i32; L.zkhip_pk_export_size_ex.argtypes = [vp, u32, vp]
-        L.zkhip_pk_export_ex.restype = i32; L.zkhip_pk_export_ex.argtypes = [vp, u32, vp, u64]
         L.zkhip_pk_import.restype = i32; L.zkhip_pk_import.argtypes = [vp, vp, sz, pp]
         L.zkhip_prog_parse.restype = i32; L.zkhip_prog_parse.argtypes = [vp, sz, pp]
         L.zkhip_prog_free.restype = None; L.zkhip_prog_free.argtypes = [vp]
@@ -173,7 +171,7 @@ class Context:
         self._check(self.lib.L.zkhip_describe(self.h, buf, 256))
         return buf.value.decode()
 
-    TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7, "ntt_cols": 8, "slots": 9, "z_gate": 10, "fuse_z": 11, "msm_fused_waves": 12, "stream_jitter": 13, "sort_kh_log": 14, "fold3_min_h": 15}
+    TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7, "ntt_cols": 8, "slots": 9, "z_gate": 10, "fuse_z": 11, "msm_fused_waves": 12, "stream_jitter": 13, "sort_kh_log": 14, "fold3_min_h": 15, "ntt_max_sublog": 16, "msm_sets": 17}
 
     def tune(self, name, value):
         """`zkhip_ctx_tune`: development / measurement knobs (window width, slices, fold form, serial streams ...)."""
@@ -248,14 +246,13 @@ class ProvingKey:
         self.ctx._check(self.ctx.lib.L.zkhip_pk_dims(self.h, _ptr(d)))
         self.m, self.hlen, self.w, self.l = (int(x) for x in d)
 
-    def export_image(self, full=False):
-        """The resident (device-layout) form of this key as bytes (`zkhip_pk_export[_ex]`): what a key cache stores.
-        full=True (ZKHIP_PK_IMAGE_FULL) includes the precomputed window multiples, else the import recomputes them."""
+    def export_image(self):
+        """The resident (device-layout) form of this key as bytes (`zkhip_pk_export`): what a key cache stores — level 0 of the
+        five base tables; the import recomputes the window multiples on the device."""
         size = C.c_uint64()
-        flags = 1 if full else 0
-        self.ctx._check(self.ctx.lib.L.zkhip_pk_export_size_ex(self.h, flags, C.byref(size)))
+        self.ctx._check(self.ctx.lib.L.zkhip_pk_export_size(self.h, C.byref(size)))
         out = np.zeros(size.value, dtype=np.uint8)
-        self.ctx._check(self.ctx.lib.L.zkhip_pk_export_ex(self.h, flags, _ptr(out), size.value))
+        self.ctx._check(self.ctx.lib.L.zkhip_pk_export(self.h, _ptr(out), size.value))
         return out
 
     @classmethod
