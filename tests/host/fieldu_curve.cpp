@@ -52,6 +52,24 @@ template <class FS, class U> int test(const char* name) {
         Xyzz<FS> z1 = Xyzz<FS>::inf(); Xyzz<U> z2 = Xyzz<U>::inf();
         xyzz_madd_acc(z1, p0); xyzz_madd_acc(z1, np); xyzz_madd_acc(z2, q0); xyzz_madd_acc(z2, nq);
         if (!z1.is_inf() || !z2.is_inf()) { if (bad++ < 3) printf("%s P-P mismatch %d %d\n", name, z1.is_inf(), z2.is_inf()); }
+        // the sign of a bucket digit handed to the mixed addition (no separate negation of the base) == adding the negated point:
+        // common path, empty accumulator, doubling (acc = -P, then P with the sign) and cancellation (acc = P, then P with the sign)
+        Xyzz<FS> s1 = a; Xyzz<U> s2 = b;
+        xyzz_madd_acc(s1, np); xyzz_madd_acc(s2, q0, true);
+        if (!same(s1, s2)) { if (bad++ < 3) printf("%s signed madd mismatch\n", name); }
+        Xyzz<FS> s3 = Xyzz<FS>::inf(); Xyzz<U> s4 = Xyzz<U>::inf();
+        xyzz_madd_acc(s3, np); xyzz_madd_acc(s4, q0, true);
+        if (!same(s3, s4)) { if (bad++ < 3) printf("%s signed madd from empty mismatch\n", name); }
+        xyzz_madd_acc(s3, np); xyzz_madd_acc(s4, q0, true);
+        if (!same(s3, s4) || s4.is_inf()) { if (bad++ < 3) printf("%s signed madd->dbl mismatch\n", name); }
+        Xyzz<U> s5 = Xyzz<U>::inf();
+        xyzz_madd_acc(s5, q0); xyzz_madd_acc(s5, q0, true);
+        if (!s5.is_inf()) { if (bad++ < 3) printf("%s signed P-P mismatch\n", name); }
+        // a long chain with alternating signs keeps every bound (ZK_CHECK_OVERFLOW aborts on a column that leaves 64 bits)
+        for (int k = 0; k < 40; ++k) {
+            xyzz_madd_acc(a, (k & 1) ? np : p1); xyzz_madd_acc(b, (k & 1) ? q0 : q1, (k & 1) != 0);
+            if (!same(a, b)) { if (bad++ < 3) printf("%s signed chain %d mismatch\n", name, k); break; }
+        }
     }
     printf("%s: %d failures\n", name, bad);
     return bad;

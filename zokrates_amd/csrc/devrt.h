@@ -365,6 +365,9 @@ inline bool grid_nonempty(const dim3& g) { return g.x != 0 && g.y != 0 && g.z !=
 #define ZK_WAVE_PRIO 3
 #endif
 #define ZK_PRIO_HIGH() __builtin_amdgcn_s_setprio(ZK_WAVE_PRIO)
+// true if the predicate holds in ANY active lane of the wavefront: a wave-uniform condition (a scalar branch, no exec masking —
+// both sides of an `if` on it are ordinary control flow whose results meet without per-lane copies)
+#define ZK_WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0)
 // -DZK_CHECKED: a debugging build whose kernels check every index they compute from data another kernel produced (sorted
 // entries, bucket offsets, partial slots, matrix columns) and trap instead of touching memory outside their buffers; with
 // ZKHIP_TRACE=1 (synchronise after every launch) the launch that trapped is the last one named on stderr.
@@ -412,6 +415,7 @@ inline JitterState& jitter_state() { static JitterState st; return st; }
     emu::launch(dim3(grid), dim3(block), (size_t)(smem), [&]() { kernel(__VA_ARGS__); })
 #define ZK_DYN_SMEM(name) unsigned char* name = emu::dyn_smem()
 #define ZK_PRIO_HIGH() ((void)0)
+#define ZK_WAVE_ANY(pred) (pred)      /* (the fibres of the emulator decide one by one: both sides compute the same result) */
 #ifdef ZK_CHECKED
 #define ZK_ASSERT_IDX(cond) do { if (!(cond)) { fprintf(stderr, "ZK_ASSERT_IDX failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); abort(); } } while (0)
 #else

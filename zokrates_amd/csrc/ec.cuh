@@ -55,7 +55,7 @@ template <bool HOT, class P> ZK_HD Fu2<P> ecs(const Fu2<P>& a) { return (HOT || 
 // at twice the registers (84 -> 168), so it is on for Fq2 only; the three-product Fq2 form (fu2_mul_kara) saves a sixth
 // of the multiply-adds but costs registers the G2 kernel does not have: 4.12 -> 4.4 ms with the fused Y3, so it is off.
 #ifndef ZK_LAZY_Y3_G1
-#define ZK_LAZY_Y3_G1 0
+#define ZK_LAZY_Y3_G1 1
 #endif
 #ifndef ZK_LAZY_Y3_G2
 #define ZK_LAZY_Y3_G2 1
@@ -63,7 +63,7 @@ template <bool HOT, class P> ZK_HD Fu2<P> ecs(const Fu2<P>& a) { return (HOT || 
 template <bool HOT, class F> ZK_HD F ec_mulsub(const F& a, const F& b, const F& c, const F& d) { return fe_sub_k<2>(ecm<HOT>(a, b), ecm<HOT>(c, d)); }
 template <bool HOT, class P> ZK_HD Fu<P> ec_mulsub(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d) {
     if (!ZK_LAZY_Y3_G1) return fe_sub_k<2>(ecm<HOT>(a, b), ecm<HOT>(c, d));
-    return fu_mul2_inl(a, b, c, fe_sub_k<8>(Fu<P>::zero(), d));
+    return fu_mul2_inl(a, b, c, fe_neg_lazy(d));          // d = PPP < 2p, TIGHT: its negation needs no carry round here; result < 2p
 }
 template <bool HOT, class P> ZK_HD Fu2<P> ec_mulsub(const Fu2<P>& a, const Fu2<P>& b, const Fu2<P>& c, const Fu2<P>& d) {
     if (ZK_LAZY_Y3_G2 && (HOT || UCfg<P>::FQ2_INLINE)) return fu2_mulsub_inl(a, b, c, d);
@@ -197,17 +197,25 @@ ZK_HD_CALL Aff<F> xyzz_to_affine(const Xyzz<F>& p) {
 // Everything is inlined, including the exceptional cases (equal or opposite x): an out-of-line call would
 // force the accumulator through scratch memory (its address escapes), which costs more than the few extra
 // instructions of a doubling that is almost never executed.
+// a += (neg ? -p : p), p affine and not infinity.  The sign of a signed bucket digit is applied where it is cheapest: y only
+// enters the common path through the product S2 = ZZZ1 * y, which takes the negated y without a carry round (fe_cneg_for_mul);
+// the rare paths (empty accumulator, doubling) negate properly.
 template <bool HOT = false, class F>
-ZK_HD void xyzz_madd_acc(Xyzz<F>& a, const Aff<F>& p) {   // a += p, p affine and not infinity
+ZK_HD void xyzz_madd_acc(Xyzz<F>& a, const Aff<F>& p, bool neg = false) {
     if (a.is_inf()) {
-        a.x = p.x; a.y = p.y; a.zz = F::one(); a.zzz = F::one();
+        a.x = p.x; a.y = neg ? fe_neg(p.y) : p.y; a.zz = F::one(); a.zzz = F::one();
         return;
     }
     // (products take the operand that may reach 4p first: the three-product Fq2 form bounds its first operand)
     F Pp = fe_sub_k<4>(ecm_k<HOT>(a.zz, p.x), a.x);         // X1 < 3p;  Pp < 6p
-    F R = fe_sub_k<4>(ecm_k<HOT>(a.zzz, p.y), a.y);         // Y1 < 3p;  R < 6p
+    F R = fe_sub_k<4>(ecm_k<HOT>(a.zzz, fe_cneg_for_mul(p.y, neg)), a.y);         // Y1 < 4p;  R < 6p
     if (fe_is_zero_modp(Pp)) {
-        a = fe_is_zero_modp(R) ? xyzz_dbl_affine_inl<HOT>(p) : Xyzz<F>::inf();
+        if (fe_is_zero_modp(R)) {
+            const Aff<F> q{p.x, neg ? fe_neg(p.y) : p.y};
+            a = xyzz_dbl_affine_inl<HOT>(q);
+        } else {
+            a = Xyzz<F>::inf();
+        }
         return;
     }
     F PP = ecs<HOT>(Pp);
@@ -215,10 +223,30 @@ ZK_HD void xyzz_madd_acc(Xyzz<F>& a, const Aff<F>& p) {   // a += p, p affine an
     F Q = ecm_k<HOT>(a.x, PP);
     a.zz = ecm_k<HOT>(a.zz, PP);
     a.zzz = ecm_k<HOT>(a.zzz, PPP);
-    F X3 = fe_relax(fe_sub_k<4>(fe_sub_k<2>(ecs<HOT>(R), PPP), fe_dbl(Q)));   // < 2 + 2 + 4 = 8p before, < 3p after
-    a.y = ec_mulsub<HOT>(R, fe_sub_k<4>(Q, X3), a.y, PPP);                    // one reduction: < 3p
+    F X3 = fe_relax(fu_x3_numerator(ecs<HOT>(R), PPP, Q));                    // R^2 - PPP - 2Q: < 10p before, < 3p after
+    a.y = ec_mulsub<HOT>(R, fe_sub_k<4>(Q, X3), a.y, PPP);                    // one reduction: < 3p (G1 fused: < 2p)
     a.x = X3;
 }
+// The common case of a += (+-)p for the accumulation kernel's fast path, cut in two so that the kernel can look at Pp before it
+// commits: xyzz_madd_begin computes Pp = U2 - X1 and R = S2 - Y1 (ys: the base's y with the digit's sign applied, normalised);
+// xyzz_madd_finish turns them into the sum, branch-free — the caller has established that a is not empty and Pp != 0 mod p.
+template <bool HOT, class F>
+ZK_HD void xyzz_madd_begin(const Xyzz<F>& a, const F& px, const F& ys, F& Pp, F& R) {
+    Pp = fe_sub_k<4>(ecm_k<HOT>(a.zz, px), a.x);            // X1 < 3p;  Pp < 6p
+    R = fe_sub_k<4>(ecm_k<HOT>(a.zzz, ys), a.y);            // Y1 < 4p;  R < 6p
+}
+template <bool HOT, class F>
+ZK_HD void xyzz_madd_finish(Xyzz<F>& a, const F& Pp, const F& R) {
+    F PP = ecs<HOT>(Pp);
+    F PPP = ecm<HOT>(Pp, PP);
+    F Q = ecm_k<HOT>(a.x, PP);
+    a.zz = ecm_k<HOT>(a.zz, PP);
+    a.zzz = ecm_k<HOT>(a.zzz, PPP);
+    F X3 = fe_relax(fu_x3_numerator(ecs<HOT>(R), PPP, Q));
+    a.y = ec_mulsub<HOT>(R, fe_sub_k<4>(Q, X3), a.y, PPP);
+    a.x = X3;
+}
+
 template <class F>
 ZK_HD void xyzz_add_acc(Xyzz<F>& a, const Xyzz<F>& b) {   // a += b, both XYZZ
     if (b.is_inf()) return;

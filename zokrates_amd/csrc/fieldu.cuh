@@ -16,6 +16,10 @@
 // (fu_from_fe / fu_to_fe), so nothing outside the MSM sees it.  Results are exact group elements either way.
 #pragma once
 #include "field.cuh"
+#if defined(ZK_CHECK_OVERFLOW) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace zk {
 
@@ -118,6 +122,19 @@ struct UConst {
         }
         return r;
     }
+    // K*p with every limb but the top one raised by 2^sh (the top limb gives the excess back): bias(k) is sh = B + 2; the
+    // un-normalised negation of a TIGHT value (fe_neg_lazy) gets by with sh = B + 1
+    static constexpr Limbs bias_spread(u32 k, int sh) {
+        Limbs c = split(times_small(modulus(), k));
+        Limbs r{};
+        const u32 up = 1u << sh, back = 1u << (sh - B);
+        for (int i = 0; i < N; ++i) {
+            if (i == 0) r.v[i] = c.v[i] + up;
+            else if (i < N - 1) r.v[i] = c.v[i] + up - back;
+            else r.v[i] = c.v[i] - back;
+        }
+        return r;
+    }
     static constexpr u32 inv_low() {   // p^-1 mod 2^32 (Newton)
         u32 p0 = P::mod(0), x = 1;
         for (int i = 0; i < 6; ++i) x *= 2 - p0 * x;
@@ -130,6 +147,7 @@ struct UConst {
     ZK_HD static constexpr u32 bias2(int i) { constexpr Limbs t = bias(2); return t.v[i]; }
     ZK_HD static constexpr u32 bias4(int i) { constexpr Limbs t = bias(4); return t.v[i]; }
     ZK_HD static constexpr u32 bias8(int i) { constexpr Limbs t = bias(8); return t.v[i]; }
+    ZK_HD static constexpr u32 nbias2(int i) { constexpr Limbs t = bias_spread(2, B + 1); return t.v[i]; }   // 2p, spread 2^(B+1)
     static constexpr u32 PINV = inv_low() & M;               //  p^-1 mod 2^B
     static constexpr u32 NINV = (0u - inv_low()) & M;        // -p^-1 mod 2^B
     static constexpr u32 P_TOP = split(modulus()).v[N - 1];
@@ -197,6 +215,47 @@ template <class P> ZK_HD Fu<P> fe_sub(const Fu<P>& a, const Fu<P>& b) { return f
 // obeys the same bounds as any other; the all-zero sentinel of the point at infinity stays all-zero
 template <class P> ZK_HD Fu<P> fe_neg(const Fu<P>& a) { return a.is_zero() ? a : fe_sub_k<2>(Fu<P>::zero(), a); }
 
+// 2p - a WITHOUT the carry round, for a TIGHT a with value < 2p (a product, an affine coordinate): limbs up to 2^(B+1) + 2^B, so
+// the result is ONLY good as one operand of a single product (fu_mul_inl) or of a two-product sum (fu_mul2_inl) whose other
+// operands are TIGHT — N * 2^(2B+1.6) + the reduction's N * 2^(2B) stay far below 2^64 — and saves the 25 instructions of
+// the carry round where a negated value is multiplied at once (the base's y of a negative digit, PPP in the fused Y3).
+template <class P>
+ZK_HD Fu<P> fe_neg_lazy(const Fu<P>& a) {
+    Fu<P> r;
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = UConst<P>::nbias2(i) - a.v[i];
+    return r;
+}
+// neg ? 2p - y : y for the y of a base that is NOT the point at infinity; the result only feeds the product S2 = ZZZ1 * y
+template <class P>
+ZK_HD Fu<P> fe_cneg_for_mul(const Fu<P>& y, bool neg) {
+    Fu<P> r;
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = neg ? UConst<P>::nbias2(i) - y.v[i] : y.v[i];
+    return r;
+}
+// neg ? 2p - y : y, normalised (TIGHT, < 2p): the y of a base that is not the point at infinity with the sign of its digit
+template <class P>
+ZK_HD Fu<P> fe_cneg(const Fu<P>& y, bool neg) {
+    u32 t[Fu<P>::N];
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) t[i] = neg ? UConst<P>::bias2(i) - y.v[i] : y.v[i];
+    return fu_norm<P>(t);
+}
+// c ? a : b, limb by limb (a v_cndmask each): where two lanes of a wavefront need different values in the same registers
+template <class P>
+ZK_HD Fu<P> fe_select(bool c, const Fu<P>& a, const Fu<P>& b) {
+    Fu<P> r;
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+// rr + 8p - ppp - 2q in ONE carry round (the numerator of X3 = R^2 - PPP - 2Q): operands TIGHT with values < 2p, result
+// TIGHT with value < 10p.  Per limb ppp_i + 2 q_i < 3 * 2^B + 24 < 2^(B+2) - 4, the bound bias8's spread is made for, and
+// rr_i + bias8_i < 2^32.  Three field operations with a carry round each (sub<2>, dbl, sub<4>: 120 instructions) become 52.
+template <class P>
+ZK_HD Fu<P> fu_x3_numerator(const Fu<P>& rr, const Fu<P>& ppp, const Fu<P>& q) {
+    u32 t[Fu<P>::N];
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) t[i] = rr.v[i] + (UConst<P>::bias8(i) - ((q.v[i] << 1) + ppp.v[i]));
+    return fu_norm<P>(t);
+}
+
 // ---- the products ----
 // Product scanning (Comba): column k collects a_i * b_(k-i) and m_i * p_(k-i) in 64-bit accumulators that never overflow
 // for TIGHT operands, m_k makes the column's low B bits vanish, the rest carries into column k+1.
@@ -213,6 +272,13 @@ template <class P> ZK_HD Fu<P> fe_neg(const Fu<P>& a) { return a.is_zero() ? a :
 #else
 #define ZK_CARRY_CHAIN(x)
 #endif
+// (Round 4 measured the alternative of writing the multiply-add as the instruction — inline v_mad_u64_u32, the carry of a column as
+// the addend of the next column's first multiply-add, so that the 17 joins per product the compiler makes with v_lshl_add_u64
+// disappear: 2 382 instead of 2 540 instructions per mixed addition, and SLOWER, 5.79 against 5.48 ms: one dependent chain per
+// wave issues a multiply-add every ~7 cycles, three waves per SIMD do not cover that (tools/mad_latency.hip: 1.97 ns per
+// instruction against 1.85 with independent chains), and the compiler puts an s_nop behind every inline-asm statement whose
+// result the next instruction reads.  The compiler's fresh chain per column IS the instruction-level parallelism this kernel
+// runs on.  profiles/r4b_accum_variants_ab.txt.)
 // one Montgomery reduction over `NT` operand pairs: r = (sum_t x[t] * y[t]) / R'.  x[t], y[t]: pointers to N limbs.
 // SQR (NT = 1, x = y): the cross terms are taken once against the doubled limb.
 template <class P, int NT, bool SQR>
@@ -224,6 +290,25 @@ ZK_HD Fu<P> fu_dot_inl(const u32* const (&x)[NT], const u32* const (&y)[NT]) {
     if (SQR) { ZK_UNROLL for (int i = 0; i < N; ++i) x2[i] = x[0][i] << 1; }
     Fu<P> r;
     u64 acc = 0;
+#if defined(ZK_CHECK_OVERFLOW) && !defined(__HIP_DEVICE_COMPILE__)
+    // host builds of the tests: the same column sums in 128 bits — a column that does not fit 64 bits is a broken bounds argument
+    {
+        unsigned __int128 wide = 0;
+        u32 mm[N];
+        for (int k = 0; k < 2 * N - 1; ++k) {
+            for (int i = 0; i < N; ++i) {
+                const int j = k - i;
+                if (j < 0 || j >= N) continue;
+                if (SQR) wide += (unsigned __int128)x[0][i] * x[0][j];
+                else for (int t = 0; t < NT; ++t) wide += (unsigned __int128)x[t][i] * y[t][j];
+                if (i < k && j >= 1) wide += (unsigned __int128)mm[i] * C::p(j);
+            }
+            if (k < N) { mm[k] = ((u32)wide * C::NINV) & M; wide += (unsigned __int128)mm[k] * C::p(0); }
+            if (wide >> 64) { fprintf(stderr, "fu_dot_inl: column %d overflows 64 bits (NT = %d)\n", k, NT); abort(); }
+            wide >>= B;
+        }
+    }
+#endif
     ZK_UNROLL for (int k = 0; k < 2 * N - 1; ++k) {
         u64 q[NQ];
         ZK_UNROLL for (int t = 0; t < NQ; ++t) q[t] = 0;
@@ -374,6 +459,22 @@ template <class P> ZK_HD Fu2<P> fe_sub(const Fu2<P>& a, const Fu2<P>& b) { retur
 template <class P> ZK_HD Fu2<P> fe_neg(const Fu2<P>& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
 template <class P> ZK_HD Fu2<P> fe_relax(const Fu2<P>& a) { return {fe_relax(a.c0), fe_relax(a.c1)}; }
 template <class P> ZK_HD bool fe_is_zero_modp(const Fu2<P>& a) { return fe_is_zero_modp(a.c0) && fe_is_zero_modp(a.c1); }
+// Fq2 keeps the carry rounds: its products are sums of two (fused Y3: four) limb products whose columns have no room for
+// un-normalised operands
+template <class P> ZK_HD Fu2<P> fe_cneg_for_mul(const Fu2<P>& y, bool neg) { return neg ? Fu2<P>{fe_sub_k<2>(Fu<P>::zero(), y.c0), fe_sub_k<2>(Fu<P>::zero(), y.c1)} : y; }
+template <class P> ZK_HD Fu2<P> fu_x3_numerator(const Fu2<P>& rr, const Fu2<P>& ppp, const Fu2<P>& q) {
+    return {fu_x3_numerator(rr.c0, ppp.c0, q.c0), fu_x3_numerator(rr.c1, ppp.c1, q.c1)};
+}
+template <class P> ZK_HD Fu2<P> fe_cneg(const Fu2<P>& y, bool neg) { return {fe_cneg(y.c0, neg), fe_cneg(y.c1, neg)}; }
+template <class P> ZK_HD Fu2<P> fe_select(bool c, const Fu2<P>& a, const Fu2<P>& b) { return {fe_select(c, a.c0, b.c0), fe_select(c, a.c1, b.c1)}; }
+template <class P> ZK_HD Fe<P> fe_cneg(const Fe<P>& y, bool neg) { return neg ? fe_neg(y) : y; }
+template <class P> ZK_HD Fe2<P> fe_cneg(const Fe2<P>& y, bool neg) { return neg ? fe_neg(y) : y; }
+template <class P> ZK_HD Fe<P> fe_select(bool c, const Fe<P>& a, const Fe<P>& b) { return c ? a : b; }
+template <class P> ZK_HD Fe2<P> fe_select(bool c, const Fe2<P>& a, const Fe2<P>& b) { return c ? a : b; }
+template <class P> ZK_HD Fe<P> fe_cneg_for_mul(const Fe<P>& y, bool neg) { return neg ? fe_neg(y) : y; }
+template <class P> ZK_HD Fe2<P> fe_cneg_for_mul(const Fe2<P>& y, bool neg) { return neg ? fe_neg(y) : y; }
+template <class P> ZK_HD Fe<P> fu_x3_numerator(const Fe<P>& rr, const Fe<P>& ppp, const Fe<P>& q) { return fe_sub(fe_sub(rr, ppp), fe_dbl(q)); }
+template <class P> ZK_HD Fe2<P> fu_x3_numerator(const Fe2<P>& rr, const Fe2<P>& ppp, const Fe2<P>& q) { return fe_sub(fe_sub(rr, ppp), fe_dbl(q)); }
 // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: two sums of two products, each reduced once
 // (the same 4 x N^2 + 2 x N^2 multiply-adds as Karatsuba's three full products, but one negation instead of five
 // additions, and results that stay below 2p whatever the operands)

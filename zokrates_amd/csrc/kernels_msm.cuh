@@ -34,11 +34,6 @@ namespace zk {
 #ifndef ZK_G2_ACCUM_WPE
 #define ZK_G2_ACCUM_WPE 1
 #endif
-#ifndef ZK_G2_TOUCH_PREFETCH
-#define ZK_G2_TOUCH_PREFETCH 0
-#endif
-template <class F> struct MsmPrefetch { static constexpr bool TOUCH = false; };
-template <class P_> struct MsmPrefetch<Fu2<P_>> { static constexpr bool TOUCH = ZK_G2_TOUCH_PREFETCH != 0; };
 // ACCUM_WPE: accumulation waves per SIMD of one MSM; FUSED_WPE: of a launch that runs several MSMs over one sorted list
 #ifndef ZK_G1_FUSED_WPE
 #define ZK_G1_FUSED_WPE 5
@@ -53,11 +48,15 @@ template <class P_> struct MsmPrefetch<Fu2<P_>> { static constexpr bool TOUCH = 
 #define ZK_G2_COLD_WPE 1
 #endif
 // (ACCUM_WPE is the kernel's register budget, SLICE_WPE / FUSED_WPE how finely the sorted list is cut: slices per SIMD lane)
-template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false; };
-template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true; };
-template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true; };
-template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false; };
-template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 1, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true; };
+#ifndef ZK_G2_PREFETCH_REGS
+#define ZK_G2_PREFETCH_REGS 1
+#endif
+// PREFETCH_REGS: the next base travels in registers (else it is only touched one entry ahead and loaded where it is used)
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true; };
+template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true, PREFETCH_REGS = true; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = ZK_G2_PREFETCH_REGS != 0; };
+template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false, PREFETCH_REGS = true; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 1, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true, PREFETCH_REGS = true; };
 // the base tables of the MSMs one launch serves (A, B1 and L of a proof share the sort of the assignment)
 static constexpr int MSM_MAX_TABLES = 3;
 struct MsmTables {
@@ -454,7 +453,19 @@ static __global__ void k_msm_find_heavy(const u32* __restrict__ off, u32 nkeys, 
 // written to partial[key + g]: along the sorted list (lane, key) only ever increase, so key + lane is unique,
 // and bucket `key` finds its partials at the contiguous slots key + g for the lanes g its range overlaps.
 // An entry names a table slot (level * stride + point index); the base is fetched packed (one 64-byte line for BN254 G1)
-// one entry ahead and unpacked into 29/28-bit limbs when it is used.
+// one entry ahead and unpacked into 29/28-bit limbs when it is used.  A lane that walked no entry of a bucket's tail it was
+// assigned (its sum cancelled, or only infinite bases) still writes the slot: the fold reads every slot of a bucket's lanes.
+// an empty statement the compiler must have every 32-bit word of `obj` in a register for: values computed before it stay before it
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+__device__ __forceinline__ void zk_pin_words(T& obj) {
+    u32* w = (u32*)&obj;
+    ZK_UNROLL for (unsigned i = 0; i < sizeof(T) / 4; ++i) asm volatile("" : "+v"(w[i]));
+}
+#define ZK_PIN_WORDS(x) zk_pin_words(x)
+#else
+#define ZK_PIN_WORDS(x) ((void)0)
+#endif
 template <class F, int WPE>
 __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const u32* __restrict__ off, const u32* __restrict__ sorted,
                                                     const u32* __restrict__ lane_key, Xyzz<F>* __restrict__ partial, u64 partial_stride, u32 nkeys, MsmCut cut) {
@@ -467,62 +478,67 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
     if (cur >= nkeys) return;
     const u32 total = off[nkeys];
     const u32 P = msm_slice_len(off, nkeys, cut);
-    const u64 p0 = (u64)g * P;
-    const u64 p1 = p0 + P < total ? p0 + P : total;
+    // (lane_key[g] < nkeys says g * P < total, and the list is shorter than 2^32 entries: positions are 32-bit)
+    const u32 p0 = g * P;
+    const u32 p1 = total - p0 > P ? p0 + P : total;
     u32 end = off[cur + 1];
-    ZK_ASSERT_IDX(p0 < total && off[cur] <= p0 && p0 < end && (u64)nkeys + cut.nlanes <= partial_stride);
+    ZK_ASSERT_IDX((u64)g * P < total && off[cur] <= p0 && p0 < end && (u64)nkeys + cut.nlanes <= partial_stride);
     Xyzz<F> acc = Xyzz<F>::inf();
     u32 e = sorted[p0];
     ZK_ASSERT_IDX((e & 0x7fffffffu) < cut.table_len);
-    if (MsmPrefetch<F>::TOUCH) {
-        // register-starved point types: the next base is only TOUCHED one entry ahead (one word: the line travels to the
-        // cache) and loaded when it is used, instead of being held in 32-48 registers through a whole addition
-        u32 sink = 0;
-        for (u64 pos = p0; pos < p1; ++pos) {
-            u32 e_next = e;
-            if (pos + 1 < p1) {
-                e_next = sorted[pos + 1];
-                sink |= ((const volatile u32*)(bases + (e_next & 0x7fffffffu)))[0];
-            }
-            if (pos == end) {
-                partial[(u64)cur + g] = acc;
-                acc = Xyzz<F>::inf();
-                do { ++cur; end = off[cur + 1]; } while (end <= pos);
-            }
-            u32 w[NW2];
-            aff_load_words<F>(bases, e & 0x7fffffffu, w);
-            Aff<F> pt = aff_unpack<F>(w);
-            if (e & 0x80000000u) pt.y = fe_neg(pt.y);
-            if (!pt.is_inf()) xyzz_madd_acc<true>(acc, pt);
-            e = e_next;
-        }
-        (void)sink;   // the volatile loads stay
-        partial[(u64)cur + g] = acc;
-        return;
-    }
+    constexpr bool IN_REGS = MsmTuning<F>::PREFETCH_REGS;
     u32 w[NW2];
-    aff_load_words<F>(bases, e & 0x7fffffffu, w);
-    for (u64 pos = p0; pos < p1; ++pos) {
-        u32 e_next = e;
-        u32 w_next[NW2];
-        ZK_UNROLL for (int q = 0; q < NW2; ++q) w_next[q] = w[q];
-        if (pos + 1 < p1) {            // fetch the next base while this one is being added
-            e_next = sorted[pos + 1];
-            ZK_ASSERT_IDX((e_next & 0x7fffffffu) < cut.table_len);
-            aff_load_words<F>(bases, e_next & 0x7fffffffu, w_next);
-        }
+    u32 touched = 0;
+    if (IN_REGS) aff_load_words<F>(bases, e & 0x7fffffffu, w);
+    // `first`: the next point STARTS a sum (slice start, bucket boundary, or the sum so far cancelled to infinity)
+    bool first = true;
+    for (u32 pos = p0; pos < p1; ++pos) {
+        // G1: the packed words are consumed by the unpacking and the same registers take the NEXT base at once (always: the last
+        // iteration fetches its own entry again): the fetch has the whole addition to arrive in, nothing is copied from a
+        // "next" set of registers to a "current" one, and no lane skips the load.
+        // G2 (PREFETCH_REGS = false): 32 registers for a base in flight are what keeps a second wave off the SIMD, and with a
+        // second wave there the latency of a cache hit is covered: the base is loaded where it is used, and the NEXT one is only
+        // touched (one word: the line travels to the cache meanwhile).
+        const u32 e_cur = e;
+        if (!IN_REGS) aff_load_words<F>(bases, e_cur & 0x7fffffffu, w);
+        Aff<F> pt = aff_unpack<F>(w);
+        if (IN_REGS) ZK_PIN_WORDS(pt);          // (the unpacking is complete HERE: the fetch below may overwrite the packed words in place)
+        const bool neg = (e_cur & 0x80000000u) != 0;
+        e = sorted[pos + 1 < p1 ? pos + 1 : pos];
+        ZK_ASSERT_IDX((e & 0x7fffffffu) < cut.table_len);
+        if (IN_REGS) aff_load_words<F>(bases, e & 0x7fffffffu, w);
+        else touched |= ((const volatile u32*)(bases + (e & 0x7fffffffu)))[0];
         if (pos == end) {
-            partial[(u64)cur + g] = acc;
-            acc = Xyzz<F>::inf();
+            partial[(u64)cur + g] = acc;      // (invariant: whenever `first` holds here, acc IS the empty sum — see the general path)
+            first = true;
             do { ++cur; ZK_ASSERT_IDX(cur < nkeys); end = off[cur + 1]; } while (end <= pos);
         }
-        Aff<F> pt = aff_unpack<F>(w);
-        if (e & 0x80000000u) pt.y = fe_neg(pt.y);
-        if (!pt.is_inf()) xyzz_madd_acc<true>(acc, pt);
-        e = e_next;
-        ZK_UNROLL for (int q = 0; q < NW2; ++q) w[q] = w_next[q];
+        // Lanes of one wavefront are at different places of their slices: at every step some lane starts a new bucket while the
+        // others add.  Written as nested per-lane branches (empty sum? equal x? infinite base?) that costs three re-convergence
+        // points per step with a copy of the whole accumulator at each.  Instead EVERY lane runs the branch-free addition and a
+        // lane that starts a sum takes the point itself by a select; the cases the branch-free code cannot handle (an infinite
+        // base, equal x: doubling or cancellation) are looked for across the wavefront first, and if ANY lane has one, the whole
+        // wavefront runs the general code for this step — a uniform branch, taken practically never on full-width scalars.
+        const bool pinf = pt.is_inf();
+        const F ys = fe_cneg(pt.y, neg);
+        F Pp, R;
+        xyzz_madd_begin<true>(acc, pt.x, ys, Pp, R);
+        const bool special = pinf || (!first && fe_is_zero_modp(Pp));
+        if (ZK_WAVE_ANY(special)) {
+            if (first) acc = Xyzz<F>::inf();
+            if (!pinf) xyzz_madd_acc<true>(acc, Aff<F>{pt.x, ys});
+            first = acc.is_inf();
+        } else {
+            if (first) {
+                acc.x = pt.x; acc.y = ys; acc.zz = F::one(); acc.zzz = F::one();
+            } else {
+                xyzz_madd_finish<true>(acc, Pp, R);
+            }
+            first = false;
+        }
     }
     partial[(u64)cur + g] = acc;
+    (void)touched;      // (the volatile loads stay)
 }
 
 // sum of one bucket's partials (after the heavy pass the first slot of a heavy bucket holds its total)
