@@ -104,9 +104,7 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_FUSE_Z 11
 #define ZKHIP_TUNE_MSM_FUSED_WAVES 12
 #define ZKHIP_TUNE_STREAM_JITTER 13
-#define ZKHIP_TUNE_SORT_KH_LOG 14  /* log2 of the buckets one LDS histogram of the sort holds (2..15; default 15): windows with more
-                                    * buckets are sorted in two passes — a test hook to reach that path with small windows          */
-#define ZKHIP_TUNE_FOLD3_MIN_H 15  /* bucket sets with at least this many rows of 256 buckets fold in three digits (default 512)  */
+/* (14, 15: the knobs of the wide-window sort and fold round 3 built and round 4 removed) */
 #define ZKHIP_TUNE_MSM_SETS 17        /* bucket sets of the MSM tables built by later key loads: 1 = every window multiple of every base
                                       * (one bucket set per MSM), 2 = every second multiple (two sets) ...; 0 = automatic: 1 while the
                                       * tables fit the device, else the smallest power of two that does (keys above 2^24 constraints) */

@@ -92,7 +92,7 @@ def test_msm_window_sizes(ctx):
     b1, _, ks = _rand_points(BN254, 40, rnd)
     want = cpu.msm(0, 1, b1, ks)
     try:
-        for c in (2, 3, 5, 8, 13, 17):               # 17: the sort's histogram is split over two workgroups per window
+        for c in (2, 3, 5, 8, 13, 16):
             ctx.tune("msm_c", c)
             assert ctx.msm(0, 1, b1, ks) == want, c
     finally:
@@ -207,28 +207,6 @@ def test_sharded_proof_virtual_ranks(ctx, curve, world):
     assert native.combine_g16(ctx, whole, [native.prove_g16_partial(ctx, whole, cs, z, r_, s_)], r_, s_) == want
 
 
-def test_prove_with_wide_windows():
-    """Tables built for c = 17 ... 20 (2^16 ... 2^19 shared buckets: the sort runs in two passes — LDS histogram on the low 15
-    bits, stable partition on the high 1 ... 4 — and from c = 18 on the fold has three digits): the proof does not depend on
-    the window width."""
-    c2 = native.Context(0, emu_library())
-    try:
-        oc = cpu.Circuit.synth(0, 40, 7)
-        tox = cpu.toxic_bytes(g16.Toxic.from_seed(BN254))
-        raw = cpu.ProvingKey.setup(oc, tox).serialize()
-        cs = native.ConstraintSystem(c2, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
-        z = oc.assignment()
-        want = cpu.trapdoor(oc, tox, z, 11, 13)
-        for c in (17, 18, 20, 4):
-            c2.tune("msm_c", c)
-            pk = native.ProvingKey(c2, 0, raw)
-            assert native.prove_g16(c2, pk, cs, z, 11, 13) == want, c
-            img = pk.export_image()
-            assert native.prove_g16(c2, native.ProvingKey.from_image(c2, 0, img), cs, z, 11, 13) == want, c
-    finally:
-        c2.close()
-
-
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 def test_prove_with_thinned_tables(curve):
     """Keys too large for every window multiple of every base (domains above 2^24: the tables of a 2^26 key would take 384 GiB)
@@ -260,37 +238,6 @@ def test_prove_with_thinned_tables(curve):
         img = native.ProvingKey(c2, curve.curve_id, raw).export_image()
         c2.tune("msm_sets", 0)
         assert native.prove_g16(c2, native.ProvingKey.from_image(c2, curve.curve_id, img), cs, z, 11, 13) == want
-    finally:
-        c2.close()
-
-
-@pytest.mark.parametrize("c,kh_log,fold3_min_h", [(12, 7, 4), (9, 4, 512)])
-def test_two_pass_sort_and_three_digit_fold_at_small_sizes(c, kh_log, fold3_min_h):
-    """The wide-window machinery with its thresholds pulled down (ZKHIP_TUNE_SORT_KH_LOG, ZKHIP_TUNE_FOLD3_MIN_H) so that a
-    circuit of a few hundred constraints fills every class of the second sort pass and every digit of the fold; dense and
-    boolean-heavy witnesses (hot buckets), Groth16 and GM17, whole key and two shards."""
-    c2 = native.Context(0, emu_library())
-    try:
-        c2.tune("sort_kh_log", kh_log)
-        c2.tune("fold3_min_h", fold3_min_h)
-        c2.tune("msm_c", c)
-        for kind, n in (("dense", 200), ("sha", 300)):
-            oc = cpu.Circuit.synth(0, n, 21, kind)
-            tox = cpu.toxic_bytes(g16.Toxic.from_seed(BN254))
-            raw = cpu.ProvingKey.setup(oc, tox).serialize()
-            cs = native.ConstraintSystem(c2, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
-            z = oc.assignment()
-            want = cpu.trapdoor(oc, tox, z, 5, 9)
-            pk = native.ProvingKey(c2, 0, raw)
-            assert native.prove_g16(c2, pk, cs, z, 5, 9) == want, kind
-            shards = [native.ProvingKey(c2, 0, raw, rank=k, world=2) for k in range(2)]
-            parts = [native.prove_g16_partial(c2, sh, cs, z, 5, 9) for sh in shards]
-            assert native.combine_g16(c2, shards[0], parts, 5, 9) == want, kind
-        from oracle import gm17
-        tb17 = cpu.gm17_toxic_bytes(gm17.Toxic.from_seed(BN254))
-        raw17 = cpu.Gm17ProvingKey.setup(oc, tb17).serialize()
-        pk17 = native.ProvingKey(c2, 0, raw17, scheme="gm17")
-        assert native.prove_gm17(c2, pk17, cs, z, 3, 4, 5) == cpu.gm17_trapdoor(oc, tb17, z, 3, 5)
     finally:
         c2.close()
 

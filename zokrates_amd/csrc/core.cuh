@@ -96,7 +96,6 @@ struct NttPlanBase {
 // result of one classification / digit / counting-sort pass; shared (read-only) by every base set paired with those scalars
 struct MsmSort {
     DBuf wm, sorted, cnt, off, cursor, chunk_sum, grand;   // wm: the scalars in word-major order
-    DBuf keys1, ent1, keys2, off1, pcnt, poff, pchunk_sum, pgrand;   // the two-pass sort of windows wider than the LDS histogram
     Event ready = nullptr;   // recorded on the main stream when the pass is complete
 };
 // workspace and stream of one MSM: the five MSMs of a proof are independent once their scalars are sorted, and the
@@ -104,7 +103,6 @@ struct MsmSort {
 struct MsmLane {
     Stream stream = 0;
     DBuf lane_key, heavy, partial, bucket, rows, cols;
-    DBuf colpart, rcol, rrow;   // three-digit fold (wide windows): column sums per row group, row totals by low / high half
     Event done = nullptr;
 };
 static constexpr int ZK_NLANES = 5;   // A, B1, L (G1), B2 (G2) over z; H over h
@@ -150,8 +148,6 @@ struct zkhip_ctx {
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_max_sublog = 11;  // largest sub-transform of a pass (2^11 elements staged per sequence); domains above twice this take three passes
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
-    int sort_kh_log = 15;     // log2 of the buckets one LDS histogram of the sort holds (windows with more buckets sort in two passes)
-    u32 fold3_min_h = 512;    // bucket sets with at least this many rows of 256 buckets fold in three digits instead of two
     u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
     int nslots = 3;           // proofs in flight in the batch calls (<= ZK_NSLOTS; measured 2 / 3 / 4: 72.0 / 76.0 / 74.8 proofs/s)
     std::string err;
@@ -438,9 +434,7 @@ struct MsmShape {
     u32 levels;     // table levels the sorted entries refer to: ceil(W / sets) (1 without a table)
     u32 nkeys;      // sets * K
     u32 Lw, H;      // fold geometry: K = H rows of Lw buckets
-    u32 ndig;       // digits of the fold: 2 (column, row), or 3 for wide windows (column, row = g * I + i: i, g)
-    u32 I, G;       // three-digit fold: H = G groups of I rows
-    u32 kh, nhi;    // sort: K = nhi classes of kh buckets (kh = what one LDS histogram holds); nhi > 1: two passes
+    static constexpr u32 ndig = 2;   // digits of the fold: column and row of the bucket index
     int level_bits() const { return c * (int)sets; }   // level t of a table holds 2^(level_bits t) P
     u32 nsums() const { return ndig * sets; }   // the fold leaves one sum per digit and bucket set: msm_combine adds them
 };
@@ -448,7 +442,7 @@ static inline int env_int(const char* name, int lo, int hi, int dflt) {
     if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
     return dflt;
 }
-static constexpr int MSM_MAX_C = 20;   // widest window: the sort's LDS histogram holds 2^15 counters and its second pass splits 16 ways
+static constexpr int MSM_MAX_C = 16;   // widest window: the sort's LDS histogram holds 2^15 counters
 static constexpr int MSM_AUTO_MAX_C = 16;   // widest window chosen automatically
 // `table`: the bases carry precomputed window multiples 2^(c j) P (resident keys); otherwise one bucket set per window.
 static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, bool table, int force_c = 0, int force_sets = 0) {
@@ -478,9 +472,7 @@ static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, b
     }
     if (ctx && ctx->msm_c_env) s.c = ctx->msm_c_env;
     if (force_c) s.c = force_c;
-    const int kh_log = ctx ? ctx->sort_kh_log : 15;
-    if (!table) s.c = std::min(s.c, kh_log + 1);     // one bucket set per window: every set must fit one LDS histogram
-    s.c = std::min(s.c, kh_log + 1 + 4);             // the second sort pass splits at most 16 ways
+    s.c = std::min(s.c, MSM_MAX_C);
     s.W = (scalar_bits + 1 + s.c - 1) / s.c;
     s.K = 1u << (s.c - 1);
     s.sets = table ? (u32)std::max(1, std::min(force_sets ? force_sets : 1, s.W)) : (u32)s.W;
@@ -488,14 +480,6 @@ static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, b
     s.nkeys = s.sets * s.K;
     s.Lw = std::min<u32>(s.K, 256);
     s.H = s.K / s.Lw;
-    s.kh = std::min<u32>(s.K, 1u << kh_log);
-    s.nhi = s.K / s.kh;
-    s.ndig = 2; s.I = s.G = 0;
-    if (table && s.sets == 1 && s.H >= (ctx ? ctx->fold3_min_h : 512u) && s.H >= 4) {
-        s.ndig = 3;
-        s.I = std::min<u32>(64, s.H / 2);
-        s.G = s.H / s.I;
-    }
     return s;
 }
 
@@ -520,52 +504,24 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     const unsigned T = 256;
     // one workgroup per (chunk of scalars, window): chunks several times larger than a window's bucket count keep the
     // global atomics (one per touched bucket per workgroup) well below one per digit
-    const u32 kh = sh.kh;
+    const u32 kh = sh.K;
     const u64 want_chunks = std::max<u64>(1, (ctx->sort_wgs + sh.W - 1) / sh.W);
     const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)kh));
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
     const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;
     const size_t hist_bytes = (size_t)kh * 4;
     ZK_LAUNCH(k_scalars_to_word_major, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, ptr<u32>(so.wm));
-    if (sh.nhi == 1) {
-        so.cnt.ensure(nk * 4);
-        so.cursor.ensure(nk * 4);
-        dev_memset(so.cnt.p, 0, nk * 4, s);
-        dev_memset(so.cursor.p, 0, nk * 4, s);
-        lds_opt_in(ctx, (const void*)k_msm_count);
-        lds_opt_in(ctx, (const void*)k_msm_place);
-        ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, sh.sets, kh,
-                  ptr<u32>(so.cnt));
-        scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
-        ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, sh.sets, kh,
-                  level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
-    } else {
-        // wider than one LDS histogram (shared buckets only): sort on the low bits, stable partition on the high bits
-        require(sh.sets == 1 && sh.nhi <= (u32)PART_MAX_CLASSES, ZKHIP_ERR_BAD_ARG, "internal: window too wide for the two-pass sort");
-        const u64 max_total = sh.n * (u64)sh.W;
-        so.cnt.ensure((size_t)kh * 4);
-        so.cursor.ensure((size_t)kh * 4);
-        so.keys1.ensure(max_total * 4);
-        so.ent1.ensure(max_total * 4);
-        so.keys2.ensure(max_total * 4);
-        dev_memset(so.cnt.p, 0, (size_t)kh * 4, s);
-        dev_memset(so.cursor.p, 0, (size_t)kh * 4, s);
-        lds_opt_in(ctx, (const void*)k_msm_count_lo);
-        lds_opt_in(ctx, (const void*)k_msm_place_lo);
-        ZK_LAUNCH(k_msm_count_lo, dim3((unsigned)sort_chunks, sh.W), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, chunk, kh, ptr<u32>(so.cnt));
-        scan_u32(s, so.cnt, so.off1, kh, so.chunk_sum, so.grand);                  // so.grand = length of the list
-        ZK_LAUNCH(k_msm_place_lo, dim3((unsigned)sort_chunks, sh.W), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, chunk, kh, level_stride,
-                  ptr<u32>(so.off1), ptr<u32>(so.cursor), ptr<u32>(so.keys1), ptr<u32>(so.ent1));
-        const u32 nchunks2 = (u32)((max_total + PART_CHUNK - 1) / PART_CHUNK);
-        const int kh_log = ilog2_floor(kh);
-        so.pcnt.ensure((size_t)sh.nhi * nchunks2 * 4);
-        ZK_LAUNCH(k_part_count, dim3(nchunks2), dim3(PART_THREADS), 0, s, ptr<u32>(so.keys1), ptr<u32>(so.grand), kh_log, sh.nhi, nchunks2, ptr<u32>(so.pcnt));
-        scan_u32(s, so.pcnt, so.poff, (u64)sh.nhi * nchunks2, so.pchunk_sum, so.pgrand);
-        ZK_LAUNCH(k_part_scatter, dim3(nchunks2), dim3(PART_THREADS), 0, s, ptr<u32>(so.keys1), ptr<u32>(so.ent1), ptr<u32>(so.grand), kh_log, sh.nhi,
-                  nchunks2, ptr<u32>(so.poff), ptr<u32>(so.keys2), ptr<u32>(so.sorted));
-        so.off.ensure((nk + 1) * 4);
-        ZK_LAUNCH(k_bucket_offsets, dim3(blocks_for(nk + 1, T)), dim3(T), 0, s, ptr<u32>(so.keys2), ptr<u32>(so.grand), sh.K, ptr<u32>(so.off));
-    }
+    so.cnt.ensure(nk * 4);
+    so.cursor.ensure(nk * 4);
+    dev_memset(so.cnt.p, 0, nk * 4, s);
+    dev_memset(so.cursor.p, 0, nk * 4, s);
+    lds_opt_in(ctx, (const void*)k_msm_count);
+    lds_opt_in(ctx, (const void*)k_msm_place);
+    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, sh.sets, kh,
+              ptr<u32>(so.cnt));
+    scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
+    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, sh.sets, kh,
+              level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
     event_record(so.ready, s);
 }
 
@@ -986,10 +942,10 @@ struct Prover {
         // (a sharded key covers only its index range of the bases, and pairs them with the same range of the scalars)
         const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
         const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
-        // (a knob that narrows the sort after the key was loaded — SORT_KH_LOG — must not silently pair the sort of one window
-        // width with tables built for another)
+        // (the shape is recomputed from the key's own (c, sets): a key whose numbers this build cannot run is refused, never
+        // paired with a sort of another window width)
         require(shz.c == pk->c_z && shh.c == pk->c_h && (int)shz.sets == pk->s_z && (int)shh.sets == pk->s_h, ZKHIP_ERR_BAD_ARG,
-                "the key's tables were built for another window width than this context's sort settings allow (SORT_KH_LOG changed): reload the key");
+                "the key's tables were built for a window width this build cannot sort: reload the key");
         const int Wmax = (int)std::max(shz.nsums(), shh.nsums());   // sums per MSM (2: the tables carry the window multiples)
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // 4 G1 MSMs + 1 G2 MSM
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));

@@ -249,7 +249,7 @@ struct Gm17 {
         const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
         const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
         require(shz.c == pk->c_z && shh.c == pk->c_h && (int)shz.sets == pk->s_z && (int)shh.sets == pk->s_h, ZKHIP_ERR_BAD_ARG,
-                "the key's tables were built for another window width than this context's sort settings allow (SORT_KH_LOG changed): reload the key");
+                "the key's tables were built for a window width this build cannot sort: reload the key");
         const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));

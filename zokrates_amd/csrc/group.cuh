@@ -78,35 +78,17 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
         ZK_LAUNCH((k_msm_fold_cols<F>), dim3(Lw / CW, sh.sets * NG, nt), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, src, set_stride, msm_stride, Lw, H, RG, dst);
     };
     FoldDigits digs{};
-    if (sh.ndig == 2) {
-        fold_cols(ptr<Xyzz<F>>(lane.bucket), sh.K, sh.nkeys, sh.Lw, sh.H, sh.H, ptr<Xyzz<F>>(lane.cols));
-        digs.d[0] = FoldDigit{lane.cols.p, sh.Lw, 1, 0};
-        digs.d[1] = FoldDigit{lane.rows.p, sh.H, 0, (u32)ilog2_floor(sh.Lw)};
-    } else {
-        // wide windows: thousands of rows.  Columns in two steps (groups of 64 rows, then the groups); the row totals as a
-        // G x I matrix whose column and row sums are the two upper digits.
-        const u32 RG = std::min<u32>(64, sh.H), NG = sh.H / RG;
-        lane.colpart.ensure((size_t)nt * sh.sets * NG * sh.Lw * sizeof(Xyzz<F>));
-        lane.rcol.ensure((size_t)nt * sh.sets * sh.I * sizeof(Xyzz<F>));
-        lane.rrow.ensure((size_t)nt * sh.sets * sh.G * sizeof(Xyzz<F>));
-        lds_opt_in(ctx, (const void*)k_msm_run_sums<F>);
-        fold_cols(ptr<Xyzz<F>>(lane.bucket), sh.K, sh.nkeys, sh.Lw, sh.H, RG, ptr<Xyzz<F>>(lane.colpart));
-        fold_cols(ptr<Xyzz<F>>(lane.colpart), (u64)NG * sh.Lw, (u64)sh.sets * NG * sh.Lw, sh.Lw, NG, NG, ptr<Xyzz<F>>(lane.cols));
-        fold_cols(ptr<Xyzz<F>>(lane.rows), sh.H, (u64)sh.sets * sh.H, sh.I, sh.G, sh.G, ptr<Xyzz<F>>(lane.rcol));
-        ZK_LAUNCH((k_msm_run_sums<F>), dim3(sh.G, sh.sets, nt), dim3(sh.I), (size_t)sh.I * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), sh.I, ptr<Xyzz<F>>(lane.rrow));
-        digs.d[0] = FoldDigit{lane.cols.p, sh.Lw, 1, 0};
-        digs.d[1] = FoldDigit{lane.rcol.p, sh.I, 0, (u32)ilog2_floor(sh.Lw)};
-        digs.d[2] = FoldDigit{lane.rrow.p, sh.G, 0, (u32)(ilog2_floor(sh.Lw) + ilog2_floor(sh.I))};
-    }
+    fold_cols(ptr<Xyzz<F>>(lane.bucket), sh.K, sh.nkeys, sh.Lw, sh.H, sh.H, ptr<Xyzz<F>>(lane.cols));
+    digs.d[0] = FoldDigit{lane.cols.p, sh.Lw, 1, 0};
+    digs.d[1] = FoldDigit{lane.rows.p, sh.H, 0, (u32)ilog2_floor(sh.Lw)};
     // the scan form of the last fold step: one workgroup of <= 256 work-items per digit; the double-and-add form (two digits
     // in one workgroup of Lw work-items) is the fallback.  Either leaves one sum per digit and bucket set.
     u32 longest = 0;
     for (u32 d = 0; d < sh.ndig; ++d) longest = std::max(longest, digs.d[d].len);
     const unsigned TS = std::max<u32>(64, longest);
-    if ((ctx->fold_scan || sh.ndig != 2) && TS <= 256) {
+    if (ctx->fold_scan && TS <= 256) {
         ZK_LAUNCH((k_msm_fold_final_scan<F, FS>), dim3(sh.sets, nt, sh.ndig), dim3(TS), TS * sizeof(Xyzz<F>), s, digs, d_window_sums, sum_stride);
     } else {
-        require(sh.ndig == 2, ZKHIP_ERR_BAD_ARG, "internal: fold geometry");
         const unsigned TF = std::max<u32>(64, sh.Lw);
         ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.sets, nt), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
                   sh.H, d_window_sums, sum_stride);

@@ -163,9 +163,10 @@ static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ w
     }
     return raw ? raw - 1 : MSM_NO_DIGIT;
 }
-// grid (nchunks, W, K / kh); dynamic LDS kh x 4 B.  cnt[key] += number of digits with that key in this chunk.
-// A workgroup histograms the buckets [z * kh, (z + 1) * kh) of its window (kh = min(K, 2^15): the histogram fits LDS up to
-// c = 16; wider windows split their buckets over blockIdx.z and every split rescans the chunk's digits).
+// grid (nchunks, W); dynamic LDS K x 4 B (K <= 2^15: windows up to c = 16).  cnt[key] += number of digits with that key in this chunk.
+// (Wider windows — a second sort pass on the high bits of the bucket, a three-digit fold — were built and measured in round 3:
+// c = 20 saves 14-28 % of the accumulation and gives it back in the sort and in a fold over 2^19 buckets, break-even at best at
+// 2^22, profiles/r3d_window_width_sweep.txt; round 4 removed them.)
 static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
                                                         u32* __restrict__ cnt) {
     ZK_PRIO_HIGH();
@@ -225,130 +226,6 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32*
         ZK_ASSERT_IDX(pos >= off[(u64)((u32)j % sets) * K + b0 + b] && pos < off[(u64)((u32)j % sets) * K + b0 + b + 1]);
         sorted[pos] = (level + (u32)i) | (d & 0x80000000u);
     }
-}
-
-// ---- 1b. windows wider than the LDS histogram (K = 2^(c-1) > kh buckets): two passes ----
-// Pass 1 is the window-major counting sort above on the LOW log2(kh) bits of the bucket — same geometry, same LDS histogram,
-// one bucket set (these windows only exist with shared buckets) — and leaves (bucket, entry) pairs grouped by those low
-// bits.  Pass 2 is a STABLE partition of that list by the high bits (K / kh <= 16 classes): inside a class the pairs keep
-// the order pass 1 gave them, i.e. they are ordered by the low bits, so the result is ordered by the whole bucket index.
-// Then off[b] = the first position whose bucket is >= b (binary search; the keys are read once more from L2).
-static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count_lo(const u32* __restrict__ wm, u64 n, int c, u64 chunk, u32 kh, u32* __restrict__ cnt) {
-    ZK_PRIO_HIGH();
-    ZK_DYN_SMEM(smem);
-    u32* hist = (u32*)smem;
-    const u32 K = 1u << (c - 1);
-    const int j = blockIdx.y;
-    for (u32 b = threadIdx.x; b < kh; b += blockDim.x) hist[b] = 0;
-    __syncthreads();
-    const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const u32 d = msm_window_digit(wm, n, i, j, c, K);
-        if (d == MSM_NO_DIGIT) continue;
-        atomicAdd(&hist[(d & 0x7fffffffu) & (kh - 1)], 1u);
-    }
-    __syncthreads();
-    for (u32 b = threadIdx.x; b < kh; b += blockDim.x)
-        if (hist[b]) atomicAdd(&cnt[b], hist[b]);
-}
-static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place_lo(const u32* __restrict__ wm, u64 n, int c, u64 chunk, u32 kh, u64 idx_stride,
-                                                           const u32* __restrict__ off, u32* __restrict__ cursor, u32* __restrict__ keys1,
-                                                           u32* __restrict__ ent1) {
-    ZK_PRIO_HIGH();
-    ZK_DYN_SMEM(smem);
-    u32* hist = (u32*)smem;
-    const u32 K = 1u << (c - 1);
-    const int j = blockIdx.y;
-    for (u32 b = threadIdx.x; b < kh; b += blockDim.x) hist[b] = 0;
-    __syncthreads();
-    const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const u32 d = msm_window_digit(wm, n, i, j, c, K);
-        if (d == MSM_NO_DIGIT) continue;
-        atomicAdd(&hist[(d & 0x7fffffffu) & (kh - 1)], 1u);
-    }
-    __syncthreads();
-    for (u32 b = threadIdx.x; b < kh; b += blockDim.x) {
-        const u32 have = hist[b];
-        if (!have) continue;
-        hist[b] = off[b] + atomicAdd(&cursor[b], have);
-    }
-    __syncthreads();
-    const u32 level = (u32)((u64)j * idx_stride);
-    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const u32 d = msm_window_digit(wm, n, i, j, c, K);
-        if (d == MSM_NO_DIGIT) continue;
-        const u32 b = d & 0x7fffffffu;
-        const u32 pos = atomicAdd(&hist[b & (kh - 1)], 1u);
-        ZK_ASSERT_IDX(pos >= off[b & (kh - 1)] && pos < off[(b & (kh - 1)) + 1]);
-        keys1[pos] = b;
-        ent1[pos] = (level + (u32)i) | (d & 0x80000000u);
-    }
-}
-// pass 2: a workgroup owns PART_CHUNK consecutive pairs, a work-item PART_PER_THREAD consecutive ones
-static constexpr int PART_THREADS = 256;
-static constexpr int PART_PER_THREAD = 16;
-static constexpr int PART_CHUNK = PART_THREADS * PART_PER_THREAD;
-static constexpr int PART_MAX_CLASSES = 16;
-static __global__ void __launch_bounds__(PART_THREADS) k_part_count(const u32* __restrict__ keys1, const u32* __restrict__ total_ptr, int kh_log, u32 nclass,
-                                                                    u32 nchunks, u32* __restrict__ pcnt) {
-    ZK_PRIO_HIGH();
-    __shared__ u32 cnt[PART_MAX_CLASSES];
-    if (threadIdx.x < PART_MAX_CLASSES) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const u32 total = *total_ptr;
-    const u64 base = (u64)blockIdx.x * PART_CHUNK + (u64)threadIdx.x * PART_PER_THREAD;
-    for (int q = 0; q < PART_PER_THREAD; ++q)
-        if (base + q < total) atomicAdd(&cnt[keys1[base + q] >> kh_log], 1u);
-    __syncthreads();
-    if (threadIdx.x < nclass) pcnt[(u64)threadIdx.x * nchunks + blockIdx.x] = cnt[threadIdx.x];
-}
-static __global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const u32* __restrict__ keys1, const u32* __restrict__ ent1, const u32* __restrict__ total_ptr,
-                                                                      int kh_log, u32 nclass, u32 nchunks, const u32* __restrict__ poff,
-                                                                      u32* __restrict__ keys2, u32* __restrict__ sorted) {
-    ZK_PRIO_HIGH();
-    // cnt[c][t]: how many pairs of class c work-item t holds, then (exclusive prefix over t) where its next one goes.  A
-    // work-item only ever touches its own column, so the counters need no atomics.
-    __shared__ u32 cnt[PART_MAX_CLASSES][PART_THREADS + 1];
-    const u32 total = *total_ptr;
-    const u32 t = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * PART_CHUNK + (u64)t * PART_PER_THREAD;
-    for (u32 c = 0; c < nclass; ++c) cnt[c][t] = 0;
-    u32 key[PART_PER_THREAD];
-    ZK_UNROLL for (int q = 0; q < PART_PER_THREAD; ++q) {
-        key[q] = base + q < total ? keys1[base + q] : 0xffffffffu;
-        if (key[q] != 0xffffffffu) ++cnt[key[q] >> kh_log][t];
-    }
-    __syncthreads();
-    if (t < nclass) {                                          // one work-item per class: exclusive prefix over the work-items
-        u32 run = poff[(u64)t * nchunks + blockIdx.x];
-        for (int i = 0; i < PART_THREADS; ++i) {
-            const u32 v = cnt[t][i];
-            cnt[t][i] = run;
-            run += v;
-        }
-    }
-    __syncthreads();
-    ZK_UNROLL for (int q = 0; q < PART_PER_THREAD; ++q) {
-        if (key[q] == 0xffffffffu) continue;
-        const u32 dst = cnt[key[q] >> kh_log][t]++;
-        ZK_ASSERT_IDX(dst < total && (key[q] >> kh_log) < nclass);
-        keys2[dst] = key[q];
-        sorted[dst] = ent1[base + q];
-    }
-}
-// off[b] = first position of the sorted list whose bucket is >= b, for b = 0 .. K (off[K] = length)
-static __global__ void k_bucket_offsets(const u32* __restrict__ keys2, const u32* __restrict__ total_ptr, u32 K, u32* __restrict__ off) {
-    ZK_PRIO_HIGH();
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > K) return;
-    const u32 total = *total_ptr;
-    u32 lo = 0, hi = total;                                    // invariant: keys2[< lo] < b, keys2[>= hi] >= b
-    while (lo < hi) {
-        const u32 mid = lo + ((hi - lo) >> 1);
-        if (keys2[mid] < b) lo = mid + 1; else hi = mid;
-    }
-    off[b] = lo;
 }
 
 // ---- 2a. exclusive scan of the counters: one workgroup per chunk of SCAN_CHUNK counters ----
@@ -654,18 +531,6 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(c
     }
     if (hg == 0) dst[lo] = sh[threadIdx.x];
 }
-// 5b'. sums of runs of I consecutive elements (the row totals of a set viewed as a G x I matrix: wide windows, three-digit
-//      fold): grid (G, sets, MSMs), I work-items (a power of two <= 256), dynamic LDS I points.
-template <class F>
-__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_run_sums(const Xyzz<F>* __restrict__ src, u32 I, Xyzz<F>* __restrict__ dst) {
-    ZK_PRIO_HIGH();
-    ZK_DYN_SMEM(smem);
-    Xyzz<F>* sh = (Xyzz<F>*)smem;
-    const u64 set = (u64)blockIdx.z * gridDim.y + blockIdx.y;
-    sh[threadIdx.x] = src[(set * gridDim.x + blockIdx.x) * I + threadIdx.x];
-    block_tree_sum<F>(sh);
-    if (threadIdx.x == 0) dst[set * gridDim.x + blockIdx.x] = sh[0];
-}
 // 5c. one workgroup per bucket set: the two weighted digit sums.
 template <class F, class FS>
 __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(const Xyzz<F>* __restrict__ rows, const Xyzz<F>* __restrict__ cols, u32 Lw, u32 H,
@@ -704,21 +569,21 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final(
 // instead of a double-and-add per element.  Every digit of the bucket index is its own workgroup (blockIdx.z) of <= 256
 // work-items — one wave per SIMD, the whole register file, no scratch even for G2 — and leaves its own sum, already
 // multiplied by the power of two its digit weighs (`dbl` doublings): window_sum[nd j + d]; the host adds the nd sums
-// (msm_combine).  Two digits (column, row) up to 2^16 buckets; three (column, row-low, row-high) for wider windows.
+// (msm_combine).  Two digits: column and row of the bucket index.
 struct FoldDigit {
     const void* src;     // totals of this digit: element t of (MSM z, set j) at src[((z * sets + j) * len + t]
     u32 len;             // a power of two <= 256
     u32 plus_one;        // weights k + 1 (the digit that carries the "+1" of bucket b <-> digit value b + 1), else k
     u32 dbl;             // log2 of the digit's place value
 };
-struct FoldDigits { FoldDigit d[3]; };
+struct FoldDigits { FoldDigit d[2]; };
 template <class F, class FS>
 __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final_scan(FoldDigits digs, Xyzz<FS>* __restrict__ window_sum, u32 sum_stride) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     Xyzz<F>* sh = (Xyzz<F>*)smem;
     const u32 j = blockIdx.x, t = threadIdx.x, nd = gridDim.z;
-    const FoldDigit dg = blockIdx.z == 0 ? digs.d[0] : blockIdx.z == 1 ? digs.d[1] : digs.d[2];
+    const FoldDigit dg = blockIdx.z == 0 ? digs.d[0] : digs.d[1];
     const u32 seglen = dg.len;
     const Xyzz<F>* src = (const Xyzz<F>*)dg.src + ((u64)blockIdx.y * gridDim.x + j) * seglen;     // blockIdx.y: which MSM of the launch
     window_sum += (u64)blockIdx.y * sum_stride;

@@ -104,7 +104,6 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         // made now, the others when a batch call first needs them (slot_init: 20 ms of stream and event creation each, which a
         // one-proof process never spends).
         ctx->g2_first = env_int("ZKHIP_G2_PRIORITY", 0, 1, 1) != 0;
-        ctx->fold3_min_h = (u32)env_int("ZKHIP_FOLD3_MIN_H", 4, 1 << 20, 512);
         slot_init(ctx.get(), ctx->slots[0]);
 #ifdef ZK_EMU
         ctx->desc = "zkhip TEST EMULATOR (not a product build)";
@@ -165,8 +164,6 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_Z_GATE: in(0, 2); ctx->z_gate = value; break;
             case ZKHIP_TUNE_FUSE_Z: in(0, 1); ctx->fuse_z = value != 0; break;
             case ZKHIP_TUNE_MSM_FUSED_WAVES: in(0, 8); ctx->msm_fused_waves = value; break;
-            case ZKHIP_TUNE_SORT_KH_LOG: in(2, 15); ctx->sort_kh_log = value; break;
-            case ZKHIP_TUNE_FOLD3_MIN_H: in(4, 1 << 16); ctx->fold3_min_h = (u32)value; break;
             case ZKHIP_TUNE_STREAM_JITTER: in(0, 5000); dev_sync_all(); jitter_state().max_us.store(value); break;
             case ZKHIP_TUNE_NTT_COLS:
                 in(1, 8);
