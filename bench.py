@@ -436,11 +436,10 @@ def main():
     # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — measured offline, same workload
     traffic, traffic_ntt = None, None
-    pmc_path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
     default_workload = args.log_domain == 20 and args.curve == "bn128" and args.kind == "dense" and not gm17
-    if os.path.exists(pmc_path) and default_workload:
-        with open(pmc_path) as f:
-            pmc = json.load(f)
+    evidence = offline_evidence() if default_workload else {"traffic": None, "valu": None, "stale": False}
+    pmc = evidence["traffic"]
+    if pmc:
         ent = pmc.get("G2" if "G2" in name else "G1", {})
         traffic = ent.get("traffic_bytes_per_launch")
         if traffic and "G1" in name:
@@ -461,10 +460,8 @@ def main():
         if serial and serial[key] > 0:
             compute["frac_serial"] = madds / (serial[key] * 1e-3) / peak
     # VALU issue occupation of the same kernel from the committed counter pass (tools/pmc_valu.py)
-    valu_path = os.path.join(ROOT, "profiles", "pmc_valu.json")
-    if compute is not None and default_workload and os.path.exists(valu_path):
-        with open(valu_path) as f:
-            pv = json.load(f)
+    pv = evidence["valu"]
+    if compute is not None and pv:
         ent = pv.get("G2" if "G2" in name else "G1")
         if ent:
             compute["valu_issue_utilisation"] = ent["issue_utilisation"]
@@ -480,6 +477,7 @@ def main():
                 "bytes_per_launch": bytes_all / launches, "ms_per_launch": ms / launches,
                 "ms_per_launch_serial": serial[key] / launches if serial else None, "launches_per_proof": launches,
                 "compute_bound": compute,
+                "offline_evidence": {k: evidence.get(k) for k in ("stale", "why", "csrc_hash", "files") if evidence.get(k) is not None},
                 "note": "bucket accumulation is bound by integer-multiply issue (Montgomery products), not by HBM; `frac` uses HIP-event "
                         "intervals on the MSM streams inside the timed region (five MSMs and two proofs overlap), `frac_serial` the same "
                         "kernels alone on one stream after it"}
@@ -671,6 +669,9 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
             # the same once more with the self check: the proof of the 2^20 circuit against the verification key at the head of its
             # proving key, by the compiled verifier on the host CPU (csrc/host/verify.cpp) — "verify_ms" and "verified" in the record
             run("native_from_key_image_with_verify", ["--key-cache", paths["cache_native"], "--verify"], native_exe)
+            # what the same process pays when it builds the window-multiple tables a RESIDENT prover works with (the CLI does not:
+            # one proof per process, `tables` in the record says which)
+            run("native_from_proving_key_full_tables", ["--full-tables"], native_exe)
         run("from_proving_key", [])
         run("first_run_with_key_cache", ["--key-cache", paths["cache"]])
         run("from_key_image", ["--key-cache", paths["cache"]])
@@ -728,6 +729,38 @@ def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one):
                 "exchange": exchange}
     except Exception as e:   # the throughput line must survive a failure of the optional leg
         return {"error": repr(e)}
+
+
+def offline_evidence(root=ROOT, pkg=None):
+    """The committed counter files (profiles/pmc_traffic.json, pmc_valu.json: rocprofv3 PMC passes, taken offline) — but only if
+    they were taken from THIS build: each file carries the fingerprint of the sources it ran on (zokrates_amd.build.csrc_hash,
+    stamped by tools/pmc_traffic.py / pmc_valu.py on the GPU box).  A file without a fingerprint or with another one is stale:
+    its figures are left out of the line and "stale" says why — a kernel change that forgets to refresh the passes can no
+    longer print old evidence next to a new time."""
+    build = importlib.import_module((pkg or _pkg) + ".build")
+    try:
+        now = build.csrc_hash(root if root != ROOT else None)
+    except Exception as e:
+        return {"traffic": None, "valu": None, "stale": True, "why": "cannot fingerprint the sources: %r" % (e,)}
+    out = {"traffic": None, "valu": None, "stale": False, "csrc_hash": now, "files": {}}
+    for key, rel in (("traffic", PMC_TRAFFIC_FILE), ("valu", os.path.join("profiles", "pmc_valu.json"))):
+        path = os.path.join(root, rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+        except Exception:
+            continue
+        have = doc.get("csrc_hash")
+        out["files"][rel] = have
+        if have == now:
+            out[key] = doc
+        else:
+            out["stale"] = True
+    if out["stale"]:
+        out["why"] = "counter file(s) taken from another build (csrc_hash differs): refresh with tools/gpu_final.sh / gpu_pmc_valu.sh"
+    return out
 
 
 def pipeline_issue_bound(pv, ms_per_step):

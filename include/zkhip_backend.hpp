@@ -147,6 +147,10 @@ class Hip {
   public:
     explicit Hip(int32_t device = 0);
     ~Hip();
+    // One proof per process (what `generate-proof` is): keys loaded from now on skip the precomputed window multiples — building
+    // them costs ten times what they save a single proof (0.15 s of kernels at 2^20 against ~5 ms of proof time) — and the MSMs
+    // fold one bucket set per window instead (ZKHIP_TUNE_MSM_SETS).  A resident prover keeps the default.
+    void one_shot();
     Hip(const Hip&) = delete;
     Hip& operator=(const Hip&) = delete;
 

@@ -143,8 +143,7 @@ def test_measuring_process_that_dies_is_reported_and_retried():
     assert d["value"] is None and "error" in d and [a["signal"] for a in d["attempts"]] == [6, 6]
 
 
-def test_pipeline_issue_bound_from_the_committed_counter_file():
-    """bench.pipeline_issue_bound: the committed VALU counter pass turned into the issue-limited time of one proof."""
+def _bench_module():
     import importlib.util
     env_before = os.environ.get("ZKHIP_BENCH_CHILD")
     os.environ["ZKHIP_BENCH_CHILD"] = "1"           # importing bench.py must not start its supervising parent
@@ -157,6 +156,47 @@ def test_pipeline_issue_bound_from_the_committed_counter_file():
             del os.environ["ZKHIP_BENCH_CHILD"]
         else:
             os.environ["ZKHIP_BENCH_CHILD"] = env_before
+    return bench
+
+
+def test_offline_evidence_is_tied_to_the_build(tmp_path):
+    """The counter figures bench.py prints (roofline.traffic, VALU issue utilisation, the pipeline's issue bound) come from files
+    committed under profiles/; each carries the fingerprint of the sources its rocprofv3 pass ran on.  Edit a kernel file and the
+    figures are gone from the line and `stale` says so."""
+    import shutil
+    from zokrates_amd.build import csrc_hash
+    bench = _bench_module()
+    root = tmp_path / "tree"
+    (root / "zokrates_amd" / "csrc").mkdir(parents=True)
+    (root / "include").mkdir()
+    (root / "profiles").mkdir()
+    src = os.path.join(ROOT, "zokrates_amd", "csrc")
+    for n in os.listdir(src):
+        if os.path.isfile(os.path.join(src, n)):
+            shutil.copy(os.path.join(src, n), root / "zokrates_amd" / "csrc" / n)
+    shutil.copy(os.path.join(ROOT, "include", "zkhip.h"), root / "include" / "zkhip.h")
+    assert csrc_hash(str(root)) == csrc_hash()                    # the same bytes, the same fingerprint, wherever the tree lies
+    for n in ("pmc_traffic.json", "pmc_valu.json"):
+        doc = json.load(open(os.path.join(ROOT, "profiles", n)))
+        doc["csrc_hash"] = csrc_hash(str(root))
+        json.dump(doc, open(root / "profiles" / n, "w"))
+    ev = bench.offline_evidence(root=str(root))
+    assert ev["stale"] is False and ev["traffic"]["G1"]["traffic_bytes_per_launch"] > 0 and ev["valu"]["G1"]["issue_utilisation"] > 0
+    with open(root / "zokrates_amd" / "csrc" / "kernels_msm.cuh", "a") as f:
+        f.write("// a kernel edit\n")
+    ev = bench.offline_evidence(root=str(root))
+    assert ev["stale"] is True and ev["traffic"] is None and ev["valu"] is None and "another build" in ev["why"]
+    # one refreshed file, one forgotten: the fresh one is used, the line still says stale
+    doc = json.load(open(root / "profiles" / "pmc_valu.json"))
+    doc["csrc_hash"] = csrc_hash(str(root))
+    json.dump(doc, open(root / "profiles" / "pmc_valu.json", "w"))
+    ev = bench.offline_evidence(root=str(root))
+    assert ev["stale"] is True and ev["traffic"] is None and ev["valu"] is not None
+
+
+def test_pipeline_issue_bound_from_the_committed_counter_file():
+    """bench.pipeline_issue_bound: the committed VALU counter pass turned into the issue-limited time of one proof."""
+    bench = _bench_module()
     pv = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
     b = bench.pipeline_issue_bound(pv, 10.57)
     assert 4.0e9 < b["valu_wave_instructions_per_proof"] < 6.0e9 and 8.0 < b["ms_per_proof_at_issue_limit"] < 11.0

@@ -45,8 +45,12 @@ nf, f = pick(fetch, "k_ntt_")
 nw, w = pick(write, "k_ntt_")
 nq, _ = pick(fetch, "k_quotient")
 if nf and nw and nq:
-    passes = 14   # pass-vectors per Groth16 proof (7 transforms x 2 passes); k_quotient runs once per proof
+    passes = 12   # pass-vectors per Groth16 proof (6 transforms x 2 passes: c takes one); k_quotient runs once per proof
     out["NTT"] = {"launches_fetch_pass": nf, "proofs": nq, "fetch_kb_raw_per_proof": f / nq, "write_kb_raw_per_proof": w / nq,
                   "traffic_bytes_per_pass": int((2 * 1024 * f / nq + 1024 * w / nq) / passes), "algorithmic_bytes_per_pass": 2 * (1 << 20) * 32}
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from zokrates_amd.build import csrc_hash  # noqa: E402
+out["csrc_hash"] = csrc_hash()     # the sources these passes ran on (bench.py refuses the figures next to another build)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

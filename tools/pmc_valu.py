@@ -47,6 +47,10 @@ for _, k, n, dur, insts, cyc, ghz, cpi, util in rows:
         if k.startswith(needle) and "Bn254" in k:
             js[tag] = {"launches": n, "avg_us": dur, "valu_wave_instructions_per_launch": insts, "gpu_cycles_per_launch": cyc, "clock_ghz": ghz,
                        "cycles_per_valu_instruction_per_simd": cpi, "issue_utilisation": 4 / cpi}
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from zokrates_amd.build import csrc_hash  # noqa: E402
+js["csrc_hash"] = csrc_hash()      # the sources this pass ran on (bench.py refuses the figures next to another build)
 if len(sys.argv) > 2:
     json.dump(js, open(re.sub(r"\.md$", "", sys.argv[2]) + ".json", "w"), indent=1)
 text = "\n".join(lines)

@@ -25,6 +25,25 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
          "-Wno-unused-variable"]
 
 
+def csrc_hash(root=None):
+    """Fingerprint of the sources libzkhip.so is built from (the kernel and host-schedule sources directly under csrc/ and the ABI header, names and bytes): what
+    ties offline evidence — the rocprofv3 counter files under profiles/ — to the build it was taken from.  bench.py prints a
+    counter figure only next to a build with the same fingerprint."""
+    import hashlib
+    here = os.path.join(root, "zokrates_amd") if root else HERE
+    files = []
+    csrc = os.path.join(here, "csrc")      # (not csrc/host: the compiled host layer is not what the counters measured)
+    files += [os.path.join(csrc, n) for n in os.listdir(csrc) if n.endswith((".cuh", ".hip", ".h"))]
+    files.append(os.path.join(here, "..", "include", "zkhip.h"))
+    h = hashlib.sha256()
+    for f in sorted(files, key=lambda f: os.path.relpath(f, here)):
+        h.update(os.path.relpath(f, here).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True

@@ -150,6 +150,7 @@ def cmd_generate_proof(args):
         worker.start()
     t0 = time.perf_counter()
     ctx = native.Context(args.device)
+    ctx.tune("msm_sets", 64)        # one proof, then the process ends: the window-multiple tables cost ten times what they save it
     lap("hip_init_ms", t0)
     if worker is None:
         load_host_side()

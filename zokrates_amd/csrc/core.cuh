@@ -681,11 +681,24 @@ struct PkLoader {
         }
     };
 
-    // upload `count` decoded points (canonical) and convert every base-field coordinate to Montgomery form
-    static void upload_points(zkhip_ctx* ctx, DBuf& dst, const std::vector<uint8_t>& host, u64 ncoords) {
-        dst.ensure(host.size());
-        dev_h2d(dst.p, host.data(), host.size(), ctx->stream);
-        ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(ncoords, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(dst), ptr<Fq>(dst), ncoords);
+    // `count` points of NC base-field coordinates each, resident in Montgomery form: entry shift + j is ark's encoding src[j]
+    // (j < nsrc), entry `extra_at` the single point `extra` (if any), every other entry the point at infinity.  Decoded straight
+    // into the pinned staging ring on a few host threads (dev_h2d_fill): one pass through host memory.
+    template <int NC>
+    static void upload_decoded(zkhip_ctx* ctx, DBuf& dst, u64 count, const uint8_t* src, u64 nsrc, u64 shift, const uint8_t* extra, u64 extra_at) {
+        constexpr size_t PB = (size_t)FQB * NC;
+        dst.ensure(count * PB);
+        dev_h2d_fill(dst.p, count * PB, PB, ctx->stream, [=](char* out, size_t off, size_t len) {
+            const u64 i0 = off / PB, i1 = (off + len) / PB;
+            for (u64 i = i0; i < i1; ++i) {
+                uint8_t* o = (uint8_t*)out + (i - i0) * PB;
+                if (i >= shift && i - shift < nsrc) decode_point<FQB, NC>(src + (i - shift) * PB, o);
+                else if (extra && i == extra_at) decode_point<FQB, NC>(extra, o);
+                else memset(o, 0, PB);
+            }
+        });
+        ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(count * NC, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(dst), ptr<Fq>(dst), count * NC);
+        stream_sync(ctx->stream);
     }
     // dev[idx] += P (host round trip of one point; P canonical ark encoding)
     template <class F, int NC>
@@ -743,40 +756,22 @@ struct PkLoader {
         pk->delta_g1_canon.assign(delta_g1, delta_g1 + G1B);
 
         const u64 me = m + 2;   // extended by the (delta, r) and (delta, s) pairs — see prove()
-        std::vector<uint8_t> host;
         // A_ext = [a_query..., delta_1, inf]          (+ alpha_1 folded into entry 0)
-        host.assign(me * G1B, 0);
-        host_parallel_for(m, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) decode_point<FQB, 2>(a_q + i * G1B, &host[i * G1B]); });
-        decode_point<FQB, 2>(delta_g1, &host[m * G1B]);
-        upload_points(ctx, pk->a_ext, host, me * 2);
-        stream_sync(ctx->stream);
+        upload_decoded<2>(ctx, pk->a_ext, me, a_q, m, 0, delta_g1, m);
         // B1_ext = [b_g1_query..., inf, delta_1]      (+ beta_1 folded into entry 0)
-        host.assign(me * G1B, 0);
-        host_parallel_for(m, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) decode_point<FQB, 2>(b1_q + i * G1B, &host[i * G1B]); });
-        decode_point<FQB, 2>(delta_g1, &host[(m + 1) * G1B]);
-        upload_points(ctx, pk->b1_ext, host, me * 2);
-        stream_sync(ctx->stream);
+        upload_decoded<2>(ctx, pk->b1_ext, me, b1_q, m, 0, delta_g1, m + 1);
         // L_ext = [inf x l, l_query..., inf, inf]
-        host.assign(me * G1B, 0);
-        host_parallel_for(w, [&](u64 lo, u64 hi) { for (u64 j = lo; j < hi; ++j) decode_point<FQB, 2>(l_q + j * G1B, &host[(l + j) * G1B]); });
-        upload_points(ctx, pk->l_ext, host, me * 2);
-        stream_sync(ctx->stream);
+        upload_decoded<2>(ctx, pk->l_ext, me, l_q, w, l, nullptr, 0);
         // B2_ext = [b_g2_query..., inf, delta_2]      (+ beta_2 folded into entry 0)
-        host.assign(me * G2B, 0);
-        host_parallel_for(m, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) decode_point<FQB, 4>(b2_q + i * G2B, &host[i * G2B]); });
-        decode_point<FQB, 4>(delta_g2, &host[(m + 1) * G2B]);
-        upload_points(ctx, pk->b2_ext, host, me * 4);
-        stream_sync(ctx->stream);
+        upload_decoded<4>(ctx, pk->b2_ext, me, b2_q, m, 0, delta_g2, m + 1);
         // h_query, permuted into the sigma order the NTT pipeline leaves h in, padded with infinity
-        host.assign(hl * G1B, 0);
-        host_parallel_for(hl, [&](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) decode_point<FQB, 2>(h_q + i * G1B, &host[i * G1B]); });
-        ctx->tmp.ensure(std::max<size_t>(host.size(), 16));
-        dev_h2d(ctx->tmp.p, host.data(), host.size(), ctx->stream);
-        ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(hl * 2, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(ctx->tmp), ptr<Fq>(ctx->tmp), hl * 2);
+        DBuf h_nat;
+        upload_decoded<2>(ctx, h_nat, std::max<u64>(hl, 1), h_q, hl, 0, nullptr, 0);
         pk->h_sigma.ensure(N * G1B);
-        ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(N, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(ctx->tmp),
+        ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(N, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(h_nat),
                   ptr<Aff<Fq>>(pk->h_sigma), N, hl, plan->N1, plan->N2, plan->N3);
         stream_sync(ctx->stream);
+        h_nat.release();
         // constant terms: z_0 = 1, so alpha/beta ride on entry 0 of their query vectors
         add_into<Fq, 2>(ctx, pk->a_ext, 0, alpha_g1);
         add_into<Fq, 2>(ctx, pk->b1_ext, 0, beta_g1);

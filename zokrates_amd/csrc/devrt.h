@@ -251,6 +251,41 @@ inline void dev_h2d(void* d, const void* h, size_t n, Stream s) {
         r.used[i] = true;
     }
 }
+// The same transfer for bytes that are PRODUCED rather than copied (a proving key decoded from ark's encoding, a key image read
+// from a mapped file): fill(dst, off, len) writes bytes [off, off + len) of the transfer to dst — straight into the ring's
+// pinned slot, on up to `threads` host threads per chunk — so the data makes one pass through host memory instead of three
+// (decode into a vector, copy into the ring, DMA).  `unit`: fill is only called with off and len that are multiples of it.
+template <class Fill>
+inline void dev_h2d_fill(void* d, size_t n, size_t unit, Stream s, Fill&& fill, unsigned threads = 8) {
+    if (!n) return;
+    StagingRing& r = staging_ring();
+    std::lock_guard<std::mutex> lock(r.mu);
+    r.init();
+    const size_t chunk = std::max<size_t>(unit, StagingRing::CHUNK / unit * unit);
+    if (chunk > StagingRing::CHUNK) throw DevError{"dev_h2d_fill: unit larger than a staging slot"};
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t len = std::min(chunk, n - off);
+        const int i = r.acquire();
+        char* dst = (char*)r.buf[i];
+        const size_t units = len / unit;
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, units / 4096));
+        if (T <= 1) {
+            fill(dst, off, len);
+        } else {
+            HostThreads th;
+            for (unsigned t = 1; t < T; ++t) {
+                const size_t lo = units * t / T * unit, hi = (t + 1 == T ? len : units * (t + 1) / T * unit);
+                th.run([&fill, dst, off, lo, hi] { fill(dst + lo, off + lo, hi - lo); });
+            }
+            fill(dst, off, units / T * unit);
+            th.join();
+        }
+        jitter_before(s);
+        ZK_HIP_CHECK(hipMemcpyAsync((char*)d + off, r.buf[i], len, hipMemcpyHostToDevice, s));
+        ZK_HIP_CHECK(hipEventRecord(r.ev[i], s));
+        r.used[i] = true;
+    }
+}
 // (the host needs the bytes, so this one returns when they are there: every caller synchronised right after it anyway)
 inline void dev_d2h(void* h, const void* d, size_t n, Stream s) {
     if (!n) return;
@@ -389,6 +424,13 @@ inline void dev_free(void* p) { free(p); }
 inline void* host_alloc_pinned(size_t bytes) { return dev_alloc(bytes); }
 inline void host_free_pinned(void* p) { free(p); }
 inline void dev_h2d(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }
+template <class Fill>
+inline void dev_h2d_fill(void* d, size_t n, size_t unit, Stream, Fill&& fill, unsigned = 8) {
+    // (the emulator has no ring: the same fill, cut at a few arbitrary unit boundaries so that the offsets are exercised)
+    const size_t units = n / unit, cut = units / 3 * unit;
+    if (cut) fill((char*)d, (size_t)0, cut);
+    if (n > cut) fill((char*)d + cut, cut, n - cut);
+}
 inline void dev_d2h(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n); }
 inline void staging_drain() {}
 inline void dev_h2d_pinned(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }

@@ -146,37 +146,19 @@ struct Gm17 {
         pk->g_gamma2_z2_canon.assign(g_gamma2_z2, g_gamma2_z2 + G1B);
 
         const u64 me = M + 2;   // extended by the (., rho) pair and one unused slot (same shape as the Groth16 key)
-        std::vector<uint8_t> host;
-        host.assign(me * G1B, 0);
-        for (u64 i = 0; i < M; ++i) decode_point<FQB, 2>(a_q + i * G1B, &host[i * G1B]);
-        decode_point<FQB, 2>(g_gamma_z, &host[M * G1B]);
-        L::upload_points(ctx, pk->a_ext, host, me * 2);
-        stream_sync(ctx->stream);
-        host.assign(me * G1B, 0);
-        for (u64 i = 0; i < M; ++i) decode_point<FQB, 2>(c2_q + i * G1B, &host[i * G1B]);
-        L::upload_points(ctx, pk->b1_ext, host, me * 2);
-        stream_sync(ctx->stream);
-        host.assign(me * G1B, 0);
-        for (u64 j = 0; j < n1; ++j) decode_point<FQB, 2>(c1_q + j * G1B, &host[(l + j) * G1B]);
-        decode_point<FQB, 2>(g_ab_gamma_z, &host[M * G1B]);
-        L::upload_points(ctx, pk->l_ext, host, me * 2);
-        stream_sync(ctx->stream);
-        host.assign(me * G2B, 0);
-        for (u64 i = 0; i < M; ++i) decode_point<FQB, 4>(b_q + i * G2B, &host[i * G2B]);
-        decode_point<FQB, 4>(h_gamma_z, &host[M * G2B]);
-        L::upload_points(ctx, pk->b2_ext, host, me * 4);
-        stream_sync(ctx->stream);
+        L::template upload_decoded<2>(ctx, pk->a_ext, me, a_q, M, 0, g_gamma_z, M);
+        L::template upload_decoded<2>(ctx, pk->b1_ext, me, c2_q, M, 0, nullptr, 0);
+        L::template upload_decoded<2>(ctx, pk->l_ext, me, c1_q, n1, l, g_ab_gamma_z, M);
+        L::template upload_decoded<4>(ctx, pk->b2_ext, me, b_q, M, 0, h_gamma_z, M);
         // g_gamma2_z_t[0..D), permuted into the sigma order the NTT pipeline leaves the quotient in (entry D pairs with
         // the d1^2 coefficient of ark's h, which the restructured prover does not produce)
-        host.assign(D * G1B, 0);
-        for (u64 i = 0; i < D; ++i) decode_point<FQB, 2>(t_q + i * G1B, &host[i * G1B]);
-        ctx->tmp.ensure(std::max<size_t>(host.size(), 16));
-        dev_h2d(ctx->tmp.p, host.data(), host.size(), ctx->stream);
-        ZK_LAUNCH((k_to_mont<Fq>), dim3(blocks_for(D * 2, 256)), dim3(256), 0, ctx->stream, ptr<Fq>(ctx->tmp), ptr<Fq>(ctx->tmp), D * 2);
+        DBuf t_nat;
+        L::template upload_decoded<2>(ctx, t_nat, D, t_q, D, 0, nullptr, 0);
         pk->h_sigma.ensure(D * G1B);
-        ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(D, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(ctx->tmp),
+        ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(D, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(t_nat),
                   ptr<Aff<Fq>>(pk->h_sigma), D, D, plan->N1, plan->N2, plan->N3);
         stream_sync(ctx->stream);
+        t_nat.release();
         L::finish_tables(ctx, pk, me, D);
     }
 

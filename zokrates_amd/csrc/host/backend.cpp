@@ -204,6 +204,7 @@ Hip::Hip(int32_t device) {
     if (rc != ZKHIP_OK) throw Error(rc, zkhip_last_error(nullptr));
 }
 Hip::~Hip() { if (ctx_) zkhip_ctx_free(ctx_); }
+void Hip::one_shot() { check(zkhip_ctx_tune(ctx_, ZKHIP_TUNE_MSM_SETS, 64)); }
 void Hip::check(int32_t rc) const {
     if (rc != ZKHIP_OK) throw Error(rc, zkhip_last_error(ctx_));
 }

@@ -12,6 +12,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -58,9 +59,18 @@ uint64_t fnv1a(const std::string& s) {
     for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
     return h;
 }
+// the CPU this thread runs on and its NUMA node (for the record in --timings: the host-side stages — reading, decoding, the
+// staging copies — depend on where the process sits relative to the GPU); -1 where the kernel does not say
+std::pair<int, int> cpu_and_node() {
+    unsigned cpu = 0, node = 0;
+#ifdef SYS_getcpu
+    if (syscall(SYS_getcpu, &cpu, &node, nullptr) == 0) return {(int)cpu, (int)node};
+#endif
+    return {-1, -1};
+}
 int usage() {
     fprintf(stderr, "usage: zkhip-cli generate-proof -i <out> -w <witness> -p <proving.key> -j <proof.json> [-s g16|gm17] [--entropy TEXT] "
-                    "[--key-cache DIR] [--device N] [--timings] [--verify]\n"
+                    "[--key-cache DIR] [--device N] [--timings] [--verify] [--full-tables]\n"
                     "       zkhip-cli setup -i <out> -p <proving.key> -v <verification.key> [-s g16|gm17] [--entropy TEXT] [--device N]\n"
                     "       zkhip-cli verify [-v <verification.key>] [-j <proof.json>]\n"
                     "       zkhip-cli print-proof [-j <proof.json>] [-f remix|json]\n");
@@ -182,13 +192,14 @@ int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "pairing-check") == 0) return cmd_pairing_check(argc, argv);
     if (argc < 2 || strcmp(argv[1], "generate-proof") != 0) return usage();
     std::string input = "out", witness_path = "witness", pk_path = "proving.key", proof_path = "proof.json", scheme_s = "g16", entropy, cache_dir;
-    bool have_entropy = false, timings = false, self_check = false;
+    bool have_entropy = false, timings = false, self_check = false, resident_tables = false;
     int device = 0;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
         if (a == "-i" || a == "--input") input = val();
         else if (a == "--verify") self_check = true;
+        else if (a == "--full-tables") resident_tables = true;      // (measurement: build the window-multiple tables a resident prover uses)
         else if (a == "-w" || a == "--witness") witness_path = val();
         else if (a == "-p" || a == "--proving-key-path") pk_path = val();
         else if (a == "-j" || a == "--proof-path") proof_path = val();
@@ -249,7 +260,7 @@ int main(int argc, char** argv) {
             char tag[64];
             snprintf(tag, sizeof(tag), "%016llx", (unsigned long long)fnv1a(pk_path + "|" + std::to_string((long long)st.st_size) + "|" +
                                                                            std::to_string((long long)st.st_mtim.tv_sec) + "." + std::to_string((long long)st.st_mtim.tv_nsec) + "|" +
-                                                                           std::to_string((unsigned long long)st.st_ino) + "|" + scheme_s + "|" + std::to_string(curve)));
+                                                                           std::to_string((unsigned long long)st.st_ino) + "|" + scheme_s + "|" + std::to_string(curve) + (resident_tables ? "|tables" : "")));
             image_path = cache_dir + "/" + tag + ".zkhippk";
             struct stat ist;
             try_image = stat(image_path.c_str(), &ist) == 0;
@@ -266,6 +277,7 @@ int main(int argc, char** argv) {
         Joiner key_joiner{key_reader};
         auto t0 = std::chrono::steady_clock::now();
         Hip hip(device);
+        if (!resident_tables) hip.one_shot();          // one proof, then the process ends: no window-multiple tables
         const double ms_init = ms_since(t0);
         t0 = std::chrono::steady_clock::now();
         key_reader.join();
@@ -336,12 +348,15 @@ int main(int argc, char** argv) {
             printf("verified against the verification key of %s\n", pk_path.c_str());
         }
         printf("generate-proof (%s): wrote %s\n", scheme_s.c_str(), proof_path.c_str());
+        const std::pair<int, int> where = cpu_and_node();
         if (timings)
             printf("timings {\"read_program_and_witness_ms\": %.3f, \"parse_program_ms\": %.3f, \"hip_init_ms\": %.3f, \"key_load_ms\": %.3f, "
                    "\"wait_for_host_side_ms\": %.3f, \"witness_to_assignment_ms\": %.3f, \"r1cs_upload_ms\": %.3f, \"prove_ms\": %.3f, "
-                   "\"proof_json_ms\": %.3f, \"verify_ms\": %.3f, \"total_in_process_ms\": %.3f, \"key_source\": \"%s\", \"constraints\": %llu}\n",
+                   "\"proof_json_ms\": %.3f, \"verify_ms\": %.3f, \"total_in_process_ms\": %.3f, \"key_source\": \"%s\", \"constraints\": %llu, "
+                   "\"tables\": \"%s\", \"host_threads\": %u, \"cpu\": %d, \"numa_node\": %d}\n",
                    ms_read, ms_parse, ms_init, ms_key, ms_wait, tm.witness_to_assignment, tm.r1cs_upload, tm.prove, ms_json, ms_verify, ms_since(t_start),
-                   key_source.c_str(), (unsigned long long)program->constraints());
+                   key_source.c_str(), (unsigned long long)program->constraints(), resident_tables ? "every window multiple" : "none (one proof per process)",
+                   std::thread::hardware_concurrency(), where.first, where.second);
         // one proof per process: the proof is on disk, so leave without tearing down 6 GiB of tables and the HIP runtime
         fflush(stdout);
         _exit(0);

@@ -557,7 +557,8 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         for (int k = 0; k < 5; ++k) {
             DBuf* b = pk_bufs(pk.get(), k);
             b->ensure(pk_table_bytes(h.curve, k, h.z_n, h.h_n, k == 4 ? pk_levels(h.curve, h.c_h, s_h) : pk_levels(h.curve, h.c_z, s_z)));
-            dev_h2d(b->p, p, h.len_buf[k], ctx->stream);
+            const uint8_t* src = p;
+            dev_h2d_fill(b->p, h.len_buf[k], 64, ctx->stream, [src](char* out, size_t off, size_t len) { memcpy(out, src + off, len); });
             p += h.len_buf[k];
         }
         stream_sync(ctx->stream);
