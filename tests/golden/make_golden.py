@@ -136,7 +136,43 @@ def gm17_embed_triples():
             "vk: h(4) g_alpha(2) h_beta(4) g_gamma(2) h_gamma(4) query(2 each)", "triples": out}
 
 
+def ptau5_points():
+    """zokrates_js/tests/powersOfTau5_0000.ptau: a snarkjs powers-of-tau file (power 5) the reference's JS tests load for the
+    universal-setup flows.  Sections (id u32, size u64): 1 header (n8, q, power), 2 tauG1 (2^6 - 1 points), 3 tauG2 (2^5),
+    4 alphaTauG1, 5 betaTauG1, 6 betaG2, 12..15 the same in the Lagrange bases of the domains 2^0 .. 2^6 / 2^5.  Coordinates are
+    Montgomery form (R = 2^256), little-endian; G2 as x.c0 x.c1 y.c0 y.c1; infinity as all-zero.  `_0000` is the ceremony's
+    starting file (tau = 1): every tauG1 entry IS the generator, and the Lagrange sections are mostly points at infinity plus
+    the generator and one domain's worth of genuine distinct points — an unfriendly base set for an MSM (infinite bases,
+    long runs of equal bases: the doubling and cancellation branches), and an independent one: none of it came out of this
+    repository's setup code."""
+    import struct
+    raw = open(os.path.join(REF, "zokrates_js/tests/powersOfTau5_0000.ptau"), "rb").read()
+    assert raw[:4] == b"ptau"
+    off, secs = 12, {}
+    while off < len(raw):
+        sid, size = struct.unpack("<IQ", raw[off:off + 12])
+        secs[sid] = (off + 12, size)
+        off += 12 + size
+    o, _ = secs[1]
+    n8 = struct.unpack("<I", raw[o:o + 4])[0]
+    q = int.from_bytes(raw[o + 4:o + 4 + n8], "little")
+    power = struct.unpack("<I", raw[o + 4 + n8:o + 8 + n8])[0]
+    assert n8 == 32 and power == 5
+    rinv = pow(1 << 256, -1, q)
+    fq = lambda b: str(int.from_bytes(b, "little") * rinv % q)
+
+    def points(sid, ncoord):
+        o, size = secs[sid]
+        sz = 32 * ncoord
+        return [[fq(raw[o + sz * i + 32 * k:o + sz * i + 32 * k + 32]) for k in range(ncoord)] for i in range(size // sz)]
+    d = {"source": "zokrates_js/tests/powersOfTau5_0000.ptau", "q": str(q), "power": power,
+         "tau_g1": points(2, 2), "tau_g2": points(3, 4), "lagrange_g1": points(12, 2), "lagrange_g2": points(13, 4)}
+    assert len(d["tau_g1"]) == 63 and len(d["tau_g2"]) == 32 and len(d["lagrange_g1"]) == 127 and len(d["lagrange_g2"]) == 63
+    return d
+
+
 def main():
+    json.dump(ptau5_points(), open(os.path.join(OUT, "ptau5_points.json"), "w"), indent=0)
     json.dump(gm17_embed_triples(), open(os.path.join(OUT, "gm17_bls12_377_embed_triples.json"), "w"), indent=1)
     json.dump(gm17_triple(), open(os.path.join(OUT, "gm17_bls12_377_triple.json"), "w"), indent=1)
     json.dump(field_kats(), open(os.path.join(OUT, "bn128_field_kats.json"), "w"), indent=1)
