@@ -4,7 +4,7 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/../../zokrates_amd/csrc"
-FLAGS="-U_FORTIFY_SOURCE -O2 -g -std=c++17 -fPIC -DZK_EMU -x c++ -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-unused-variable -Wno-restrict"
+FLAGS="-U_FORTIFY_SOURCE -O2 -g -std=c++17 -fPIC -DZK_EMU ${EMU_FLAGS:-} -x c++ -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-unused-variable -Wno-restrict"
 mkdir -p "$HERE/obj"
 for f in curve_bn254 curve_bls381 bn254_g1 bn254_g2 bls381_g1 bls381_g2 zkhip_api ingest; do
   g++ $FLAGS -c "$SRC/$f.hip" -o "$HERE/obj/$f.o" &

@@ -19,6 +19,13 @@ timeout 600 python bench.py --kind sha --cpu-seconds 0 --e2e 0 > "$out/bench_sha
 timeout 600 python bench.py --cpu-seconds 0 --constraints 1048576 --steps 16 --e2e 0 > "$out/bench_n2e20_literal_domain2e21.json" 2>> "$out/bench.err"
 timeout 900 python bench.py --cpu-seconds 0 --log-domain 22 --steps 8 --members 8 --e2e 0 > "$out/bench_config3_2e22_members8.json" 2>> "$out/bench.err"
 timeout 600 python bench.py --cpu-seconds 0 --members 8 --steps 16 --e2e 0 > "$out/bench_2e20_members8.json" 2>> "$out/bench.err"
+# domains above 2^22 (three NTT passes): Groth16 over the literal n = 2^22 (domain 2^23), GM17 over n = 2^22 - 2 (SAP domain 2^23)
+timeout 900 python bench.py --constraints 4194304 --log-domain 23 --steps 8 --warmup 2 --witnesses 2 --cpu-seconds 0 --e2e 0 > "$out/bench_g16_n2e22_domain2e23.json" 2>> "$out/bench.err"
+timeout 900 python bench.py --scheme gm17 --log-domain 22 --steps 6 --warmup 2 --witnesses 2 --cpu-seconds 0 --e2e 0 > "$out/bench_gm17_n2e22_sap2e23.json" 2>> "$out/bench.err"
+# and one size nobody asked for, to show there is no cap left: n = 2^24 - 2 (domain 2^24; a 6.4 GB key, 96 GiB of tables)
+[ -n "${WITH_2E24:-}" ] && timeout 900 python bench.py --log-domain 24 --steps 4 --warmup 1 --witnesses 1 --serial-proofs 1 --cpu-seconds 0 --e2e 0 > "$out/bench_g16_domain2e24.json" 2>> "$out/bench.err"
+# `bench.py --gpus 2` with no launcher: it starts the ranks itself (here both on this box's one GPU over gloo)
+ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 8 --warmup 2 --e2e 0 > "$out/bench_gpus2_self_spawned_one_gpu.json" 2>> "$out/bench.err"
 # the N > 1 code path of bench.py on real hardware: two ranks sharing this box's one GPU (gloo instead of RCCL, which wants
 # one device per rank); rank 0 also drives the in-library multi leg
 ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 \
@@ -37,6 +44,11 @@ ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python -m torch.distrib
     python "$root/tools/pmc_traffic.py" "$f" "$w" "$out/pmc_traffic.json" "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate runs), ZKHIP_SERIAL=1 python bench.py --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0; profiles/${tag}_pmc_FETCH_SIZE.md, ${tag}_pmc_WRITE_SIZE.md" > /dev/null \
       && cp "$out/pmc_traffic.json" "$root/profiles/pmc_traffic.json" && echo "pmc_traffic.json refreshed"
   else echo "PMC passes incomplete: profiles/pmc_traffic.json unchanged"; fi
+  # VALU issue occupation of the same kernels -> pmc_valu.json (tools/pmc_valu.py)
+  ZKHIP_SERIAL=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d "$out/prof_pmc_VALU" -o pmc -- \
+    python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0 > "$out/prof_pmc_VALU.log" 2>&1
+  db=$(find "$out/prof_pmc_VALU" -name "*.db" 2>/dev/null | head -1)
+  [ -n "$db" ] && python "$root/tools/pmc_valu.py" "$db" "$out/${tag}_pmc_VALU.md" > /dev/null && cp "$out/${tag}_pmc_VALU.json" "$out/pmc_valu.json" && echo "pmc_valu.json written"
   find "$out" -name "*.db" -size +8M -delete )
 cat "$out/smoke.log" | tail -1; [ -f "$out/pytest_gpu.log" ] && tail -12 "$out/pytest_gpu.log"
 python - "$out/bench_two_ranks_one_gpu.json" <<'PY'
@@ -45,7 +57,7 @@ for line in open(sys.argv[1]):
     if line.startswith('{'):
         d=json.loads(line); print('two ranks on one GPU:', round(d['value'],2), 'proofs/s aggregate, n_gpus', d['n_gpus'], '| sharded', d.get('sharded_single_proof'), '| multi', {k:v for k,v in (d.get('multi_single_proof') or {}).items() if k in ('ms','members','distinct_gpus','identical_to_unsharded','error')})
 PY
-for f in default gm17 poseidon_bls12_381_2e18 sha_like n2e20_literal_domain2e21 config3_2e22_members8 2e20_members8; do python - "$out/bench_$f.json" <<'PY'
+for f in default gm17 poseidon_bls12_381_2e18 sha_like n2e20_literal_domain2e21 config3_2e22_members8 2e20_members8 g16_n2e22_domain2e23 gm17_n2e22_sap2e23 g16_domain2e24 gpus2_self_spawned_one_gpu; do python - "$out/bench_$f.json" <<'PY'
 import json,sys
 for line in open(sys.argv[1]):
     try:

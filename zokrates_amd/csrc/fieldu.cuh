@@ -148,6 +148,8 @@ struct UConst {
     ZK_HD static constexpr u32 bias4(int i) { constexpr Limbs t = bias(4); return t.v[i]; }
     ZK_HD static constexpr u32 bias8(int i) { constexpr Limbs t = bias(8); return t.v[i]; }
     ZK_HD static constexpr u32 nbias2(int i) { constexpr Limbs t = bias_spread(2, B + 1); return t.v[i]; }   // 2p, spread 2^(B+1)
+    ZK_HD static constexpr u32 nbias4(int i) { constexpr Limbs t = bias_spread(4, B + 1); return t.v[i]; }
+    ZK_HD static constexpr u32 nbias8(int i) { constexpr Limbs t = bias_spread(8, B + 1); return t.v[i]; }
     static constexpr u32 PINV = inv_low() & M;               //  p^-1 mod 2^B
     static constexpr u32 NINV = (0u - inv_low()) & M;        // -p^-1 mod 2^B
     static constexpr u32 P_TOP = split(modulus()).v[N - 1];
@@ -223,6 +225,23 @@ template <class P>
 ZK_HD Fu<P> fe_neg_lazy(const Fu<P>& a) {
     Fu<P> r;
     ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = UConst<P>::nbias2(i) - a.v[i];
+    return r;
+}
+// a + K p - b and a + b WITHOUT the carry round, for TIGHT a and b (value(b) < K p): limbs up to 2^(B+2), so the result is ONLY
+// good as the operand of a single product whose other operand is TIGHT with limbs < 2^B exactly — a twiddle factor unpacked
+// from its table: N * 2^(2B+2) + the reduction's N * 2^(2B) < 2^64 for both limb widths.  The butterflies of the transforms
+// multiply most of their sums and differences at once (kernels_ntt.cuh): 25 instructions less each.
+template <int K, class P>
+ZK_HD Fu<P> fe_sub_k_lazy(const Fu<P>& a, const Fu<P>& b) {
+    typedef UConst<P> C;
+    Fu<P> r;
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = a.v[i] + ((K == 2 ? C::nbias2(i) : K == 4 ? C::nbias4(i) : C::nbias8(i)) - b.v[i]);
+    return r;
+}
+template <class P>
+ZK_HD Fu<P> fe_add_lazy(const Fu<P>& a, const Fu<P>& b) {
+    Fu<P> r;
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = a.v[i] + b.v[i];
     return r;
 }
 // neg ? 2p - y : y for the y of a base that is NOT the point at infinity; the result only feeds the product S2 = ZZZ1 * y

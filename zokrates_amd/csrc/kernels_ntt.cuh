@@ -274,7 +274,8 @@ __device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn,
                 {
                     const U bq = lds_get_u<P>(lds, PL, s1), d = lds_get_u<P>(lds, PL, s3);
                     t2 = fe_add(bq, d);
-                    t3 = fu_mul_inl(fe_sub_k<4>(bq, d), ntt_plan_get<P>(plan, plen, plen - 1));   // * w4
+                    t3 = fu_mul_inl(fe_sub_k_lazy<4>(bq, d), ntt_plan_get<P>(plan, plen, plen - 1));   // * w4 (a difference that is
+                                                                                  // multiplied at once skips its carry round: fieldu.cuh)
                 }
                 U t0, t1;
                 {
@@ -284,9 +285,9 @@ __device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn,
                 }
                 lds_put_u<P>(lds, PL, s0, fe_relax(fe_add(t0, t2)));
                 if (L > 4) {
-                    lds_put_u<P>(lds, PL, s1, fu_mul_inl(fe_sub_k<8>(t0, t2), ntt_plan_get<P>(plan, plen, off + q + pos)));
-                    lds_put_u<P>(lds, PL, s2, fu_mul_inl(fe_add(t1, t3), ntt_plan_get<P>(plan, plen, off + pos)));
-                    lds_put_u<P>(lds, PL, s3, fu_mul_inl(fe_sub_k<4>(t1, t3), ntt_plan_get<P>(plan, plen, off + 2 * q + pos)));
+                    lds_put_u<P>(lds, PL, s1, fu_mul_inl(fe_sub_k_lazy<8>(t0, t2), ntt_plan_get<P>(plan, plen, off + q + pos)));
+                    lds_put_u<P>(lds, PL, s2, fu_mul_inl(fe_add_lazy(t1, t3), ntt_plan_get<P>(plan, plen, off + pos)));
+                    lds_put_u<P>(lds, PL, s3, fu_mul_inl(fe_sub_k_lazy<4>(t1, t3), ntt_plan_get<P>(plan, plen, off + 2 * q + pos)));
                 } else {
                     lds_put_u<P>(lds, PL, s1, fe_sub_k<8>(t0, t2));
                     lds_put_u<P>(lds, PL, s2, fe_add(t1, t3));
