@@ -143,7 +143,7 @@ def launch_ranks(n):
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=err))
     # a rank that dies before the rendezvous would leave the others waiting in it: watch all of them, end all on the first failure
     budget = float(os.environ.get("ZKHIP_BENCH_LAUNCH_TIMEOUT_S", "1800"))
-    t0, failed = time.time(), None
+    t0, failed, t_done = time.time(), None, None
     import threading
     out0 = []
     reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
@@ -156,6 +156,15 @@ def launch_ranks(n):
             break
         if all(c == 0 for c in codes):
             break
+        if codes[0] == 0:
+            # rank 0 is done (its line is on the pipe): the others only have to leave; one that does not — stuck behind an optional
+            # leg rank 0 abandoned — is ended after a grace period instead of holding the finished measurement back
+            t_done = t_done or time.time()
+            if time.time() - t_done > 30:
+                for p in procs[1:]:
+                    if p.poll() is None:
+                        p.kill()
+                break
         if time.time() - t0 > budget:
             failed = "ranks still running after %.0f s" % budget
             break

@@ -108,6 +108,9 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_MSM_SETS 17        /* bucket sets of the MSM tables built by later key loads: 1 = every window multiple of every base
                                       * (one bucket set per MSM), 2 = every second multiple (two sets) ...; 0 = automatic: 1 while the
                                       * tables fit the device, else the smallest power of two that does (keys above 2^24 constraints) */
+#define ZKHIP_TUNE_SKIP_INF 18        /* how the bucket accumulation meets bases at infinity: 0 = per table, from a count made at key load
+                                      * (a table with more than one such base in 2048 lets lanes sit them out, the others send the rare
+                                      * one through the general code), 1 = lanes always sit them out, 2 = always the general code        */
 #define ZKHIP_TUNE_NTT_MAX_SUBLOG 16 /* log2 of the longest sub-transform of an NTT pass (2..11; default 11): domains above 2^(2 x this)
                                       * take three passes instead of two — a test hook to reach the three-pass path (domains above
                                       * 2^22) with small domains.  Keys loaded before a change must be reloaded (their h order)        */

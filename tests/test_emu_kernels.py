@@ -242,6 +242,30 @@ def test_prove_with_thinned_tables(curve):
         c2.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["lanes-sit-out", "wavefront-vote"])
+def test_both_ways_of_meeting_bases_at_infinity(mode):
+    """The accumulation kernel exists twice: tables with many points at infinity (real circuits: b_query) let a lane sit such a
+    base out, tables with next to none send the rare one through the general code by a wavefront vote; the key load picks per table
+    from a count.  Both kernels over both kinds of data — a dense circuit, a sha-like one whose B matrix leaves most variables out,
+    an ad-hoc MSM with infinite and repeated bases — must give the oracle's results."""
+    c2 = native.Context(0, emu_library())
+    c2.tune("skip_inf", mode)
+    try:
+        for curve, kind, n in ((BN254, "dense", 21), (BN254, "sha", 45), (BLS12_381, "sha", 30)):
+            oc = cpu.Circuit.synth(curve.curve_id, n, 0x5EED0040 + n, kind)
+            tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+            opk = cpu.ProvingKey.setup(oc, tox)
+            z = oc.assignment()
+            cs = native.ConstraintSystem(c2, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+            pk = native.ProvingKey(c2, curve.curve_id, opk.serialize())
+            assert native.prove_g16(c2, pk, cs, z, 11, 13) == cpu.trapdoor(oc, tox, z, 11, 13), (curve.name, kind)
+        rnd = random.Random(77)
+        b1, b2, ks = _rand_points(BN254, 40, rnd)
+        assert c2.msm(0, 1, b1, ks) == cpu.msm(0, 1, b1, ks) and c2.msm(0, 2, b2, ks) == cpu.msm(0, 2, b2, ks)
+    finally:
+        c2.close()
+
+
 def test_schedule_does_not_change_proofs(ctx):
     schedule_invariance(ctx, logn=5, kinds=("dense",))
 

@@ -10,10 +10,11 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -Wno-unused-variable --cuda-device-only -S \
   ${ISA_FLAGS:-} "$root/zokrates_amd/csrc/bn254_g1.hip" -o "$tmp/g1.s" 2>/dev/null
-python3 - "$tmp/g1.s" <<'PY' | tee "${1:-/dev/stdout}"
+python3 - "$tmp/g1.s" ${ISA_VARIANT:-dense} <<'PY' | tee "${1:-/dev/stdout}"
 import re, sys, collections
 src = open(sys.argv[1]).read().split("\n")
-start = next(i for i, l in enumerate(src) if re.match(r"^_ZN2zk11k_msm_accumINS_2FuINS_7Bn254FqEEELi\d+E.*:", l))
+variant = "1" if sys.argv[2:] and sys.argv[2] == "sparse" else "0"      # SKIP_INF: ISA_VARIANT=sparse picks the kernel of tables with many points at infinity
+start = next(i for i, l in enumerate(src) if re.match(r"^_ZN2zk11k_msm_accumINS_2FuINS_7Bn254FqEEELi\d+ELb" + variant + r"E.*:", l))
 end = next(i for i in range(start, len(src)) if ".amdhsa_kernel" in src[i])
 body = src[start:end]
 regs = [l.strip() for l in src[end:end + 60] if "next_free_vgpr" in l or "private_segment_fixed" in l]
@@ -42,7 +43,7 @@ for l in hot:
     if not t or t[0].startswith(".") or t[0].endswith(":"): continue
     mix[t[0]] += 1
 total = sum(mix.values())
-print(f"k_msm_accum<Fu<Bn254Fq>>: {total} instructions per sorted entry on the hot path ({note}); {', '.join(regs)}")
+print(f"k_msm_accum<Fu<Bn254Fq>, SKIP_INF = {bool(sys.argv[2:] and sys.argv[2] == 'sparse')}>: {total} instructions per sorted entry on the hot path ({note}); {', '.join(regs)}")
 for k, v in mix.most_common(18):
     print(f"  {v:5d}  {100.0 * v / total:5.1f} %  {k}")
 PY

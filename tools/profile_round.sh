@@ -28,8 +28,8 @@ export ZKHIP_SERIAL=1
 run serial --kernel-trace --stats -d "$out/prof_serial" -o serial -- python "$root/bench.py" --cpu-seconds 0 --steps 8 --serial-proofs 0 --e2e 0
 db=$(find "$out/prof_serial" -name "*.db" | head -1)
 [ -n "$db" ] && python "$root/tools/rocpd_stats.py" "$db" "$out/${tag}_g16_serial_kernel_stats.md" > /dev/null
-# 3. / 4. counters (their own runs: --pmc with the kernel trace only)
-for ctr in FETCH_SIZE WRITE_SIZE; do
+# 3. / 4. counters (their own runs: --pmc with the kernel trace only); SKIP_PMC=1: tools/gpu_final.sh took them already
+for ctr in ${SKIP_PMC:+} $([ -z "${SKIP_PMC:-}" ] && echo FETCH_SIZE WRITE_SIZE); do
   run pmc_$ctr --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0
   db=$(find "$out/prof_pmc_$ctr" -name "*.db" | head -1)
   [ -n "$db" ] && python "$root/tools/pmc_stats.py" "$db" "$out/${tag}_pmc_$ctr.md" > /dev/null
@@ -44,4 +44,4 @@ db=$(find "$out/prof_gm17" -name "*.db" | head -1)
 [ -n "$db" ] && python "$root/tools/rocpd_stats.py" "$db" "$out/${tag}_gm17_pipelined_kernel_stats.md" > /dev/null
 grep -h '^{"metric"' "$out/prof_gm17.log" > "$out/${tag}_gm17_bench_under_rocprof.json"
 find "$out" -name "*.db" -size +8M -delete     # keep the merge-back small
-head -12 "$out/${tag}_g16_serial_kernel_stats.md"; cat "$out/${tag}_g16_pipelined_timeline.txt"; cat "$out/pmc_traffic.json"
+head -14 "$out/${tag}_g16_serial_kernel_stats.md"; cat "$out/${tag}_g16_pipelined_timeline.txt"; [ -f "$out/pmc_traffic.json" ] && cat "$out/pmc_traffic.json"

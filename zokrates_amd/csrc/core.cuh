@@ -136,6 +136,7 @@ struct zkhip_ctx {
     // tunables (zkhip_ctx_tune; the environment variables ZKHIP_SERIAL, ZKHIP_MSM_C, ZKHIP_MSM_WAVES and
     // ZKHIP_NTT_SINGLE_MAX_LOG give their initial values, read ONCE when the context is created)
     int msm_c_env = 0;        // window width of the tables built / ad-hoc MSMs run from now on (0 = automatic)
+    int skip_inf_mode = 0;    // which accumulation kernel meets bases at infinity how: 0 per table (MsmShape::skip_inf), 1 lanes always sit them out, 2 always the vote
     int msm_sets = 0;         // bucket sets of the tables built from now on: 1 = every window multiple, 2 = every second ... (0 = what fits the device)
     int msm_waves = 0;        // accumulation waves per SIMD (0 = per point type)
     u32 msm_lanes = 0;        // slices of the sorted list (0 = one per resident work-item)
@@ -436,6 +437,8 @@ struct MsmShape {
     u32 Lw, H;      // fold geometry: K = H rows of Lw buckets
     static constexpr u32 ndig = 2;   // digits of the fold: column and row of the bucket index
     int level_bits() const { return c * (int)sets; }   // level t of a table holds 2^(level_bits t) P
+    bool skip_inf = true;   // which accumulation kernel: lanes sit out bases at infinity (tables that hold many: kernels_msm.cuh
+                            // k_msm_accum SKIP_INF), or the rare one goes through the general code (tables that hold next to none)
     u32 nsums() const { return ndig * sets; }   // the fold leaves one sum per digit and bucket set: msm_combine adds them
 };
 static inline int env_int(const char* name, int lo, int hi, int dflt) {
@@ -483,6 +486,7 @@ static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, b
     return s;
 }
 
+static inline MsmShape with_inf(MsmShape sh, bool many) { sh.skip_inf = many; return sh; }
 // exclusive scan of nk counters (cnt -> off, off[nk] = their sum, also left in *grand)
 static inline void scan_u32(Stream s, const DBuf& cnt, DBuf& off, u64 nk, DBuf& chunk_sum, DBuf& grand) {
     const u32 nchunks = (u32)((nk + SCAN_CHUNK - 1) / SCAN_CHUNK);
@@ -543,6 +547,8 @@ void points_to_packed(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
 // levels 1 .. L-1 (2^(bits j) P) behind a level 0 of `count` points; synchronises ctx->stream
 template <class F>
 void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int bits, int L);
+template <class F>
+u64 count_infinite(zkhip_ctx* ctx, const void* d_table, u64 count);
 template <class F> static constexpr size_t packed_point_bytes() { return sizeof(AffPacked<typename Unsat<F>::type>); }
 // fixed-base tables / multiplications for setup (N3); also per-group code
 template <class F>
@@ -610,6 +616,8 @@ struct zkhip_pk {
     u32 rank = 0, world = 1;
     u64 z_lo = 0, z_n = 0, h_lo = 0, h_n = 0;
     int c_z = 0, c_h = 0;
+    bool inf_many[5] = {true, true, true, true, true};   // per table (a, b1, l, b2, h): more than one base in 2048 is the point at
+                                                       // infinity -> the accumulation lets lanes sit those out (MsmShape::skip_inf)
     int s_z = 1, s_h = 1;     // bucket sets of the MSMs over z / over h = every s-th window multiple is in the tables (MsmShape::sets)
     // log2 N1 of the NTT plan the sigma order of h_sigma was made for (N = N1 * N2): a context whose plan for this domain
     // splits differently (ZKHIP_TUNE_NTT_SINGLE_MAX_LOG changed after the key was loaded, or an image written under
@@ -813,6 +821,7 @@ struct PkLoader {
         to_table<Fq>(ctx, pk->l_ext, pk->z_lo, pk->z_n, shz);
         to_table<Fq2>(ctx, pk->b2_ext, pk->z_lo, pk->z_n, shz);
         to_table<Fq>(ctx, pk->h_sigma, pk->h_lo, pk->h_n, shh);
+        count_points_at_infinity(ctx, pk);
     }
     // levels 1 .. W-1 of the five tables of a key whose level 0 is in place (zkhip_pk_import of a compact image)
     static void table_levels(zkhip_ctx* ctx, zkhip_pk* pk) {
@@ -822,6 +831,12 @@ struct PkLoader {
         msm_table_levels<Fq>(ctx, pk->l_ext.p, pk->z_n, shz.level_bits(), (int)shz.levels);
         msm_table_levels<Fq2>(ctx, pk->b2_ext.p, pk->z_n, shz.level_bits(), (int)shz.levels);
         msm_table_levels<Fq>(ctx, pk->h_sigma.p, pk->h_n, shh.level_bits(), (int)shh.levels);
+        count_points_at_infinity(ctx, pk);
+    }
+    static void count_points_at_infinity(zkhip_ctx* ctx, zkhip_pk* pk) {
+        const u64 cnt[5] = {count_infinite<Fq>(ctx, pk->a_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->b1_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->l_ext.p, pk->z_n),
+                            count_infinite<Fq2>(ctx, pk->b2_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->h_sigma.p, pk->h_n)};
+        for (int k = 0; k < 5; ++k) pk->inf_many[k] = cnt[k] * 2048 > (k == 4 ? pk->h_n : pk->z_n);
     }
     template <class F>
     static void to_table(zkhip_ctx* ctx, DBuf& buf, u64 lo, u64 count, const MsmShape& sh) {
@@ -954,7 +969,7 @@ struct Prover {
         if (pk->z_n) {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
             if (gate < 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
+                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, with_inf(shz, pk->inf_many[3]), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
         }
 
         // ---- K1-K4 and the h-sort, on the NTT stream: the main stream is free for the next proof's staging and z-sort
@@ -969,7 +984,7 @@ struct Prover {
         if (pk->z_n) {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
+                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, with_inf(shz, pk->inf_many[3]), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
             run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready);
         } else {
             empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
@@ -978,7 +993,7 @@ struct Prover {
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
         if (pk->h_n) {
             msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
-            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, with_inf(shh, pk->inf_many[4]), ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
         } else {
             empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
         }
@@ -990,7 +1005,7 @@ struct Prover {
     static void run_z_g1(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const MsmShape& shz, Xyzz<Fq>* ws1, int Wmax, Event h_ready) {
         if (ctx->fuse_z) {
             const void* tabs[3] = {pk->a_ext.p, pk->b1_ext.p, pk->l_ext.p};
-            msm_run_tables<Fq>(ctx, sl.lanes[0], sl.sorts[0], tabs, 3, shz, ws1, (u32)Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
+            msm_run_tables<Fq>(ctx, sl.lanes[0], sl.sorts[0], tabs, 3, with_inf(shz, pk->inf_many[0] || pk->inf_many[1] || pk->inf_many[2]), ws1, (u32)Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
             Stream s0 = ctx->serial ? ctx->stream : sl.lanes[0].stream;      // lanes 1 and 2 are part of lane 0's launches
             for (int k = 1; k < 3; ++k) {
                 event_record(sl.acc_b[k], s0);
@@ -999,9 +1014,9 @@ struct Prover {
             }
             return;
         }
-        msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, shz, ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
-        msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, shz, ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
-        msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, shz, ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
+        msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, with_inf(shz, pk->inf_many[0]), ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
+        msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, with_inf(shz, pk->inf_many[1]), ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
+        msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, with_inf(shz, pk->inf_many[2]), ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
     }
 
     // ---- window sums to the host, on a stream of their own so that the main stream can start the next proof

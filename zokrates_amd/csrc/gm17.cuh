@@ -242,7 +242,7 @@ struct Gm17 {
         if (pk->z_n) {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
             if (gate < 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
+                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, with_inf(shz, pk->inf_many[3]), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
         }
 
         // ---- quotient h0 = (U^2 - W)/Z: iNTT + coset NTT of U, pointwise square, coset iNTT minus W's coefficients / Z (sigma order, canonical)
@@ -264,7 +264,7 @@ struct Gm17 {
         if (pk->z_n) {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, shz, ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
+                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, with_inf(shz, pk->inf_many[3]), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
             P::run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready);
         } else {
             P::empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
@@ -273,7 +273,7 @@ struct Gm17 {
         // ---- G = MSM(g_gamma2_z_t, h0)
         if (pk->h_n) {
             msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
-            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, shh, ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, with_inf(shh, pk->inf_many[4]), ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
         } else {
             P::empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
         }

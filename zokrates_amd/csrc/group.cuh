@@ -67,8 +67,12 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
               ptr<u32>(lane.heavy));
     if (accum_after && !ctx->serial) stream_wait_event(s, accum_after);   // (the slicing above only needs the sort)
     if (ev_begin) event_record(ev_begin, s);
-    ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE>), dim3(blocks_for(nlanes, T), nt), dim3(T), 0, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
-              ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), partial_stride, sh.nkeys, cut);
+    if (ctx->skip_inf_mode == 1 || (ctx->skip_inf_mode == 0 && sh.skip_inf))
+        ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, true>), dim3(blocks_for(nlanes, T), nt), dim3(T), 0, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
+                  ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), partial_stride, sh.nkeys, cut);
+    else
+        ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, false>), dim3(blocks_for(nlanes, T), nt), dim3(T), 0, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
+                  ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), partial_stride, sh.nkeys, cut);
     if (ev_end) event_record(ev_end, s);
     ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.sets, nt), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
               ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));
@@ -95,6 +99,20 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     }
     event_record(lane.done, s);
 }
+// number of points at infinity among the first `count` entries (level 0) of a packed table; synchronises ctx->stream
+template <class FS>
+u64 count_infinite(zkhip_ctx* ctx, const void* d_table, u64 count) {
+    typedef typename Unsat<FS>::type F;
+    if (!count) return 0;
+    DBuf d;
+    d.ensure(4);
+    dev_memset(d.p, 0, 4, ctx->stream);
+    ZK_LAUNCH((k_count_infinite<F>), dim3(blocks_for(count, 256)), dim3(256), 0, ctx->stream, (const AffPacked<F>*)d_table, count, ptr<u32>(d));
+    u32 n = 0;
+    dev_d2h(&n, d.p, 4, ctx->stream);
+    stream_sync(ctx->stream);
+    return n;
+}
 template <class FS>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<FS>* d_window_sums,
              Event ev_begin, Event ev_end, Event accum_after) {
@@ -120,6 +138,7 @@ void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scal
     template void msm_run_tables<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void* const*, int, const MsmShape&, Xyzz<F>*, u32, Event, Event, Event); \
     template void points_to_packed<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                    \
     template void msm_table_levels<F>(zkhip_ctx*, void*, u64, int, int);                         \
+    template u64 count_infinite<F>(zkhip_ctx*, const void*, u64);                                \
     template void fixed_base_table<F>(zkhip_ctx*, const Aff<F>*, int, DBuf&);                                           \
     template void fixed_base_mul<F>(zkhip_ctx*, const DBuf&, int, const u32*, u64, Aff<F>*);
 

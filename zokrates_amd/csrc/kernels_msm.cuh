@@ -343,7 +343,12 @@ __device__ __forceinline__ void zk_pin_words(T& obj) {
 #else
 #define ZK_PIN_WORDS(x) ((void)0)
 #endif
-template <class F, int WPE>
+// SKIP_INF: how a base at infinity is met.  true: the lane sits the step out (one more per-lane branch per step: ≈ 1.5 % more
+// instructions on a table without such bases); false: the wavefront's vote sends the step through the general code (free when it
+// never happens, twice the price of a step when it does).  Real circuits leave many points at infinity in b_query (every variable
+// that does not occur in B: a third of the Poseidon chain's, half of a GM17 key's) — the host picks per table from a count made
+// at key load (zkhip_pk::inf_many).
+template <class F, int WPE, bool SKIP_INF>
 __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const u32* __restrict__ off, const u32* __restrict__ sorted,
                                                     const u32* __restrict__ lane_key, Xyzz<F>* __restrict__ partial, u64 partial_stride, u32 nkeys, MsmCut cut) {
     constexpr int NW2 = 2 * AffPacked<F>::NW;
@@ -392,26 +397,28 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
         }
         // Lanes of one wavefront are at different places of their slices: at every step some lane starts a new bucket while the
         // others add.  Written as nested per-lane branches (empty sum? equal x? infinite base?) that costs three re-convergence
-        // points per step with a copy of the whole accumulator at each.  Instead EVERY lane runs the branch-free addition and a
-        // lane that starts a sum takes the point itself by a select; the cases the branch-free code cannot handle (an infinite
-        // base, equal x: doubling or cancellation) are looked for across the wavefront first, and if ANY lane has one, the whole
-        // wavefront runs the general code for this step — a uniform branch, taken practically never on full-width scalars.
+        // points per step with a copy of the whole accumulator at each.  Instead EVERY lane computes Pp and R, and the one case
+        // the branch-free addition cannot take — Pp = 0: doubling or cancellation — is looked for across the wavefront first: if
+        // ANY lane has it, the whole wavefront runs the general code for this step (a uniform branch, taken practically never
+        // on full-width scalars).  Otherwise a lane whose base is the point at infinity sits the step out (real circuits leave
+        // many of those in b_query: every variable that does not occur in B), a lane that starts a sum takes the point itself,
+        // and the others add.
         const bool pinf = pt.is_inf();
         const F ys = fe_cneg(pt.y, neg);
         F Pp, R;
         xyzz_madd_begin<true>(acc, pt.x, ys, Pp, R);
-        const bool special = pinf || (!first && fe_is_zero_modp(Pp));
+        const bool special = SKIP_INF ? (!pinf && !first && fe_is_zero_modp(Pp)) : (pinf || (!first && fe_is_zero_modp(Pp)));
         if (ZK_WAVE_ANY(special)) {
             if (first) acc = Xyzz<F>::inf();
             if (!pinf) xyzz_madd_acc<true>(acc, Aff<F>{pt.x, ys});
             first = acc.is_inf();
-        } else {
-            if (first) {
-                acc.x = pt.x; acc.y = ys; acc.zz = F::one(); acc.zzz = F::one();
-            } else {
-                xyzz_madd_finish<true>(acc, Pp, R);
-            }
+        } else if (SKIP_INF && pinf) {
+            if (first) acc = Xyzz<F>::inf();      // (keeps the invariant: `first` and a stale sum never meet a store)
+        } else if (first) {
+            acc.x = pt.x; acc.y = ys; acc.zz = F::one(); acc.zzz = F::one();
             first = false;
+        } else {
+            xyzz_madd_finish<true>(acc, Pp, R);
         }
     }
     partial[(u64)cur + g] = acc;
@@ -657,6 +664,17 @@ __global__ void __launch_bounds__(256) k_msm_table_levels(AffPacked<F>* __restri
 }
 
 // ---- key preparation ----
+// how many of the n packed points are the point at infinity (all-zero)
+template <class F>
+__global__ void k_count_infinite(const AffPacked<F>* __restrict__ tbl, u64 n, u32* __restrict__ count) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[2 * AffPacked<F>::NW];
+    aff_load_words<F>(tbl, i, w);
+    u32 any = 0;
+    ZK_UNROLL for (int q = 0; q < 2 * AffPacked<F>::NW; ++q) any |= w[q];
+    if (!any) atomicAdd(count, 1u);
+}
 // out[p] = (idx < n_src) ? in[idx] : infinity, idx = natural index of sigma position p (h_query layout)
 template <class PT>
 __global__ void k_sigma_gather_points(const PT* __restrict__ in, PT* __restrict__ out, u64 n, u64 n_src, u32 n1, u32 n2, u32 n3) {
