@@ -266,6 +266,54 @@ def test_both_ways_of_meeting_bases_at_infinity(mode):
         c2.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["own-list", "common-list"])
+def test_b_family_on_a_list_of_its_own(mode):
+    """Variables that do not occur in the B matrix have the point at infinity in b_g1_query AND b_g2_query; when a tenth of a key's
+    are like that (a third of the Poseidon chain's) the MSMs over b_query get a sorted list of their own without them
+    (zkhip_pk::b_sort: one more counting sort, a third less of the most expensive MSM).  Forced on and off here (ZKHIP_TUNE_B_SORT)
+    over circuits with and without such variables: Groth16 on both curves (b1 and b2 on the thinned list, A and L fused on the
+    common one), GM17 (only its G2 MSM), a sharded key (the bitmap of a shard covers its own index range), a key image."""
+    c2 = native.Context(0, emu_library())
+    c2.tune("b_sort", mode)
+    try:
+        for curve, kind, n in ((BN254, "sha", 45), (BN254, "dense", 21), (BLS12_381, "sha", 30)):
+            oc = cpu.Circuit.synth(curve.curve_id, n, 0x5EED0050 + n, kind)
+            tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+            opk = cpu.ProvingKey.setup(oc, tox)
+            z = oc.assignment()
+            cs = native.ConstraintSystem(c2, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+            raw = opk.serialize()
+            pk = native.ProvingKey(c2, curve.curve_id, raw)
+            want = cpu.trapdoor(oc, tox, z, 11, 13)
+            assert native.prove_g16(c2, pk, cs, z, 11, 13) == want, (curve.name, kind)
+            proofs, _ = native.prove_g16_batch(c2, pk, cs, np.concatenate([z, z, z]), [(11, 13), (5, 6), (11, 13)])
+            assert proofs[0] == want and proofs[2] == want
+            assert native.prove_g16(c2, native.ProvingKey.from_image(c2, curve.curve_id, pk.export_image()), cs, z, 11, 13) == want
+            shards = [native.ProvingKey(c2, curve.curve_id, raw, rank=k, world=3) for k in range(3)]
+            parts = [native.prove_g16_partial(c2, sh, cs, z, 11, 13) for sh in shards]
+            assert native.combine_g16(c2, shards[0], parts, 11, 13) == want
+            c2.tune("fuse_z", 0)
+            assert native.prove_g16(c2, pk, cs, z, 11, 13) == want
+            c2.tune("fuse_z", 1)
+            if curve is BN254:
+                tb17 = tox[:96] + tox[128:160]
+                pk17 = native.ProvingKey(c2, 0, cpu.Gm17ProvingKey.setup(oc, tb17).serialize(), scheme="gm17")
+                assert native.prove_gm17(c2, pk17, cs, z, 21, 7, 23) == cpu.gm17_trapdoor(oc, tb17, z, 21, 23), kind
+        # a circuit the flattener makes: one Poseidon hash, a third of whose variables never occur in B
+        from zokrates_amd import poseidon
+        ch = poseidon.chain(0, 1)
+        absent = ch.m - len(np.unique(ch.mats()[1][1]))
+        assert absent * 10 > ch.m
+        oc = cpu.Circuit.from_csr(0, ch.n, ch.l, ch.w, ch.mats())
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(BN254))
+        z = ch.assignment(3)
+        cs = native.ConstraintSystem(c2, 0, ch.n, ch.l, ch.w, ch.mats())
+        pk = native.ProvingKey(c2, 0, cpu.ProvingKey.setup(oc, tox).serialize())
+        assert native.prove_g16(c2, pk, cs, z, 5, 6) == cpu.trapdoor(oc, tox, z, 5, 6)
+    finally:
+        c2.close()
+
+
 def test_schedule_does_not_change_proofs(ctx):
     schedule_invariance(ctx, logn=5, kinds=("dense",))
 

@@ -110,7 +110,7 @@ static constexpr int ZK_NSLOTS = 4;   // most proofs in flight (zkhip_prove_g16*
 // everything one proof in flight owns: its scalars, NTT vectors, sort results, MSM workspaces, window sums and events
 struct ProofSlot {
     DBuf scalars, zmont, va, vb, vc, ws1, ws2, zflag;   // zflag: one word, set by k_check_canonical when a host assignment is staged
-    MsmSort sorts[2];
+    MsmSort sorts[3];         // over z (every table), over h, over z without the variables whose B bases are at infinity (zkhip_pk::b_sort)
     MsmLane lanes[ZK_NLANES];
     void* h_ws = nullptr;      // pinned host copy of the window sums
     size_t h_ws_cap = 0;
@@ -136,6 +136,7 @@ struct zkhip_ctx {
     // tunables (zkhip_ctx_tune; the environment variables ZKHIP_SERIAL, ZKHIP_MSM_C, ZKHIP_MSM_WAVES and
     // ZKHIP_NTT_SINGLE_MAX_LOG give their initial values, read ONCE when the context is created)
     int msm_c_env = 0;        // window width of the tables built / ad-hoc MSMs run from now on (0 = automatic)
+    int b_sort_mode = 0;      // the B family's own sort (zkhip_pk::b_sort): 0 when a tenth of its bases are at infinity, 1 always, 2 never
     int skip_inf_mode = 0;    // which accumulation kernel meets bases at infinity how: 0 per table (MsmShape::skip_inf), 1 lanes always sit them out, 2 always the vote
     int msm_sets = 0;         // bucket sets of the tables built from now on: 1 = every window multiple, 2 = every second ... (0 = what fits the device)
     int msm_waves = 0;        // accumulation waves per SIMD (0 = per point type)
@@ -499,11 +500,13 @@ static inline void scan_u32(Stream s, const DBuf& cnt, DBuf& off, u64 nk, DBuf& 
 }
 // digits + counting sort on the main stream; leaves so.off / so.sorted describing every bucket's point list.
 // level_stride: distance between two levels of the base tables this sort will be paired with (table mode), else 0.
-static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32* d_scalars, const MsmShape& sh, u64 level_stride) {
+// `keep`: bitmap of the scalars that take part (null: all); `wm_of`: a sort of the SAME scalars whose word-major copy is reused
+static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32* d_scalars, const MsmShape& sh, u64 level_stride,
+                               const u32* keep = nullptr, const MsmSort* wm_of = nullptr) {
     const u64 nk = sh.nkeys;
     require(sh.n * (u64)sh.W < ((u64)1 << 32) - sh.nkeys, ZKHIP_ERR_BAD_ARG, "MSM too large for 32-bit sort offsets");
     require(level_stride * (u64)sh.levels < ((u64)1 << 31) && sh.n < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "MSM too large for 31-bit table indices");
-    so.wm.ensure(sh.n * 32);
+    if (!wm_of) so.wm.ensure(sh.n * 32);
     so.sorted.ensure(sh.n * sh.W * 4);
     const unsigned T = 256;
     // one workgroup per (chunk of scalars, window): chunks several times larger than a window's bucket count keep the
@@ -514,18 +517,19 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
     const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;
     const size_t hist_bytes = (size_t)kh * 4;
-    ZK_LAUNCH(k_scalars_to_word_major, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, ptr<u32>(so.wm));
+    if (!wm_of) ZK_LAUNCH(k_scalars_to_word_major, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, ptr<u32>(so.wm));
+    const u32* wm = wm_of ? ptr<u32>(wm_of->wm) : ptr<u32>(so.wm);
     so.cnt.ensure(nk * 4);
     so.cursor.ensure(nk * 4);
     dev_memset(so.cnt.p, 0, nk * 4, s);
     dev_memset(so.cursor.p, 0, nk * 4, s);
     lds_opt_in(ctx, (const void*)k_msm_count);
     lds_opt_in(ctx, (const void*)k_msm_place);
-    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, sh.sets, kh,
-              ptr<u32>(so.cnt));
+    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
+              ptr<u32>(so.cnt), keep);
     scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
-    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, ptr<u32>(so.wm), sh.n, sh.c, sh.W, chunk, sh.sets, kh,
-              level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted));
+    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
+              level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted), keep);
     event_record(so.ready, s);
 }
 
@@ -549,6 +553,8 @@ template <class F>
 void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int bits, int L);
 template <class F>
 u64 count_infinite(zkhip_ctx* ctx, const void* d_table, u64 count);
+template <class F>
+void mark_finite(zkhip_ctx* ctx, const void* d_table, u64 count, u32* d_bitmap);
 template <class F> static constexpr size_t packed_point_bytes() { return sizeof(AffPacked<typename Unsat<F>::type>); }
 // fixed-base tables / multiplications for setup (N3); also per-group code
 template <class F>
@@ -616,6 +622,13 @@ struct zkhip_pk {
     u32 rank = 0, world = 1;
     u64 z_lo = 0, z_n = 0, h_lo = 0, h_n = 0;
     int c_z = 0, c_h = 0;
+    // The B-family MSMs (b_g2_query, and b_g1_query of a Groth16 key) get a sort of their own that leaves out the variables whose
+    // bases are the point at infinity — every variable that does not occur in the B matrix: a third of the Poseidon chain's —
+    // when there are enough of them to pay for a second counting sort (b_sort); b_keep: one bit per entry of the z range, set
+    // where some B base is finite.
+    DBuf b_keep;
+    bool b_sort = false, b_sort_g1 = false;      // b_sort_g1: b1_ext rides on that sort too (Groth16; a GM17 key holds c_query_2 there)
+    bool inf_many_b[2] = {true, true};           // inf_many of b1_ext / b2_ext on the B family's own (thinned) list
     bool inf_many[5] = {true, true, true, true, true};   // per table (a, b1, l, b2, h): more than one base in 2048 is the point at
                                                        // infinity -> the accumulation lets lanes sit those out (MsmShape::skip_inf)
     int s_z = 1, s_h = 1;     // bucket sets of the MSMs over z / over h = every s-th window multiple is in the tables (MsmShape::sets)
@@ -837,6 +850,28 @@ struct PkLoader {
         const u64 cnt[5] = {count_infinite<Fq>(ctx, pk->a_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->b1_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->l_ext.p, pk->z_n),
                             count_infinite<Fq2>(ctx, pk->b2_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->h_sigma.p, pk->h_n)};
         for (int k = 0; k < 5; ++k) pk->inf_many[k] = cnt[k] * 2048 > (k == 4 ? pk->h_n : pk->z_n);
+        // a sort of their own for the B family once a tenth of its bases are at infinity (ZKHIP_TUNE_B_SORT: 1 always, 2 never)
+        pk->b_sort_g1 = pk->scheme == 0;      // (measured against keeping b1_ext in the fused G1 launch: +2.5 % / +4 % proofs/s at 2^18 / 2^20
+                                              // on the Poseidon chain, -0.6 ms / +0.5 ms single proof; profiles/r4h_b_family_sort_ab.txt)
+        const u64 b_inf = pk->b_sort_g1 ? std::min(cnt[1], cnt[3]) : cnt[3];
+        pk->b_sort = pk->z_n > 0 && (ctx->b_sort_mode == 1 || (ctx->b_sort_mode == 0 && b_inf * 10 > pk->z_n));
+        if (pk->b_sort) {
+            const size_t words = (size_t)((pk->z_n + 31) / 32);
+            pk->b_keep.ensure(words * 4);
+            dev_memset(pk->b_keep.p, 0, words * 4, ctx->stream);
+            mark_finite<Fq2>(ctx, pk->b2_ext.p, pk->z_n, ptr<u32>(pk->b_keep));
+            if (pk->b_sort_g1) mark_finite<Fq>(ctx, pk->b1_ext.p, pk->z_n, ptr<u32>(pk->b_keep));
+            std::vector<u32> host(words);
+            dev_d2h(host.data(), pk->b_keep.p, words * 4, ctx->stream);
+            stream_sync(ctx->stream);
+            u64 left_out = 0;
+            for (u64 i = 0; i < pk->z_n; ++i) left_out += !((host[i >> 5] >> (i & 31)) & 1u);
+            // what the B tables still meet at infinity on the thinned list
+            pk->inf_many_b[0] = (cnt[1] - std::min(cnt[1], left_out)) * 2048 > pk->z_n;
+            pk->inf_many_b[1] = (cnt[3] - std::min(cnt[3], left_out)) * 2048 > pk->z_n;
+        } else {
+            pk->b_keep.release();
+        }
     }
     template <class F>
     static void to_table(zkhip_ctx* ctx, DBuf& buf, u64 lo, u64 count, const MsmShape& sh) {
@@ -966,10 +1001,13 @@ struct Prover {
         // everything.  So the G2 lane (the longest chain of a proof) starts at once, the witness map runs beside it, and
         // the G1 lanes over z wait for h (`z_gate`; 2 = the G2 lane waits as well).
         const int gate = z_gate(ctx);
+        const MsmSort& sort_b = pk->b_sort ? sl.sorts[2] : sl.sorts[0];            // what the B family pairs with (zkhip_pk::b_sort)
+        const bool inf_b2 = pk->b_sort ? pk->inf_many_b[1] : pk->inf_many[3];
         if (pk->z_n) {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
+            if (pk->b_sort) msm_prepare(ctx, st, sl.sorts[2], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n, ptr<u32>(pk->b_keep), &sl.sorts[0]);
             if (gate < 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, with_inf(shz, pk->inf_many[3]), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
+                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
         }
 
         // ---- K1-K4 and the h-sort, on the NTT stream: the main stream is free for the next proof's staging and z-sort
@@ -984,7 +1022,7 @@ struct Prover {
         if (pk->z_n) {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sl.sorts[0], pk->b2_ext.p, with_inf(shz, pk->inf_many[3]), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
+                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
             run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready);
         } else {
             empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
@@ -1003,19 +1041,32 @@ struct Prover {
 
     // ---- A, B1, L: the three G1 MSMs over the sorted assignment (window sums to ws1 + {0, 1, 2} * Wmax)
     static void run_z_g1(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const MsmShape& shz, Xyzz<Fq>* ws1, int Wmax, Event h_ready) {
+        // b1_ext on the B family's own list (a Groth16 key whose B bases are often at infinity), else on the common one
+        const bool b1_apart = pk->b_sort && pk->b_sort_g1;
+        const MsmSort& sort_b1 = b1_apart ? sl.sorts[2] : sl.sorts[0];
+        const bool inf_b1 = b1_apart ? pk->inf_many_b[0] : pk->inf_many[1];
+        Stream s0 = ctx->serial ? ctx->stream : sl.lanes[0].stream;      // the lanes that are part of lane 0's launches
+        auto rides_on_lane0 = [&](int k) {
+            event_record(sl.acc_b[k], s0);
+            event_record(sl.acc_e[k], s0);
+            event_record(sl.lanes[k].done, s0);
+        };
+        if (ctx->fuse_z && b1_apart) {
+            const void* tabs[2] = {pk->a_ext.p, pk->l_ext.p};            // A -> ws1 + 0, L -> ws1 + 2 Wmax
+            msm_run_tables<Fq>(ctx, sl.lanes[0], sl.sorts[0], tabs, 2, with_inf(shz, pk->inf_many[0] || pk->inf_many[2]), ws1, (u32)(2 * Wmax), sl.acc_b[0], sl.acc_e[0], h_ready);
+            rides_on_lane0(2);
+            msm_run<Fq>(ctx, sl.lanes[1], sort_b1, pk->b1_ext.p, with_inf(shz, inf_b1), ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
+            return;
+        }
         if (ctx->fuse_z) {
             const void* tabs[3] = {pk->a_ext.p, pk->b1_ext.p, pk->l_ext.p};
             msm_run_tables<Fq>(ctx, sl.lanes[0], sl.sorts[0], tabs, 3, with_inf(shz, pk->inf_many[0] || pk->inf_many[1] || pk->inf_many[2]), ws1, (u32)Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
-            Stream s0 = ctx->serial ? ctx->stream : sl.lanes[0].stream;      // lanes 1 and 2 are part of lane 0's launches
-            for (int k = 1; k < 3; ++k) {
-                event_record(sl.acc_b[k], s0);
-                event_record(sl.acc_e[k], s0);
-                event_record(sl.lanes[k].done, s0);
-            }
+            rides_on_lane0(1);
+            rides_on_lane0(2);
             return;
         }
         msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, with_inf(shz, pk->inf_many[0]), ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
-        msm_run<Fq>(ctx, sl.lanes[1], sl.sorts[0], pk->b1_ext.p, with_inf(shz, pk->inf_many[1]), ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
+        msm_run<Fq>(ctx, sl.lanes[1], sort_b1, pk->b1_ext.p, with_inf(shz, inf_b1), ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
         msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, with_inf(shz, pk->inf_many[2]), ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
     }
 

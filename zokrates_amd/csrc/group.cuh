@@ -113,6 +113,12 @@ u64 count_infinite(zkhip_ctx* ctx, const void* d_table, u64 count) {
     stream_sync(ctx->stream);
     return n;
 }
+// sets, in a bitmap over the first `count` entries (level 0) of a packed table, the bit of every FINITE point; on ctx->stream
+template <class FS>
+void mark_finite(zkhip_ctx* ctx, const void* d_table, u64 count, u32* d_bitmap) {
+    typedef typename Unsat<FS>::type F;
+    ZK_LAUNCH((k_mark_finite<F>), dim3(blocks_for(count, 256)), dim3(256), 0, ctx->stream, (const AffPacked<F>*)d_table, count, d_bitmap);
+}
 template <class FS>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<FS>* d_window_sums,
              Event ev_begin, Event ev_end, Event accum_after) {
@@ -139,6 +145,7 @@ void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scal
     template void points_to_packed<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                    \
     template void msm_table_levels<F>(zkhip_ctx*, void*, u64, int, int);                         \
     template u64 count_infinite<F>(zkhip_ctx*, const void*, u64);                                \
+    template void mark_finite<F>(zkhip_ctx*, const void*, u64, u32*);                            \
     template void fixed_base_table<F>(zkhip_ctx*, const Aff<F>*, int, DBuf&);                                           \
     template void fixed_base_mul<F>(zkhip_ctx*, const DBuf&, int, const u32*, u64, Aff<F>*);
 

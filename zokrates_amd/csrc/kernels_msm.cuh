@@ -167,8 +167,11 @@ static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ w
 // (Wider windows — a second sort pass on the high bits of the bucket, a three-digit fold — were built and measured in round 3:
 // c = 20 saves 14-28 % of the accumulation and gives it back in the sort and in a fold over 2^19 buckets, break-even at best at
 // 2^22, profiles/r3d_window_width_sweep.txt; round 4 removed them.)
+// `keep` (may be null: everything takes part): bit i CLEAR = scalar i takes no part — the sort of the B-family MSMs leaves out the
+// variables whose bases are the point at infinity (zkhip_pk::b_keep).
+static __device__ __forceinline__ bool msm_skipped(const u32* __restrict__ keep, u64 i) { return keep && !((keep[i >> 5] >> (i & 31)) & 1u); }
 static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
-                                                        u32* __restrict__ cnt) {
+                                                        u32* __restrict__ cnt, const u32* __restrict__ keep) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
@@ -179,6 +182,7 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32*
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        if (msm_skipped(keep, i)) continue;
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
         const u32 b = (d & 0x7fffffffu) - b0;
@@ -192,7 +196,7 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32*
 // bucket), then place the entries with LDS atomics.
 static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
                                                         u64 idx_stride, const u32* __restrict__ off, u32* __restrict__ cursor,
-                                                        u32* __restrict__ sorted) {
+                                                        u32* __restrict__ sorted, const u32* __restrict__ keep) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     u32* hist = (u32*)smem;
@@ -203,6 +207,7 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32*
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        if (msm_skipped(keep, i)) continue;
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
         const u32 b = (d & 0x7fffffffu) - b0;
@@ -218,6 +223,7 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32*
     __syncthreads();
     const u32 level = (u32)((u64)((u32)j / sets) * idx_stride);
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        if (msm_skipped(keep, i)) continue;
         const u32 d = msm_window_digit(wm, n, i, j, c, K);
         if (d == MSM_NO_DIGIT) continue;
         const u32 b = (d & 0x7fffffffu) - b0;
@@ -664,6 +670,18 @@ __global__ void __launch_bounds__(256) k_msm_table_levels(AffPacked<F>* __restri
 }
 
 // ---- key preparation ----
+// bitmap[i / 32] bit i % 32 |= "point i of this table is NOT the point at infinity" (the caller starts from all zero and runs the
+// tables of a family through it: a variable stays in the family's sort if any of its bases is finite)
+template <class F>
+__global__ void k_mark_finite(const AffPacked<F>* __restrict__ tbl, u64 n, u32* __restrict__ bitmap) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[2 * AffPacked<F>::NW];
+    aff_load_words<F>(tbl, i, w);
+    u32 any = 0;
+    ZK_UNROLL for (int q = 0; q < 2 * AffPacked<F>::NW; ++q) any |= w[q];
+    if (any) atomicOr(&bitmap[i >> 5], 1u << (i & 31));
+}
 // how many of the n packed points are the point at infinity (all-zero)
 template <class F>
 __global__ void k_count_infinite(const AffPacked<F>* __restrict__ tbl, u64 n, u32* __restrict__ count) {

@@ -154,6 +154,7 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_MSM_C: if (value) in(2, MSM_MAX_C); ctx->msm_c_env = value; break;
             case ZKHIP_TUNE_MSM_SETS: in(0, 64); ctx->msm_sets = value; break;
             case ZKHIP_TUNE_SKIP_INF: in(0, 2); ctx->skip_inf_mode = value; break;
+            case ZKHIP_TUNE_B_SORT: in(0, 2); ctx->b_sort_mode = value; break;
             case ZKHIP_TUNE_MSM_WAVES: in(0, 8); ctx->msm_waves = value; break;
             case ZKHIP_TUNE_MSM_LANES: in(0, 1 << 24); ctx->msm_lanes = (u32)value; break;
             case ZKHIP_TUNE_MSM_MIN_SLICE: in(1, 1 << 20); ctx->msm_min_slice = (u32)value; break;
