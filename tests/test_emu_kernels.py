@@ -268,11 +268,13 @@ def test_both_ways_of_meeting_bases_at_infinity(mode):
 
 @pytest.mark.parametrize("mode", [1, 2], ids=["own-list", "common-list"])
 def test_b_family_on_a_list_of_its_own(mode):
-    """Variables that do not occur in the B matrix have the point at infinity in b_g1_query AND b_g2_query; when a tenth of a key's
-    are like that (a third of the Poseidon chain's) the MSMs over b_query get a sorted list of their own without them
-    (zkhip_pk::b_sort: one more counting sort, a third less of the most expensive MSM).  Forced on and off here (ZKHIP_TUNE_B_SORT)
-    over circuits with and without such variables: Groth16 on both curves (b1 and b2 on the thinned list, A and L fused on the
-    common one), GM17 (only its G2 MSM), a sharded key (the bitmap of a shard covers its own index range), a key image."""
+    """Variables that do not occur in the B matrix have the point at infinity in b_g1_query AND b_g2_query (a third of the Poseidon
+    chain's); a GM17 key holds it for the same half of its variables in a_query, c_query_2 and b_query.  The tables with many such
+    bases form a family whose MSMs pair with a sorted list of their own without the variables at infinity in all of them
+    (zkhip_pk::thin_mask: one more counting sort, the most expensive MSMs shrink by that share).  Forced on and off here
+    (ZKHIP_TUNE_B_SORT) over circuits with and without such variables: Groth16 on both curves (b1 and b2 on the thinned list, A and
+    L fused on the common one), GM17 (a, c2 and b on it, c1 alone on the common one), the unfused launches, a sharded key (the
+    bitmap of a shard covers its own index range), a key image."""
     c2 = native.Context(0, emu_library())
     c2.tune("b_sort", mode)
     try:

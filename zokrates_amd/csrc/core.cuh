@@ -110,7 +110,7 @@ static constexpr int ZK_NSLOTS = 4;   // most proofs in flight (zkhip_prove_g16*
 // everything one proof in flight owns: its scalars, NTT vectors, sort results, MSM workspaces, window sums and events
 struct ProofSlot {
     DBuf scalars, zmont, va, vb, vc, ws1, ws2, zflag;   // zflag: one word, set by k_check_canonical when a host assignment is staged
-    MsmSort sorts[3];         // over z (every table), over h, over z without the variables whose B bases are at infinity (zkhip_pk::b_sort)
+    MsmSort sorts[3];         // over z (every table), over h, over z without the variables a family of tables holds at infinity (zkhip_pk::thin_mask)
     MsmLane lanes[ZK_NLANES];
     void* h_ws = nullptr;      // pinned host copy of the window sums
     size_t h_ws_cap = 0;
@@ -136,7 +136,7 @@ struct zkhip_ctx {
     // tunables (zkhip_ctx_tune; the environment variables ZKHIP_SERIAL, ZKHIP_MSM_C, ZKHIP_MSM_WAVES and
     // ZKHIP_NTT_SINGLE_MAX_LOG give their initial values, read ONCE when the context is created)
     int msm_c_env = 0;        // window width of the tables built / ad-hoc MSMs run from now on (0 = automatic)
-    int b_sort_mode = 0;      // the B family's own sort (zkhip_pk::b_sort): 0 when a tenth of its bases are at infinity, 1 always, 2 never
+    int b_sort_mode = 0;      // the thinned list (zkhip_pk::thin_mask): 0 when a tenth of a family's bases are at infinity, 1 always, 2 never
     int skip_inf_mode = 0;    // which accumulation kernel meets bases at infinity how: 0 per table (MsmShape::skip_inf), 1 lanes always sit them out, 2 always the vote
     int msm_sets = 0;         // bucket sets of the tables built from now on: 1 = every window multiple, 2 = every second ... (0 = what fits the device)
     int msm_waves = 0;        // accumulation waves per SIMD (0 = per point type)
@@ -622,13 +622,15 @@ struct zkhip_pk {
     u32 rank = 0, world = 1;
     u64 z_lo = 0, z_n = 0, h_lo = 0, h_n = 0;
     int c_z = 0, c_h = 0;
-    // The B-family MSMs (b_g2_query, and b_g1_query of a Groth16 key) get a sort of their own that leaves out the variables whose
-    // bases are the point at infinity — every variable that does not occur in the B matrix: a third of the Poseidon chain's —
-    // when there are enough of them to pay for a second counting sort (b_sort); b_keep: one bit per entry of the z range, set
-    // where some B base is finite.
-    DBuf b_keep;
-    bool b_sort = false, b_sort_g1 = false;      // b_sort_g1: b1_ext rides on that sort too (Groth16; a GM17 key holds c_query_2 there)
-    bool inf_many_b[2] = {true, true};           // inf_many of b1_ext / b2_ext on the B family's own (thinned) list
+    // The thinned list.  Variables that do not occur in the B matrix have the point at infinity in b_g1_query AND b_g2_query (a
+    // third of the Poseidon chain's); a GM17 key holds it for the same half of its variables in a_query, c_query_2 and b_query.
+    // The z tables that hold many such bases (a tenth or more) form a family (`thin_mask`: bit k = table k of a_ext, b1_ext,
+    // l_ext, b2_ext) whose MSMs pair with a sorted list of their own that leaves out the variables at infinity in ALL of them
+    // (`thin_keep`: one bit per entry of the z range, set where some base of the family is finite) — one more counting sort, and
+    // the most expensive MSMs of a real circuit shrink by that share.  0: every table on the common list.
+    DBuf thin_keep;
+    u32 thin_mask = 0;
+    bool inf_many_thin[4] = {true, true, true, true};   // inf_many of the family's tables on the thinned list
     bool inf_many[5] = {true, true, true, true, true};   // per table (a, b1, l, b2, h): more than one base in 2048 is the point at
                                                        // infinity -> the accumulation lets lanes sit those out (MsmShape::skip_inf)
     int s_z = 1, s_h = 1;     // bucket sets of the MSMs over z / over h = every s-th window multiple is in the tables (MsmShape::sets)
@@ -850,27 +852,36 @@ struct PkLoader {
         const u64 cnt[5] = {count_infinite<Fq>(ctx, pk->a_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->b1_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->l_ext.p, pk->z_n),
                             count_infinite<Fq2>(ctx, pk->b2_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->h_sigma.p, pk->h_n)};
         for (int k = 0; k < 5; ++k) pk->inf_many[k] = cnt[k] * 2048 > (k == 4 ? pk->h_n : pk->z_n);
-        // a sort of their own for the B family once a tenth of its bases are at infinity (ZKHIP_TUNE_B_SORT: 1 always, 2 never)
-        pk->b_sort_g1 = pk->scheme == 0;      // (measured against keeping b1_ext in the fused G1 launch: +2.5 % / +4 % proofs/s at 2^18 / 2^20
-                                              // on the Poseidon chain, -0.6 ms / +0.5 ms single proof; profiles/r4h_b_family_sort_ab.txt)
-        const u64 b_inf = pk->b_sort_g1 ? std::min(cnt[1], cnt[3]) : cnt[3];
-        pk->b_sort = pk->z_n > 0 && (ctx->b_sort_mode == 1 || (ctx->b_sort_mode == 0 && b_inf * 10 > pk->z_n));
-        if (pk->b_sort) {
+        // the thinned list (zkhip_pk::thin_mask): ZKHIP_TUNE_B_SORT 0 = the tables a tenth of whose bases are at infinity, if leaving
+        // out what they share drops a tenth of the list; 1 = the families the key formats predict, whatever the counts; 2 = never
+        const bool gm17 = pk->scheme == 1;
+        u32 family = 0;
+        if (ctx->b_sort_mode == 1) family = gm17 ? 0xbu : 0xau;          // GM17: a, c_query_2, b; Groth16: b_g1, b_g2
+        else if (ctx->b_sort_mode == 0)
+            for (int k = 0; k < 4; ++k)
+                if (cnt[k] * 10 > pk->z_n) family |= 1u << k;
+        pk->thin_mask = 0;
+        pk->thin_keep.release();
+        if (family && pk->z_n) {
             const size_t words = (size_t)((pk->z_n + 31) / 32);
-            pk->b_keep.ensure(words * 4);
-            dev_memset(pk->b_keep.p, 0, words * 4, ctx->stream);
-            mark_finite<Fq2>(ctx, pk->b2_ext.p, pk->z_n, ptr<u32>(pk->b_keep));
-            if (pk->b_sort_g1) mark_finite<Fq>(ctx, pk->b1_ext.p, pk->z_n, ptr<u32>(pk->b_keep));
+            pk->thin_keep.ensure(words * 4);
+            dev_memset(pk->thin_keep.p, 0, words * 4, ctx->stream);
+            if (family & 1) mark_finite<Fq>(ctx, pk->a_ext.p, pk->z_n, ptr<u32>(pk->thin_keep));
+            if (family & 2) mark_finite<Fq>(ctx, pk->b1_ext.p, pk->z_n, ptr<u32>(pk->thin_keep));
+            if (family & 4) mark_finite<Fq>(ctx, pk->l_ext.p, pk->z_n, ptr<u32>(pk->thin_keep));
+            if (family & 8) mark_finite<Fq2>(ctx, pk->b2_ext.p, pk->z_n, ptr<u32>(pk->thin_keep));
             std::vector<u32> host(words);
-            dev_d2h(host.data(), pk->b_keep.p, words * 4, ctx->stream);
+            dev_d2h(host.data(), pk->thin_keep.p, words * 4, ctx->stream);
             stream_sync(ctx->stream);
             u64 left_out = 0;
             for (u64 i = 0; i < pk->z_n; ++i) left_out += !((host[i >> 5] >> (i & 31)) & 1u);
-            // what the B tables still meet at infinity on the thinned list
-            pk->inf_many_b[0] = (cnt[1] - std::min(cnt[1], left_out)) * 2048 > pk->z_n;
-            pk->inf_many_b[1] = (cnt[3] - std::min(cnt[3], left_out)) * 2048 > pk->z_n;
-        } else {
-            pk->b_keep.release();
+            if (ctx->b_sort_mode == 1 || left_out * 10 > pk->z_n) {
+                pk->thin_mask = family;
+                // what the family's tables still meet at infinity on the thinned list
+                for (int k = 0; k < 4; ++k) pk->inf_many_thin[k] = (cnt[k] - std::min(cnt[k], left_out)) * 2048 > pk->z_n;
+            } else {
+                pk->thin_keep.release();          // (the tables' points at infinity do not coincide: nothing to gain)
+            }
         }
     }
     template <class F>
@@ -1001,11 +1012,11 @@ struct Prover {
         // everything.  So the G2 lane (the longest chain of a proof) starts at once, the witness map runs beside it, and
         // the G1 lanes over z wait for h (`z_gate`; 2 = the G2 lane waits as well).
         const int gate = z_gate(ctx);
-        const MsmSort& sort_b = pk->b_sort ? sl.sorts[2] : sl.sorts[0];            // what the B family pairs with (zkhip_pk::b_sort)
-        const bool inf_b2 = pk->b_sort ? pk->inf_many_b[1] : pk->inf_many[3];
+        const MsmSort& sort_b = (pk->thin_mask & 8) ? sl.sorts[2] : sl.sorts[0];   // the list b2_ext pairs with (zkhip_pk::thin_mask)
+        const bool inf_b2 = (pk->thin_mask & 8) ? pk->inf_many_thin[3] : pk->inf_many[3];
         if (pk->z_n) {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
-            if (pk->b_sort) msm_prepare(ctx, st, sl.sorts[2], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n, ptr<u32>(pk->b_keep), &sl.sorts[0]);
+            if (pk->thin_mask) msm_prepare(ctx, st, sl.sorts[2], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n, ptr<u32>(pk->thin_keep), &sl.sorts[0]);
             if (gate < 2)
                 msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
         }
@@ -1041,33 +1052,36 @@ struct Prover {
 
     // ---- A, B1, L: the three G1 MSMs over the sorted assignment (window sums to ws1 + {0, 1, 2} * Wmax)
     static void run_z_g1(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const MsmShape& shz, Xyzz<Fq>* ws1, int Wmax, Event h_ready) {
-        // b1_ext on the B family's own list (a Groth16 key whose B bases are often at infinity), else on the common one
-        const bool b1_apart = pk->b_sort && pk->b_sort_g1;
-        const MsmSort& sort_b1 = b1_apart ? sl.sorts[2] : sl.sorts[0];
-        const bool inf_b1 = b1_apart ? pk->inf_many_b[0] : pk->inf_many[1];
-        Stream s0 = ctx->serial ? ctx->stream : sl.lanes[0].stream;      // the lanes that are part of lane 0's launches
-        auto rides_on_lane0 = [&](int k) {
-            event_record(sl.acc_b[k], s0);
-            event_record(sl.acc_e[k], s0);
-            event_record(sl.lanes[k].done, s0);
-        };
-        if (ctx->fuse_z && b1_apart) {
-            const void* tabs[2] = {pk->a_ext.p, pk->l_ext.p};            // A -> ws1 + 0, L -> ws1 + 2 Wmax
-            msm_run_tables<Fq>(ctx, sl.lanes[0], sl.sorts[0], tabs, 2, with_inf(shz, pk->inf_many[0] || pk->inf_many[2]), ws1, (u32)(2 * Wmax), sl.acc_b[0], sl.acc_e[0], h_ready);
-            rides_on_lane0(2);
-            msm_run<Fq>(ctx, sl.lanes[1], sort_b1, pk->b1_ext.p, with_inf(shz, inf_b1), ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
+        const void* tab[3] = {pk->a_ext.p, pk->b1_ext.p, pk->l_ext.p};
+        auto thin = [&](int k) { return (pk->thin_mask >> k) & 1u; };
+        auto inf_many = [&](int k) { return thin(k) ? pk->inf_many_thin[k] : pk->inf_many[k]; };
+        if (!ctx->fuse_z) {
+            for (int k = 0; k < 3; ++k)
+                msm_run<Fq>(ctx, sl.lanes[k], thin(k) ? sl.sorts[2] : sl.sorts[0], tab[k], with_inf(shz, inf_many(k)), ws1 + k * Wmax, sl.acc_b[k], sl.acc_e[k], h_ready);
             return;
         }
-        if (ctx->fuse_z) {
-            const void* tabs[3] = {pk->a_ext.p, pk->b1_ext.p, pk->l_ext.p};
-            msm_run_tables<Fq>(ctx, sl.lanes[0], sl.sorts[0], tabs, 3, with_inf(shz, pk->inf_many[0] || pk->inf_many[1] || pk->inf_many[2]), ws1, (u32)Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
-            rides_on_lane0(1);
-            rides_on_lane0(2);
-            return;
+        // One launch per sorted list: the tables on the common list together, the tables on the thinned list together (up to three
+        // tables on one, none on the other).  The first table of a group lends its lane; the others ride on its launches.
+        for (u32 which = 0; which < 2; ++which) {
+            int member[3], nm = 0;
+            for (int k = 0; k < 3; ++k)
+                if (thin(k) == which) member[nm++] = k;
+            if (!nm) continue;
+            const int lead = member[0];
+            const void* tabs[3];
+            bool many = false;
+            for (int q = 0; q < nm; ++q) { tabs[q] = tab[member[q]]; many = many || inf_many(member[q]); }
+            // destination slots: lead, then every `step` slots (any subset of {0, 1, 2} is an arithmetic progression)
+            const int step = nm > 1 ? member[1] - member[0] : 1;
+            msm_run_tables<Fq>(ctx, sl.lanes[lead], which ? sl.sorts[2] : sl.sorts[0], tabs, nm, with_inf(shz, many), ws1 + lead * Wmax, (u32)(step * Wmax),
+                               sl.acc_b[lead], sl.acc_e[lead], h_ready);
+            Stream s0 = ctx->serial ? ctx->stream : sl.lanes[lead].stream;
+            for (int q = 1; q < nm; ++q) {
+                event_record(sl.acc_b[member[q]], s0);
+                event_record(sl.acc_e[member[q]], s0);
+                event_record(sl.lanes[member[q]].done, s0);
+            }
         }
-        msm_run<Fq>(ctx, sl.lanes[0], sl.sorts[0], pk->a_ext.p, with_inf(shz, pk->inf_many[0]), ws1 + 0 * Wmax, sl.acc_b[0], sl.acc_e[0], h_ready);
-        msm_run<Fq>(ctx, sl.lanes[1], sort_b1, pk->b1_ext.p, with_inf(shz, inf_b1), ws1 + 1 * Wmax, sl.acc_b[1], sl.acc_e[1], h_ready);
-        msm_run<Fq>(ctx, sl.lanes[2], sl.sorts[0], pk->l_ext.p, with_inf(shz, pk->inf_many[2]), ws1 + 2 * Wmax, sl.acc_b[2], sl.acc_e[2], h_ready);
     }
 
     // ---- window sums to the host, on a stream of their own so that the main stream can start the next proof

@@ -239,11 +239,11 @@ struct Gm17 {
         // (a sharded key covers only its index range of the bases and pairs them with the same range of the scalars)
         // (the G1 lanes wait for the transforms, as in Prover::enqueue: the G2 lane starts at once)
         const int gate = z_gate(ctx);
-        const MsmSort& sort_b = pk->b_sort ? sl.sorts[2] : sl.sorts[0];            // the G2 MSM on its own list (zkhip_pk::b_sort)
-        const bool inf_b2 = pk->b_sort ? pk->inf_many_b[1] : pk->inf_many[3];
+        const MsmSort& sort_b = (pk->thin_mask & 8) ? sl.sorts[2] : sl.sorts[0];   // the list b2_ext pairs with (zkhip_pk::thin_mask)
+        const bool inf_b2 = (pk->thin_mask & 8) ? pk->inf_many_thin[3] : pk->inf_many[3];
         if (pk->z_n) {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
-            if (pk->b_sort) msm_prepare(ctx, st, sl.sorts[2], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n, ptr<u32>(pk->b_keep), &sl.sorts[0]);
+            if (pk->thin_mask) msm_prepare(ctx, st, sl.sorts[2], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n, ptr<u32>(pk->thin_keep), &sl.sorts[0]);
             if (gate < 2)
                 msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
         }

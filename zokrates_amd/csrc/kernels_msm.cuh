@@ -168,7 +168,7 @@ static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ w
 // c = 20 saves 14-28 % of the accumulation and gives it back in the sort and in a fold over 2^19 buckets, break-even at best at
 // 2^22, profiles/r3d_window_width_sweep.txt; round 4 removed them.)
 // `keep` (may be null: everything takes part): bit i CLEAR = scalar i takes no part — the sort of the B-family MSMs leaves out the
-// variables whose bases are the point at infinity (zkhip_pk::b_keep).
+// variables whose bases are the point at infinity (zkhip_pk::thin_keep).
 static __device__ __forceinline__ bool msm_skipped(const u32* __restrict__ keep, u64 i) { return keep && !((keep[i >> 5] >> (i & 31)) & 1u); }
 static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
                                                         u32* __restrict__ cnt, const u32* __restrict__ keep) {
