@@ -499,14 +499,20 @@ template <class P> ZK_HD Fe2<P> fu_x3_numerator(const Fe2<P>& rr, const Fe2<P>& 
 // additions, and results that stay below 2p whatever the operands)
 template <class P>
 ZK_HD Fu2<P> fu2_mul_inl(const Fu2<P>& a, const Fu2<P>& b) {
-    const Fu<P> nb1 = fe_sub_k<8>(Fu<P>::zero(), b.c1);
+    // 8p - b1 without its carry round (limbs < 2^(B+1) + 2^B): it is multiplied at once, in a column of two products whose other
+    // operands are TIGHT — N (2^(2B) + 2^(2B+1.6)) + N 2^(2B) stays below 2^64 for both limb widths (ZK_CHECK_OVERFLOW builds check)
+    Fu<P> nb1;
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) nb1.v[i] = UConst<P>::nbias8(i) - b.c1.v[i];
     return {fu_mul2_inl(a.c0, b.c0, a.c1, nb1), fu_mul2_inl(a.c0, b.c1, a.c1, b.c0)};
 }
 // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u: two single products.  Operands < 6p keep (a0 + a1) < 12p and
 // (a0 + 8p - a1) < 14p, so the result stays below 12*14/169 + 1 < 2p.
 template <class P>
 ZK_HD Fu2<P> fu2_sqr_inl(const Fu2<P>& a) {
-    return {fu_mul_inl(fe_add(a.c0, a.c1), fe_sub_k<8>(a.c0, a.c1)), fu_mul_inl(fe_dbl(a.c0), a.c1)};
+    // (the sum and the doubled limb are multiplied at once by a TIGHT operand: no carry round for them)
+    Fu<P> d0;
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) d0.v[i] = a.c0.v[i] << 1;
+    return {fu_mul_inl(fe_add_lazy(a.c0, a.c1), fe_sub_k<8>(a.c0, a.c1)), fu_mul_inl(d0, a.c1)};
 }
 // The same product with THREE limb products instead of four (Karatsuba on the columns, before any reduction):
 //   c0 = a0 b0 + a1 (8p - b1),   c1 = (a0 + a1)(b0 + b1) - a0 b0 + a1 (8p - b1)      [a1 (8p - b1) = -a1 b1 mod p]
