@@ -51,12 +51,15 @@ namespace zk {
 #ifndef ZK_G2_PREFETCH_REGS
 #define ZK_G2_PREFETCH_REGS 1
 #endif
+#ifndef ZK_G2_ZZ_LDS
+#define ZK_G2_ZZ_LDS 1
+#endif
 // PREFETCH_REGS: the next base travels in registers (else it is only touched one entry ahead and loaded where it is used)
-template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true; };
-template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true, PREFETCH_REGS = true; };
-template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = ZK_G2_PREFETCH_REGS != 0; };
-template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false, PREFETCH_REGS = true; };
-template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 1, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true, PREFETCH_REGS = true; };
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
+template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = ZK_G2_PREFETCH_REGS != 0, ZZ_IN_LDS = ZK_G2_ZZ_LDS != 0; };
+template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 1, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
 // the base tables of the MSMs one launch serves (A, B1 and L of a proof share the sort of the assignment)
 static constexpr int MSM_MAX_TABLES = 3;
 struct MsmTables {
@@ -346,8 +349,10 @@ __device__ __forceinline__ void zk_pin_words(T& obj) {
     ZK_UNROLL for (unsigned i = 0; i < sizeof(T) / 4; ++i) asm volatile("" : "+v"(w[i]));
 }
 #define ZK_PIN_WORDS(x) zk_pin_words(x)
+#define ZK_LDS_REREAD() asm volatile("" ::: "memory")
 #else
 #define ZK_PIN_WORDS(x) ((void)0)
+#define ZK_LDS_REREAD() ((void)0)
 #endif
 // SKIP_INF: how a base at infinity is met.  true: the lane sits the step out (one more per-lane branch per step: ≈ 1.5 % more
 // instructions on a table without such bases); false: the wavefront's vote sends the step through the general code (free when it
@@ -371,7 +376,29 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
     const u32 p1 = total - p0 > P ? p0 + P : total;
     u32 end = off[cur + 1];
     ZK_ASSERT_IDX((u64)g * P < total && off[cur] <= p0 && p0 < end && (u64)nkeys + cut.nlanes <= partial_stride);
-    Xyzz<F> acc = Xyzz<F>::inf();
+    // The running sum: X and Y in registers; ZZ and ZZZ in registers too, or (ZZ_IN_LDS) in the lane's own words of LDS — each is
+    // read twice and written once per addition, and the 36 registers they would hold through the whole step are what decides
+    // whether a second G2 wave fits a SIMD.
+    constexpr bool ZZ_LDS = MsmTuning<F>::ZZ_IN_LDS;
+    constexpr int FW = (int)(sizeof(F) / 4);
+    __shared__ u32 zz_lds[ZZ_LDS ? 2 * FW * 256 : 1];
+    F ax = F::zero(), ay = F::zero(), rzz[2] = {F::zero(), F::zero()};
+    auto get_zz = [&](int which) -> F {
+        if (!ZZ_LDS) return rzz[which];
+        F r;
+        u32* wv = (u32*)&r;
+        ZK_LDS_REREAD();          // (every fetch is a fresh read: a value kept in registers between its two uses is what this avoids)
+        ZK_UNROLL for (int q = 0; q < FW; ++q) wv[q] = zz_lds[(which * FW + q) * 256 + threadIdx.x];
+        return r;
+    };
+    auto put_zz = [&](int which, const F& v) {
+        if (!ZZ_LDS) { rzz[which] = v; return; }
+        const u32* wv = (const u32*)&v;
+        ZK_UNROLL for (int q = 0; q < FW; ++q) zz_lds[(which * FW + q) * 256 + threadIdx.x] = wv[q];
+    };
+    auto whole = [&]() -> Xyzz<F> { return {ax, ay, get_zz(0), get_zz(1)}; };
+    auto set_whole = [&](const Xyzz<F>& t) { ax = t.x; ay = t.y; put_zz(0, t.zz); put_zz(1, t.zzz); };
+    set_whole(Xyzz<F>::inf());
     u32 e = sorted[p0];
     ZK_ASSERT_IDX((e & 0x7fffffffu) < cut.table_len);
     constexpr bool IN_REGS = MsmTuning<F>::PREFETCH_REGS;
@@ -381,12 +408,10 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
     // `first`: the next point STARTS a sum (slice start, bucket boundary, or the sum so far cancelled to infinity)
     bool first = true;
     for (u32 pos = p0; pos < p1; ++pos) {
-        // G1: the packed words are consumed by the unpacking and the same registers take the NEXT base at once (always: the last
-        // iteration fetches its own entry again): the fetch has the whole addition to arrive in, nothing is copied from a
-        // "next" set of registers to a "current" one, and no lane skips the load.
-        // G2 (PREFETCH_REGS = false): 32 registers for a base in flight are what keeps a second wave off the SIMD, and with a
-        // second wave there the latency of a cache hit is covered: the base is loaded where it is used, and the NEXT one is only
-        // touched (one word: the line travels to the cache meanwhile).
+        // PREFETCH_REGS: the packed words are consumed by the unpacking and the same registers take the NEXT base at once (always:
+        // the last iteration fetches its own entry again): the fetch has the whole addition to arrive in, nothing is copied from a
+        // "next" set of registers to a "current" one, and no lane skips the load.  Otherwise the base is loaded where it is used
+        // and the NEXT one is only touched (one word: the line travels to the cache meanwhile).
         const u32 e_cur = e;
         if (!IN_REGS) aff_load_words<F>(bases, e_cur & 0x7fffffffu, w);
         Aff<F> pt = aff_unpack<F>(w);
@@ -397,7 +422,7 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
         if (IN_REGS) aff_load_words<F>(bases, e & 0x7fffffffu, w);
         else touched |= ((const volatile u32*)(bases + (e & 0x7fffffffu)))[0];
         if (pos == end) {
-            partial[(u64)cur + g] = acc;      // (invariant: whenever `first` holds here, acc IS the empty sum — see the general path)
+            partial[(u64)cur + g] = whole();  // (invariant: whenever `first` holds here, the sum IS the empty one — see the general path)
             first = true;
             do { ++cur; ZK_ASSERT_IDX(cur < nkeys); end = off[cur + 1]; } while (end <= pos);
         }
@@ -411,23 +436,32 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
         // and the others add.
         const bool pinf = pt.is_inf();
         const F ys = fe_cneg(pt.y, neg);
-        F Pp, R;
-        xyzz_madd_begin<true>(acc, pt.x, ys, Pp, R);
+        const F Pp = fe_sub_k<4>(ecm_k<true>(get_zz(0), pt.x), ax);            // X1 < 3p;  Pp < 6p
+        const F R = fe_sub_k<4>(ecm_k<true>(get_zz(1), ys), ay);               // Y1 < 4p;  R < 6p
         const bool special = SKIP_INF ? (!pinf && !first && fe_is_zero_modp(Pp)) : (pinf || (!first && fe_is_zero_modp(Pp)));
         if (ZK_WAVE_ANY(special)) {
-            if (first) acc = Xyzz<F>::inf();
-            if (!pinf) xyzz_madd_acc<true>(acc, Aff<F>{pt.x, ys});
-            first = acc.is_inf();
+            Xyzz<F> t = first ? Xyzz<F>::inf() : whole();
+            if (!pinf) xyzz_madd_acc<true>(t, Aff<F>{pt.x, ys});
+            set_whole(t);
+            first = t.is_inf();
         } else if (SKIP_INF && pinf) {
-            if (first) acc = Xyzz<F>::inf();      // (keeps the invariant: `first` and a stale sum never meet a store)
+            if (first) set_whole(Xyzz<F>::inf());      // (keeps the invariant: `first` and a stale sum never meet a store)
         } else if (first) {
-            acc.x = pt.x; acc.y = ys; acc.zz = F::one(); acc.zzz = F::one();
+            ax = pt.x; ay = ys; put_zz(0, F::one()); put_zz(1, F::one());
             first = false;
         } else {
-            xyzz_madd_finish<true>(acc, Pp, R);
+            // the addition proper (ec.cuh xyzz_madd_finish, with ZZ / ZZZ fetched where they are multiplied)
+            const F PP = ecs<true>(Pp);
+            const F PPP = ecm<true>(Pp, PP);
+            const F Q = ecm_k<true>(ax, PP);
+            put_zz(0, ecm_k<true>(get_zz(0), PP));
+            put_zz(1, ecm_k<true>(get_zz(1), PPP));
+            const F X3 = fe_relax(fu_x3_numerator(ecs<true>(R), PPP, Q));     // R^2 - PPP - 2Q: < 10p before, < 3p after
+            ay = ec_mulsub<true>(R, fe_sub_k<4>(Q, X3), ay, PPP);              // one reduction: < 3p (G1 fused: < 2p)
+            ax = X3;
         }
     }
-    partial[(u64)cur + g] = acc;
+    partial[(u64)cur + g] = whole();
     (void)touched;      // (the volatile loads stay)
 }
 
