@@ -55,7 +55,13 @@ namespace zk {
 #define ZK_G2_ZZ_LDS 1
 #endif
 // PREFETCH_REGS: the next base travels in registers (else it is only touched one entry ahead and loaded where it is used)
-template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = 3, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
+#ifndef ZK_G1_ZZ_LDS
+#define ZK_G1_ZZ_LDS 0
+#endif
+#ifndef ZK_G1_ACCUM_WPE
+#define ZK_G1_ACCUM_WPE 3
+#endif
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = ZK_G1_ACCUM_WPE, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = ZK_G1_ZZ_LDS != 0; };
 template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
 template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = ZK_G2_PREFETCH_REGS != 0, ZZ_IN_LDS = ZK_G2_ZZ_LDS != 0; };
 template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
