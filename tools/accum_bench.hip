@@ -12,13 +12,13 @@ using namespace zk;
 
 template <class F, int WPE>
 float run(const MsmTables& tb, int nt, const u32* off, const u32* sorted, u32* lane_key, Xyzz<F>* partial, u32 nkeys, u32 nlanes) {
-    const MsmCut cut{nlanes, 1};
+    const MsmCut cut{nlanes, 1, 0x7fffffffu};
     hipLaunchKernelGGL(k_msm_lane_keys, dim3((nlanes + 255) / 256), dim3(256), 0, 0, off, nkeys, cut, lane_key);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e30f;
     for (int r = 0; r < 3; ++r) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((k_msm_accum<F, WPE>), dim3((nlanes + 255) / 256, nt), dim3(256), 0, 0, tb, off, sorted, lane_key, partial, (u64)nkeys + nlanes, nkeys, cut);
+        hipLaunchKernelGGL((k_msm_accum<F, WPE, false>), dim3((nlanes + 255) / 256, nt), dim3(256), 0, 0, tb, off, sorted, lane_key, partial, (u64)nkeys + nlanes, nkeys, cut);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
     }
