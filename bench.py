@@ -463,9 +463,9 @@ def main():
     compute = None
     if W and args.curve == "bn128" and args.kind == "dense":   # (sparse / boolean witnesses drop their zero digits: no fixed addition count)
         madds = (((m + 2) if "G2" in name else (3 * (m + 2) + N)) * W)
-        peak = 5.29e9 if "G2" in name else 13.75e9
+        peak = 5.18e9 if "G2" in name else 13.65e9
         compute = {"unit": "mixed additions/s", "achieved": madds / (ms * 1e-3), "peak": peak, "frac": madds / (ms * 1e-3) / peak,
-                   "peak_source": "tools/accum_bench.hip on MI355X (same arithmetic, synthetic sorted lists)"}
+                   "peak_source": "tools/accum_bench.hip on MI355X (this round's kernel on synthetic sorted lists with equal buckets, best slicing: profiles/r4l_accum_bench.txt)"}
         if serial and serial[key] > 0:
             compute["frac_serial"] = madds / (serial[key] * 1e-3) / peak
     # VALU issue occupation of the same kernel from the committed counter pass (tools/pmc_valu.py)

@@ -42,6 +42,63 @@ def test_ntt_three_passes(ctx, curve_id, logn):
     assert ctx.ntt(curve_id, ctx.ntt(curve_id, a, "coset_fft"), "coset_ifft").tobytes() == a.tobytes()
 
 
+def _fr_of(curve_id):
+    from oracle.fields import BN254, BLS12_381
+    return (BN254, BLS12_381)[curve_id]
+
+
+def _at(arr, k):
+    return int.from_bytes(arr[32 * k:32 * k + 32].tobytes(), "little")
+
+
+@pytest.mark.parametrize("curve_id,logn", [(0, 25), (1, 26), (0, 28)])
+def test_ntt_up_to_the_two_adicity(ctx, curve_id, logn):
+    """Sizes the oracle's radix-2 transform cannot finish in a test's time, up to bn128's whole two-adicity (2^28: the last
+    domain `Radix2EvaluationDomain` offers there), through what the transform IS: for x = sum_j c_j delta_j the outputs are
+    X_k = sum_j c_j w^(jk) (the coset form: sum_j c_j (g w^k)^j) — checked at sampled k with the oracle's root and generator —
+    and by linearity the same differences must appear between the transforms of a dense random vector and of that vector
+    plus x (dense arithmetic through all three passes).  2^28 is the sparse check only, and only where the host has the memory."""
+    import random
+    import psutil
+    C = _fr_of(curve_id)
+    r, N = C.r, 1 << logn
+    if psutil.virtual_memory().available < 6 * N * 32:
+        pytest.skip("host memory: %d GiB needed" % (6 * N * 32 >> 30))
+    w = pow(C.two_adic_root, 1 << (C.two_adicity - logn), r)
+    rnd = random.Random(1000 * curve_id + logn)
+    js = [0, 1, N - 1, N // 2, (1 << (logn // 3)) + 1] + [rnd.randrange(N) for _ in range(5)]   # every digit of the index in use
+    cs_ = [rnd.randrange(1, r) for _ in js]
+    ks = [0, 1, N - 1, N // 2 + 1] + [rnd.randrange(N) for _ in range(60)]
+    x = np.zeros(N * 32, dtype=np.uint8)
+    acc = {}
+    for j, c in zip(js, cs_):
+        acc[j] = (acc.get(j, 0) + c) % r
+    for j, c in acc.items():
+        x[32 * j:32 * j + 32] = np.frombuffer(c.to_bytes(32, "little"), dtype=np.uint8)
+    want = {d: [sum(c * pow((C.fr_generator if d == "coset_fft" else 1) * pow(w, k, r) % r, j, r) for j, c in acc.items()) % r for k in ks]
+            for d in ("fft", "coset_fft")}
+    for d in ("fft", "coset_fft"):
+        X = ctx.ntt(curve_id, x, d)
+        assert [_at(X, k) for k in ks] == want[d], d
+        if d == "coset_fft":      # and back: the inverse over the coset returns the deltas, everything else zero
+            back = ctx.ntt(curve_id, X, "coset_ifft")
+            assert back.tobytes() == x.tobytes()
+            del back
+        del X
+    if logn > 26:
+        return
+    a = _rand_fr(N, 77 + logn)
+    b = a.copy()
+    for j, c in acc.items():
+        b[32 * j:32 * j + 32] = np.frombuffer(((_at(a, j) + c) % r).to_bytes(32, "little"), dtype=np.uint8)
+    for d in ("fft", "coset_fft"):
+        A, B = ctx.ntt(curve_id, a, d), ctx.ntt(curve_id, b, d)
+        assert [(_at(B, k) - _at(A, k)) % r for k in ks] == want[d], d
+        if d == "fft":
+            assert ctx.ntt(curve_id, A, "ifft").tobytes() == a.tobytes()
+        del A, B
+
+
 def test_groth16_literal_2e22_constraints(ctx):
     """n = 2^22 constraints exactly (BASELINE.json configs[2] read literally): n + l = 2^22 + 2 -> domain 2^23, three NTT passes."""
     circ = synth.circuit(0, n=1 << 22)
