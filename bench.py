@@ -306,7 +306,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-domain", type=int, default=20)
     ap.add_argument("--curve", default="bn128")
-    ap.add_argument("--kind", default="dense", choices=["dense", "sha", "poseidon"])
+    ap.add_argument("--kind", default="dense", choices=["dense", "sha", "sha256", "poseidon"])
     ap.add_argument("--scheme", default="g16", choices=["g16", "gm17"])
     ap.add_argument("--witnesses", type=int, default=0, help="distinct assignments kept resident (0 = one per timed step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -335,6 +335,11 @@ def main():
         poseidon = importlib.import_module(_pkg + ".poseidon")
         depth = 1024 << (args.log_domain - 18) if args.log_domain >= 18 else max(1, ((1 << args.log_domain) - 4) // 243)
         circ = poseidon.chain(curve_id, depth)
+    elif args.kind == "sha256":   # BASELINE.json configs[0]: stdlib sha256/512bitPacked.zok, as many calls side by side as the domain holds
+        sha = importlib.import_module(_pkg + ".sha256_circuit")
+        per_hash = len(sha.template()[0])
+        circ = sha.circuit(curve_id, max(1, (1 << args.log_domain) // (per_hash + 7)))
+        args.log_domain = int(np.log2(circ.N))
     else:
         circ = synth.circuit(curve_id, args.log_domain, n=args.constraints or None, kind=args.kind)
         args.log_domain = int(np.log2(circ.N))
@@ -513,6 +518,9 @@ def main():
                 f"4 NTTs + 5 MSMs per proof") if gm17 else (
         (f"Poseidon hash chain depth {circ.depth} (t = 3, 243 constraints per hash), n = {circ.n} constraints (QAP domain 2^{args.log_domain}), "
          if args.kind == "poseidon" else
+         f"{circ.hashes} x stdlib sha256/512bitPacked.zok (48972 constraints per call, every wire a SHA-256 wire; C rows of up to 7041 terms), "
+         f"n = {circ.n} constraints (QAP domain 2^{args.log_domain}), "
+         if args.kind == "sha256" else
          f"synthetic R1CS {args.kind}, n = {circ.n} constraints (QAP domain 2^{args.log_domain})"
          + (" [stand-in for BASELINE configs[0], stdlib sha256/512bitPacked.zok: the ZoKrates compiler cannot run here, so the wire "
             "statistics of a SHA-256 circuit (90 % boolean) are generated directly], " if args.kind == "sha" else ", "))

@@ -29,7 +29,7 @@ def run_bench(args, extra_env=None, timeout=900, expect_rc=0):
 @pytest.mark.parametrize("args,metric", [
     (["--log-domain", "5"], "groth16_proofs_per_sec"),
     (["--log-domain", "5", "--scheme", "gm17"], "gm17_proofs_per_sec"),
-    (["--log-domain", "9", "--kind", "poseidon", "--curve", "bls12_381"], "groth16_proofs_per_sec"),
+    (["--log-domain", "8", "--kind", "poseidon", "--curve", "bls12_381"], "groth16_proofs_per_sec"),
 ])
 def test_single_rank_contract(args, metric):
     with_cli_leg = "--scheme" not in args and "--kind" not in args      # the CLI-shaped leg (seven subprocesses) once is enough

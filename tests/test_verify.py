@@ -271,7 +271,7 @@ def test_proof_json_round_trip_through_the_cpp_reader(tmp_path):
 
 
 def test_mutated_files_never_crash_the_verifier(tmp_path):
-    """tests/host/verify_fuzz.cpp under ASan + UBSan: 250 byte-level mutations of a (verification key, proof) pair; a verdict or an
+    """tests/host/verify_fuzz.cpp under ASan + UBSan: 120 byte-level mutations of a (verification key, proof) pair; a verdict or an
     Error every time, and PASSED only when the parsed values are the original ones."""
     env = _env()
     d = str(tmp_path)
@@ -283,7 +283,7 @@ def test_mutated_files_never_crash_the_verifier(tmp_path):
     root = os.path.dirname(HERE)
     subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17",
                            os.path.join(HERE, "host", "verify_fuzz.cpp"), os.path.join(root, "zokrates_amd", "csrc", "host", "verify.cpp"), "-o", exe])
-    r = subprocess.run([exe, p("verification.key"), p("proof.json"), "250", "11"], capture_output=True, text=True)
+    r = subprocess.run([exe, p("verification.key"), p("proof.json"), "120", "11"], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert r.stdout.startswith("verified ") and "errors" in r.stdout
 
