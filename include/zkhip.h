@@ -114,6 +114,8 @@ const char* zkhip_last_error(const zkhip_ctx* ctx);
 #define ZKHIP_TUNE_B_SORT 19          /* keys loaded from now on: the MSMs over b_query (G2, and G1 of a Groth16 key) on a sorted list of
                                       * their own that leaves out the variables whose B bases are the point at infinity — 0 = when a tenth
                                       * of them are (real circuits: every variable that does not occur in B), 1 = always, 2 = never       */
+#define ZKHIP_TUNE_HEAVY_RUNS 20      /* 1 (default): the partials of a bucket spread over many slices (the ones of a witness of bits) are
+                                      * first summed run by run by a kernel of their own; 0: by the one workgroup of the bucket's row      */
 #define ZKHIP_TUNE_NTT_MAX_SUBLOG 16 /* log2 of the longest sub-transform of an NTT pass (2..11; default 11): domains above 2^(2 x this)
                                       * take three passes instead of two — a test hook to reach the three-pass path (domains above
                                       * 2^22) with small domains.  Keys loaded before a change must be reloaded (their h order)        */

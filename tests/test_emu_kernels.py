@@ -142,7 +142,29 @@ def test_msm_skewed_scalars(ctx):
             assert ctx.msm(0, 1, b1, le(ks)) == want1, (P, lanes, c)
             if P in (2, 32) or lanes == 3:
                 assert ctx.msm(0, 2, b2, le(ks[:24])) == want2, (P, lanes, c)
+        # a bucket over hundreds of slices (the ones of a witness of bits): k_msm_heavy_reduce sums its partials run by run
+        # before the fold (runs of 2, 3 and 5 slices here), or the row's workgroup sums them alone — the same point either way
+        ks2 = [1] * 140 + [hot] * 6 + [0] * 4
+        rnd.shuffle(ks2)
+        p1b = (p1 * 3)[:150 * 2 + 20]
+        ks3 = ([1] * 300 + ks2)[:len(p1b)]
+        b1b = np.frombuffer(b"".join(formats.ser_g1(curve, P) for P in p1b), dtype=np.uint8)
+        for bases, scalars in ((b1, ks2), (b1b, ks3)):
+            want = cpu.msm(0, 1, bases, le(scalars))
+            for runs in (1, 0):
+                ctx.tune("heavy_runs", runs)
+                for P, lanes, c in ((1, 0, 4), (2, 0, 6)):
+                    ctx.tune("msm_min_slice", P)
+                    ctx.tune("msm_lanes", lanes)
+                    ctx.tune("msm_c", c)
+                    assert ctx.msm(0, 1, bases, le(scalars)) == want, (runs, P, lanes, c)
+        ctx.tune("heavy_runs", 1)
+        ctx.tune("msm_min_slice", 1)
+        ctx.tune("msm_c", 4)
+        k24 = ([1] * 22 + [hot, 0])
+        assert ctx.msm(0, 2, b2, le(k24)) == cpu.msm(0, 2, b2, le(k24))
     finally:
+        ctx.tune("heavy_runs", 1)
         ctx.tune("msm_min_slice", 8)
         ctx.tune("msm_lanes", 0)
         ctx.tune("msm_c", 0)

@@ -142,6 +142,7 @@ struct zkhip_ctx {
     int msm_waves = 0;        // accumulation waves per SIMD (0 = per point type)
     u32 msm_lanes = 0;        // slices of the sorted list (0 = one per resident work-item)
     u32 msm_min_slice = 8;    // finest cut of the sorted list
+    bool heavy_runs = true;   // k_msm_heavy_reduce before the fold (ZKHIP_MSM_HEAVY_RUNS=0: the row's workgroup sums a heavy bucket alone)
     bool fold_scan = true;    // scan form of the last fold step (else double-and-add)
     bool fuse_z = true;       // A, B1 and L of a proof (one sorted list) as ONE slicing / accumulation / fold launch each
     int msm_fused_waves = 0;  // accumulation waves per SIMD of that launch (0 = per point type)
@@ -647,6 +648,9 @@ struct zkhip_r1cs {
     int logN;
     DBuf rp[3], col[3], val[3];
     u64 nnz[3];
+    u64 nnz_short[3];     // without the rows of more than MATVEC_LONG terms (what the lanes-per-row choice of k_matvec is made from)
+    DBuf long_rows;       // those rows, matrix << 32 | row (k_matvec_long)
+    u64 n_long = 0;
 };
 // the matrices of a resident constraint system back in host memory (setup, N3: key generation walks them on the host; the
 // prover never needs them there, so zkhip_r1cs_load keeps no host copy).  Values come back as they are resident:
@@ -909,9 +913,12 @@ struct Prover {
     // K1: a = A z, b = B z, c = C z over rows [0, n) (+ the l instance rows of A), zero-filled up to N
     static void matvec(zkhip_ctx* ctx, const zkhip_r1cs* cs, const Fr* zmont, Fr* a, Fr* b, Fr* c, u64 n, u64 l, u64 N) {
         int g[3];
-        for (int k = 0; k < 3; ++k) g[k] = matvec_group(cs->nnz[k], cs->n);
+        for (int k = 0; k < 3; ++k) g[k] = matvec_group(cs->nnz_short[k], cs->n);
         ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), 3), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
                   l, N, g[0], g[1], g[2], cs->l + cs->w);
+        if (cs->n_long)
+            ZK_LAUNCH((k_matvec_long<Fr>), dim3(blocks_for(cs->n_long, 4)), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c,
+                      ptr<u64>(cs->long_rows), cs->n_long, cs->l + cs->w);
     }
     static unsigned gmax_rows(const int g[3]) { return (unsigned)std::max(g[0], std::max(g[1], g[2])); }
 
@@ -1454,10 +1461,17 @@ struct Prover {
 
     static void r1cs_load(zkhip_ctx* ctx, zkhip_r1cs* cs, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]) {
         Stream s = ctx->stream;
+        std::vector<u64> long_rows;
         for (int k = 0; k < 3; ++k) {
             const u64 nnz = rp[k][cs->n];
             require(rp[k][0] == 0, ZKHIP_ERR_BAD_ARG, "rowptr[0] must be 0");
             for (u64 i = 0; i < cs->n; ++i) require(rp[k][i] <= rp[k][i + 1], ZKHIP_ERR_BAD_ARG, "rowptr not monotone");
+            cs->nnz_short[k] = nnz;
+            for (u64 i = 0; i < cs->n; ++i)
+                if (rp[k][i + 1] - rp[k][i] > MATVEC_LONG) {
+                    long_rows.push_back((u64)k << 32 | i);
+                    cs->nnz_short[k] -= rp[k][i + 1] - rp[k][i];
+                }
             for (u64 q = 0; q < nnz; ++q) require(col[k][q] < cs->l + cs->w, ZKHIP_ERR_BAD_ARG, "column index out of range");
             cs->nnz[k] = nnz;
             cs->rp[k].ensure((cs->n + 1) * 8);
@@ -1469,6 +1483,11 @@ struct Prover {
                 dev_h2d(cs->val[k].p, val[k], nnz * 32, s);
                 ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(nnz, 256)), dim3(256), 0, s, ptr<Fr>(cs->val[k]), ptr<Fr>(cs->val[k]), nnz);
             }
+        }
+        cs->n_long = long_rows.size();
+        if (cs->n_long) {
+            cs->long_rows.ensure(cs->n_long * 8);
+            dev_h2d(cs->long_rows.p, long_rows.data(), cs->n_long * 8, s);
         }
         stream_sync(s);
     }

@@ -74,8 +74,14 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
         ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, false>), dim3(blocks_for(nlanes, T), nt), dim3(T), 0, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
                   ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), partial_stride, sh.nkeys, cut);
     if (ev_end) event_record(ev_end, s);
+    if (ctx->heavy_runs) {
+        lds_opt_in(ctx, (const void*)k_msm_heavy_reduce<F>);
+        ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(MSM_HEAVY_CHUNKS, nt), dim3(T), (size_t)T * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
+                  ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy));
+    }
     ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.sets, nt), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
-              ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy), ptr<Xyzz<F>>(lane.bucket), ptr<Xyzz<F>>(lane.rows));
+              ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy), ctx->heavy_runs ? 1u : 0u, ptr<Xyzz<F>>(lane.bucket),
+              ptr<Xyzz<F>>(lane.rows));
     // column sums of the K = H x Lw buckets of a set; work-item (lo, hg) adds RG / HG rows serially
     auto fold_cols = [&](const Xyzz<F>* src, u64 set_stride, u64 msm_stride, u32 Lw, u32 H, u32 RG, Xyzz<F>* dst) {
         const u32 CW = std::min<u32>(Lw, 32), HG = std::max<u32>(1, std::min<u32>(8, RG)), NG = H / RG;

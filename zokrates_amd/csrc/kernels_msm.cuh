@@ -520,9 +520,49 @@ __device__ __forceinline__ Xyzz<F> xyzz_mul_small(const Xyzz<F>& p, u32 k) {
 //     tree-sum the row.  A heavy bucket (more than MSM_HEAVY partials; k_msm_find_heavy lists them) is first summed by
 //     the whole workgroup of its row into its first slot — no kernel of its own: a launch that only finds an empty list
 //     still waits for a place on a machine full of accumulation waves (5 ms in a trace).
+//     A VERY heavy bucket — a witness of bits puts every variable that is 1 into bucket 1 of the lowest window: a quarter of a
+//     SHA-256 circuit's entries, tens of thousands of partials — would keep that one workgroup busy for milliseconds (2.7 ms for
+//     G2 in a trace of zokrates_amd/sha256_circuit.py), so k_msm_heavy_reduce goes first: the partials of a heavy bucket are cut
+//     into MSM_HEAVY_CHUNKS runs, workgroup c sums run c of every heavy bucket into the run's first slot, and the row's
+//     workgroup below only adds the run heads.  With an empty list the kernel returns at once.
+static constexpr u32 MSM_HEAVY_CHUNKS = 64;
+struct HeavyRun {
+    u32 g0, g1, len;     // the bucket's lanes [g0, g1], lanes per run
+};
+static __device__ __forceinline__ HeavyRun msm_heavy_run(const u32* __restrict__ off, u32 key, u32 P) {
+    HeavyRun r;
+    r.g0 = off[key] / P;
+    r.g1 = (off[key + 1] - 1) / P;
+    r.len = (r.g1 - r.g0 + MSM_HEAVY_CHUNKS) / MSM_HEAVY_CHUNKS;
+    return r;
+}
+template <class F>
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_heavy_reduce(Xyzz<F>* partial, u64 partial_stride, const u32* __restrict__ off, u32 nkeys, MsmCut cut,
+                                                                                  const u32* __restrict__ heavy_list, const u32* __restrict__ heavy_count) {
+    ZK_PRIO_HIGH();
+    const u32 nh = *heavy_count;
+    if (nh == 0) return;
+    ZK_DYN_SMEM(smem);
+    Xyzz<F>* sh = (Xyzz<F>*)smem;
+    partial += (u64)blockIdx.y * partial_stride;           // blockIdx.y: which MSM of the launch
+    const u32 P = msm_slice_len(off, nkeys, cut), lo = threadIdx.x;
+    for (u32 h = 0; h < nh; ++h) {
+        const u32 hk = heavy_list[h];
+        const HeavyRun r = msm_heavy_run(off, hk, P);
+        const u32 b = r.g0 + blockIdx.x * r.len;
+        if (b > r.g1 || r.len == 1) continue;    // (uniform over the workgroup)
+        const u32 e = b + r.len - 1 < r.g1 ? b + r.len - 1 : r.g1;
+        Xyzz<F> s = Xyzz<F>::inf();
+        for (u32 g = b + lo; g <= e; g += blockDim.x) xyzz_add_acc(s, partial[(u64)hk + g]);
+        sh[lo] = s;
+        block_tree_sum<F>(sh);
+        if (lo == 0) partial[(u64)hk + b] = sh[0];
+        __syncthreads();
+    }
+}
 template <class F>
 __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(Xyzz<F>* partial, u64 partial_stride, const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32 K, u32 Lw,
-                                                        const u32* __restrict__ heavy_list, const u32* __restrict__ heavy_count,
+                                                        const u32* __restrict__ heavy_list, const u32* __restrict__ heavy_count, u32 heavy_runs,
                                                         Xyzz<F>* __restrict__ bucket, Xyzz<F>* __restrict__ rows) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
@@ -537,9 +577,10 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(X
     for (u32 h = 0; h < nh; ++h) {
         const u32 hk = heavy_list[h];
         if (hk - row0 >= Lw) continue;           // (uniform over the workgroup)
-        const u32 g0 = off[hk] / P, g1 = (off[hk + 1] - 1) / P;
+        const HeavyRun r = msm_heavy_run(off, hk, P);
+        const u32 g0 = r.g0, g1 = r.g1, step = heavy_runs ? r.len : 1;     // heavy_runs: k_msm_heavy_reduce left one sum per run
         Xyzz<F> s = Xyzz<F>::inf();
-        for (u32 g = g0 + lo; g <= g1; g += blockDim.x) xyzz_add_acc(s, partial[(u64)hk + g]);
+        for (u64 g = g0 + (u64)lo * step; g <= g1; g += (u64)blockDim.x * step) xyzz_add_acc(s, partial[(u64)hk + g]);
         sh[lo] = s;
         block_tree_sum<F>(sh);
         if (lo == 0) partial[(u64)hk + g0] = sh[0];

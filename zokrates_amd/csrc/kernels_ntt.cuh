@@ -152,6 +152,11 @@ struct CsrDev {
 // length): compiler-made circuits have combinations of tens to hundreds of terms (every partial Poseidon round, every
 // SHA-256 word sum), which one work-item per row would walk serially with a dependent random gather per term.  The G
 // partial sums meet in an LDS tree.  G = 1 is the plain one-row-per-work-item kernel.
+// Rows of more than MATVEC_LONG terms are left to k_matvec_long (a wavefront per row): the reference's optimizer inlines every
+// linear definition, so the sum check of a lazily added u32 of a SHA-256 round is ONE row over every wire the value was ever
+// added up from — thousands of terms next to one-term boolean checks (zokrates_amd/sha256_circuit.py) — and G lanes walking
+// such a row hold their whole workgroup for milliseconds.
+static constexpr u32 MATVEC_LONG = 32;
 template <class F>
 __global__ void __launch_bounds__(256) k_matvec(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ oa, F* __restrict__ ob,
                                                 F* __restrict__ oc, u64 n, u64 l, u64 N, int gA, int gB, int gC, u64 m_vars) {
@@ -166,13 +171,16 @@ __global__ void __launch_bounds__(256) k_matvec(CsrDev A, CsrDev B, CsrDev C, co
     const CsrDev M = which == 0 ? A : which == 1 ? B : C;
     F* out = which == 0 ? oa : which == 1 ? ob : oc;
     F acc = F::zero();
+    bool mine = true;               // false: a long row, written by k_matvec_long
     if (i < n) {
         const F* val = (const F*)M.val;
-        const u64 e = M.rowptr[i + 1];
-        for (u64 k = M.rowptr[i] + lane; k < e; k += (u32)G) {
-            ZK_ASSERT_IDX(M.col[k] < m_vars);
-            acc = fe_add(acc, fe_mul(val[k], z[M.col[k]]));
-        }
+        const u64 b = M.rowptr[i], e = M.rowptr[i + 1];
+        mine = e - b <= MATVEC_LONG;
+        if (mine)
+            for (u64 k = b + lane; k < e; k += (u32)G) {
+                ZK_ASSERT_IDX(M.col[k] < m_vars);
+                acc = fe_add(acc, fe_mul(val[k], z[M.col[k]]));
+            }
     } else if (which == 0 && i < n + l && lane == 0) {
         acc = z[i - n];
     }
@@ -187,7 +195,40 @@ __global__ void __launch_bounds__(256) k_matvec(CsrDev A, CsrDev B, CsrDev C, co
             __syncthreads();
         }
     }
-    if (i < N && lane == 0) out[i] = acc;
+    if (i < N && lane == 0 && mine) out[i] = acc;
+}
+// one wavefront per long row (four rows per workgroup): rows[] = matrix << 32 | row, listed on the host when the system is loaded
+template <class F>
+__global__ void __launch_bounds__(256) k_matvec_long(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ oa, F* __restrict__ ob,
+                                                     F* __restrict__ oc, const u64* __restrict__ rows, u64 n_long, u64 m_vars) {
+    ZK_PRIO_HIGH();
+    __shared__ F sh[256];
+    const u32 lane = threadIdx.x & 63u;
+    const u64 slot = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool live = slot < n_long;
+    const u64 r = live ? rows[slot] : 0;
+    const int which = (int)(r >> 32);
+    const u64 i = r & 0xffffffffu;
+    const CsrDev M = which == 0 ? A : which == 1 ? B : C;
+    F acc = F::zero();
+    if (live) {
+        const F* val = (const F*)M.val;
+        const u64 e = M.rowptr[i + 1];
+        for (u64 k = M.rowptr[i] + lane; k < e; k += 64) {
+            ZK_ASSERT_IDX(M.col[k] < m_vars);
+            acc = fe_add(acc, fe_mul(val[k], z[M.col[k]]));
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 st = 32; st > 0; st >>= 1) {
+        if (lane < st) {
+            acc = fe_add(acc, sh[threadIdx.x + st]);
+            sh[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (live && lane == 0) (which == 0 ? oa : which == 1 ? ob : oc)[i] = acc;
 }
 // lanes per row for a matrix with `nnz` entries in `n` rows: the largest power of two <= half the average row length
 static inline int matvec_group(u64 nnz, u64 n) {

@@ -94,6 +94,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
+        ctx->heavy_runs = env_int("ZKHIP_MSM_HEAVY_RUNS", 0, 1, 1) != 0;
         ctx->msm_fused_waves = env_int("ZKHIP_MSM_FUSED_WAVES", 1, 8, 0);
         ctx->msm_g1_waves = env_int("ZKHIP_MSM_G1_WAVES", 1, 16, 0);
         ctx->msm_g2_waves = env_int("ZKHIP_MSM_G2_WAVES", 1, 16, 0);
@@ -155,6 +156,7 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_MSM_SETS: in(0, 64); ctx->msm_sets = value; break;
             case ZKHIP_TUNE_SKIP_INF: in(0, 2); ctx->skip_inf_mode = value; break;
             case ZKHIP_TUNE_B_SORT: in(0, 2); ctx->b_sort_mode = value; break;
+            case ZKHIP_TUNE_HEAVY_RUNS: in(0, 1); ctx->heavy_runs = value != 0; break;
             case ZKHIP_TUNE_MSM_WAVES: in(0, 8); ctx->msm_waves = value; break;
             case ZKHIP_TUNE_MSM_LANES: in(0, 1 << 24); ctx->msm_lanes = (u32)value; break;
             case ZKHIP_TUNE_MSM_MIN_SLICE: in(1, 1 << 20); ctx->msm_min_slice = (u32)value; break;
