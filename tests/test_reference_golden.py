@@ -54,3 +54,21 @@ def test_reference_proof_bytes_on_emulator(case):
 def test_reference_proof_bytes_on_gpu(case):
     ctx = native.Context(0)
     assert _same_proof(_prove_like_the_cli(ctx, ctx.lib, case), json.load(open(os.path.join(case, "proof.json"))))
+
+
+SHA_CASE = os.path.join(ROOT, "tests", "golden", "reference", "sha256_bn128_g16")
+
+
+@pytest.mark.skipif(not os.path.isdir(SHA_CASE), reason="no reference-compiled sha256/512bitPacked (tools/make_reference_golden.sh, case 5)")
+def test_the_restated_sha256_circuit_has_the_compiled_shape():
+    """zokrates_amd/sha256_circuit.py restates the reference's passes for `512bitPacked.zok` without a compiler to compare with.  The
+    kit's fifth case IS that program compiled by the reference (its four arguments private, so only ONE and the two outputs are
+    instance variables): the constraint and variable counts and the widest row must be the restatement's."""
+    from emu_util import emu_library
+    from zokrates_amd import sha256_circuit as sha
+    prog = native.Program(np.fromfile(os.path.join(SHA_CASE, "out"), dtype=np.uint8), emu_library())
+    rows, _, nvar = sha.template()
+    assert prog.n == len(rows)
+    assert prog.m == 1 + 4 + 2 + nvar
+    widest = max(int(np.diff(rp).max()) for rp, _, _ in prog.mats())
+    assert widest == max(len(c) for _, _, c in rows)
