@@ -16,6 +16,7 @@ timeout 600 python bench.py > "$out/bench_default.json" 2> "$out/bench.err"
 timeout 600 python bench.py --scheme gm17 --e2e 0 > "$out/bench_gm17.json" 2>> "$out/bench.err"
 timeout 600 python bench.py --curve bls12_381 --log-domain 18 --kind poseidon --e2e 0 > "$out/bench_poseidon_bls12_381_2e18.json" 2>> "$out/bench.err"
 timeout 600 python bench.py --kind sha --cpu-seconds 0 --e2e 0 > "$out/bench_sha_like.json" 2>> "$out/bench.err"
+timeout 600 python bench.py --kind sha256 --e2e 0 > "$out/bench_sha256_stdlib_2e20.json" 2>> "$out/bench.err"
 timeout 600 python bench.py --cpu-seconds 0 --constraints 1048576 --steps 16 --e2e 0 > "$out/bench_n2e20_literal_domain2e21.json" 2>> "$out/bench.err"
 timeout 900 python bench.py --cpu-seconds 0 --log-domain 22 --steps 8 --members 8 --e2e 0 > "$out/bench_config3_2e22_members8.json" 2>> "$out/bench.err"
 timeout 600 python bench.py --cpu-seconds 0 --members 8 --steps 16 --e2e 0 > "$out/bench_2e20_members8.json" 2>> "$out/bench.err"
@@ -57,7 +58,7 @@ for line in open(sys.argv[1]):
     if line.startswith('{'):
         d=json.loads(line); print('two ranks on one GPU:', round(d['value'],2), 'proofs/s aggregate, n_gpus', d['n_gpus'], '| sharded', d.get('sharded_single_proof'), '| multi', {k:v for k,v in (d.get('multi_single_proof') or {}).items() if k in ('ms','members','distinct_gpus','identical_to_unsharded','error')})
 PY
-for f in default gm17 poseidon_bls12_381_2e18 sha_like n2e20_literal_domain2e21 config3_2e22_members8 2e20_members8 g16_n2e22_domain2e23 gm17_n2e22_sap2e23 g16_domain2e24 gpus2_self_spawned_one_gpu; do python - "$out/bench_$f.json" <<'PY'
+for f in default gm17 poseidon_bls12_381_2e18 sha_like sha256_stdlib_2e20 n2e20_literal_domain2e21 config3_2e22_members8 2e20_members8 g16_n2e22_domain2e23 gm17_n2e22_sap2e23 g16_domain2e24 gpus2_self_spawned_one_gpu; do python - "$out/bench_$f.json" <<'PY'
 import json,sys
 for line in open(sys.argv[1]):
     try:
