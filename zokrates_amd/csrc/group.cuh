@@ -84,7 +84,7 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
               ptr<Xyzz<F>>(lane.rows));
     // column sums of the K = H x Lw buckets of a set; work-item (lo, hg) adds RG / HG rows serially
     auto fold_cols = [&](const Xyzz<F>* src, u64 set_stride, u64 msm_stride, u32 Lw, u32 H, u32 RG, Xyzz<F>* dst) {
-        const u32 CW = std::min<u32>(Lw, 32), HG = std::max<u32>(1, std::min<u32>(8, RG)), NG = H / RG;
+        const u32 HG = std::max<u32>(1, std::min<u32>((u32)ctx->fold_hg, RG)), CW = std::min<u32>(Lw, 256 / HG), NG = H / RG;
         ZK_LAUNCH((k_msm_fold_cols<F>), dim3(Lw / CW, sh.sets * NG, nt), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, src, set_stride, msm_stride, Lw, H, RG, dst);
     };
     FoldDigits digs{};

@@ -95,6 +95,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
         ctx->heavy_runs = env_int("ZKHIP_MSM_HEAVY_RUNS", 0, 1, 1) != 0;
+        { const int hg = env_int("ZKHIP_FOLD_HG", 1, 256, 32); ctx->fold_hg = 1 << ilog2_floor((u64)hg); }
         ctx->msm_fused_waves = env_int("ZKHIP_MSM_FUSED_WAVES", 1, 8, 0);
         ctx->msm_g1_waves = env_int("ZKHIP_MSM_G1_WAVES", 1, 16, 0);
         ctx->msm_g2_waves = env_int("ZKHIP_MSM_G2_WAVES", 1, 16, 0);
