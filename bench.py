@@ -630,6 +630,13 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
         t0 = time.perf_counter()
         ids = np.arange(circ.m, dtype=np.int64)
         prog_bytes = native.write_program(curve_id, circ.n, circ.m, circ.mats(), ids=ids, args=[(j, False) for j in range(1, circ.l)])
+        chk = native.Program(prog_bytes)       # the reader allocates columns as ark's generate_constraints does; the key was made for circ's
+        in_order = bool((chk.variable_order() == ids).all())
+        del chk
+        if not in_order:
+            res["error"] = ("the generated system's columns are not in generate_constraints order: the key of this run would not fit the program "
+                            "file (kinds dense, poseidon and sha256 are; the statistical 'sha' stand-in is not)")
+            return res
         paths = {k: os.path.join(d, k) for k in ("out", "witness", "proving.key", "proof.json", "cache")}
         prog_bytes.tofile(paths["out"])
         native.write_witness(ids, z).tofile(paths["witness"])

@@ -67,7 +67,7 @@ def test_the_restated_sha256_circuit_has_the_compiled_shape():
     from emu_util import emu_library
     from zokrates_amd import sha256_circuit as sha
     prog = native.Program(np.fromfile(os.path.join(SHA_CASE, "out"), dtype=np.uint8), emu_library())
-    rows, _, nvar = sha.template()
+    rows, _, nvar, _ = sha.template()
     assert prog.n == len(rows)
     assert prog.m == 1 + 4 + 2 + nvar
     widest = max(int(np.diff(rp).max()) for rp, _, _ in prog.mats())

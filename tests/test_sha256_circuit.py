@@ -34,7 +34,7 @@ def test_the_function_is_sha256():
 
 def test_shape_of_one_hash():
     """What the reference's rules give for one call: the count is a consequence, pinned here so that a change of the rules shows."""
-    rows, tape, nvar = sha.template()
+    rows, tape, nvar, _ = sha.template()
     assert (len(rows), nvar) == (48972, 48654)
     # 4 x (128 bit checks + 1 sum), 2 outputs; per compression: 64 x (32 ch + 64 maj + 4 x 32 xor) and the decompositions
     bool_rows = sum(1 for a, b, c in rows if a == b == c and len(a) == 1)
@@ -49,7 +49,7 @@ def test_shape_of_one_hash():
 @pytest.mark.parametrize("curve", [BN254, BLS12_381], ids=lambda c: c.name)
 def test_r1cs_and_witness(curve):
     c = sha.circuit(curve.curve_id, 2)
-    rows, _, nvar = sha.template()
+    rows, _, nvar, _ = sha.template()
     assert (c.l, c.w, c.n, c.N) == (13, 2 * nvar, 2 * len(rows), 1 << 17)
     cs = g16.R1CS(l=c.l, w=c.w)
     cs.A, cs.B, cs.C = (_rows(m, c.n) for m in c.mats())
@@ -67,6 +67,23 @@ def test_r1cs_and_witness(curve):
     # the assignment() of the bench: seeded preimages
     zs = _ints(c.assignment(0x5EED), c.m)
     assert cs.is_satisfied(zs, curve.r) and zs[9:11] == sha.sha256_packed(zs[1:5])
+
+
+def test_columns_are_in_generate_constraints_order():
+    """The system written as a ZoKrates `out` program and read back by the product's reader (which allocates columns the way
+    ark's generate_constraints does: arguments, then every variable when a constraint first names it) is the system itself —
+    same columns, same matrices: a key made for one fits the other (the CLI-shaped legs of bench.py rely on it)."""
+    from emu_util import emu_library
+    from zokrates_amd import native
+    lib = emu_library()
+    c = sha.circuit(0, 2)
+    ids = np.arange(c.m, dtype=np.int64)
+    out = native.write_program(0, c.n, c.m, c.mats(), ids=ids, args=[(j, False) for j in range(1, c.l)], library=lib)
+    prog = native.Program(out, lib)
+    assert (prog.n, prog.l, prog.w) == (c.n, c.l, c.w)
+    assert (prog.variable_order() == ids).all()
+    for (rp, col, val), (rp2, col2, val2) in zip(c.mats(), prog.mats()):
+        assert (rp == rp2).all() and (col == col2).all() and (np.asarray(val).reshape(-1) == np.asarray(val2).reshape(-1)).all()
 
 
 def test_witness_map_and_proof_on_the_emulator():

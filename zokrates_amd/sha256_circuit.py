@@ -25,8 +25,9 @@ the public outputs against hashlib:
   opposite corner of the sparse mat-vec from synth.py's two-term rows;
 * sub-expressions over constants only (the IV in the first rounds, the whole message schedule of the padding block) are
   folded, as the reference's propagation does before flattening.
-Variables in ark order (/root/reference/zokrates_ark/src/lib.rs:80-129): column 0 = ONE, the public inputs, the public outputs
-`~out_i`, then the witness in allocation order.  What is NOT claimed: equality constraint for constraint with a compiled
+Variables in ark order (/root/reference/zokrates_ark/src/lib.rs:41-129): column 0 = ONE, the public inputs, the public outputs
+`~out_i`, then the witness in the order the constraints first name them (a, b, c of each constraint in turn) — so that the
+same system read back from an `out` file by `zkhip_prog_parse` has the same columns, and a key made for one fits the other.  What is NOT claimed: equality constraint for constraint with a compiled
 `out` file (there is none to compare with); the count per hash is what the rules above give.
 """
 import functools
@@ -218,7 +219,8 @@ def _sha_round(fl, block, current):
 
 @functools.lru_cache(maxsize=None)
 def template():
-    """One `512bitPacked` call with symbolic inputs ("in", 0..3) and outputs ("out", 0..1): (rows, tape, witness count)."""
+    """One `512bitPacked` call with symbolic inputs ("in", 0..3) and outputs ("out", 0..1): (rows over the columns of
+    generate_constraints, the tape over the flattener's own variable numbers, witness count, column of each tape variable)."""
     fl = _Flattener()
     words = []
     for j in range(4):                                   # unpack128: embed.rs:560-640
@@ -238,7 +240,19 @@ def template():
             for i, b in enumerate(fl.bits_of(digest[4 * j + k])):
                 _acc(lc, b, 1 << (127 - 32 * k - i))
         fl.rows.append(({ONE: 1}, lc, {("out", j): 1}))
-    return fl.rows, fl.tape, fl.nvar
+    # columns in the order ark's generate_constraints allocates them (zokrates_ark/src/lib.rs:41-75, :112-119): a variable gets
+    # its column when a constraint first names it, walking a, then b, then c of every constraint in program order — not when
+    # the flattener created it (unpack128 checks its bits from the last one up; a maj bit is named by its bc product first).
+    # Within one combination the terms are kept sorted by column, so new variables of one combination take consecutive columns.
+    new_of = {}
+    for row in fl.rows:
+        for lc in row:
+            for k in sorted(k for k in lc if isinstance(k, int) and k not in new_of):
+                new_of[k] = len(new_of)
+    assert len(new_of) == fl.nvar
+    renamed = [tuple({(new_of[k] if isinstance(k, int) else k): v for k, v in lc.items()} for lc in row) for row in fl.rows]
+    column_of = np.array([new_of[k] for k in range(fl.nvar)], dtype=np.int64)
+    return renamed, fl.tape, fl.nvar, column_of
 
 
 def sha256_packed(preimage):
@@ -255,7 +269,7 @@ class Sha256Packed:
         self.curve_id = CURVE_IDS.get(curve, curve)
         self.hashes, self.kind = hashes, "sha256"
         p = self.p = FR_MODULUS[self.curve_id]
-        rows, _, V = template()
+        rows, _, V, _ = template()
         H = hashes
         self.vars_per_hash = V
         self.l, self.w = 1 + 6 * H, V * H
@@ -293,7 +307,7 @@ class Sha256Packed:
     def witness(self, preimages):
         """The witness block of every hash, (hashes, vars_per_hash) int64 (every wire is a bit), for preimages[h] = four
         integers below 2^128: the tape of the template, run for all hashes at once."""
-        _, tape, V = template()
+        _, tape, V, column_of = template()
         H = len(preimages)
         Z = np.zeros((V + 2, H), dtype=np.int64)         # rows V, V + 1: the constant bits 0 and 1
         Z[V + 1] = 1
@@ -338,7 +352,9 @@ class Sha256Packed:
                 x, y, z = Z[ix(a)], Z[ix(b)], Z[ix(c)]
                 Z[bcs] = y & z
                 Z[out] = (x & y) ^ (x & z) ^ (y & z)
-        return np.ascontiguousarray(Z[:V].T)
+        out = np.empty((H, V), dtype=np.int64)
+        out[:, column_of] = Z[:V].T
+        return out
 
     def values(self, preimages):
         """[1, inputs, outputs, witness...] as one uint8 array (canonical LE, 32 bytes per variable)."""
