@@ -106,3 +106,63 @@ def test_random_systems_on_gpu():
     for curve, seed, n, l, extra in CASES + [(BN254, 6, 3000, 9, 100), (BLS12_381, 7, 1500, 4, 33), (BN254, 8, 20000, 2, 5)]:
         run(ctx, curve, seed, n, l, extra)
     ctx.close()
+
+
+def _rows_of_every_length(curve, rnd, lengths, l=3):
+    """A system whose k-th constraint has lengths[k] terms in A, lengths[-1-k] in B and lengths[(k + 1) % n] in C — each matrix
+    meets every length, rows on either side of the mat-vec's 32-term boundary sit next to each other.  z is chosen first; A and B
+    are random, C is random up to one coefficient solved for (its variable's value is invertible)."""
+    r = curve.r
+    m = max(lengths) + 8
+    z = [1] + [rnd.randrange(1, r) for _ in range(m - 1)]
+    ev = lambda row: sum(c * z[j] for j, c in row) % r
+    A, B, C = [], [], []
+    n = len(lengths)
+    for k in range(n):
+        def lc(length):
+            cols = rnd.sample(range(m), length)
+            return [(c, rnd.choice([1, r - 1, rnd.randrange(1 << 40), rnd.randrange(r)])) for c in cols]
+        a, b, c = lc(lengths[k]), lc(lengths[n - 1 - k]), lc(lengths[(k + 1) % n])
+        if c:
+            j, _ = c[-1]
+            rest = ev(c[:-1])
+            c[-1] = (j, (ev(a) * ev(b) - rest) * pow(z[j], r - 2, r) % r)
+        else:
+            a = []
+        A.append(a); B.append(b); C.append(c)
+    cs = g16.R1CS(l=l, w=m - l)
+    cs.A, cs.B, cs.C = A, B, C
+    assert cs.is_satisfied(z, r)
+    return cs, z
+
+
+def _check_row_lengths(ctx, curve):
+    lengths = [0, 1, 2, 31, 32, 33, 34, 63, 64, 65, 127, 128, 129, 300, 1000, 32, 33, 1, 0, 64, 500, 33]
+    cs, z = _rows_of_every_length(curve, random.Random(77 + curve.curve_id), lengths)
+    mats = [csr(cs.A), csr(cs.B), csr(cs.C)]
+    zb = le(z)
+    dcs = native.ConstraintSystem(ctx, curve.curve_id, len(lengths), cs.l, cs.w, mats)
+    oc = cpu.Circuit.from_csr(curve.curve_id, len(lengths), cs.l, cs.w, mats)
+    assert dcs.witness_map(zb).tobytes() == cpu.witness_map(oc, zb).tobytes()
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381], ids=lambda c: c.name)
+def test_rows_around_the_long_row_boundary_on_emulator(curve):
+    """k_matvec leaves rows of more than 32 terms to k_matvec_long (a wavefront per row): every length around the boundary, in
+    every matrix, next to empty and one-term rows."""
+    from emu_util import emu_library
+    ctx = native.Context(0, emu_library())
+    try:
+        _check_row_lengths(ctx, curve)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_rows_around_the_long_row_boundary_on_gpu():
+    ctx = native.Context(0)
+    try:
+        for curve in (BN254, BLS12_381):
+            _check_row_lengths(ctx, curve)
+    finally:
+        ctx.close()
