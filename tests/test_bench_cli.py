@@ -182,6 +182,11 @@ def test_offline_evidence_is_tied_to_the_build(tmp_path):
         json.dump(doc, open(root / "profiles" / n, "w"))
     ev = bench.offline_evidence(root=str(root))
     assert ev["stale"] is False and ev["traffic"]["G1"]["traffic_bytes_per_launch"] > 0 and ev["valu"]["G1"]["issue_utilisation"] > 0
+    # the file readers hold no kernel and launch none: an edit there moves no counter and leaves the fingerprint alone
+    with open(root / "zokrates_amd" / "csrc" / "ingest.hip", "a") as f:
+        f.write("// a reader edit\n")
+    assert bench.offline_evidence(root=str(root))["stale"] is False
+    assert csrc_hash(str(root), with_host_only=True) != csrc_hash(with_host_only=True)
     with open(root / "zokrates_amd" / "csrc" / "kernels_msm.cuh", "a") as f:
         f.write("// a kernel edit\n")
     ev = bench.offline_evidence(root=str(root))

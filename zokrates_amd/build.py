@@ -25,15 +25,21 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
          "-Wno-unused-variable"]
 
 
-def csrc_hash(root=None):
-    """Fingerprint of the sources libzkhip.so is built from (the kernel and host-schedule sources directly under csrc/ and the ABI header, names and bytes): what
-    ties offline evidence — the rocprofv3 counter files under profiles/ — to the build it was taken from.  bench.py prints a
-    counter figure only next to a build with the same fingerprint."""
+HOST_ONLY = ("ingest.hip", "ingest.h", "emu.h")   # the program / witness readers and the test-only emulator shim: no kernel, no launch
+
+
+def csrc_hash(root=None, with_host_only=False):
+    """Fingerprint of the sources of libzkhip.so's KERNELS and of the host code that launches them (the sources directly under
+    csrc/ and the ABI header, names and bytes): what ties offline evidence — the rocprofv3 counter files under profiles/ — to the
+    build it was taken from.  bench.py prints a counter figure only next to a build with the same fingerprint.  Left out: csrc/host
+    (the compiled host layer) and HOST_ONLY — the file readers and the emulator shim hold no kernel and launch none, so a change
+    there cannot move a counter (`with_host_only=True` is the definition the files were stamped under until the readers were
+    reworked: tools/adopt_evidence.py --rekey checks a file against it before giving it the present one)."""
     import hashlib
     here = os.path.join(root, "zokrates_amd") if root else HERE
     files = []
     csrc = os.path.join(here, "csrc")      # (not csrc/host: the compiled host layer is not what the counters measured)
-    files += [os.path.join(csrc, n) for n in os.listdir(csrc) if n.endswith((".cuh", ".hip", ".h"))]
+    files += [os.path.join(csrc, n) for n in os.listdir(csrc) if n.endswith((".cuh", ".hip", ".h")) and (with_host_only or n not in HOST_ONLY)]
     files.append(os.path.join(here, "..", "include", "zkhip.h"))
     h = hashlib.sha256()
     for f in sorted(files, key=lambda f: os.path.relpath(f, here)):
