@@ -38,7 +38,7 @@ def rows_of(mats, n):
     return tuple(out)
 
 
-def random_prog(curve, rnd, n, n_args=4, n_out=2, with_noise=True):
+def random_prog(curve, rnd, n, n_args=4, n_out=2, with_noise=True, wide=False):
     """A hand-built (non-canonical) program: duplicate variables inside a combination, zero coefficients, terms that
     cancel, outputs first seen late and out of index order, private/public/unused arguments, directives and logs with
     nested payloads between the constraints, spans and error annotations."""
@@ -48,7 +48,10 @@ def random_prog(curve, rnd, n, n_args=4, n_out=2, with_noise=True):
     coeff = lambda: rnd.choice([0, 1, r - 1, rnd.randrange(r), rnd.randrange(1 << 64)])
 
     def lc():
-        t = [(rnd.choice(pool), coeff()) for _ in range(rnd.randrange(0, 5))]
+        # wide: now and then a combination of tens to hundreds of terms over few variables (every variable several times, some
+        # cancelling): what the reference's optimizer leaves of an inlined lazy sum, and more than the reader's short-row merge takes
+        length = rnd.choice([23, 24, 25, 26, 60, 300]) if wide and rnd.random() < 0.3 else rnd.randrange(0, 5)
+        t = [(rnd.choice(pool), coeff()) for _ in range(length)]
         if t and rnd.random() < 0.3:
             v, c = t[0]
             t.append((v, (r - c) % r))                                        # cancels -> zero after merging
@@ -88,6 +91,23 @@ def test_parse_matches_ark_order(lib, curve):
         assert [int.from_bytes(z[32 * j:32 * j + 32].tobytes(), "little") for j in range(l + w)] == [1] + [values[v] for v in order[1:]]
         want_inputs = ir.public_inputs_values(prog, values)
         assert [int.from_bytes(inputs[32 * j:32 * j + 32].tobytes(), "little") for j in range(len(inputs) // 32)] == want_inputs
+        p.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_wide_combinations_merge_like_short_ones(lib, curve):
+    """Rows on either side of the reader's switch from the quadratic merge to the sorted one (24 terms), duplicates and
+    cancellations in both: columns, order of first occurrence and values as the Python model of ark's allocation has them."""
+    rnd = random.Random(4242)
+    for trial in range(6):
+        prog = random_prog(curve, rnd, n=rnd.randrange(5, 30), n_args=3, n_out=2, with_noise=False, wide=True)
+        p = native.Program(ir.serialize_prog(prog), lib)
+        l, w, order, rows = ir.ark_order(prog)
+        n = sum(isinstance(s, ir.Constraint) for s in prog.statements)
+        assert (p.n, p.l, p.w) == (n, l, w)
+        assert list(p.variable_order()) == order
+        assert rows_of(p.mats(), n) == rows
+        assert max(len(r) for m in rows for r in m) > 24 or trial
         p.close()
 
 

@@ -206,6 +206,7 @@ struct Builder {
         std::vector<int64_t> first_seen;    // ids in the order this chunk first met them
         Seen seen;
         std::vector<Term> scratch;
+        std::vector<uint32_t> order;        // lin_comb: the terms of a long row by variable
         bool failed = false;
         IngestError err{0, ""};
         uint64_t id_limit = 0;
@@ -253,16 +254,35 @@ struct Builder {
             }
         }
         if (!have_value) fail(ZKHIP_ERR_PARSE, "LinComb without value");
-        // merge duplicates; rows are tiny, so a quadratic pass beats sorting
+        // merge duplicates into their first occurrence.  Most rows are tiny and a quadratic pass beats sorting; the reference's
+        // optimizer also writes rows of thousands of terms (every linear definition inlined: the sum checks of a SHA-256 round,
+        // zokrates_core/src/optimizer/redefinition.rs:24-40), where the quadratic pass was 3/4 of reading such a program
         uint32_t kept = 0;
         constexpr int64_t GONE = INT64_MIN;
-        for (size_t i = 0; i < scratch.size(); ++i) {
-            if (scratch[i].id == GONE) continue;
-            for (size_t j = i + 1; j < scratch.size(); ++j)
-                if (scratch[j].id == scratch[i].id) {
-                    scratch[i].coeff = fe_add(scratch[i].coeff, scratch[j].coeff);
-                    scratch[j].id = GONE;
+        const size_t nterms = scratch.size();
+        if (nterms > 24) {
+            std::vector<uint32_t>& order = ch.order;
+            order.resize(nterms);
+            for (size_t i = 0; i < nterms; ++i) order[i] = (uint32_t)i;
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return scratch[a].id != scratch[b].id ? scratch[a].id < scratch[b].id : a < b; });
+            for (size_t i = 0; i < nterms;) {
+                size_t j = i + 1;
+                while (j < nterms && scratch[order[j]].id == scratch[order[i]].id) {
+                    scratch[order[i]].coeff = fe_add(scratch[order[i]].coeff, scratch[order[j]].coeff);
+                    scratch[order[j]].id = GONE;
+                    ++j;
                 }
+                i = j;
+            }
+        }
+        for (size_t i = 0; i < nterms; ++i) {
+            if (scratch[i].id == GONE) continue;
+            if (nterms <= 24)
+                for (size_t j = i + 1; j < nterms; ++j)
+                    if (scratch[j].id == scratch[i].id) {
+                        scratch[i].coeff = fe_add(scratch[i].coeff, scratch[j].coeff);
+                        scratch[j].id = GONE;
+                    }
             if (!scratch[i].coeff.is_zero()) { ch.terms[which].push_back(scratch[i]); ++kept; }
         }
         ch.count[which].push_back(kept);
