@@ -57,7 +57,7 @@ def test_single_rank_contract(args, metric):
     assert chk["verified"] is True and chk["verify_ms"] > 0 and chk["proof_json_identical_to_resident_prover"] is True, chk
 
 
-@pytest.mark.parametrize("scheme,port", [("g16", "29541"), ("gm17", "29543")])
+@pytest.mark.parametrize("scheme,port", [("g16", "29541")])      # (the sharded GM17 proof over two processes: tests/test_multiprocess.py)
 def test_two_ranks_real_bench_script(scheme, port):
     world = 2
     procs = []

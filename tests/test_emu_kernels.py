@@ -229,7 +229,7 @@ def test_sharded_proof_virtual_ranks(ctx, curve, world):
     assert native.combine_g16(ctx, whole, [native.prove_g16_partial(ctx, whole, cs, z, r_, s_)], r_, s_) == want
 
 
-@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("curve", [BN254], ids=lambda c: c.name)      # (the sets / levels pairing is curve-independent host code)
 def test_prove_with_thinned_tables(curve):
     """Keys too large for every window multiple of every base (domains above 2^24: the tables of a 2^26 key would take 384 GiB)
     keep every 2nd / 4th / ... multiple and fold as many bucket sets (ZKHIP_TUNE_MSM_SETS; automatic by device memory otherwise);

@@ -391,7 +391,7 @@ def test_emu_gm17_sharded_virtual_ranks(emu_ctx, curve, world):
 
 
 def test_emu_gm17_more_ranks_than_points(emu_ctx):
-    _gm17_sharded_checks(emu_ctx, BN254, 64, n=3)     # most ranks own an empty range
+    _gm17_sharded_checks(emu_ctx, BN254, 9, n=3)     # most ranks own an empty range
 
 
 @pytest.mark.gpu

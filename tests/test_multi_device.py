@@ -71,7 +71,7 @@ def test_emu_multi_device(curve, ndev):
 
 
 def test_emu_multi_more_members_than_points():
-    _checks(emu_library(), [0] * 9, BN254, 2)
+    _checks(emu_library(), [0] * 6, BN254, 2)
 
 
 def test_multi_bad_arguments():

@@ -48,25 +48,27 @@ def test_shape_of_one_hash():
 
 @pytest.mark.parametrize("curve", [BN254, BLS12_381], ids=lambda c: c.name)
 def test_r1cs_and_witness(curve):
-    c = sha.circuit(curve.curve_id, 2)
+    H = 2 if curve is BN254 else 1          # (the second hash is the first one shifted: once is enough)
+    c = sha.circuit(curve.curve_id, H)
     rows, _, nvar, _ = sha.template()
-    assert (c.l, c.w, c.n, c.N) == (13, 2 * nvar, 2 * len(rows), 1 << 17)
+    assert (c.l, c.w, c.n, c.N) == (1 + 6 * H, H * nvar, H * len(rows), 1 << (16 + H - 1))
     cs = g16.R1CS(l=c.l, w=c.w)
     cs.A, cs.B, cs.C = (_rows(m, c.n) for m in c.mats())
-    pre = [REFERENCE_KAT[0], [(1 << 128) - 1, 0x0123456789abcdef << 60, 1, 0]]
+    pre = [REFERENCE_KAT[0], [(1 << 128) - 1, 0x0123456789abcdef << 60, 1, 0]][:H]
     z = c.values(pre)
     zi = _ints(z, c.m)
     assert cs.is_satisfied(zi, curve.r)
-    assert zi[:c.l] == [1] + pre[0] + pre[1] + REFERENCE_KAT[1] + sha.sha256_packed(pre[1])     # ark order: ONE, inputs, outputs
+    assert zi[:c.l] == [1] + [v for p_ in pre for v in p_] + [v for p_ in pre for v in sha.sha256_packed(p_)]     # ark order: ONE, inputs, outputs
+    assert zi[1 + 4 * H:3 + 4 * H] == REFERENCE_KAT[1]
     # every wire behind the public part is a bit
     assert set(np.unique(z.reshape(-1, 32)[c.l:, 0]).tolist()) <= {0, 1} and not z.reshape(-1, 32)[c.l:, 1:].any()
-    for j in (9, 12, 13, c.l + 128 * 4 + 40, c.m - 1):      # a wrong digest, a flipped wire: not a witness
+    for j in (1 + 4 * H, c.l - 1, c.l, c.l + 128 * 4 + 40, c.m - 1):      # a wrong digest, a flipped wire: not a witness
         bad = list(zi)
         bad[j] = (bad[j] + 1) % curve.r
         assert not cs.is_satisfied(bad, curve.r), j
     # the assignment() of the bench: seeded preimages
     zs = _ints(c.assignment(0x5EED), c.m)
-    assert cs.is_satisfied(zs, curve.r) and zs[9:11] == sha.sha256_packed(zs[1:5])
+    assert cs.is_satisfied(zs, curve.r) and zs[1 + 4 * H:3 + 4 * H] == sha.sha256_packed(zs[1:5])
 
 
 def test_columns_are_in_generate_constraints_order():
@@ -76,7 +78,7 @@ def test_columns_are_in_generate_constraints_order():
     from emu_util import emu_library
     from zokrates_amd import native
     lib = emu_library()
-    c = sha.circuit(0, 2)
+    c = sha.circuit(0, 1)
     ids = np.arange(c.m, dtype=np.int64)
     out = native.write_program(0, c.n, c.m, c.mats(), ids=ids, args=[(j, False) for j in range(1, c.l)], library=lib)
     prog = native.Program(out, lib)
