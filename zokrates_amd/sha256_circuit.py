@@ -21,7 +21,7 @@ the public outputs against hashlib:
   input * 1 = sum), `pack128` a linear combination of the digest's bits;
 * linear definitions do not survive the optimizer (zokrates_core/src/optimizer/redefinition.rs:24-40: `lin == k*v` becomes a
   substitution), so the lazy sums are INLINED into the sum checks: the value of `e` in round i is the combination of every
-  wire it was ever added up from.  These are the widest rows any workload here has (tens of thousands of terms in C): the
+  wire it was ever added up from.  These are the widest rows any workload here has (up to 7 041 terms in C): the
   opposite corner of the sparse mat-vec from synth.py's two-term rows;
 * sub-expressions over constants only (the IV in the first rounds, the whole message schedule of the padding block) are
   folded, as the reference's propagation does before flattening.
