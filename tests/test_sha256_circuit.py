@@ -46,6 +46,18 @@ def test_shape_of_one_hash():
     assert max(len(c) for _, _, c in rows) > 5000           # the inlined lazy sums: the widest rows of any workload here
 
 
+def test_generated_bytes_are_pinned():
+    """The matrices of one call over bn128 and the assignment for seed 1, as digests: bench lines and proofs made from this
+    generator stay comparable across rounds only while it emits the same bytes (a deliberate change of the rules updates these)."""
+    c = sha.circuit(0, 1)
+    h = hashlib.sha256()
+    for rp, col, val in c.mats():
+        for a in (rp, col, val):
+            h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == "23e20149c76f28f719889e135d2728701953bef7d1c5c7816a970c6ca8eeed6b"
+    assert hashlib.sha256(c.assignment(1).tobytes()).hexdigest() == "dba1e8c2fa5911b4e24b468cddbe7093610995d80ae7723265e31c93c672ad92"
+
+
 @pytest.mark.parametrize("curve", [BN254, BLS12_381], ids=lambda c: c.name)
 def test_r1cs_and_witness(curve):
     H = 2 if curve is BN254 else 1          # (the second hash is the first one shifted: once is enough)
