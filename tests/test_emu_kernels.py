@@ -170,6 +170,37 @@ def test_msm_skewed_scalars(ctx):
         ctx.tune("msm_c", 0)
 
 
+@pytest.mark.parametrize("scheme", ["g16", "gm17"])
+def test_prove_with_the_ones_bucket_over_hundreds_of_slices(ctx, scheme):
+    """A witness of bits at the finest slicing: the bucket of the ones is spread over hundreds of slices in every table of the
+    fused launch (window-multiple tables, A / B1 / L on one sorted list, G2 on the thinned one), so k_msm_heavy_reduce leaves run
+    sums in three tables at once; the proof must be the oracle's with and without it."""
+    from oracle import gm17
+    curve = BN254
+    oc = cpu.Circuit.synth(curve.curve_id, 400, 0x5EED0011, "sha")
+    z = oc.assignment()
+    cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    if scheme == "g16":
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        pk = native.ProvingKey(ctx, curve.curve_id, cpu.ProvingKey.setup(oc, tox).serialize())
+        want = cpu.trapdoor(oc, tox, z, 5, 6)
+        prove = lambda: native.prove_g16(ctx, pk, cs, z, 5, 6)
+    else:
+        tox = cpu.gm17_toxic_bytes(gm17.Toxic.from_seed(curve))
+        pk = native.ProvingKey(ctx, curve.curve_id, cpu.Gm17ProvingKey.setup(oc, tox).serialize(), scheme="gm17")
+        want = cpu.gm17_trapdoor(oc, tox, z, 5, 7)
+        prove = lambda: native.prove_gm17(ctx, pk, cs, z, 5, 6, 7)
+    try:
+        ctx.tune("msm_min_slice", 1)
+        for runs in (1, 0):
+            ctx.tune("heavy_runs", runs)
+            assert prove() == want, runs
+    finally:
+        ctx.tune("heavy_runs", 1)
+        ctx.tune("msm_min_slice", 8)
+        pk.close()
+
+
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("kind", ["dense", "sha"])
 def test_prove_matches_oracle(ctx, curve, kind):
