@@ -170,13 +170,12 @@ def test_msm_skewed_scalars(ctx):
         ctx.tune("msm_c", 0)
 
 
-@pytest.mark.parametrize("scheme", ["g16", "gm17"])
-def test_prove_with_the_ones_bucket_over_hundreds_of_slices(ctx, scheme):
+@pytest.mark.parametrize("curve,scheme", [(BN254, "g16"), (BN254, "gm17"), (BLS12_381, "g16")], ids=lambda v: getattr(v, "name", v))
+def test_prove_with_the_ones_bucket_over_hundreds_of_slices(ctx, curve, scheme):
     """A witness of bits at the finest slicing: the bucket of the ones is spread over hundreds of slices in every table of the
     fused launch (window-multiple tables, A / B1 / L on one sorted list, G2 on the thinned one), so k_msm_heavy_reduce leaves run
     sums in three tables at once; the proof must be the oracle's with and without it."""
     from oracle import gm17
-    curve = BN254
     oc = cpu.Circuit.synth(curve.curve_id, 400, 0x5EED0011, "sha")
     z = oc.assignment()
     cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
