@@ -6,12 +6,23 @@
 #include <string>
 #include <vector>
 
+// a vector whose resize() leaves new elements uninitialised: the matrices are hundreds of megabytes that the reader's workers
+// write in full, and value-initialising them first was one serial pass over all of it (100 ms of a 2^20-constraint program
+// whatever the thread count: the part of the reader that did not scale)
+template <class T>
+struct zkhip_default_init : std::allocator<T> {
+    template <class U> struct rebind { typedef zkhip_default_init<U> other; };
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class A0, class... A> void construct(U* p, A0&& a0, A&&... a) { ::new ((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+template <class T> using zkhip_raw_vector = std::vector<T, zkhip_default_init<T>>;
+
 struct zkhip_prog {
     int curve = 0;
     uint64_t n = 0, l = 0, w = 0, return_count = 0;
-    std::vector<uint64_t> rp[3];
-    std::vector<uint32_t> col[3];
-    std::vector<uint8_t> val[3];           // canonical LE, 32 B per entry
+    zkhip_raw_vector<uint64_t> rp[3];
+    zkhip_raw_vector<uint32_t> col[3];
+    zkhip_raw_vector<uint8_t> val[3];      // canonical LE, 32 B per entry
     std::vector<int64_t> order;            // ZoKrates variable id (flat/variable.rs: 0 = ~one, k > 0 = _{k-1}, -k = ~out_{k-1}) of column j
     std::vector<int64_t> public_args;      // ids of the public arguments, in argument order
 };

@@ -457,6 +457,8 @@ struct Builder {
             out->col[k].resize(nnz[k]);
             out->val[k].resize(nnz[k] * 32);
         }
+        const auto t_alloc = now();
+        if (prof) fprintf(stderr, "[zkhip ingest] output arrays %.1f ms\n", ms(t_merged, t_alloc));
         // columns, values and row pointers of every chunk's rows (independent: in parallel)
         auto emit = [&](Chunk& ch) {
             for (int k = 0; k < 3; ++k) {
