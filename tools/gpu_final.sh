@@ -58,7 +58,7 @@ for line in open(sys.argv[1]):
     if line.startswith('{'):
         d=json.loads(line); print('two ranks on one GPU:', round(d['value'],2), 'proofs/s aggregate, n_gpus', d['n_gpus'], '| sharded', d.get('sharded_single_proof'), '| multi', {k:v for k,v in (d.get('multi_single_proof') or {}).items() if k in ('ms','members','distinct_gpus','identical_to_unsharded','error')})
 PY
-for f in default gm17 poseidon_bls12_381_2e18 sha_like sha256_stdlib_2e20 n2e20_literal_domain2e21 config3_2e22_members8 2e20_members8 g16_n2e22_domain2e23 gm17_n2e22_sap2e23 g16_domain2e24 gpus2_self_spawned_one_gpu; do python - "$out/bench_$f.json" <<'PY'
+for f in default gm17 poseidon_bls12_381_2e18 sha_like sha256_stdlib_2e20 n2e20_literal_domain2e21 config3_2e22_members8 2e20_members8 g16_n2e22_domain2e23 gm17_n2e22_sap2e23 g16_domain2e24 gpus2_self_spawned_one_gpu; do [ -f "$out/bench_$f.json" ] || continue; python - "$out/bench_$f.json" <<'PY'
 import json,sys
 for line in open(sys.argv[1]):
     try:
