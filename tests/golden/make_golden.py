@@ -171,7 +171,17 @@ def ptau5_points():
     return d
 
 
+def sha256_packed_kat():
+    """The reference's known answer for stdlib hashes/sha256/512bitPacked.zok (its own test of that program)."""
+    rel = "zokrates_stdlib/tests/tests/hashes/sha256/512bitPacked.json"
+    doc = json.load(open(os.path.join(REF, rel)))
+    assert doc["entry_point"].endswith("hashes/sha256/512bitPacked.zok") and doc["curves"] == ["Bn128"]
+    t = doc["tests"][0]
+    return {"source": rel, "input": t["input"]["values"][0], "output": t["output"]["Ok"]["value"]}
+
+
 def main():
+    json.dump(sha256_packed_kat(), open(os.path.join(OUT, "sha256_packed_kat.json"), "w"), indent=1)
     json.dump(ptau5_points(), open(os.path.join(OUT, "ptau5_points.json"), "w"), indent=0)
     json.dump(gm17_embed_triples(), open(os.path.join(OUT, "gm17_bls12_377_embed_triples.json"), "w"), indent=1)
     json.dump(gm17_triple(), open(os.path.join(OUT, "gm17_bls12_377_triple.json"), "w"), indent=1)

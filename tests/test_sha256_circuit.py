@@ -12,7 +12,12 @@ from oracle import groth16 as g16
 from oracle.fields import BN254, BLS12_381
 from zokrates_amd import sha256_circuit as sha
 
-REFERENCE_KAT = ([0, 0, 0, 5], [263561599766550617289250058199814760685, 65303172752238645975888084098459749904])
+import json
+import os
+
+_KAT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sha256_packed_kat.json")))   # tests/golden/make_golden.py
+REFERENCE_KAT = ([int(v) for v in _KAT["input"]], [int(v) for v in _KAT["output"]])
+assert REFERENCE_KAT == ([0, 0, 0, 5], [263561599766550617289250058199814760685, 65303172752238645975888084098459749904])
 
 
 def _rows(mat, n):
