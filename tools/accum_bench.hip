@@ -16,9 +16,11 @@ float run(const MsmTables& tb, int nt, const u32* off, const u32* sorted, u32* l
     hipLaunchKernelGGL(k_msm_lane_keys, dim3((nlanes + 255) / 256), dim3(256), 0, 0, off, nkeys, cut, lane_key);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e30f;
+    constexpr size_t acc_lds = msm_accum_lds_bytes<F>();
+    if (acc_lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k_msm_accum<F, WPE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (int r = 0; r < 3; ++r) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL((k_msm_accum<F, WPE, false>), dim3((nlanes + 255) / 256, nt), dim3(256), 0, 0, tb, off, sorted, lane_key, partial, (u64)nkeys + nlanes, nkeys, cut);
+        hipLaunchKernelGGL((k_msm_accum<F, WPE, false>), dim3((nlanes + 255) / 256, nt), dim3(256), acc_lds, 0, tb, off, sorted, lane_key, partial, (u64)nkeys + nlanes, nkeys, cut);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
     }

@@ -247,6 +247,20 @@ ZK_HD void xyzz_madd_finish(Xyzz<F>& a, const F& Pp, const F& R) {
     a.x = X3;
 }
 
+// The same addition OUT OF LINE, for the accumulation kernel's general path (the wavefront's vote found an infinite base, a
+// doubling or a cancellation: practically never on full-width scalars).  Inlined there, its registers — the doubling's
+// temporaries next to the addition's — set the kernel's allocation and the hot loop pays for them in spills; as a call it has a
+// frame of its own (arguments and result by value: nothing of the caller escapes to memory outside the cold branch).
+#ifndef ZK_ACCUM_COLD_CALL
+#define ZK_ACCUM_COLD_CALL 1
+#endif
+template <class F>
+ZK_HD_CALL Xyzz<F> xyzz_madd_cold(const Xyzz<F> a, const Aff<F> p) {
+    Xyzz<F> t = a;
+    xyzz_madd_acc<false>(t, p);
+    return t;
+}
+
 template <class F>
 ZK_HD void xyzz_add_acc(Xyzz<F>& a, const Xyzz<F>& b) {   // a += b, both XYZZ
     if (b.is_inf()) return;

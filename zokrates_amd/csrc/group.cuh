@@ -67,12 +67,16 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
               ptr<u32>(lane.heavy));
     if (accum_after && !ctx->serial) stream_wait_event(s, accum_after);   // (the slicing above only needs the sort)
     if (ev_begin) event_record(ev_begin, s);
-    if (ctx->skip_inf_mode == 1 || (ctx->skip_inf_mode == 0 && sh.skip_inf))
-        ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, true>), dim3(blocks_for(nlanes, T), nt), dim3(T), 0, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
+    constexpr size_t acc_lds = msm_accum_lds_bytes<F>();      // the coordinates of the running sums that live in LDS (kernels_msm.cuh)
+    if (ctx->skip_inf_mode == 1 || (ctx->skip_inf_mode == 0 && sh.skip_inf)) {
+        if (acc_lds > 64 * 1024) lds_opt_in(ctx, (const void*)k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, true>);
+        ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, true>), dim3(blocks_for(nlanes, T), nt), dim3(T), acc_lds, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
                   ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), partial_stride, sh.nkeys, cut);
-    else
-        ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, false>), dim3(blocks_for(nlanes, T), nt), dim3(T), 0, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
+    } else {
+        if (acc_lds > 64 * 1024) lds_opt_in(ctx, (const void*)k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, false>);
+        ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, false>), dim3(blocks_for(nlanes, T), nt), dim3(T), acc_lds, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
                   ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), partial_stride, sh.nkeys, cut);
+    }
     if (ev_end) event_record(ev_end, s);
     if (ctx->heavy_runs) {
         lds_opt_in(ctx, (const void*)k_msm_heavy_reduce<F>);

@@ -58,14 +58,19 @@ namespace zk {
 #ifndef ZK_G1_ZZ_LDS
 #define ZK_G1_ZZ_LDS 0
 #endif
+#ifndef ZK_G2_XY_LDS
+#define ZK_G2_XY_LDS 0
+#endif
 #ifndef ZK_G1_ACCUM_WPE
 #define ZK_G1_ACCUM_WPE 3
 #endif
-template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = ZK_G1_ACCUM_WPE, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = ZK_G1_ZZ_LDS != 0; };
-template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
-template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = ZK_G2_PREFETCH_REGS != 0, ZZ_IN_LDS = ZK_G2_ZZ_LDS != 0; };
-template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
-template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 1, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false; };
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = ZK_G1_ACCUM_WPE, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = ZK_G1_ZZ_LDS != 0, XY_IN_LDS = false; };
+template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false, XY_IN_LDS = false; };
+template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = ZK_G2_PREFETCH_REGS != 0, ZZ_IN_LDS = ZK_G2_ZZ_LDS != 0, XY_IN_LDS = ZK_G2_XY_LDS != 0; };
+template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = false, XY_IN_LDS = false; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 1, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false, XY_IN_LDS = false; };
+// dynamic LDS of one accumulation workgroup (256 work-items): the coordinates of the running sum that live there, word-major
+template <class F> constexpr size_t msm_accum_lds_bytes() { return (size_t)((MsmTuning<F>::ZZ_IN_LDS ? 2 : 0) + (MsmTuning<F>::XY_IN_LDS ? 2 : 0)) * (sizeof(F) / 4) * 256 * 4; }
 // the base tables of the MSMs one launch serves (A, B1 and L of a proof share the sort of the assignment)
 static constexpr int MSM_MAX_TABLES = 3;
 struct MsmTables {
@@ -360,6 +365,16 @@ __device__ __forceinline__ void zk_pin_words(T& obj) {
 #define ZK_PIN_WORDS(x) ((void)0)
 #define ZK_LDS_REREAD() ((void)0)
 #endif
+// a point the instruction scheduler may not move anything across: between the products of the hot addition it keeps the compiler
+// from interleaving independent products (whose operands and columns would then all be live at once)
+#ifndef ZK_ACCUM_FENCE
+#define ZK_ACCUM_FENCE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_SCHED_FENCE(on) do { if (on) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ZK_SCHED_FENCE(on) ((void)0)
+#endif
 // SKIP_INF: how a base at infinity is met.  true: the lane sits the step out (one more per-lane branch per step: ≈ 1.5 % more
 // instructions on a table without such bases); false: the wavefront's vote sends the step through the general code (free when it
 // never happens, twice the price of a step when it does).  Real circuits leave many points at infinity in b_query (every variable
@@ -385,25 +400,29 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
     // The running sum: X and Y in registers; ZZ and ZZZ in registers too, or (ZZ_IN_LDS) in the lane's own words of LDS — each is
     // read twice and written once per addition, and the 36 registers they would hold through the whole step are what decides
     // whether a second G2 wave fits a SIMD.
-    constexpr bool ZZ_LDS = MsmTuning<F>::ZZ_IN_LDS;
+    constexpr bool ZZ_LDS = MsmTuning<F>::ZZ_IN_LDS, XY_LDS = MsmTuning<F>::XY_IN_LDS;
     constexpr int FW = (int)(sizeof(F) / 4);
-    __shared__ u32 zz_lds[ZZ_LDS ? 2 * FW * 256 : 1];
-    F ax = F::zero(), ay = F::zero(), rzz[2] = {F::zero(), F::zero()};
-    auto get_zz = [&](int which) -> F {
-        if (!ZZ_LDS) return rzz[which];
+    ZK_DYN_SMEM(acc_smem);                    // msm_accum_lds_bytes<F>(): coordinate `which` (0 ZZ, 1 ZZZ, 2 X, 3 Y; only those that live here), word-major
+    u32* const acc_lds = (u32*)acc_smem;
+    constexpr int XY_BASE = ZZ_LDS ? 2 : 0;
+    F rxy[2] = {F::zero(), F::zero()}, rzz[2] = {F::zero(), F::zero()};
+    auto lds_get = [&](int slot) -> F {
         F r;
         u32* wv = (u32*)&r;
         ZK_LDS_REREAD();          // (every fetch is a fresh read: a value kept in registers between its two uses is what this avoids)
-        ZK_UNROLL for (int q = 0; q < FW; ++q) wv[q] = zz_lds[(which * FW + q) * 256 + threadIdx.x];
+        ZK_UNROLL for (int q = 0; q < FW; ++q) wv[q] = acc_lds[(slot * FW + q) * 256 + threadIdx.x];
         return r;
     };
-    auto put_zz = [&](int which, const F& v) {
-        if (!ZZ_LDS) { rzz[which] = v; return; }
+    auto lds_put = [&](int slot, const F& v) {
         const u32* wv = (const u32*)&v;
-        ZK_UNROLL for (int q = 0; q < FW; ++q) zz_lds[(which * FW + q) * 256 + threadIdx.x] = wv[q];
+        ZK_UNROLL for (int q = 0; q < FW; ++q) acc_lds[(slot * FW + q) * 256 + threadIdx.x] = wv[q];
     };
-    auto whole = [&]() -> Xyzz<F> { return {ax, ay, get_zz(0), get_zz(1)}; };
-    auto set_whole = [&](const Xyzz<F>& t) { ax = t.x; ay = t.y; put_zz(0, t.zz); put_zz(1, t.zzz); };
+    auto get_zz = [&](int which) -> F { return ZZ_LDS ? lds_get(which) : rzz[which]; };
+    auto put_zz = [&](int which, const F& v) { if (ZZ_LDS) lds_put(which, v); else rzz[which] = v; };
+    auto get_xy = [&](int which) -> F { return XY_LDS ? lds_get(XY_BASE + which) : rxy[which]; };
+    auto put_xy = [&](int which, const F& v) { if (XY_LDS) lds_put(XY_BASE + which, v); else rxy[which] = v; };
+    auto whole = [&]() -> Xyzz<F> { return {get_xy(0), get_xy(1), get_zz(0), get_zz(1)}; };
+    auto set_whole = [&](const Xyzz<F>& t) { put_xy(0, t.x); put_xy(1, t.y); put_zz(0, t.zz); put_zz(1, t.zzz); };
     set_whole(Xyzz<F>::inf());
     u32 e = sorted[p0];
     ZK_ASSERT_IDX((e & 0x7fffffffu) < cut.table_len);
@@ -442,29 +461,46 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
         // and the others add.
         const bool pinf = pt.is_inf();
         const F ys = fe_cneg(pt.y, neg);
-        const F Pp = fe_sub_k<4>(ecm_k<true>(get_zz(0), pt.x), ax);            // X1 < 3p;  Pp < 6p
-        const F R = fe_sub_k<4>(ecm_k<true>(get_zz(1), ys), ay);               // Y1 < 4p;  R < 6p
+        const F Pp = fe_sub_k<4>(ecm_k<true>(get_zz(0), pt.x), get_xy(0));     // X1 < 3p;  Pp < 6p
+        const F R = fe_sub_k<4>(ecm_k<true>(get_zz(1), ys), get_xy(1));        // Y1 < 4p;  R < 6p
         const bool special = SKIP_INF ? (!pinf && !first && fe_is_zero_modp(Pp)) : (pinf || (!first && fe_is_zero_modp(Pp)));
         if (ZK_WAVE_ANY(special)) {
+            // (the base is fetched AGAIN here: holding its coordinates across the vote for a path that practically never runs costs
+            // the hot path their registers — 36 for G2, which the compiler then spills on every step)
+            u32 wg[NW2];
+            aff_load_words<F>(bases, e_cur & 0x7fffffffu, wg);
+            const Aff<F> pg = aff_unpack<F>(wg);
             Xyzz<F> t = first ? Xyzz<F>::inf() : whole();
-            if (!pinf) xyzz_madd_acc<true>(t, Aff<F>{pt.x, ys});
+            if (!pinf) {
+                if (ZK_ACCUM_COLD_CALL) t = xyzz_madd_cold(t, Aff<F>{pg.x, fe_cneg(pg.y, neg)});
+                else xyzz_madd_acc<true>(t, Aff<F>{pg.x, fe_cneg(pg.y, neg)});
+            }
             set_whole(t);
             first = t.is_inf();
         } else if (SKIP_INF && pinf) {
             if (first) set_whole(Xyzz<F>::inf());      // (keeps the invariant: `first` and a stale sum never meet a store)
         } else if (first) {
-            ax = pt.x; ay = ys; put_zz(0, F::one()); put_zz(1, F::one());
+            put_xy(0, pt.x); put_xy(1, ys); put_zz(0, F::one()); put_zz(1, F::one());
             first = false;
         } else {
             // the addition proper (ec.cuh xyzz_madd_finish, with ZZ / ZZZ fetched where they are multiplied)
+            constexpr bool FENCE = (ZK_ACCUM_FENCE & (MsmTuning<F>::IS_EXT ? 2 : 1)) != 0;
+            ZK_SCHED_FENCE(FENCE);
             const F PP = ecs<true>(Pp);
-            const F PPP = ecm<true>(Pp, PP);
-            const F Q = ecm_k<true>(ax, PP);
+            ZK_SCHED_FENCE(FENCE);
             put_zz(0, ecm_k<true>(get_zz(0), PP));
+            ZK_SCHED_FENCE(FENCE);
+            const F PPP = ecm<true>(Pp, PP);
+            ZK_SCHED_FENCE(FENCE);
             put_zz(1, ecm_k<true>(get_zz(1), PPP));
+            ZK_SCHED_FENCE(FENCE);
+            const F Q = ecm_k<true>(get_xy(0), PP);
+            ZK_SCHED_FENCE(FENCE);
             const F X3 = fe_relax(fu_x3_numerator(ecs<true>(R), PPP, Q));     // R^2 - PPP - 2Q: < 10p before, < 3p after
-            ay = ec_mulsub<true>(R, fe_sub_k<4>(Q, X3), ay, PPP);              // one reduction: < 3p (G1 fused: < 2p)
-            ax = X3;
+            ZK_SCHED_FENCE(FENCE);
+            put_xy(1, ec_mulsub<true>(R, fe_sub_k<4>(Q, X3), get_xy(1), PPP));  // one reduction: < 3p (G1 fused: < 2p)
+            put_xy(0, X3);
+            ZK_SCHED_FENCE(FENCE);
         }
     }
     partial[(u64)cur + g] = whole();
