@@ -311,6 +311,9 @@ def main():
     ap.add_argument("--witnesses", type=int, default=0, help="distinct assignments kept resident (0 = one per timed step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--serial-proofs", type=int, default=3, help="proofs of the one-stream leg after the timed region (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions in all: `value` is the FIRST (the contract's K steps after W warm-up steps); the others repeat it and "
+                         "`repeats` reports every region, the median and the spread")
     ap.add_argument("--constraints", type=int, default=0, help="exact constraint count (default 2^log_domain - 2, i.e. a domain of exactly 2^log_domain)")
     ap.add_argument("--e2e", type=int, default=1,
                     help="after the timed region, time the reference-shaped flow `generate-proof` (program + witness + proving.key files -> "
@@ -367,6 +370,8 @@ def main():
     else:
         raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own: %d visible — one GPU per rank, or fewer ranks"
                          % (ranks.rank, local_rank, ndev))
+    pci = native.default_library().device_pci_bus_id(device)
+    placement = numa_placement(pci, pin=ranks.world > 1)      # N > 1: every rank's host threads on the NUMA node of its GPU
     ctx = native.Context(device)
     mark("context_created")
     if os.environ.get("ZKHIP_BENCH_TEST_DIE") in (os.environ.get("ZKHIP_BENCH_ATTEMPT", "-"), "*"):
@@ -407,13 +412,27 @@ def main():
         prove_many([resident[i % nw] for i in range(4)], [rs(100 + i) for i in range(4)])
     steps = [args.warmup + i for i in range(args.steps)]
     mark("warmup_done")
+    sampler = LoadSampler(pci)
+    idle_reading = sampler.read_once()
+    sampler.start()
     barrier_sync()
     t_begin = time.perf_counter()
     proofs, acc = prove_many([resident[j % nw] for j in steps], [rs(j) for j in steps])
     barrier_sync()
-    elapsed = time.perf_counter() - t_begin
+    elapsed_local = time.perf_counter() - t_begin
     mark("timed_region_done")
-    elapsed = ranks.max_over_ranks(elapsed)
+    elapsed = ranks.max_over_ranks(elapsed_local)
+    # the same region again (`value` stays the first one): how far a number taken over K x 10 ms can be trusted
+    region_ms = [1000.0 * elapsed / args.steps]
+    for rep in range(1, max(1, args.repeats)):
+        barrier_sync()
+        t0 = time.perf_counter()
+        prove_many([resident[j % nw] for j in steps], [rs(j + 1000 * rep) for j in steps])
+        barrier_sync()
+        region_ms.append(1000.0 * ranks.max_over_ranks(time.perf_counter() - t0) / args.steps)
+    sampler.stop()
+    mark("repeats_done")
+    per_rank = gather_per_rank(ranks, device, pci, placement, args.steps, elapsed_local)
     # isolated single-proof latency (not part of the timed region): resident assignment, then from host memory
     for i in range(3):
         _, tm1 = prove_one(resident[i % nw], rs(200 + i))
@@ -464,13 +483,13 @@ def main():
         traffic_ntt = pmc.get("NTT", {}).get("traffic_bytes_per_pass")
     # the honest bound of this kernel: mixed additions per second against the multiplier-limited rate of the same
     # kernel on synthetic data (tools/accum_bench.hip); one mixed addition per non-zero signed digit, W digits per scalar
-    W = (synth.FR_BITS[curve_id] + 1 + 15) // 16 if args.log_domain >= 15 else None
+    W = msm_windows(synth.FR_BITS[curve_id], m + 2) if args.log_domain >= 15 else None
     compute = None
     if W and args.curve == "bn128" and args.kind == "dense":   # (sparse / boolean witnesses drop their zero digits: no fixed addition count)
         madds = (((m + 2) if "G2" in name else (3 * (m + 2) + N)) * W)
-        peak = 5.18e9 if "G2" in name else 13.65e9
-        compute = {"unit": "mixed additions/s", "achieved": madds / (ms * 1e-3), "peak": peak, "frac": madds / (ms * 1e-3) / peak,
-                   "peak_source": "tools/accum_bench.hip on MI355X (this round's kernel on synthetic sorted lists with equal buckets, best slicing: profiles/r4l_accum_bench.txt)"}
+        peak = 5.57e9 if "G2" in name else 13.4e9
+        compute = {"unit": "mixed additions/s", "achieved": madds / (ms * 1e-3), "peak": peak, "frac": madds / (ms * 1e-3) / peak, "windows": W,
+                   "peak_source": "tools/accum_bench.hip on MI355X (this round's kernel on synthetic sorted lists with equal buckets, best slicing: profiles/r5a_accum_bench.txt)"}
         if serial and serial[key] > 0:
             compute["frac_serial"] = madds / (serial[key] * 1e-3) / peak
     # VALU issue occupation of the same kernel from the committed counter pass (tools/pmc_valu.py)
@@ -543,6 +562,12 @@ def main():
                     "witness_generation_total": 1000 * t_witness},
         "timeline_s": timeline,
         "device": ctx.describe(),
+        "repeats": {"regions": len(region_ms), "ms_per_step": region_ms, "median_ms_per_step": float(np.median(region_ms)),
+                    "spread": (max(region_ms) - min(region_ms)) / float(np.median(region_ms)),
+                    "value_of_median": world * 1000.0 / float(np.median(region_ms)),
+                    "note": "`value` / `ms_per_step` are the FIRST region; every region is K steps over the same K resident witnesses"},
+        "under_load": sampler.summary(idle_reading),
+        "per_rank": per_rank,
     }
     # ---- optional legs (latency mode): a watchdog guarantees that the throughput line is printed even if one of them hangs
     # (a collective after an asymmetric failure; the in-library path on hardware this container cannot test)
@@ -753,6 +778,120 @@ def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one):
                 "exchange": exchange}
     except Exception as e:   # the throughput line must survive a failure of the optional leg
         return {"error": repr(e)}
+
+
+def msm_windows(scalar_bits, n):
+    """Windows per scalar of a resident key's MSMs — the rule of csrc/core.cuh msm_shape(table = true): the fewest windows the widest
+    admissible width (17 bits, or log2 n + 1) gives.  254-bit scalars: 15 (17-bit windows); 255-bit: 16."""
+    lg = max(int(n), 1).bit_length() - 1
+    cmax = max(2, min(17, lg + 1))
+    return (scalar_bits + 1 + cmax - 1) // cmax
+
+
+def numa_placement(pci, pin):
+    """The NUMA node of the GPU at PCI address `pci` (/sys/bus/pci/devices/<pci>/numa_node) and, with `pin`, this process bound to
+    that node's CPUs (os.sched_setaffinity: the staging memcpy of an assignment is the host work that scales with the circuit).
+    Returns what happened, for the line's per_rank list."""
+    rec = {"pci": pci, "numa_node": None, "pinned": False}
+    try:
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci).read().strip())
+        rec["numa_node"] = node
+        if pin and node >= 0 and not os.environ.get("ZKHIP_BENCH_NO_PIN"):
+            cpus = set()
+            for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                rec["pinned"] = True
+        rec["cpus_allowed"] = len(os.sched_getaffinity(0))
+    except Exception as e:      # no such file (emulator, container without sysfs): nothing to pin to
+        rec["note"] = repr(e)[:120]
+    return rec
+
+
+def gather_per_rank(ranks, device, pci, placement, steps, elapsed_local):
+    """One record per rank — rank, device ordinal, PCI address, NUMA node, its OWN proofs/s and ms per step of the first timed
+    region (the line's `value` uses the slowest rank's time) — gathered over the process group: with N ranks the list has N entries."""
+    mine = np.array([ranks.rank, device, placement.get("numa_node") if placement.get("numa_node") is not None else -2,
+                     1.0 if placement.get("pinned") else 0.0, elapsed_local], dtype=np.float64)
+    label = (pci or "?").encode()[:16].ljust(16, b" ")
+    blob = np.frombuffer(mine.tobytes() + label, dtype=np.uint8)
+    out = []
+    for rec in ranks.all_gather_bytes(blob):
+        raw = bytes(np.asarray(rec, dtype=np.uint8))
+        v = np.frombuffer(raw[:40], dtype=np.float64)
+        out.append({"rank": int(v[0]), "device": int(v[1]), "pci": raw[40:56].decode(errors="replace").strip(),
+                    "numa_node": None if v[2] == -2 else int(v[2]), "pinned_to_numa_node": bool(v[3]),
+                    "value": steps / v[4] if v[4] > 0 else None, "ms_per_step": 1000.0 * v[4] / steps})
+    return out
+
+
+class LoadSampler:
+    """Clocks, power and temperatures of the rank's GPU WHILE the timed regions run: a host thread reads the amdgpu hwmon files of
+    the device (found through its PCI address) every few milliseconds.  The prover's calls release the GIL, so the thread runs
+    beside them; a read is a few tens of microseconds of host time.  rocm-smi after the run only ever showed an idle chip."""
+    FILES = (("power_w", ("power1_average", "power1_input"), 1e-6), ("sclk_mhz", ("freq1_input",), 1e-6), ("mclk_mhz", ("freq2_input",), 1e-6),
+             ("temp_edge_c", ("temp1_input",), 1e-3), ("temp_junction_c", ("temp2_input",), 1e-3), ("temp_mem_c", ("temp3_input",), 1e-3))
+
+    def __init__(self, pci, period_s=0.004):
+        import glob
+        import threading
+        self.period = period_s
+        self.paths = {}
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+        base = "/sys/bus/pci/devices/%s" % pci if pci else None
+        if base and os.path.isdir(base):
+            for hw in sorted(glob.glob(base + "/hwmon/hwmon*")):
+                for key, names, scale in self.FILES:
+                    for nme in names:
+                        f = os.path.join(hw, nme)
+                        if key not in self.paths and os.path.exists(f):
+                            self.paths[key] = (f, scale)
+            busy = os.path.join(base, "gpu_busy_percent")
+            if os.path.exists(busy):
+                self.paths["gpu_busy_percent"] = (busy, 1.0)
+
+    def read_once(self):
+        rec = {}
+        for key, (f, scale) in self.paths.items():
+            try:
+                with open(f) as fh:
+                    rec[key] = float(fh.read().strip()) * scale
+            except Exception:
+                pass
+        return rec
+
+    def start(self):
+        import threading
+        if not self.paths:
+            return
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self.read_once())
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2)
+
+    def summary(self, idle):
+        if not self.paths:
+            return {"source": None, "note": "no amdgpu hwmon files for this device (no sysfs view of the GPU here)"}
+        out = {"source": "amdgpu hwmon (sysfs) of the rank's GPU, sampled every %.0f ms on a host thread across the timed regions" % (1000 * self.period),
+               "samples": len(self.samples), "idle_before": idle}
+        for key in self.paths:
+            vals = [smp[key] for smp in self.samples if key in smp]
+            if vals:
+                out[key] = {"min": min(vals), "mean": sum(vals) / len(vals), "max": max(vals)}
+        return out
 
 
 def offline_evidence(root=ROOT, pkg=None):

@@ -71,6 +71,10 @@ typedef struct zkhip_timings {
 /* ---- context ---- */
 /* Number of usable HIP devices (0 if none / no runtime). */
 int32_t zkhip_device_count(void);
+/* PCI address of HIP device `device` as "dddd:bb:dd.f" (NUL-terminated, at most cap bytes): what ties a device ordinal to the
+ * host's view of the same GPU — /sys/bus/pci/devices/<address>/numa_node for the NUMA node a rank's host thread should run
+ * on, .../hwmon for clocks and power under load.  No context needed. */
+int32_t zkhip_device_pci_bus_id(int32_t device, char* out, size_t cap);
 /* Create a context on HIP device `device`. */
 int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out);
 void zkhip_ctx_free(zkhip_ctx* ctx);

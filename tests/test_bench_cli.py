@@ -46,6 +46,10 @@ def test_single_rank_contract(args, metric):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_proof_identical"] is True
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000
+    rp = d["repeats"]                                   # the timed region three times over; `value` is the first
+    assert rp["regions"] == 3 and len(rp["ms_per_step"]) == 3 and abs(rp["ms_per_step"][0] - d["ms_per_step"]) < 1e-9 and rp["spread"] >= 0
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and abs(d["per_rank"][0]["ms_per_step"] - d["ms_per_step"]) < 1e-6
+    assert "under_load" in d                            # (no sysfs view of a GPU here: the sampler says so instead of inventing numbers)
     if not with_cli_leg:
         return
     e = d["cli_end_to_end_ms"]                         # the reference-shaped flow: files -> proof.json, one process per proof
@@ -96,6 +100,9 @@ def test_gpus_flag_alone_starts_the_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "2 rank(s)" in d["config"]["process_group"] and "itself" in d["config"]["launcher"]
+    pr = d["per_rank"]                                  # one record per rank that ran, each with its own rate
+    assert len(pr) == 2 and sorted(r["rank"] for r in pr) == [0, 1] and all(r["value"] > 0 and r["device"] == 0 for r in pr)
+    assert max(r["ms_per_step"] for r in pr) <= d["ms_per_step"] * (1 + 1e-6)      # the line's time is the slowest rank's
     assert d["sharded_single_proof"]["identical_to_unsharded"] is True and d["multi_single_proof"]["identical_to_unsharded"] is True
     for k in REQUIRED:
         assert k in d, k

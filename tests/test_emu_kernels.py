@@ -92,7 +92,7 @@ def test_msm_window_sizes(ctx):
     b1, _, ks = _rand_points(BN254, 40, rnd)
     want = cpu.msm(0, 1, b1, ks)
     try:
-        for c in (2, 3, 5, 8, 13, 16):
+        for c in (2, 3, 5, 8, 13, 16, 17):      # (17: more buckets than one sort workgroup's histogram holds: two halves)
             ctx.tune("msm_c", c)
             assert ctx.msm(0, 1, b1, ks) == want, c
     finally:
@@ -290,6 +290,28 @@ def test_prove_with_thinned_tables(curve):
         img = native.ProvingKey(c2, curve.curve_id, raw).export_image()
         c2.tune("msm_sets", 0)
         assert native.prove_g16(c2, native.ProvingKey.from_image(c2, curve.curve_id, img), cs, z, 11, 13) == want
+    finally:
+        c2.close()
+
+
+def test_prove_with_17_bit_windows():
+    """254-bit scalars take 15 windows of 17 bits instead of 16 of 16 (what a key of 2^16 points or more gets by itself): 2^16
+    buckets per MSM, which the sort's workgroups take in two halves (their LDS histogram holds 2^15 counters), a fold over 256 rows
+    of 256 buckets, tables of 15 levels.  Forced here on a toy key; same proof, also through a key image."""
+    c2 = native.Context(0, emu_library())
+    try:
+        oc = cpu.Circuit.synth(0, 40, 7)
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(BN254))
+        raw = cpu.ProvingKey.setup(oc, tox).serialize()
+        cs = native.ConstraintSystem(c2, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+        z = oc.assignment()
+        want = cpu.trapdoor(oc, tox, z, 11, 13)
+        c2.tune("msm_c", 17)
+        pk = native.ProvingKey(c2, 0, raw)
+        assert native.prove_g16(c2, pk, cs, z, 11, 13) == want
+        img = pk.export_image()
+        c2.tune("msm_c", 0)
+        assert native.prove_g16(c2, native.ProvingKey.from_image(c2, 0, img), cs, z, 11, 13) == want
     finally:
         c2.close()
 

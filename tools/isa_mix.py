@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of the accumulation loop of k_msm_accum (no GPU needed).
 
-    tools/isa_mix.py g1|g2 [--sparse] [--asm FILE] [-D...]
+    tools/isa_mix.py g1|g2 [--curve bn254|bls381] [--sparse] [--asm FILE] [-D...]
 
 Compiles csrc/bn254_<group>.hip to device assembly (or reads --asm), finds the kernel's loop and cuts it at its
 WAVE-UNIFORM branch (the vote "does any lane have an infinite base / an equal-x case?"): the side every wavefront runs for a
@@ -19,11 +19,11 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def asm_for(group, flags):
+def asm_for(group, flags, curve="bn254"):
     tmp = tempfile.mkdtemp()
     out = os.path.join(tmp, group + ".s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "-Wno-unused-variable",
-                           "--cuda-device-only", "-S"] + flags + [os.path.join(ROOT, "zokrates_amd", "csrc", "bn254_%s.hip" % group), "-o", out],
+                           "--cuda-device-only", "-S"] + flags + [os.path.join(ROOT, "zokrates_amd", "csrc", "%s_%s.hip" % (curve, group)), "-o", out],
                           stderr=subprocess.DEVNULL)
     return out
 
@@ -53,9 +53,11 @@ def main():
     if "--asm" in args:
         asm = args[args.index("--asm") + 1]
     flags = [a for a in args if a.startswith("-D")]
-    path = asm or asm_for(group, flags)
+    curve = args[args.index("--curve") + 1] if "--curve" in args else "bn254"
+    path = asm or asm_for(group, flags, curve)
     src = open(path).read().split("\n")
-    ftype = "2FuINS_7Bn254FqEEE" if group == "g1" else "3Fu2INS_7Bn254FqEEE"
+    fq = "7Bn254Fq" if curve == "bn254" else "8Bls381Fq"
+    ftype = ("2FuINS_%sEEE" if group == "g1" else "3Fu2INS_%sEEE") % fq
     pat = re.compile(r"^_ZN2zk11k_msm_accumINS_" + ftype + r"Li\d+ELb" + ("1" if sparse else "0") + r"E.*:")
     start = next(i for i, l in enumerate(src) if pat.match(l))
     end = next(i for i in range(start, len(src)) if ".amdhsa_kernel" in src[i])
@@ -83,7 +85,7 @@ def main():
     else:
         hot, general = loop, []
     outside = body[:first] + body[exit_:]
-    name = "k_msm_accum<%s, SKIP_INF = %s>" % ("Fu<Bn254Fq>" if group == "g1" else "Fu2<Bn254Fq>", sparse)
+    name = "k_msm_accum<%s<%s>, SKIP_INF = %s>" % ("Fu" if group == "g1" else "Fu2", "Bn254Fq" if curve == "bn254" else "Bls381Fq", sparse)
     print("%s  %s  [%s]" % (name, " ".join(flags), ", ".join(regs)))
     for title, part in (("HOT path (every sorted entry)", hot), ("general path (vote taken: infinite base, doubling, cancellation)", general),
                         ("outside the loop (prologue, last store)", outside)):

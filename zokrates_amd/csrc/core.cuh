@@ -449,27 +449,34 @@ static inline int env_int(const char* name, int lo, int hi, int dflt) {
     if (const char* e = getenv(name)) { int v = atoi(e); if (v >= lo && v <= hi) return v; }
     return dflt;
 }
-static constexpr int MSM_MAX_C = 16;   // widest window: the sort's LDS histogram holds 2^15 counters
-static constexpr int MSM_AUTO_MAX_C = 16;   // widest window chosen automatically
+static constexpr int MSM_MAX_C = 17;         // widest window: 2^16 buckets, which the sort takes in two halves of MSM_SORT_MAX_KH counters
+static constexpr int MSM_AUTO_MAX_C = 17;    // widest window chosen automatically (resident tables)
+static constexpr int MSM_ADHOC_MAX_C = 16;   // ... and without a table (a bucket set per window: the fold grows with every bucket)
+static constexpr u32 MSM_SORT_MAX_KH = 1u << 15;   // counters of one sort workgroup's LDS histogram (128 KiB)
 // `table`: the bases carry precomputed window multiples 2^(c j) P (resident keys); otherwise one bucket set per window.
 static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, bool table, int force_c = 0, int force_sets = 0) {
     MsmShape s;
     s.n = n;
     const int lg = ilog2_floor(std::max<u64>(n, 1));
     if (table) {
-        // one fold per MSM whatever c is, so c only trades additions (n * W) against buckets (2^(c-1)): as wide as the
-        // sort's histogram allows once there are a few points per bucket
-        s.c = std::max(2, std::min(MSM_AUTO_MAX_C, lg + 1));
+        // one fold per MSM whatever c is, so c only trades additions (n * W) against buckets (2^(c-1)): the fewest windows the
+        // widest admissible width gives (a few points per bucket at least), and of the widths with that many windows the
+        // narrowest — 254-bit scalars: 15 windows of 17 bits instead of 16 of 16 (6 % fewer additions in all five MSMs for twice
+        // the buckets); 255-bit scalars need 16 windows either way and stay at 16 bits
+        const int cmax = std::max(2, std::min(MSM_AUTO_MAX_C, lg + 1));
+        const int Wmin = (scalar_bits + 1 + cmax - 1) / cmax;
+        s.c = cmax;
+        while (s.c > 2 && (scalar_bits + 1 + (s.c - 1) - 1) / (s.c - 1) == Wmin) --s.c;
     } else {
         // Window width: about log2(n) - 5 (measured optimum at 2^20: 15), but never one that leaves the top window
         // with only a few significant bits — its handful of buckets would each receive a large share of all points
         // (same-address atomics in the sort, one bucket spread over thousands of slices).
-        const int want = std::max(2, std::min(MSM_AUTO_MAX_C, lg - 5));
+        const int want = std::max(2, std::min(MSM_ADHOC_MAX_C, lg - 5));
         s.c = want;
         for (int d = 0; d <= 14; ++d) {
             bool found = false;
             for (int cand : {want + d, want - d}) {
-                if (cand < 2 || cand > MSM_AUTO_MAX_C) continue;
+                if (cand < 2 || cand > MSM_ADHOC_MAX_C) continue;
                 const int W = (scalar_bits + 1 + cand - 1) / cand;
                 const int top_bits = scalar_bits + 1 - (W - 1) * cand;
                 if (top_bits >= cand || (n >> (top_bits - 1)) <= 4096) { s.c = cand; found = true; break; }   // <= 4096 points per top bucket
@@ -514,8 +521,10 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     const unsigned T = 256;
     // one workgroup per (chunk of scalars, window): chunks several times larger than a window's bucket count keep the
     // global atomics (one per touched bucket per workgroup) well below one per digit
-    const u32 kh = sh.K;
-    const u64 want_chunks = std::max<u64>(1, (ctx->sort_wgs + sh.W - 1) / sh.W);
+    // (a window of more than 16 bits has more buckets than one histogram holds: its workgroups come in `halves`, each reading the
+    // chunk's digits and keeping the ones of its own range of buckets)
+    const u32 kh = std::min(sh.K, MSM_SORT_MAX_KH), halves = sh.K / kh;
+    const u64 want_chunks = halves > 1 ? std::max<u64>(1, ctx->sort_wgs / (sh.W * halves)) : std::max<u64>(1, (ctx->sort_wgs + sh.W - 1) / sh.W);
     const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)kh));
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
     const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;
@@ -528,10 +537,10 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     dev_memset(so.cursor.p, 0, nk * 4, s);
     lds_opt_in(ctx, (const void*)k_msm_count);
     lds_opt_in(ctx, (const void*)k_msm_place);
-    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
+    ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, halves), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
               ptr<u32>(so.cnt), keep);
     scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
-    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, 1), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
+    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, halves), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
               level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted), keep);
     event_record(so.ready, s);
 }

@@ -88,6 +88,7 @@ inline int dev_count() {
     return n;
 }
 inline void dev_set(int d) { ZK_HIP_CHECK(hipSetDevice(d)); }
+inline void dev_pci_bus_id(int d, char* out, size_t cap) { ZK_HIP_CHECK(hipDeviceGetPCIBusId(out, (int)cap, d)); }
 // Device allocations.  Two measured effects on MI355X, both on the latency-bound fold kernels (same device code, run times
 // differing by 2x between allocation patterns):
 //  * buffers whose sizes are not multiples of 2 MiB can end up on small pages -> every allocation is a whole number of
@@ -419,6 +420,7 @@ typedef int Stream;
 typedef double* Event;
 inline int dev_count() { return 1; }
 inline void dev_set(int) {}
+inline void dev_pci_bus_id(int, char* out, size_t cap) { snprintf(out, cap, "0000:00:00.0"); }   // (the emulator's one "device")
 inline void* dev_alloc(size_t bytes) { return aligned_alloc(256, ((bytes ? bytes : 16) + 255) / 256 * 256); }
 inline void dev_free(void* p) { free(p); }
 inline void* host_alloc_pinned(size_t bytes) { return dev_alloc(bytes); }

@@ -25,29 +25,29 @@
 
 namespace zk {
 
-// per point type tuning (measured on MI355X with tools/accum_bench.hip, 2^24 mixed additions on the unsaturated field:
-// G1 1.22 ms at 3 waves per SIMD; G2 3.17 ms at 2 waves per SIMD).  *_WPE = waves per SIMD the register allocator must
-// leave room for; the accumulation kernel is launched with exactly that many waves per SIMD on every CU, one slice each.
-// (G2: ONE wave per SIMD for the register allocator — 256 VGPRs + AGPRs instead of 256 VGPRs + 464 B of scratch per work-item.
-// Same speed on a fast box (profiles/r2e_g2_register_ab_runs.jsonl, variant B), and scratch is what differed between box
-// kinds; the slices stay two per SIMD lane.)
+// per point type tuning.  ACCUM_WPE: waves per SIMD the accumulation kernel's registers must leave room for; SLICE_WPE / FUSED_WPE:
+// how finely the sorted list is cut — slices per SIMD lane of a launch over one table / over the tables that share a list.
+// Round 5 (profiles/r5a_*, r5b_*: same-box sessions): with the general path of the addition out of line (ec.cuh
+// xyzz_madd_cold) the hot loop needs 128 registers for G1 and 256 for G2 without a spill — FOUR waves per SIMD for G1, TWO for G2
+// (round 4: 168 registers = three waves with four scratch accesses per step; 427 = one wave, which cannot issue more than three
+// cycles in four).  More slices than resident waves: the launch then runs in rounds and the dispatcher evens out what one round of
+// equal slices cannot (CUs do not all run at the same speed): G1 over three tables 5.43 ms at 5 slices per lane, 4.96 at 6, 5.15 at
+// 8, 5.78 at 4 (= one round); G2 3.38 ms at 2, 3.30 at 4.
 #ifndef ZK_G2_ACCUM_WPE
-#define ZK_G2_ACCUM_WPE 1
+#define ZK_G2_ACCUM_WPE 2
 #endif
-// ACCUM_WPE: accumulation waves per SIMD of one MSM; FUSED_WPE: of a launch that runs several MSMs over one sorted list
 #ifndef ZK_G1_FUSED_WPE
-#define ZK_G1_FUSED_WPE 5
+#define ZK_G1_FUSED_WPE 6
 #endif
 #ifndef ZK_G1_SLICE_WPE
-#define ZK_G1_SLICE_WPE 3
+#define ZK_G1_SLICE_WPE 4
 #endif
 #ifndef ZK_G2_SLICE_WPE
-#define ZK_G2_SLICE_WPE 2
+#define ZK_G2_SLICE_WPE 4
 #endif
 #ifndef ZK_G2_COLD_WPE
 #define ZK_G2_COLD_WPE 1
 #endif
-// (ACCUM_WPE is the kernel's register budget, SLICE_WPE / FUSED_WPE how finely the sorted list is cut: slices per SIMD lane)
 #ifndef ZK_G2_PREFETCH_REGS
 #define ZK_G2_PREFETCH_REGS 1
 #endif
@@ -62,13 +62,31 @@ namespace zk {
 #define ZK_G2_XY_LDS 0
 #endif
 #ifndef ZK_G1_ACCUM_WPE
-#define ZK_G1_ACCUM_WPE 3
+#define ZK_G1_ACCUM_WPE 4
 #endif
 template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = ZK_G1_ACCUM_WPE, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = ZK_G1_ZZ_LDS != 0, XY_IN_LDS = false; };
 template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false, XY_IN_LDS = false; };
 template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = ZK_G2_PREFETCH_REGS != 0, ZZ_IN_LDS = ZK_G2_ZZ_LDS != 0, XY_IN_LDS = ZK_G2_XY_LDS != 0; };
-template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 3, FUSED_WPE = 3, SLICE_WPE = 2; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = false, XY_IN_LDS = false; };
-template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = 1, COLD_WPE = 1, FUSED_WPE = 1, SLICE_WPE = 1; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false, XY_IN_LDS = false; };
+#ifndef ZK_BLS_G1_ACCUM_WPE
+#define ZK_BLS_G1_ACCUM_WPE 2
+#endif
+#ifndef ZK_BLS_G2_ACCUM_WPE
+#define ZK_BLS_G2_ACCUM_WPE 1
+#endif
+#ifndef ZK_BLS_G1_FUSED_WPE
+#define ZK_BLS_G1_FUSED_WPE 3
+#endif
+#ifndef ZK_BLS_G1_SLICE_WPE
+#define ZK_BLS_G1_SLICE_WPE 2
+#endif
+#ifndef ZK_BLS_G2_SLICE_WPE
+#define ZK_BLS_G2_SLICE_WPE 1
+#endif
+#ifndef ZK_BLS_G2_ZZ_LDS
+#define ZK_BLS_G2_ZZ_LDS 0
+#endif
+template <> struct MsmTuning<Fu<Bls381Fq>> { static constexpr int ACCUM_WPE = ZK_BLS_G1_ACCUM_WPE, COLD_WPE = 3, FUSED_WPE = ZK_BLS_G1_FUSED_WPE, SLICE_WPE = ZK_BLS_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = false, XY_IN_LDS = false; };
+template <> struct MsmTuning<Fu2<Bls381Fq>> { static constexpr int ACCUM_WPE = ZK_BLS_G2_ACCUM_WPE, COLD_WPE = 1, FUSED_WPE = ZK_BLS_G2_SLICE_WPE, SLICE_WPE = ZK_BLS_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = ZK_BLS_G2_ZZ_LDS != 0, XY_IN_LDS = false; };
 // dynamic LDS of one accumulation workgroup (256 work-items): the coordinates of the running sum that live there, word-major
 template <class F> constexpr size_t msm_accum_lds_bytes() { return (size_t)((MsmTuning<F>::ZZ_IN_LDS ? 2 : 0) + (MsmTuning<F>::XY_IN_LDS ? 2 : 0)) * (sizeof(F) / 4) * 256 * 4; }
 // the base tables of the MSMs one launch serves (A, B1 and L of a proof share the sort of the assignment)
@@ -361,9 +379,11 @@ __device__ __forceinline__ void zk_pin_words(T& obj) {
 }
 #define ZK_PIN_WORDS(x) zk_pin_words(x)
 #define ZK_LDS_REREAD() asm volatile("" ::: "memory")
+#define ZK_OPAQUE(x) asm volatile("" : "+v"(x))      /* the compiler may not assume it knows this 32-bit value: nothing derived from it is hoisted */
 #else
 #define ZK_PIN_WORDS(x) ((void)0)
 #define ZK_LDS_REREAD() ((void)0)
+#define ZK_OPAQUE(x) ((void)0)
 #endif
 // a point the instruction scheduler may not move anything across: between the products of the hot addition it keeps the compiler
 // from interleaving independent products (whose operands and columns would then all be live at once)
@@ -395,7 +415,10 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
     // (lane_key[g] < nkeys says g * P < total, and the list is shorter than 2^32 entries: positions are 32-bit)
     const u32 p0 = g * P;
     const u32 p1 = total - p0 > P ? p0 + P : total;
-    u32 end = off[cur + 1];
+    // `end`: where the lane's current bucket ends; `nend`: where the NEXT one does — fetched one bucket ahead, so that crossing a
+    // boundary never waits for memory (buckets are a few hundred entries deep: some lane of a wavefront crosses one every few
+    // steps, and a wait parks all 64 — 8-12 % of the wave cycles of round 4's kernel, profiles/r5a_stall_r4.md)
+    u32 end = off[cur + 1], nend = off[cur + 2 < nkeys ? cur + 2 : nkeys];
     ZK_ASSERT_IDX((u64)g * P < total && off[cur] <= p0 && p0 < end && (u64)nkeys + cut.nlanes <= partial_stride);
     // The running sum: X and Y in registers; ZZ and ZZZ in registers too, or (ZZ_IN_LDS) in the lane's own words of LDS — each is
     // read twice and written once per addition, and the 36 registers they would hold through the whole step are what decides
@@ -424,7 +447,9 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
     auto whole = [&]() -> Xyzz<F> { return {get_xy(0), get_xy(1), get_zz(0), get_zz(1)}; };
     auto set_whole = [&](const Xyzz<F>& t) { put_xy(0, t.x); put_xy(1, t.y); put_zz(0, t.zz); put_zz(1, t.zzz); };
     set_whole(Xyzz<F>::inf());
-    u32 e = sorted[p0];
+    // the sorted entries travel TWO steps ahead of their use (e: the next step's, whose base is fetched now; e_ahead: the one
+    // after), the bases one: no address of this loop is computed from a load of the same step
+    u32 e = sorted[p0], e_ahead = sorted[p0 + 1 < p1 ? p0 + 1 : p0];
     ZK_ASSERT_IDX((e & 0x7fffffffu) < cut.table_len);
     constexpr bool IN_REGS = MsmTuning<F>::PREFETCH_REGS;
     u32 w[NW2];
@@ -442,15 +467,28 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
         Aff<F> pt = aff_unpack<F>(w);
         if (IN_REGS) ZK_PIN_WORDS(pt);          // (the unpacking is complete HERE: the fetch below may overwrite the packed words in place)
         const bool neg = (e_cur & 0x80000000u) != 0;
-        e = sorted[pos + 1 < p1 ? pos + 1 : pos];
+        if (pos == end) {
+            const u32 done = cur;
+            do {           // (more than one round only across empty buckets; the new fetch goes out BEFORE the stores below: taking
+                ++cur;     // `nend` waits for whatever is in flight, and at this point that is nothing recent)
+                ZK_ASSERT_IDX(cur < nkeys);
+                end = nend;
+                nend = off[cur + 2 < nkeys ? cur + 2 : nkeys];
+            } while (end <= pos);
+            // (the slot's address is computed HERE from the lane's number: kept across the loop as a lane-invariant 64-bit value it
+            // was spilled, and its reload waited for the fetch above)
+            u32 g_here = g;
+            ZK_OPAQUE(g_here);
+            partial[(u64)done + g_here] = whole();  // (invariant: whenever `first` holds here, the sum IS the empty one — see the general path)
+            first = true;
+        }
+        // (the fetches of this step are issued AFTER the boundary code: what that code waits for — the bucket end fetched a whole bucket
+        // ago, as far as the hardware's in-order counter is concerned everything in flight — must not include loads issued just now)
+        e = e_ahead;                                   // entry pos + 1 (the last step fetches its own entry's base again)
+        e_ahead = sorted[pos + 2 < p1 ? pos + 2 : p1 - 1];
         ZK_ASSERT_IDX((e & 0x7fffffffu) < cut.table_len);
         if (IN_REGS) aff_load_words<F>(bases, e & 0x7fffffffu, w);
         else touched |= ((const volatile u32*)(bases + (e & 0x7fffffffu)))[0];
-        if (pos == end) {
-            partial[(u64)cur + g] = whole();  // (invariant: whenever `first` holds here, the sum IS the empty one — see the general path)
-            first = true;
-            do { ++cur; ZK_ASSERT_IDX(cur < nkeys); end = off[cur + 1]; } while (end <= pos);
-        }
         // Lanes of one wavefront are at different places of their slices: at every step some lane starts a new bucket while the
         // others add.  Written as nested per-lane branches (empty sum? equal x? infinite base?) that costs three re-convergence
         // points per step with a copy of the whole accumulator at each.  Instead EVERY lane computes Pp and R, and the one case

@@ -69,6 +69,15 @@ extern "C" {
 
 int32_t zkhip_device_count(void) { return dev_count(); }
 
+int32_t zkhip_device_pci_bus_id(int32_t device, char* out, size_t cap) {
+    if (!out || cap < 13) { g_create_err = "out is NULL or shorter than 13 bytes"; return ZKHIP_ERR_BAD_ARG; }
+    out[0] = 0;
+    return guarded(nullptr, [&] {
+        require(device >= 0 && device < dev_count(), ZKHIP_ERR_BAD_ARG, "device index out of range");
+        dev_pci_bus_id(device, out, cap);
+    });
+}
+
 int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
     if (!out) { g_create_err = "out is NULL"; return ZKHIP_ERR_BAD_ARG; }
     *out = nullptr;

@@ -49,7 +49,7 @@ class Library:
     """One loaded copy of the C ABI."""
 
     SYMBOLS = [
-        "zkhip_device_count", "zkhip_ctx_create", "zkhip_ctx_free", "zkhip_last_error", "zkhip_pk_load_g16",
+        "zkhip_device_count", "zkhip_device_pci_bus_id", "zkhip_ctx_create", "zkhip_ctx_free", "zkhip_last_error", "zkhip_pk_load_g16",
         "zkhip_pk_free", "zkhip_pk_dims", "zkhip_r1cs_load", "zkhip_r1cs_free", "zkhip_prove_g16",
         "zkhip_prove_g16_batch", "zkhip_assignment_upload", "zkhip_assignment_free", "zkhip_prove_g16_resident", "zkhip_prove_g16_resident_batch",
         "zkhip_pk_load_g16_shard", "zkhip_partial_size", "zkhip_prove_g16_partial", "zkhip_combine_g16", "zkhip_ntt", "zkhip_witness_map", "zkhip_msm_g1", "zkhip_msm_g2",
@@ -74,6 +74,7 @@ class Library:
         vp, u64, u32, i32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_size_t
         pp = C.POINTER(C.c_void_p)
         L.zkhip_device_count.restype = i32
+        L.zkhip_device_pci_bus_id.restype = i32; L.zkhip_device_pci_bus_id.argtypes = [i32, C.c_char_p, sz]
         L.zkhip_ctx_create.restype = i32; L.zkhip_ctx_create.argtypes = [i32, pp]
         L.zkhip_ctx_free.restype = None; L.zkhip_ctx_free.argtypes = [vp]
         L.zkhip_ctx_tune.restype = i32; L.zkhip_ctx_tune.argtypes = [vp, i32, i32]
@@ -140,6 +141,13 @@ class Library:
 
     def device_count(self):
         return int(self.L.zkhip_device_count())
+
+    def device_pci_bus_id(self, device):
+        """"dddd:bb:dd.f" of HIP device `device`: /sys/bus/pci/devices/<that>/numa_node, .../hwmon (None if the runtime cannot tell)."""
+        buf = C.create_string_buffer(32)
+        if self.L.zkhip_device_pci_bus_id(int(device), buf, 32) != 0:
+            return None
+        return buf.value.decode().lower() or None
 
 
 _default = None
