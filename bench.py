@@ -39,7 +39,8 @@ import sys
 import time
 
 T_PROCESS_START = time.time()
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: the library drives 7 streams per context
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (torch may start it before libzkhip is loaded, whose own
+                                                    # constructor asks for the same): the library drives ~20 streams per context
 
 
 def supervise():
@@ -404,12 +405,16 @@ def main():
         prove_one = lambda a, rnd: (native.prove_g16_resident if isinstance(a, native.Assignment) else native.prove_g16)(ctx, pk, cs, a, *rnd, want_timings=True)
         prove_many = lambda aa, rnds: native.prove_g16_resident_batch(ctx, pk, cs, aa, rnds)
     single = []
-    for i in range(args.warmup):
-        _, tm1 = prove_one(resident[i % nw], rs(i))
+    if args.warmup:
+        # The W warm-up steps run the way the timed steps do — through the pipelined batch call — so that the timed region starts
+        # on a chip in the state it will be measured in (clocks and power ramp over the first tens of milliseconds of load: with
+        # W isolated proofs as warm-up the first of three identical regions was 1-2.5 % slower than the third,
+        # profiles/r5c_bench_driver_command.json).  Every proof slot the library can keep in flight (ZK_NSLOTS = 4) allocates its
+        # workspaces the first time it is used, so never fewer than 4 proofs; one isolated proof first (its latency is reported).
+        _, tm1 = prove_one(resident[0], rs(0))
         single.append(tm1["total_ms"])
-    if args.warmup:   # warm the pipelined path too: every proof slot the library can keep in flight (ZK_NSLOTS = 4) allocates
-        # its workspaces the first time it is used, and none of that belongs in the timed region
-        prove_many([resident[i % nw] for i in range(4)], [rs(100 + i) for i in range(4)])
+        nwarm = max(args.warmup, 4)
+        prove_many([resident[i % nw] for i in range(nwarm)], [rs(100 + i) for i in range(nwarm)])
     steps = [args.warmup + i for i in range(args.steps)]
     mark("warmup_done")
     sampler = LoadSampler(pci)
@@ -686,10 +691,14 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
 
         t_leg = time.perf_counter()
 
+        gap_s = float(os.environ.get("ZKHIP_BENCH_CLI_GAP_S", "0"))
+
         def run(name, extra, exe=None):
             if time.perf_counter() - t_leg > 150:          # the leg must never hold the throughput line back for long
                 res[name] = {"skipped": "time budget of this leg (150 s) spent"}
                 return
+            if gap_s > 0:                                  # (experiment: does a process pay for the previous one's teardown in the driver?)
+                time.sleep(gap_s)
             if os.path.exists(paths["proof.json"]):
                 os.remove(paths["proof.json"])
             cmd = ([exe] if exe else [sys.executable, "-m", _pkg + ".cli"]) + [

@@ -154,6 +154,8 @@ struct zkhip_ctx {
     int ntt_max_sublog = 11;  // largest sub-transform of a pass (2^11 elements staged per sequence); domains above twice this take three passes
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
     u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
+    int sort_kh_log = 15;     // log2 of the counters of one sort workgroup's LDS histogram (ZKHIP_SORT_KH_LOG: development knob — a smaller
+                              // histogram leaves LDS to the kernels beside it and reads the digits once more per halving)
     int nslots = 3;           // proofs in flight in the batch calls (<= ZK_NSLOTS; measured 2 / 3 / 4: 72.0 / 76.0 / 74.8 proofs/s)
     std::string err;
     std::string desc;
@@ -523,7 +525,7 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     // global atomics (one per touched bucket per workgroup) well below one per digit
     // (a window of more than 16 bits has more buckets than one histogram holds: its workgroups come in `halves`, each reading the
     // chunk's digits and keeping the ones of its own range of buckets)
-    const u32 kh = std::min(sh.K, MSM_SORT_MAX_KH), halves = sh.K / kh;
+    const u32 kh = std::min(sh.K, std::min(MSM_SORT_MAX_KH, 1u << ctx->sort_kh_log)), halves = sh.K / kh;
     const u64 want_chunks = halves > 1 ? std::max<u64>(1, ctx->sort_wgs / (sh.W * halves)) : std::max<u64>(1, (ctx->sort_wgs + sh.W - 1) / sh.W);
     const u64 max_chunks = std::max<u64>(1, sh.n / (2 * (u64)kh));
     const u64 sort_chunks = std::min(want_chunks, max_chunks);

@@ -65,6 +65,15 @@ static int32_t guarded_host(Fn&& fn) {
         return ZKHIP_ERR_PARSE;
     }
 }
+#ifndef ZK_EMU
+// The library keeps ~20 HIP streams busy per context (a stream per proof slot and MSM, the transform pipeline, staging, copy-out);
+// the runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams that share a queue
+// serialise: 16 queues measured +1.5-2 % proofs/s over 8 and +6 % over 4 (profiles/r5d_scheduling_knobs.txt).  The runtime reads
+// the variable when it initialises (the first HIP call of the process), so the library sets it when it is loaded — unless the
+// process, or a HIP user that initialised the runtime earlier, has decided already.
+__attribute__((constructor)) static void zkhip_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+#endif
+
 extern "C" {
 
 int32_t zkhip_device_count(void) { return dev_count(); }
@@ -109,6 +118,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->msm_g1_waves = env_int("ZKHIP_MSM_G1_WAVES", 1, 16, 0);
         ctx->msm_g2_waves = env_int("ZKHIP_MSM_G2_WAVES", 1, 16, 0);
         ctx->sort_wgs = (u32)env_int("ZKHIP_SORT_WGS", 16, 4096, 256);
+        ctx->sort_kh_log = env_int("ZKHIP_SORT_KH_LOG", 8, 15, 15);
         // every (slot, lane) has a stream of its own: with one stream per lane shared by the slots, the accumulation of
         // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
         // fold workgroup holding the machine 16 % of the time).  Slot 0 — the one single proofs and the primitives use — is
