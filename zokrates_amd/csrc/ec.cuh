@@ -261,6 +261,9 @@ ZK_HD_CALL Xyzz<F> xyzz_madd_cold(const Xyzz<F> a, const Aff<F> p) {
     return t;
 }
 
+#ifndef ZK_FOLD_DBL_CALL
+#define ZK_FOLD_DBL_CALL 1
+#endif
 template <class F>
 ZK_HD void xyzz_add_acc(Xyzz<F>& a, const Xyzz<F>& b) {   // a += b, both XYZZ
     if (b.is_inf()) return;
@@ -270,7 +273,9 @@ ZK_HD void xyzz_add_acc(Xyzz<F>& a, const Xyzz<F>& b) {   // a += b, both XYZZ
     F Pp = fe_sub_k<2>(ec_mul(b.x, a.zz), U1);            // < 4p
     F R = fe_sub_k<2>(ec_mul(b.y, a.zzz), S1);
     if (fe_is_zero_modp(Pp)) {
-        a = fe_is_zero_modp(R) ? xyzz_dbl_inl(a) : Xyzz<F>::inf();
+        // (equal points: practically never among bucket sums — the doubling is a CALL, so that its temporaries do not set the register
+        // count of the fold kernels, whose waves sit beside the accumulation's: ZK_FOLD_DBL_CALL)
+        a = fe_is_zero_modp(R) ? (ZK_FOLD_DBL_CALL ? xyzz_dbl(a) : xyzz_dbl_inl(a)) : Xyzz<F>::inf();
         return;
     }
     F PP = ec_sqr(Pp);

@@ -45,8 +45,12 @@ namespace zk {
 #ifndef ZK_G2_SLICE_WPE
 #define ZK_G2_SLICE_WPE 4
 #endif
+// COLD_WPE: the register budget of the fold / heavy-bucket kernels, whose waves sit BESIDE the accumulation's: a fold wave of 361
+// registers (round 4's G2 fold) leaves a SIMD room for one G1 accumulation wave and no G2 one for as long as it runs.  With the
+// doubling of their general addition out of line (ec.cuh ZK_FOLD_DBL_CALL) they get by with the accumulation's own budgets:
+// same box, 101-103 proofs/s at 3 / 1 waves per SIMD, 105-106 at 4 / 2 (profiles/r5f_fold_register_budgets_ab.txt).
 #ifndef ZK_G2_COLD_WPE
-#define ZK_G2_COLD_WPE 1
+#define ZK_G2_COLD_WPE 2
 #endif
 #ifndef ZK_G2_PREFETCH_REGS
 #define ZK_G2_PREFETCH_REGS 1
@@ -64,7 +68,10 @@ namespace zk {
 #ifndef ZK_G1_ACCUM_WPE
 #define ZK_G1_ACCUM_WPE 4
 #endif
-template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = ZK_G1_ACCUM_WPE, COLD_WPE = 3, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = ZK_G1_ZZ_LDS != 0, XY_IN_LDS = false; };
+#ifndef ZK_G1_COLD_WPE
+#define ZK_G1_COLD_WPE 4
+#endif
+template <class F> struct MsmTuning { static constexpr int ACCUM_WPE = ZK_G1_ACCUM_WPE, COLD_WPE = ZK_G1_COLD_WPE, FUSED_WPE = ZK_G1_FUSED_WPE, SLICE_WPE = ZK_G1_SLICE_WPE; static constexpr bool IS_EXT = false, PREFETCH_REGS = true, ZZ_IN_LDS = ZK_G1_ZZ_LDS != 0, XY_IN_LDS = false; };
 template <class P_> struct MsmTuning<Fe2<P_>> { static constexpr int ACCUM_WPE = 2, COLD_WPE = 2, FUSED_WPE = 2, SLICE_WPE = 2; static constexpr bool IS_EXT = true, PREFETCH_REGS = true, ZZ_IN_LDS = false, XY_IN_LDS = false; };
 template <class P_> struct MsmTuning<Fu2<P_>> { static constexpr int ACCUM_WPE = ZK_G2_ACCUM_WPE, COLD_WPE = ZK_G2_COLD_WPE, FUSED_WPE = ZK_G2_SLICE_WPE, SLICE_WPE = ZK_G2_SLICE_WPE; static constexpr bool IS_EXT = true, PREFETCH_REGS = ZK_G2_PREFETCH_REGS != 0, ZZ_IN_LDS = ZK_G2_ZZ_LDS != 0, XY_IN_LDS = ZK_G2_XY_LDS != 0; };
 #ifndef ZK_BLS_G1_ACCUM_WPE
