@@ -95,7 +95,7 @@ struct NttPlanBase {
 };
 // result of one classification / digit / counting-sort pass; shared (read-only) by every base set paired with those scalars
 struct MsmSort {
-    DBuf wm, sorted, cnt, off, cursor, chunk_sum, grand;   // wm: the scalars in word-major order
+    DBuf dig, sorted, cnt, off, cursor, chunk_sum, grand;   // dig: the scalars' signed digits, window-major (k_msm_digits)
     Event ready = nullptr;   // recorded on the main stream when the pass is complete
 };
 // workspace and stream of one MSM: the five MSMs of a proof are independent once their scalars are sorted, and the
@@ -512,13 +512,13 @@ static inline void scan_u32(Stream s, const DBuf& cnt, DBuf& off, u64 nk, DBuf& 
 }
 // digits + counting sort on the main stream; leaves so.off / so.sorted describing every bucket's point list.
 // level_stride: distance between two levels of the base tables this sort will be paired with (table mode), else 0.
-// `keep`: bitmap of the scalars that take part (null: all); `wm_of`: a sort of the SAME scalars whose word-major copy is reused
+// `keep`: bitmap of the scalars that take part (null: all); `wm_of`: a sort of the SAME scalars (same shape) whose digits are reused
 static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32* d_scalars, const MsmShape& sh, u64 level_stride,
                                const u32* keep = nullptr, const MsmSort* wm_of = nullptr) {
     const u64 nk = sh.nkeys;
     require(sh.n * (u64)sh.W < ((u64)1 << 32) - sh.nkeys, ZKHIP_ERR_BAD_ARG, "MSM too large for 32-bit sort offsets");
     require(level_stride * (u64)sh.levels < ((u64)1 << 31) && sh.n < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "MSM too large for 31-bit table indices");
-    if (!wm_of) so.wm.ensure(sh.n * 32);
+    if (!wm_of) so.dig.ensure(sh.n * (u64)sh.W * 4);
     so.sorted.ensure(sh.n * sh.W * 4);
     const unsigned T = 256;
     // one workgroup per (chunk of scalars, window): chunks several times larger than a window's bucket count keep the
@@ -531,8 +531,8 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
     const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;
     const size_t hist_bytes = (size_t)kh * 4;
-    if (!wm_of) ZK_LAUNCH(k_scalars_to_word_major, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, ptr<u32>(so.wm));
-    const u32* wm = wm_of ? ptr<u32>(wm_of->wm) : ptr<u32>(so.wm);
+    if (!wm_of) ZK_LAUNCH(k_msm_digits, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, sh.c, sh.W, ptr<u32>(so.dig));
+    const u32* wm = wm_of ? ptr<u32>(wm_of->dig) : ptr<u32>(so.dig);
     so.cnt.ensure(nk * 4);
     so.cursor.ensure(nk * 4);
     dev_memset(so.cnt.p, 0, nk * 4, s);

@@ -163,53 +163,53 @@ static constexpr u32 MSM_HEAVY = 16;  // a bucket spread over more slices than t
 // ---- 1. signed-digit recoding, counting sort — window-major, histograms in LDS ----
 // One scalar produces W digits; doing the sort with one global atomic per digit makes it atomic-bound (17.8 M atomics per
 // pass at 2^20).  Here a workgroup owns ONE window of a chunk of scalars, so all its keys fall into one set of K buckets:
-// the histogram lives in LDS (K x 4 B <= 128 KB) and only one global atomic per touched (workgroup, bucket) remains.
-// Scalars are first transposed to word-major order so that a window reads the two 32-bit words it needs with unit stride.
+// the histogram lives in LDS (up to 128 KiB) and only one global atomic per touched (workgroup, bucket) remains.
+// The digits are computed ONCE (k_msm_digits: one work-item per scalar walks its windows with the carry in a register) and laid
+// down window-major, dig[j * n + i]: the count and place passes then read one coalesced word per entry — round 4 recomputed every
+// digit from the scalar's words in each of the three passes over it (and once more per half with 17-bit windows), four dependent
+// global loads per entry at two waves per SIMD, which is what those kernels' time was (0.6 ms per sort at c = 17; now ~0.2).
 // Window j belongs to bucket set j % sets and pairs with table level j / sets (level t holds 2^(c sets t) P): sets = 1 — every
 // window multiple precomputed, ONE bucket set; sets = W — no table, a bucket set per window; in between, keys too large for
 // W levels of every base (domains above 2^24) keep every sets-th multiple and fold `sets` bucket sets.
 // key = (j % sets) * K + bucket;  sorted entry = ((j / sets) * idx_stride + i) | sign << 31 (idx_stride = table level stride).
-static __global__ void k_scalars_to_word_major(const u32* __restrict__ scalars, u64 n, u32* __restrict__ wm) {
+// Signed digit of window j: bucket (|d| - 1) | sign << 31, or MSM_NO_DIGIT.  digit = raw + carry_in, minus 2^c (and a carry out)
+// when that exceeds K = 2^(c-1); zero digits are dropped (a scalar 0 costs nothing, a scalar 1 is one entry of bucket 0).
+static __global__ void k_msm_digits(const u32* __restrict__ scalars, u64 n, int c, int W, u32* __restrict__ dig) {
     ZK_PRIO_HIGH();
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint4* sp = (const uint4*)(scalars + i * 8);
-    const uint4 lo = sp[0], hi = sp[1];
-    wm[0 * n + i] = lo.x; wm[1 * n + i] = lo.y; wm[2 * n + i] = lo.z; wm[3 * n + i] = lo.w;
-    wm[4 * n + i] = hi.x; wm[5 * n + i] = hi.y; wm[6 * n + i] = hi.z; wm[7 * n + i] = hi.w;
-}
-// bits [bit, bit + c) of scalar i (zero beyond bit 255)
-static __device__ __forceinline__ u32 msm_window_raw(const u32* __restrict__ wm, u64 n, u64 i, int bit, int c) {
-    if (bit >= 256) return 0;
-    const int limb = bit >> 5, off = bit & 31;
-    u64 two = wm[(u64)limb * n + i];
-    if (off + c > 32 && limb + 1 < 8) two |= (u64)wm[(u64)(limb + 1) * n + i] << 32;
-    return (u32)(two >> off) & ((1u << c) - 1);
-}
-// Signed digit of window j: bucket (|d| - 1) | sign << 31, or MSM_NO_DIGIT.  digit = raw + carry_in, minus 2^c (and a
-// carry out) when that exceeds K = 2^(c-1).  The carry into window j is decided by window j-1 alone unless its raw
-// value is exactly K, in which case it inherits the carry from below.
-static __device__ __forceinline__ u32 msm_window_digit(const u32* __restrict__ wm, u64 n, u64 i, int j, int c, u32 K) {
-    u32 raw = msm_window_raw(wm, n, i, j * c, c);
-    for (int jj = j - 1; jj >= 0; --jj) {
-        const u32 r = msm_window_raw(wm, n, i, jj * c, c);
-        if (r > K) { raw += 1; break; }
-        if (r < K) break;
+    const u32* __restrict__ sw = scalars + i * 8;        // 8 canonical words (their 32 bytes stay in the cache across the windows)
+    const u32 K = 1u << (c - 1), full = 1u << c;
+    u32 carry = 0;
+    for (int j = 0; j < W; ++j) {
+        const int bit = j * c;
+        u32 raw = 0;
+        if (bit < 256) {
+            const int limb = bit >> 5, offb = bit & 31;
+            u64 two = sw[limb];
+            if (offb + c > 32 && limb + 1 < 8) two |= (u64)sw[limb + 1] << 32;
+            raw = (u32)(two >> offb) & (full - 1);
+        }
+        raw += carry;
+        u32 d;
+        if (raw > K) {
+            const u32 mag = full - raw;                   // raw == 2^c (an all-ones window plus the carry) is digit 0 with a carry out
+            d = mag ? ((mag - 1) | 0x80000000u) : MSM_NO_DIGIT;
+            carry = 1;
+        } else {
+            d = raw ? raw - 1 : MSM_NO_DIGIT;
+            carry = 0;
+        }
+        dig[(u64)j * n + i] = d;
     }
-    if (raw > K) {
-        const u32 mag = (1u << c) - raw;   // raw == 2^c (all-ones digit + carry) is digit 0 with a borrow
-        return mag ? ((mag - 1) | 0x80000000u) : MSM_NO_DIGIT;
-    }
-    return raw ? raw - 1 : MSM_NO_DIGIT;
 }
-// grid (nchunks, W); dynamic LDS K x 4 B (K <= 2^15: windows up to c = 16).  cnt[key] += number of digits with that key in this chunk.
-// (Wider windows — a second sort pass on the high bits of the bucket, a three-digit fold — were built and measured in round 3:
-// c = 20 saves 14-28 % of the accumulation and gives it back in the sort and in a fold over 2^19 buckets, break-even at best at
-// 2^22, profiles/r3d_window_width_sweep.txt; round 4 removed them.)
 // `keep` (may be null: everything takes part): bit i CLEAR = scalar i takes no part — the sort of the B-family MSMs leaves out the
 // variables whose bases are the point at infinity (zkhip_pk::thin_keep).
 static __device__ __forceinline__ bool msm_skipped(const u32* __restrict__ keep, u64 i) { return keep && !((keep[i >> 5] >> (i & 31)) & 1u); }
-static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
+static constexpr int MSM_SORT_ILP = 4;     // entries a work-item of the sort has in flight per round (their loads are issued together)
+// grid (nchunks, W, K / kh); dynamic LDS kh x 4 B (kh <= 2^15: a window of more than 16 bits comes in halves, blockIdx.z, each
+// workgroup keeping the digits of its own range of buckets).  cnt[key] += number of digits with that key in this chunk.
+static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32* __restrict__ dig, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
                                                         u32* __restrict__ cnt, const u32* __restrict__ keep) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
@@ -217,23 +217,29 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_count(const u32*
     const u32 K = 1u << (c - 1);
     const int j = blockIdx.y;
     const u32 b0 = blockIdx.z * kh;
+    const u32* __restrict__ dj = dig + (u64)j * n;
     for (u32 b = threadIdx.x; b < kh; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        if (msm_skipped(keep, i)) continue;
-        const u32 d = msm_window_digit(wm, n, i, j, c, K);
-        if (d == MSM_NO_DIGIT) continue;
-        const u32 b = (d & 0x7fffffffu) - b0;
-        if (b < kh) atomicAdd(&hist[b], 1u);
+    for (u64 i = i0 + threadIdx.x; i < i1; i += (u64)MSM_SORT_ILP * blockDim.x) {
+        u32 d[MSM_SORT_ILP];
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            const u64 ii = i + (u64)q * blockDim.x;
+            d[q] = (ii < i1 && !msm_skipped(keep, ii)) ? dj[ii] : MSM_NO_DIGIT;
+        }
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            if (d[q] == MSM_NO_DIGIT) continue;
+            const u32 b = (d[q] & 0x7fffffffu) - b0;
+            if (b < kh) atomicAdd(&hist[b], 1u);
+        }
     }
     __syncthreads();
     for (u32 b = threadIdx.x; b < kh; b += blockDim.x)
         if (hist[b]) atomicAdd(&cnt[(u64)((u32)j % sets) * K + b0 + b], hist[b]);
 }
 // same geometry; after the scan: reserve this workgroup's run inside every bucket it touches (one global atomic per
-// bucket), then place the entries with LDS atomics.
-static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32* __restrict__ wm, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
+// bucket, several in flight per work-item), then place the entries with LDS atomics.
+static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32* __restrict__ dig, u64 n, int c, int W, u64 chunk, u32 sets, u32 kh,
                                                         u64 idx_stride, const u32* __restrict__ off, u32* __restrict__ cursor,
                                                         u32* __restrict__ sorted, const u32* __restrict__ keep) {
     ZK_PRIO_HIGH();
@@ -242,34 +248,53 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32*
     const u32 K = 1u << (c - 1);
     const int j = blockIdx.y;
     const u32 b0 = blockIdx.z * kh;
+    const u32* __restrict__ dj = dig + (u64)j * n;
     for (u32 b = threadIdx.x; b < kh; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        if (msm_skipped(keep, i)) continue;
-        const u32 d = msm_window_digit(wm, n, i, j, c, K);
-        if (d == MSM_NO_DIGIT) continue;
-        const u32 b = (d & 0x7fffffffu) - b0;
-        if (b < kh) atomicAdd(&hist[b], 1u);
+    for (u64 i = i0 + threadIdx.x; i < i1; i += (u64)MSM_SORT_ILP * blockDim.x) {
+        u32 d[MSM_SORT_ILP];
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            const u64 ii = i + (u64)q * blockDim.x;
+            d[q] = (ii < i1 && !msm_skipped(keep, ii)) ? dj[ii] : MSM_NO_DIGIT;
+        }
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            if (d[q] == MSM_NO_DIGIT) continue;
+            const u32 b = (d[q] & 0x7fffffffu) - b0;
+            if (b < kh) atomicAdd(&hist[b], 1u);
+        }
     }
     __syncthreads();
-    for (u32 b = threadIdx.x; b < kh; b += blockDim.x) {
-        const u32 have = hist[b];
-        if (!have) continue;
-        const u64 key = (u64)((u32)j % sets) * K + b0 + b;
-        hist[b] = off[key] + atomicAdd(&cursor[key], have);   // global position of this workgroup's first entry
+    const u64 key0 = (u64)((u32)j % sets) * K + b0;
+    for (u32 b = threadIdx.x; b < kh; b += MSM_SORT_ILP * blockDim.x) {
+        u32 have[MSM_SORT_ILP], start[MSM_SORT_ILP];
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            const u32 bq = b + q * blockDim.x;
+            have[q] = bq < kh ? hist[bq] : 0;
+        }
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            const u32 bq = b + q * blockDim.x;
+            start[q] = have[q] ? off[key0 + bq] + atomicAdd(&cursor[key0 + bq], have[q]) : 0;   // global position of this workgroup's first entry
+        }
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q)
+            if (have[q]) hist[b + q * blockDim.x] = start[q];
     }
     __syncthreads();
     const u32 level = (u32)((u64)((u32)j / sets) * idx_stride);
-    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        if (msm_skipped(keep, i)) continue;
-        const u32 d = msm_window_digit(wm, n, i, j, c, K);
-        if (d == MSM_NO_DIGIT) continue;
-        const u32 b = (d & 0x7fffffffu) - b0;
-        if (b >= kh) continue;
-        const u32 pos = atomicAdd(&hist[b], 1u);
-        ZK_ASSERT_IDX(pos >= off[(u64)((u32)j % sets) * K + b0 + b] && pos < off[(u64)((u32)j % sets) * K + b0 + b + 1]);
-        sorted[pos] = (level + (u32)i) | (d & 0x80000000u);
+    for (u64 i = i0 + threadIdx.x; i < i1; i += (u64)MSM_SORT_ILP * blockDim.x) {
+        u32 d[MSM_SORT_ILP];
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            const u64 ii = i + (u64)q * blockDim.x;
+            d[q] = (ii < i1 && !msm_skipped(keep, ii)) ? dj[ii] : MSM_NO_DIGIT;
+        }
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            if (d[q] == MSM_NO_DIGIT) continue;
+            const u32 b = (d[q] & 0x7fffffffu) - b0;
+            if (b >= kh) continue;
+            const u32 pos = atomicAdd(&hist[b], 1u);
+            ZK_ASSERT_IDX(pos >= off[key0 + b] && pos < off[key0 + b + 1]);
+            sorted[pos] = (level + (u32)(i + (u64)q * blockDim.x)) | (d[q] & 0x80000000u);
+        }
     }
 }
 
