@@ -500,6 +500,19 @@ static inline MsmShape msm_shape(const zkhip_ctx* ctx, u64 n, int scalar_bits, b
 }
 
 static inline MsmShape with_inf(MsmShape sh, bool many) { sh.skip_inf = many; return sh; }
+// Device memory the window-multiple tables of a key may take: 60 % of what is free now, less what the proofs themselves will
+// allocate later beside them — per proof slot the digits and sorted lists of up to three sorts, the transform vectors, scalars, and
+// the partial / bucket arrays of five MSMs — and the transient of the table construction (msm_table_levels: < 1 GiB).  Several
+// contexts sharing one device each see the same "free" figure: the margin is what keeps the first batch prove from failing where
+// the key load succeeded.
+static inline u64 msm_table_budget(const zkhip_ctx* ctx, u64 z_n, u64 h_n, u64 N, int W, u32 K) {
+    size_t free_b = 0, total_b = 0;
+    dev_mem_info(&free_b, &total_b);
+    const u64 per_slot = (2 * z_n + h_n) * (u64)W * 8 + 3 * N * 32 + (z_n + 2) * 64 + 6 * ((u64)K + (1u << 19)) * 288;
+    const u64 later = (u64)std::max(1, ctx->nslots) * per_slot + ((u64)1 << 30);
+    const u64 budget = (u64)(0.6 * (double)free_b);
+    return budget > later ? budget - later : 0;
+}
 // exclusive scan of nk counters (cnt -> off, off[nk] = their sum, also left in *grand)
 static inline void scan_u32(Stream s, const DBuf& cnt, DBuf& off, u64 nk, DBuf& chunk_sum, DBuf& grand) {
     const u32 nchunks = (u32)((nk + SCAN_CHUNK - 1) / SCAN_CHUNK);
@@ -830,9 +843,7 @@ struct PkLoader {
         // fold as many bucket sets (the reference has no size limit below the field's two-adicity; this is how it is met).
         int sets = ctx->msm_sets;
         if (!sets) {
-            size_t free_b = 0, total_b = 0;
-            dev_mem_info(&free_b, &total_b);
-            const u64 budget = (u64)(0.6 * (double)free_b);
+            const u64 budget = msm_table_budget(ctx, pk->z_n, pk->h_n, hdom, shz.W, shz.K);
             const u64 g1 = packed_point_bytes<Fq>(), g2 = packed_point_bytes<Fq2>();
             sets = 1;
             for (;;) {

@@ -217,6 +217,15 @@ template <class P> ZK_HD Fu<P> fe_sub(const Fu<P>& a, const Fu<P>& b) { return f
 // obeys the same bounds as any other; the all-zero sentinel of the point at infinity stays all-zero
 template <class P> ZK_HD Fu<P> fe_neg(const Fu<P>& a) { return a.is_zero() ? a : fe_sub_k<2>(Fu<P>::zero(), a); }
 
+// The helpers below subtract limb by limb from a SPREAD multiple of p without a carry round: no limb may go negative.  The lower
+// limbs are safe by the spread (2^(B+1) above any TIGHT limb); the TOP limb is (K p)_top - 2 - b_top, which wraps if the subtrahend's
+// top limb exceeds that — i.e. the VALUE precondition: subtrahend < about (K - 1) p (a Montgomery product or an affine coordinate
+// against 2p; the column checks of ZK_CHECK_OVERFLOW do not see a wrapped limb, so the builds that carry them check this too).
+#if defined(ZK_CHECK_OVERFLOW) && !defined(__HIP_DEVICE_COMPILE__)
+#define ZK_LAZY_TOP_CHECK(P_, bias_top, b_top, who) do { if ((b_top) > (bias_top)) { fprintf(stderr, "%s: top limb of the subtrahend (%u) above the bias's (%u): a wrapped limb would be multiplied\n", who, (unsigned)(b_top), (unsigned)(bias_top)); abort(); } } while (0)
+#else
+#define ZK_LAZY_TOP_CHECK(P_, bias_top, b_top, who) ((void)0)
+#endif
 // 2p - a WITHOUT the carry round, for a TIGHT a with value < 2p (a product, an affine coordinate): limbs up to 2^(B+1) + 2^B, so
 // the result is ONLY good as one operand of a single product (fu_mul_inl) or of a two-product sum (fu_mul2_inl) whose other
 // operands are TIGHT — N * 2^(2B+1.6) + the reduction's N * 2^(2B) stay far below 2^64 — and saves the 25 instructions of
@@ -224,6 +233,7 @@ template <class P> ZK_HD Fu<P> fe_neg(const Fu<P>& a) { return a.is_zero() ? a :
 template <class P>
 ZK_HD Fu<P> fe_neg_lazy(const Fu<P>& a) {
     Fu<P> r;
+    ZK_LAZY_TOP_CHECK(P, UConst<P>::nbias2(Fu<P>::N - 1), a.v[Fu<P>::N - 1], "fe_neg_lazy");
     ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = UConst<P>::nbias2(i) - a.v[i];
     return r;
 }
@@ -235,6 +245,7 @@ template <int K, class P>
 ZK_HD Fu<P> fe_sub_k_lazy(const Fu<P>& a, const Fu<P>& b) {
     typedef UConst<P> C;
     Fu<P> r;
+    ZK_LAZY_TOP_CHECK(P, (K == 2 ? C::nbias2(Fu<P>::N - 1) : K == 4 ? C::nbias4(Fu<P>::N - 1) : C::nbias8(Fu<P>::N - 1)), b.v[Fu<P>::N - 1], "fe_sub_k_lazy");
     ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = a.v[i] + ((K == 2 ? C::nbias2(i) : K == 4 ? C::nbias4(i) : C::nbias8(i)) - b.v[i]);
     return r;
 }
@@ -248,6 +259,7 @@ ZK_HD Fu<P> fe_add_lazy(const Fu<P>& a, const Fu<P>& b) {
 template <class P>
 ZK_HD Fu<P> fe_cneg_for_mul(const Fu<P>& y, bool neg) {
     Fu<P> r;
+    if (neg) ZK_LAZY_TOP_CHECK(P, UConst<P>::nbias2(Fu<P>::N - 1), y.v[Fu<P>::N - 1], "fe_cneg_for_mul");
     ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) r.v[i] = neg ? UConst<P>::nbias2(i) - y.v[i] : y.v[i];
     return r;
 }
@@ -502,6 +514,7 @@ ZK_HD Fu2<P> fu2_mul_inl(const Fu2<P>& a, const Fu2<P>& b) {
     // 8p - b1 without its carry round (limbs < 2^(B+1) + 2^B): it is multiplied at once, in a column of two products whose other
     // operands are TIGHT — N (2^(2B) + 2^(2B+1.6)) + N 2^(2B) stays below 2^64 for both limb widths (ZK_CHECK_OVERFLOW builds check)
     Fu<P> nb1;
+    ZK_LAZY_TOP_CHECK(P, UConst<P>::nbias8(Fu<P>::N - 1), b.c1.v[Fu<P>::N - 1], "fu2_mul_inl");
     ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) nb1.v[i] = UConst<P>::nbias8(i) - b.c1.v[i];
     return {fu_mul2_inl(a.c0, b.c0, a.c1, nb1), fu_mul2_inl(a.c0, b.c1, a.c1, b.c0)};
 }

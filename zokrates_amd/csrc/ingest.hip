@@ -466,10 +466,30 @@ struct Builder {
                 const Term* t = ch.terms[k].data();
                 uint32_t* col = out->col[k].data();
                 uint8_t* val = out->val[k].data();
+                std::vector<std::pair<uint32_t, uint32_t>> byc;      // (column, position in the row) of a long row
                 for (size_t r = 0; r < ch.count[k].size(); ++r) {
                     out->rp[k][ch.row0 + r] = q;
                     const uint64_t a = q;
-                    for (uint32_t j = 0; j < ch.count[k][r]; ++j, ++t, ++q) {
+                    const uint32_t cnt = ch.count[k][r];
+                    if (cnt > 24) {
+                        // a long row (compiled programs have combinations of thousands of terms, in whatever order the compiler
+                        // left them): the insertion sort below would move 32-byte values O(k^2) times — sort (column, position)
+                        // pairs and place every value once
+                        byc.resize(cnt);
+                        for (uint32_t j = 0; j < cnt; ++j) {
+                            const uint32_t tag = sym.find(t[j].id);
+                            byc[j] = {(tag & WIT_TAG) ? (uint32_t)(l + (tag & ~WIT_TAG)) : tag, j};
+                        }
+                        std::sort(byc.begin(), byc.end());
+                        for (uint32_t j = 0; j < cnt; ++j) {
+                            col[q + j] = byc[j].first;
+                            memcpy(val + (q + j) * 32, t[byc[j].second].coeff.v, 32);
+                        }
+                        t += cnt;
+                        q += cnt;
+                        continue;
+                    }
+                    for (uint32_t j = 0; j < cnt; ++j, ++t, ++q) {
                         const uint32_t tag = sym.find(t->id);
                         const uint32_t cj = (tag & WIT_TAG) ? (uint32_t)(l + (tag & ~WIT_TAG)) : tag;
                         // ark keeps a row sorted by variable (One, Instance(i), Witness(i)): same order as the final column

@@ -554,7 +554,7 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
             total += part;
         }
         require(total == len, ZKHIP_ERR_PARSE, "trailing bytes after key image");
-        const int s_z = h.sets & 0xff, s_h = (h.sets >> 8) & 0xff;
+        int s_z = h.sets & 0xff, s_h = (h.sets >> 8) & 0xff;
         require(h.world >= 1 && h.rank < h.world && h.logN >= 0 && h.logN <= 3 * NTT_MAX_SUBLOG && h.N == ((uint64_t)1 << h.logN) && h.z_n <= h.m + 2 &&
                     h.h_n <= h.N && h.c_z >= 2 && h.c_z <= MSM_MAX_C && h.c_h >= 2 && h.c_h <= MSM_MAX_C && s_z >= 1 && s_h >= 1 && (h.sets >> 16) == 0,
                 ZKHIP_ERR_PARSE, "key image: inconsistent header");
@@ -566,7 +566,23 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         require(sizes_ok, ZKHIP_ERR_PARSE, "key image: array sizes do not match the header");
         require(ops->ntt_log1(ctx, h.logN) == h.ntt_split, ZKHIP_ERR_PARSE,
                 "key image: written under another NTT split (NTT_SINGLE_MAX_LOG / NTT_MAX_SUBLOG) than this context uses; re-import the proving key");
-        // (c, sets) must be a shape this context's sort can run (SORT_KH_LOG may have changed since the image was written)
+        // The image carries level 0 only and the window multiples are recomputed here, so how many of them THIS device keeps is this
+        // context's decision, not the exporter's: ZKHIP_TUNE_MSM_SETS if set, else the header's count, doubled until the tables fit
+        // 60 % of the free device memory (PkLoader::finish_tables' rule: an image written on an empty 288 GB device must still load
+        // beside other tenants, with more bucket sets instead of an allocation failure).
+        {
+            const int W_z = (ops->fr_bits + 1 + h.c_z - 1) / h.c_z, W_h = (ops->fr_bits + 1 + h.c_h - 1) / h.c_h;
+            if (ctx->msm_sets) s_z = std::min(ctx->msm_sets, W_z), s_h = std::min(ctx->msm_sets, W_h);
+            const uint64_t budget = msm_table_budget(ctx, h.z_n, h.h_n, h.N, W_z, 1u << (h.c_z - 1));
+            while (!ctx->msm_sets) {
+                uint64_t need = 0;
+                for (int k = 0; k < 5; ++k) need += pk_table_bytes(h.curve, k, h.z_n, h.h_n, k == 4 ? pk_levels(h.curve, h.c_h, s_h) : pk_levels(h.curve, h.c_z, s_z));
+                if (need <= budget || (s_z >= W_z && s_h >= W_h)) break;
+                s_z = std::min(2 * s_z, W_z);
+                s_h = std::min(2 * s_h, W_h);
+            }
+        }
+        // (c, sets) must be a shape this context's sort can run
         require(ops->msm_shape_ok(ctx, h.z_n, h.c_z, s_z) && ops->msm_shape_ok(ctx, h.h_n, h.c_h, s_h), ZKHIP_ERR_PARSE,
                 "key image: window width / bucket sets not usable under this context's settings; re-import the proving key");
         std::unique_ptr<zkhip_pk> pk(new zkhip_pk());
