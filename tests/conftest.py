@@ -31,3 +31,26 @@ def pytest_collection_modifyitems(session, config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def _vram_used_gib():
+    import json
+    import subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--json"], capture_output=True, text=True, timeout=30).stdout
+        d = next(iter(json.loads(txt[txt.index("{"):]).values()))
+        return [int(v) for k, v in d.items() if "Used" in k][0] / 2 ** 30
+    except Exception:
+        return None
+
+
+@pytest.fixture(autouse=True)
+def _device_memory_log(request):
+    """ZKHIP_TEST_MEMLOG=<file>: device memory in use after every test (rocm-smi), one line per test — which test leaves how much
+    behind in the suite's one process (an out-of-resources abort late in the suite is the sum of its predecessors)."""
+    yield
+    path = os.environ.get("ZKHIP_TEST_MEMLOG")
+    if path:
+        u = _vram_used_gib()
+        with open(path, "a") as f:
+            f.write("%8.2f GiB  %s\n" % (u if u is not None else -1.0, request.node.nodeid))

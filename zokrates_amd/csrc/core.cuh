@@ -156,6 +156,7 @@ struct zkhip_ctx {
     u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
     int sort_kh_log = 15;     // log2 of the counters of one sort workgroup's LDS histogram (ZKHIP_SORT_KH_LOG: development knob — a smaller
                               // histogram leaves LDS to the kernels beside it and reads the digits once more per halving)
+    int tenants = 1;          // contexts of one zkhip_multi that share this context's device (their keys are sized for a share of its memory)
     int nslots = 3;           // proofs in flight in the batch calls (<= ZK_NSLOTS; measured 2 / 3 / 4: 72.0 / 76.0 / 74.8 proofs/s)
     std::string err;
     std::string desc;
@@ -508,9 +509,9 @@ static inline MsmShape with_inf(MsmShape sh, bool many) { sh.skip_inf = many; re
 static inline u64 msm_table_budget(const zkhip_ctx* ctx, u64 z_n, u64 h_n, u64 N, int W, u32 K) {
     size_t free_b = 0, total_b = 0;
     dev_mem_info(&free_b, &total_b);
-    const u64 per_slot = (2 * z_n + h_n) * (u64)W * 8 + 3 * N * 32 + (z_n + 2) * 64 + 6 * ((u64)K + (1u << 19)) * 288;
+    const u64 per_slot = (2 * z_n + h_n) * (u64)W * 8 + 4 * N * 32 + (z_n + 2) * 64 + 6 * ((u64)K + (1u << 19)) * 288 + ((u64)1 << 29);
     const u64 later = (u64)std::max(1, ctx->nslots) * per_slot + ((u64)1 << 30);
-    const u64 budget = (u64)(0.6 * (double)free_b);
+    const u64 budget = (u64)((ctx->tenants > 1 ? 0.5 : 0.6) * (double)free_b) / (u64)std::max(1, ctx->tenants);
     return budget > later ? budget - later : 0;
 }
 // exclusive scan of nk counters (cnt -> off, off[nk] = their sum, also left in *grand)
@@ -1450,6 +1451,14 @@ struct Prover {
         ZK_LAUNCH((k_from_rp<Fr>), dim3(B), dim3(T), 0, s, b, b, N);
         dev_d2h(data, b, N * 32, s);
         stream_sync(s);
+        // A stand-alone transform of a very large domain leaves 8 N x 32 bytes behind (five factor tables of its plan, three work
+        // vectors: 69 GiB at 2^28) that nothing else will use at that size: given back at once.  A prover at such a domain keeps its
+        // plan (it is rebuilt in about a second if a transform of this kind evicted it).
+        if (log_n > 24) {
+            ctx->cur->va.release(); ctx->cur->vb.release(); ctx->cur->vc.release();
+            for (size_t k = 0; k < ctx->plans.size(); ++k)
+                if (ctx->plans[k].get() == pl) { ctx->plans.erase(ctx->plans.begin() + (long)k); break; }
+        }
     }
 
     static void witness_map_api(zkhip_ctx* ctx, const zkhip_r1cs* cs, const uint8_t* z, uint8_t* h_out) {

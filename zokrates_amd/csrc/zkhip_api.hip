@@ -732,6 +732,12 @@ int32_t zkhip_ctx_create_multi(const int32_t* devices, int32_t n, zkhip_multi** 
         }
         m->ctx.push_back(c);  // (capacity reserved above)
     }
+    // members that share a device share its memory: each sizes its tables for its share of what is free (msm_table_budget)
+    for (int32_t k = 0; k < n; ++k) {
+        int same = 0;
+        for (int32_t q = 0; q < n; ++q) same += devices[q] == devices[k];
+        m->ctx[k]->tenants = same;
+    }
     *out = m.release();
     return ZKHIP_OK;
 }
