@@ -151,6 +151,7 @@ def cmd_generate_proof(args):
     t0 = time.perf_counter()
     ctx = native.Context(args.device)
     ctx.tune("msm_sets", 64)        # one proof, then the process ends: the window-multiple tables cost ten times what they save it
+    ctx.tune("serial", 1)           # ... and one stream: the streams a resident prover overlaps proofs on cost ~10 ms of set-up each
     lap("hip_init_ms", t0)
     if worker is None:
         load_host_side()

@@ -101,7 +101,9 @@ struct MsmSort {
 // workspace and stream of one MSM: the five MSMs of a proof are independent once their scalars are sorted, and the
 // fold stages are latency-bound (few, long dependent chains), so they run concurrently and fill each other's gaps
 struct MsmLane {
-    Stream stream = 0;
+    Stream stream = 0;        // made on first use (lane_stream): a stream is ~10 ms of queue set-up, and a process that proves once on
+    bool made = false;        // one stream (the CLI: ZKHIP_TUNE_SERIAL) never needs the ~20 a resident prover keeps busy
+    bool high_priority = false;
     DBuf lane_key, heavy, partial, bucket, rows, cols;
     Event done = nullptr;
 };
@@ -129,6 +131,7 @@ struct zkhip_ctx {
     Stream out_stream = 0;    // copies the window sums out once every MSM of a proof is done
     Stream ntt_stream = 0;    // the mat-vec / NTT / h-sort pipeline of a proof in flight (high priority): off the main stream, so that
                               // the next proof's staging and z-sort (what its four big MSMs wait for) do not queue behind it
+    bool out_made = false, ntt_made = false;   // (both made on first use: ctx_out_stream, ctx_ntt_stream)
     Stream ws = 0;            // the stream the mat-vec / NTT helpers launch on right now (ntt_stream inside a proof, else `stream`)
     bool serial = false;      // ZKHIP_SERIAL=1: every MSM on the main stream (debugging / per-kernel timing)
     bool g2_first = true;     // the G2 lane's stream at high priority (see slot_init)
@@ -175,7 +178,7 @@ static inline void slot_init(zkhip_ctx* ctx, ProofSlot& sl) {
     for (int k = 0; k < ZK_NLANES; ++k) {
         // lane 3 is the G2 MSM: the longest accumulation AND the longest fold tail of a proof; at high priority its
         // workgroups are dispatched first, it finishes early and its tail hides under the G1 accumulations
-        sl.lanes[k].stream = (k == 3 && ctx->g2_first) ? stream_create_high_priority() : stream_create();
+        sl.lanes[k].high_priority = k == 3 && ctx->g2_first;       // (the stream itself is made when a launch first needs it: lane_stream)
         sl.lanes[k].done = event_create();
         sl.acc_b[k] = event_create();
         sl.acc_e[k] = event_create();
@@ -184,6 +187,19 @@ static inline void slot_init(zkhip_ctx* ctx, ProofSlot& sl) {
     sl.ntt_b = event_create();
     sl.ntt_e = event_create();
     sl.ready = true;
+}
+// streams made when they are first needed
+static inline Stream lane_stream(MsmLane& lane) {
+    if (!lane.made) { lane.stream = lane.high_priority ? stream_create_high_priority() : stream_create(); lane.made = true; }
+    return lane.stream;
+}
+static inline Stream ctx_out_stream(zkhip_ctx* ctx) {
+    if (!ctx->out_made) { ctx->out_stream = stream_create(); ctx->out_made = true; }
+    return ctx->out_stream;
+}
+static inline Stream ctx_ntt_stream(zkhip_ctx* ctx) {
+    if (!ctx->ntt_made) { ctx->ntt_stream = stream_create_high_priority(); ctx->ntt_made = true; }
+    return ctx->ntt_stream;
 }
 // gfx950 has 160 KiB of LDS per CU; anything above the 64 KiB default must be opted into, per kernel and per device
 // the z-lane gate of the proof being enqueued (see Prover::enqueue)
@@ -1054,7 +1070,7 @@ struct Prover {
         }
 
         // ---- K1-K4 and the h-sort, on the NTT stream: the main stream is free for the next proof's staging and z-sort
-        Stream wn = ctx->serial ? st : ctx->ntt_stream;
+        Stream wn = ctx->serial ? st : ctx_ntt_stream(ctx);
         stream_wait_event(wn, sl.ev[0]);
         event_record(sl.ev[1], wn);
         ctx->ws = wn;
@@ -1107,7 +1123,7 @@ struct Prover {
             const int step = nm > 1 ? member[1] - member[0] : 1;
             msm_run_tables<Fq>(ctx, sl.lanes[lead], which ? sl.sorts[2] : sl.sorts[0], tabs, nm, with_inf(shz, many), ws1 + lead * Wmax, (u32)(step * Wmax),
                                sl.acc_b[lead], sl.acc_e[lead], h_ready);
-            Stream s0 = ctx->serial ? ctx->stream : sl.lanes[lead].stream;
+            Stream s0 = ctx->serial ? ctx->stream : lane_stream(sl.lanes[lead]);
             for (int q = 1; q < nm; ++q) {
                 event_record(sl.acc_b[member[q]], s0);
                 event_record(sl.acc_e[member[q]], s0);
@@ -1120,7 +1136,7 @@ struct Prover {
     static void copy_out(zkhip_ctx* ctx, ProofSlot& sl, int Wmax) {
         Stream st = ctx->stream;
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
-        Stream so = ctx->serial ? st : ctx->out_stream;
+        Stream so = ctx->serial ? st : ctx_out_stream(ctx);
         for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(so, sl.lanes[k].done);
         const size_t b1 = (size_t)4 * Wmax * sizeof(Xyzz<Fq>), b2 = (size_t)Wmax * sizeof(Xyzz<Fq2>);
         if (sl.h_ws_cap < b1 + b2 + 4) {

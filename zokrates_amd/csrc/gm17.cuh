@@ -250,7 +250,7 @@ struct Gm17 {
 
         // ---- quotient h0 = (U^2 - W)/Z: iNTT + coset NTT of U, pointwise square, coset iNTT minus W's coefficients / Z (sigma order, canonical)
         // the transforms and the h-sort run on the NTT stream (the SAP rows above feed the z-sort and stay on the main one)
-        Stream wn = ctx->serial ? st : ctx->ntt_stream;
+        Stream wn = ctx->serial ? st : ctx_ntt_stream(ctx);
         stream_wait_event(wn, sl.ev[1]);
         ctx->ws = wn;
         event_record(sl.ntt_b, wn);

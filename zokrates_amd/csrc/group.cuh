@@ -39,7 +39,7 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     require(nt >= 1 && nt <= MSM_MAX_TABLES, ZKHIP_ERR_BAD_ARG, "internal: number of tables of one MSM launch");
     MsmTables tables{};
     for (int t = 0; t < nt; ++t) tables.p[t] = d_tables[t];
-    Stream s = ctx->serial ? ctx->stream : lane.stream;
+    Stream s = ctx->serial ? ctx->stream : lane_stream(lane);
     stream_wait_event(s, so.ready);
     // one slice of the sorted list per work-item the machine holds (never finer than MSM_MIN_SLICE entries)
     // (the slices may outnumber the work-items the kernel's registers let the machine hold: SLICE_WPE >= ACCUM_WPE)

@@ -204,7 +204,13 @@ Hip::Hip(int32_t device) {
     if (rc != ZKHIP_OK) throw Error(rc, zkhip_last_error(nullptr));
 }
 Hip::~Hip() { if (ctx_) zkhip_ctx_free(ctx_); }
-void Hip::one_shot() { check(zkhip_ctx_tune(ctx_, ZKHIP_TUNE_MSM_SETS, 64)); }
+// One proof, then the process ends: no window-multiple tables (ten times what they would save one proof), and every kernel on the
+// context's one stream — the ~20 streams a resident prover overlaps its proofs on cost ~10 ms of queue set-up each, ~90 ms of a
+// process whose proof takes 25 (profiles/r5_cli_start_profile.txt).
+void Hip::one_shot() {
+    check(zkhip_ctx_tune(ctx_, ZKHIP_TUNE_MSM_SETS, 64));
+    check(zkhip_ctx_tune(ctx_, ZKHIP_TUNE_SERIAL, 1));
+}
 void Hip::check(int32_t rc) const {
     if (rc != ZKHIP_OK) throw Error(rc, zkhip_last_error(ctx_));
 }

@@ -91,15 +91,26 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
     if (!out) { g_create_err = "out is NULL"; return ZKHIP_ERR_BAD_ARG; }
     *out = nullptr;
     return guarded(nullptr, [&] {
+        // ZKHIP_INIT_PROFILE=1: where the start of a process goes (stderr; a one-proof CLI run is mostly this)
+        const bool prof = getenv("ZKHIP_INIT_PROFILE") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!prof) return;
+            const auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "[zkhip init] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+            t_last = t;
+        };
         const int n = dev_count();
+        lap("runtime start (device count)");
         require(n > 0, ZKHIP_ERR_DEVICE, "no HIP device available (libzkhip has no CPU fallback)");
         require(device >= 0 && device < n, ZKHIP_ERR_BAD_ARG, "device index out of range");
         dev_set(device);
+        lap("set device");
         std::unique_ptr<zkhip_ctx> ctx(new zkhip_ctx());
         ctx->device = device;
         ctx->stream = stream_create_high_priority();
-        ctx->out_stream = stream_create();
-        ctx->ntt_stream = stream_create_high_priority();
+        lap("first stream");
+
         ctx->ws = ctx->stream;
         ctx->serial = getenv("ZKHIP_SERIAL") != nullptr;
         ctx->msm_c_env = env_int("ZKHIP_MSM_C", 2, MSM_MAX_C, 0);
@@ -126,6 +137,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         // one-proof process never spends).
         ctx->g2_first = env_int("ZKHIP_G2_PRIORITY", 0, 1, 1) != 0;
         slot_init(ctx.get(), ctx->slots[0]);
+        lap("slot 0: events");
 #ifdef ZK_EMU
         ctx->desc = "zkhip TEST EMULATOR (not a product build)";
 #else
@@ -136,6 +148,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
                  prop.totalGlobalMem / 1073741824.0);
         ctx->desc = buf;
         ctx->cus = std::max(1, prop.multiProcessorCount);
+        lap("device properties");
 #endif
         *out = ctx.release();
     });
@@ -155,15 +168,15 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
             event_destroy(sl.lanes[k].done);
             event_destroy(sl.acc_b[k]);
             event_destroy(sl.acc_e[k]);
-            stream_destroy(sl.lanes[k].stream);
+            if (sl.lanes[k].made) stream_destroy(sl.lanes[k].stream);
         }
         for (auto& e : sl.ev) event_destroy(e);
         event_destroy(sl.ntt_b);
         event_destroy(sl.ntt_e);
         host_free_pinned(sl.h_ws);
     }
-    stream_destroy(ctx->out_stream);
-    stream_destroy(ctx->ntt_stream);
+    if (ctx->out_made) stream_destroy(ctx->out_stream);
+    if (ctx->ntt_made) stream_destroy(ctx->ntt_stream);
     stream_destroy(ctx->stream);
     delete ctx;
 }
