@@ -26,11 +26,11 @@ timeout 900 python bench.py --scheme gm17 --log-domain 22 --steps 6 --warmup 2 -
 # and one size nobody asked for, to show there is no cap left: n = 2^24 - 2 (domain 2^24; a 6.4 GB key, 96 GiB of tables)
 [ -n "${WITH_2E24:-}" ] && timeout 900 python bench.py --log-domain 24 --steps 4 --warmup 1 --witnesses 1 --serial-proofs 1 --cpu-seconds 0 --e2e 0 > "$out/bench_g16_domain2e24.json" 2>> "$out/bench.err"
 # `bench.py --gpus 2` with no launcher: it starts the ranks itself (here both on this box's one GPU over gloo)
-ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 8 --warmup 2 --e2e 0 > "$out/bench_gpus2_self_spawned_one_gpu.json" 2>> "$out/bench.err"
+ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 16 --warmup 4 --e2e 0 > "$out/bench_gpus2_self_spawned_one_gpu.json" 2>> "$out/bench.err"
 # the N > 1 code path of bench.py on real hardware: two ranks sharing this box's one GPU (gloo instead of RCCL, which wants
 # one device per rank); rank 0 also drives the in-library multi leg
 ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 \
-  bench.py --gpus 2 --steps 8 --warmup 2 --e2e 0 > "$out/bench_two_ranks_one_gpu.json" 2>> "$out/bench.err"
+  bench.py --gpus 2 --steps 16 --warmup 4 --e2e 0 > "$out/bench_two_ranks_one_gpu.json" 2>> "$out/bench.err"
 # HBM traffic of the accumulation / transform kernels -> profiles/pmc_traffic.json (what the NEXT bench lines report as
 # roofline.traffic): two PMC passes (their own runs, kernel trace only), one stream; a pass that does not finish in 200 s is
 # given up.  Last, so that a profiler pass that hangs (one did: 900 s) cannot cost the bench lines.
