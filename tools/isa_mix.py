@@ -94,7 +94,7 @@ def main():
         mads = mix.get("v_mad_u64_u32", 0)
         print("  %-68s %6d instructions, %5d v_mad_u64_u32, scratch loads %d stores %d" % (title + ":", total, mads, scratch["load"], scratch["store"]))
         if part is hot:
-            for k, v in mix.most_common(14):
+            for k, v in mix.most_common(int(os.environ.get("ISA_MIX_TOP", "14"))):
                 print("      %5d  %5.1f %%  %s" % (v, 100.0 * v / max(total, 1), k))
 
 

@@ -45,6 +45,9 @@ ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F>& p) {
 // whose fully inlined form takes minutes to compile).
 template <bool HOT, class F> ZK_HD F ecm(const F& a, const F& b) { return ec_mul(a, b); }
 template <bool HOT, class F> ZK_HD F ecs(const F& a) { return ec_sqr(a); }
+// (the accumulation kernel's single products over the base field: loose quotient digits, fieldu.cuh fu_mul_loose)
+template <bool HOT, class P> ZK_HD Fu<P> ecm(const Fu<P>& a, const Fu<P>& b) { return HOT ? fu_mul_loose(a, b) : ec_mul(a, b); }
+template <bool HOT, class P> ZK_HD Fu<P> ecs(const Fu<P>& a) { return HOT ? fu_sqr_loose(a) : ec_sqr(a); }
 template <bool HOT, class P> ZK_HD Fu2<P> ecm(const Fu2<P>& a, const Fu2<P>& b) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_mul_inl(a, b) : fu2_mul_call(a, b); }
 template <bool HOT, class P> ZK_HD Fu2<P> ecs(const Fu2<P>& a) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_sqr_inl(a) : fu2_sqr_call(a); }
 

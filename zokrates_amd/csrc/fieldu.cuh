@@ -152,6 +152,11 @@ struct UConst {
     ZK_HD static constexpr u32 nbias8(int i) { constexpr Limbs t = bias_spread(8, B + 1); return t.v[i]; }
     static constexpr u32 PINV = inv_low() & M;               //  p^-1 mod 2^B
     static constexpr u32 NINV = (0u - inv_low()) & M;        // -p^-1 mod 2^B
+    static constexpr u32 NINV32 = 0u - inv_low();            // -p^-1 mod 2^32 (the loose quotient digits of fu_dot_inl<.., LOOSE>)
+    static constexpr u64 limb_sum() { u64 t = 0; for (int i = 0; i < N; ++i) t += split(modulus()).v[i]; return t; }
+    // LOOSE quotient digits are 32-bit: a column then holds up to 2^32 * (sum of p's limbs) of them next to N products of one TIGHT
+    // and one lazily added / negated operand (limbs < 2^(B+2)): both must fit the 64-bit accumulator
+    static constexpr bool LOOSE_OK = (limb_sum() << 30) + ((u64)N << (2 * B)) < ((u64)1 << 62);      // (the inequality divided by four)
     static constexpr u32 P_TOP = split(modulus()).v[N - 1];
     static constexpr u32 Q_MAGIC = (u32)(((u64)1 << 32) / ((u64)P_TOP + 1));   // floor(2^32 / (p_top + 1))
 };
@@ -312,8 +317,14 @@ ZK_HD Fu<P> fu_x3_numerator(const Fu<P>& rr, const Fu<P>& ppp, const Fu<P>& q) {
 // runs on.  profiles/r4b_accum_variants_ab.txt.)
 // one Montgomery reduction over `NT` operand pairs: r = (sum_t x[t] * y[t]) / R'.  x[t], y[t]: pointers to N limbs.
 // SQR (NT = 1, x = y): the cross terms are taken once against the doubled limb.
-template <class P, int NT, bool SQR>
+// LOOSE (NT = 1 only): the quotient digits m_k of all columns but the last are taken as the full 32-bit product lo32(acc) * (-p^-1
+// mod 2^32) instead of its low B bits — acc + m_k p_0 then vanishes mod 2^32, a fortiori mod 2^B, which is all the reduction
+// needs — and lose their mask (8 of the ~220 instructions of a product).  The LAST digit keeps it: the result is
+// (T + M p) / R' with M < (m_(N-1) + 8) 2^(B(N-1)) < R' (1 + 2^-25), i.e. the same "< T / R' + p" as ever.  What changes is the
+// size of the columns (UConst::LOOSE_OK), so only single products of the curve arithmetic's hot path use it.
+template <class P, int NT, bool SQR, bool LOOSE = false>
 ZK_HD Fu<P> fu_dot_inl(const u32* const (&x)[NT], const u32* const (&y)[NT]) {
+    static_assert(!LOOSE || (NT == 1 && UConst<P>::LOOSE_OK), "loose quotient digits: single products of a field whose columns have the room");
     typedef UConst<P> C;
     constexpr int N = Fu<P>::N, B = Fu<P>::B, NQ = UCfg<P>::MUL_NQ;
     constexpr u32 M = Fu<P>::M;
@@ -334,7 +345,7 @@ ZK_HD Fu<P> fu_dot_inl(const u32* const (&x)[NT], const u32* const (&y)[NT]) {
                 else for (int t = 0; t < NT; ++t) wide += (unsigned __int128)x[t][i] * y[t][j];
                 if (i < k && j >= 1) wide += (unsigned __int128)mm[i] * C::p(j);
             }
-            if (k < N) { mm[k] = ((u32)wide * C::NINV) & M; wide += (unsigned __int128)mm[k] * C::p(0); }
+            if (k < N) { mm[k] = (LOOSE && k < N - 1) ? (u32)wide * C::NINV32 : (((u32)wide * C::NINV) & M); wide += (unsigned __int128)mm[k] * C::p(0); }
             if (wide >> 64) { fprintf(stderr, "fu_dot_inl: column %d overflows 64 bits (NT = %d)\n", k, NT); abort(); }
             wide >>= B;
         }
@@ -362,7 +373,7 @@ ZK_HD Fu<P> fu_dot_inl(const u32* const (&x)[NT], const u32* const (&y)[NT]) {
             ZK_UNROLL for (int t = 0; t < NT; ++t) acc += (u64)x[t][k] * y[t][0];
         }
         if (k < N) {
-            m[k] = ((u32)acc * C::NINV) & M;
+            m[k] = (LOOSE && k < N - 1) ? (u32)acc * C::NINV32 : (((u32)acc * C::NINV) & M);
             acc += (u64)m[k] * C::p(0);
         } else {
             r.v[k - N] = (u32)acc & M;
@@ -385,6 +396,21 @@ template <class P>
 ZK_HD Fu<P> fu_sqr_inl(const Fu<P>& a) {
     const u32* const x[1] = {a.v};
     return fu_dot_inl<P, 1, true>(x, x);
+}
+// the same two with loose quotient digits (fu_dot_inl): operands TIGHT, at most one of them lazily negated / added (limbs < 2^(B+2))
+#ifndef ZK_LOOSE_M
+#define ZK_LOOSE_M 1
+#endif
+template <class P>
+ZK_HD Fu<P> fu_mul_loose(const Fu<P>& a, const Fu<P>& b) {
+    const u32* const x[1] = {a.v};
+    const u32* const y[1] = {b.v};
+    return fu_dot_inl<P, 1, false, ZK_LOOSE_M && UConst<P>::LOOSE_OK>(x, y);
+}
+template <class P>
+ZK_HD Fu<P> fu_sqr_loose(const Fu<P>& a) {
+    const u32* const x[1] = {a.v};
+    return fu_dot_inl<P, 1, true, ZK_LOOSE_M && UConst<P>::LOOSE_OK>(x, x);
 }
 // (a*b + c*d)/R' with one reduction — the building block of the Fq2 product
 template <class P>
