@@ -214,3 +214,16 @@ def test_pipeline_issue_bound_from_the_committed_counter_file():
     assert 4.0e9 < b["valu_wave_instructions_per_proof"] < 6.0e9 and 8.0 < b["ms_per_proof_at_issue_limit"] < 11.0
     assert abs(b["frac_of_ms_per_step"] - b["ms_per_proof_at_issue_limit"] / 10.57) < 1e-12
     assert bench.pipeline_issue_bound({}, 10.0) is None and bench.pipeline_issue_bound({"G1": {}}, 10.0) is None
+
+
+def test_bench_window_count_mirrors_the_library_rule():
+    """bench.py prices the accumulation in mixed additions = scalars x windows; the window count is the library's rule for resident
+    keys (csrc/core.cuh msm_shape): 17-bit windows for 254-bit scalars (15), 16 for 255-bit ones, log2 n + 1 bits for small keys."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module_for_test", os.path.join(ROOT, "bench.py"))
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    ns = {}
+    start = src.index("def msm_windows(")
+    exec(src[start:src.index("def numa_placement(")], ns)
+    assert ns["msm_windows"](254, (1 << 20) + 2) == 15 and ns["msm_windows"](255, (1 << 20) + 2) == 16
+    assert ns["msm_windows"](254, 1 << 10) == (254 + 1 + 10) // 11 and ns["msm_windows"](254, 1 << 24) == 15
