@@ -76,3 +76,13 @@ def test_rust_bindings_and_integration_excerpt_follow_the_header():
     assert excerpt and set(excerpt) <= set(ffi), set(excerpt) - set(ffi)
     for name, nargs in excerpt.items():
         assert ffi[name] == nargs, name
+
+
+def test_device_pci_bus_id_on_the_emulator_and_without_a_gpu(lib_path):
+    """zkhip_device_pci_bus_id: what ties a device ordinal to /sys/bus/pci/devices/<address> (NUMA node, hwmon).  The emulator's one
+    "device" answers a fixed address; the product library without a GPU answers an error, not a made-up address."""
+    from emu_util import emu_library
+    assert emu_library().device_pci_bus_id(0) == "0000:00:00.0"
+    lib = native.Library(lib_path)
+    if lib.device_count() == 0:
+        assert lib.device_pci_bus_id(0) is None
