@@ -39,8 +39,8 @@ import sys
 import time
 
 T_PROCESS_START = time.time()
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (torch may start it before libzkhip is loaded, whose own
-                                                    # constructor asks for the same): the library drives ~20 streams per context
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts: the library drives ~20 streams per context and asks for 8
+                                                    # queues by itself; ONE resident prover per process can afford 16 (+1.5-2 %, zkhip_api.hip)
 
 
 def supervise():

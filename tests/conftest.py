@@ -9,10 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# The suite runs ~100 tests in ONE process: dozens of contexts, multi-member provers with eight contexts each, RCCL, transforms up to
-# 2^28.  Every hardware queue of the process reserves scratch for the largest frame launched on it, and libzkhip asks for 16 queues
-# when it is loaded (a resident prover wants them: +2 %); the suite keeps the 8 it ran on through rounds 2-4 — two of four runs with
-# 16 ended in a runtime abort (out of resources) in a 2^22 test late in the process, none of the runs with 4 or 8 ever did.
+# The suite runs ~100 tests in ONE process: dozens of contexts, multi-member provers with eight contexts each, RCCL, both curves,
+# transforms up to 2^28.  Every hardware queue of the process reserves scratch for the largest frame launched on it; with 16 queues
+# three of five runs of this process ended in HSA_STATUS_ERROR_OUT_OF_RESOURCES (264 GB of device memory free) late in the suite,
+# with 4 or 8 none ever did (profiles/r5_q16_suite_abort.txt).  8 is also what libzkhip asks for by itself.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 

@@ -68,10 +68,14 @@ static int32_t guarded_host(Fn&& fn) {
 #ifndef ZK_EMU
 // The library keeps ~20 HIP streams busy per context (a stream per proof slot and MSM, the transform pipeline, staging, copy-out);
 // the runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams that share a queue
-// serialise: 16 queues measured +1.5-2 % proofs/s over 8 and +6 % over 4 (profiles/r5d_scheduling_knobs.txt).  The runtime reads
+// serialise: 8 queues measured +4 % proofs/s over 4, 16 another +1.5-2 % (profiles/r5d_scheduling_knobs.txt).  The runtime reads
 // the variable when it initialises (the first HIP call of the process), so the library sets it when it is loaded — unless the
-// process, or a HIP user that initialised the runtime earlier, has decided already.
-__attribute__((constructor)) static void zkhip_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// process, or a HIP user that initialised the runtime earlier, has decided already.  EIGHT, not sixteen: every queue reserves
+// scratch for the largest frame launched on it, and a process that drives many contexts and both curves through 16 queues ran out
+// of that resource (HSA_STATUS_ERROR_OUT_OF_RESOURCES with 264 GB of device memory free: three of five runs of the GPU suite's
+// one process, profiles/r5_q16_suite_abort.txt; never at 4 or 8).  A process with ONE resident prover can ask for 16 itself
+// (bench.py does: a few hundred runs, no failure).
+__attribute__((constructor)) static void zkhip_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 #endif
 
 extern "C" {
