@@ -48,8 +48,8 @@ template <bool HOT, class F> ZK_HD F ecs(const F& a) { return ec_sqr(a); }
 // (the accumulation kernel's single products over the base field: loose quotient digits, fieldu.cuh fu_mul_loose)
 template <bool HOT, class P> ZK_HD Fu<P> ecm(const Fu<P>& a, const Fu<P>& b) { return HOT ? fu_mul_loose(a, b) : ec_mul(a, b); }
 template <bool HOT, class P> ZK_HD Fu<P> ecs(const Fu<P>& a) { return HOT ? fu_sqr_loose(a) : ec_sqr(a); }
-template <bool HOT, class P> ZK_HD Fu2<P> ecm(const Fu2<P>& a, const Fu2<P>& b) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_mul_inl(a, b) : fu2_mul_call(a, b); }
-template <bool HOT, class P> ZK_HD Fu2<P> ecs(const Fu2<P>& a) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_sqr_inl(a) : fu2_sqr_call(a); }
+template <bool HOT, class P> ZK_HD Fu2<P> ecm(const Fu2<P>& a, const Fu2<P>& b) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_mul_inl<P, HOT>(a, b) : fu2_mul_call(a, b); }
+template <bool HOT, class P> ZK_HD Fu2<P> ecs(const Fu2<P>& a) { return (HOT || UCfg<P>::FQ2_INLINE) ? fu2_sqr_inl<P, HOT>(a) : fu2_sqr_call(a); }
 
 // a*b - c*d, the tail of Y3 = R (Q - X3) - Y1 PPP: ONE reduction (per component) instead of two products and a subtraction
 // on the hot path of the unsaturated fields; plain arithmetic elsewhere.  Result < 3p.
@@ -66,10 +66,10 @@ template <bool HOT, class P> ZK_HD Fu2<P> ecs(const Fu2<P>& a) { return (HOT || 
 template <bool HOT, class F> ZK_HD F ec_mulsub(const F& a, const F& b, const F& c, const F& d) { return fe_sub_k<2>(ecm<HOT>(a, b), ecm<HOT>(c, d)); }
 template <bool HOT, class P> ZK_HD Fu<P> ec_mulsub(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d) {
     if (!ZK_LAZY_Y3_G1) return fe_sub_k<2>(ecm<HOT>(a, b), ecm<HOT>(c, d));
-    return fu_mul2_inl(a, b, c, fe_neg_lazy(d));          // d = PPP < 2p, TIGHT: its negation needs no carry round here; result < 2p
+    return fu_mul2_inl<P, HOT>(a, b, c, fe_neg_lazy(d));  // d = PPP < 2p, TIGHT: its negation needs no carry round here; result < 2p
 }
 template <bool HOT, class P> ZK_HD Fu2<P> ec_mulsub(const Fu2<P>& a, const Fu2<P>& b, const Fu2<P>& c, const Fu2<P>& d) {
-    if (ZK_LAZY_Y3_G2 && (HOT || UCfg<P>::FQ2_INLINE)) return fu2_mulsub_inl(a, b, c, d);
+    if (ZK_LAZY_Y3_G2 && (HOT || UCfg<P>::FQ2_INLINE)) return fu2_mulsub_inl<P, HOT>(a, b, c, d);
     return fe_sub_k<2>(ecm<HOT>(a, b), ecm<HOT>(c, d));
 }
 #ifndef ZK_FQ2_KARATSUBA

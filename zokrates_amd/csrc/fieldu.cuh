@@ -147,6 +147,7 @@ struct UConst {
     ZK_HD static constexpr u32 bias2(int i) { constexpr Limbs t = bias(2); return t.v[i]; }
     ZK_HD static constexpr u32 bias4(int i) { constexpr Limbs t = bias(4); return t.v[i]; }
     ZK_HD static constexpr u32 bias8(int i) { constexpr Limbs t = bias(8); return t.v[i]; }
+    ZK_HD static constexpr u32 bias16(int i) { constexpr Limbs t = bias(16); return t.v[i]; }
     ZK_HD static constexpr u32 nbias2(int i) { constexpr Limbs t = bias_spread(2, B + 1); return t.v[i]; }   // 2p, spread 2^(B+1)
     ZK_HD static constexpr u32 nbias4(int i) { constexpr Limbs t = bias_spread(4, B + 1); return t.v[i]; }
     ZK_HD static constexpr u32 nbias8(int i) { constexpr Limbs t = bias_spread(8, B + 1); return t.v[i]; }
@@ -154,9 +155,10 @@ struct UConst {
     static constexpr u32 NINV = (0u - inv_low()) & M;        // -p^-1 mod 2^B
     static constexpr u32 NINV32 = 0u - inv_low();            // -p^-1 mod 2^32 (the loose quotient digits of fu_dot_inl<.., LOOSE>)
     static constexpr u64 limb_sum() { u64 t = 0; for (int i = 0; i < N; ++i) t += split(modulus()).v[i]; return t; }
-    // LOOSE quotient digits are 32-bit: a column then holds up to 2^32 * (sum of p's limbs) of them next to N products of one TIGHT
-    // and one lazily added / negated operand (limbs < 2^(B+2)): both must fit the 64-bit accumulator
-    static constexpr bool LOOSE_OK = (limb_sum() << 30) + ((u64)N << (2 * B)) < ((u64)1 << 62);      // (the inequality divided by four)
+    // LOOSE quotient digits are 32-bit: a column then holds up to 2^32 * (sum of p's limbs) of them next to N * 2^(2B+2) of products
+    // — one product of a TIGHT and a lazily added / negated operand (limbs < 2^(B+2)), the two products of an Fq2 component (TIGHT x
+    // TIGHT + TIGHT x 3 * 2^B), or the four TIGHT products of the fused Y3: both must fit the 64-bit accumulator
+    static constexpr bool LOOSE_OK = (limb_sum() << 30) + ((u64)N << (2 * B)) < ((u64)1 << 62) - ((u64)1 << 57);   // (divided by four; 3 % to spare)
     static constexpr u32 P_TOP = split(modulus()).v[N - 1];
     static constexpr u32 Q_MAGIC = (u32)(((u64)1 << 32) / ((u64)P_TOP + 1));   // floor(2^32 / (p_top + 1))
 };
@@ -209,12 +211,13 @@ ZK_HD Fu<P> fe_dbl(const Fu<P>& a) {
     ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) t[i] = a.v[i] << 1;
     return fu_norm<P>(t);
 }
-// a + K*p - b for K in {2, 4, 8}; needs value(b) < K*p
+// a + K*p - b for K in {2, 4, 8, 16}; needs value(b) < K*p
 template <int K, class P>
 ZK_HD Fu<P> fe_sub_k(const Fu<P>& a, const Fu<P>& b) {
     typedef UConst<P> C;
+    static_assert(K == 2 || K == 4 || K == 8 || K == 16, "fe_sub_k: K in {2, 4, 8, 16}");
     u32 t[Fu<P>::N];
-    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) t[i] = a.v[i] + (K == 2 ? C::bias2(i) : K == 4 ? C::bias4(i) : C::bias8(i)) - b.v[i];
+    ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) t[i] = a.v[i] + (K == 2 ? C::bias2(i) : K == 4 ? C::bias4(i) : K == 8 ? C::bias8(i) : C::bias16(i)) - b.v[i];
     return fu_norm<P>(t);
 }
 template <class P> ZK_HD Fu<P> fe_sub(const Fu<P>& a, const Fu<P>& b) { return fe_sub_k<4>(a, b); }
@@ -292,6 +295,9 @@ ZK_HD Fu<P> fu_x3_numerator(const Fu<P>& rr, const Fu<P>& ppp, const Fu<P>& q) {
     return fu_norm<P>(t);
 }
 
+#ifndef ZK_LOOSE_M
+#define ZK_LOOSE_M 1
+#endif
 // ---- the products ----
 // Product scanning (Comba): column k collects a_i * b_(k-i) and m_i * p_(k-i) in 64-bit accumulators that never overflow
 // for TIGHT operands, m_k makes the column's low B bits vanish, the rest carries into column k+1.
@@ -317,14 +323,14 @@ ZK_HD Fu<P> fu_x3_numerator(const Fu<P>& rr, const Fu<P>& ppp, const Fu<P>& q) {
 // runs on.  profiles/r4b_accum_variants_ab.txt.)
 // one Montgomery reduction over `NT` operand pairs: r = (sum_t x[t] * y[t]) / R'.  x[t], y[t]: pointers to N limbs.
 // SQR (NT = 1, x = y): the cross terms are taken once against the doubled limb.
-// LOOSE (NT = 1 only): the quotient digits m_k of all columns but the last are taken as the full 32-bit product lo32(acc) * (-p^-1
+// LOOSE: the quotient digits m_k of all columns but the last are taken as the full 32-bit product lo32(acc) * (-p^-1
 // mod 2^32) instead of its low B bits — acc + m_k p_0 then vanishes mod 2^32, a fortiori mod 2^B, which is all the reduction
 // needs — and lose their mask (8 of the ~220 instructions of a product).  The LAST digit keeps it: the result is
 // (T + M p) / R' with M < (m_(N-1) + 8) 2^(B(N-1)) < R' (1 + 2^-25), i.e. the same "< T / R' + p" as ever.  What changes is the
-// size of the columns (UConst::LOOSE_OK), so only single products of the curve arithmetic's hot path use it.
+// size of the columns (UConst::LOOSE_OK: operands as the accumulation kernel's hot path hands them over — see there), so only that path uses it.
 template <class P, int NT, bool SQR, bool LOOSE = false>
 ZK_HD Fu<P> fu_dot_inl(const u32* const (&x)[NT], const u32* const (&y)[NT]) {
-    static_assert(!LOOSE || (NT == 1 && UConst<P>::LOOSE_OK), "loose quotient digits: single products of a field whose columns have the room");
+    static_assert(!LOOSE || (NT <= 4 && UConst<P>::LOOSE_OK), "loose quotient digits: a field whose columns have the room");
     typedef UConst<P> C;
     constexpr int N = Fu<P>::N, B = Fu<P>::B, NQ = UCfg<P>::MUL_NQ;
     constexpr u32 M = Fu<P>::M;
@@ -398,9 +404,6 @@ ZK_HD Fu<P> fu_sqr_inl(const Fu<P>& a) {
     return fu_dot_inl<P, 1, true>(x, x);
 }
 // the same two with loose quotient digits (fu_dot_inl): operands TIGHT, at most one of them lazily negated / added (limbs < 2^(B+2))
-#ifndef ZK_LOOSE_M
-#define ZK_LOOSE_M 1
-#endif
 template <class P>
 ZK_HD Fu<P> fu_mul_loose(const Fu<P>& a, const Fu<P>& b) {
     const u32* const x[1] = {a.v};
@@ -413,20 +416,20 @@ ZK_HD Fu<P> fu_sqr_loose(const Fu<P>& a) {
     return fu_dot_inl<P, 1, true, ZK_LOOSE_M && UConst<P>::LOOSE_OK>(x, x);
 }
 // (a*b + c*d)/R' with one reduction — the building block of the Fq2 product
-template <class P>
+template <class P, bool LOOSE = false>
 ZK_HD Fu<P> fu_mul2_inl(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d) {
     const u32* const x[2] = {a.v, c.v};
     const u32* const y[2] = {b.v, d.v};
-    return fu_dot_inl<P, 2, false>(x, y);
+    return fu_dot_inl<P, 2, false, LOOSE && ZK_LOOSE_M && UConst<P>::LOOSE_OK>(x, y);
 }
 // (a*b + c*d + e*f + g*h)/R' with one reduction: four products of TIGHT operands still fit the 64-bit column accumulators
 // (4 * 9 * 2^58 + 9 * 2^58 < 2^63.4).  Operand values < 8p: result < (4 * 64 p^2) / R' + p < 3p for both base fields' R' >= 2^7 p.
-template <class P>
+template <class P, bool LOOSE = false>
 ZK_HD Fu<P> fu_mul4_inl(const Fu<P>& a, const Fu<P>& b, const Fu<P>& c, const Fu<P>& d, const Fu<P>& e, const Fu<P>& f, const Fu<P>& g,
                         const Fu<P>& h) {
     const u32* const x[4] = {a.v, c.v, e.v, g.v};
     const u32* const y[4] = {b.v, d.v, f.v, h.v};
-    return fu_dot_inl<P, 4, false>(x, y);
+    return fu_dot_inl<P, 4, false, LOOSE && ZK_LOOSE_M && UConst<P>::LOOSE_OK>(x, y);
 }
 // out-of-line forms (operands by value in VGPRs) — what the curve code calls; see fe_mul_nc in field.cuh
 template <class P> ZK_HD_CALL Fu<P> fu_mul(const Fu<P> a, const Fu<P> b) { return fu_mul_inl(a, b); }
@@ -465,7 +468,7 @@ ZK_HD Fu<P> fe_relax(const Fu<P>& x) {
     return r;
 }
 
-// x == 0 (mod p) for a TIGHT x with value < 16p.  The low limb of a multiple j*p is j*p0 mod 2^B, so
+// x == 0 (mod p) for a TIGHT x with value < 32p.  The low limb of a multiple j*p is j*p0 mod 2^B, so
 // j = x0 * p0^-1 mod 2^B must be tiny: everything else (all but 2^-25 of the calls) is rejected by one multiply.
 template <class P>
 ZK_HD_CALL bool fu_is_zero_modp_slow(const Fu<P> x, u32 j) {
@@ -489,7 +492,7 @@ ZK_HD_CALL bool fu_is_zero_modp_slow(const Fu<P> x, u32 j) {
 template <class P>
 ZK_HD bool fe_is_zero_modp(const Fu<P>& x) {
     const u32 j = (x.v[0] * UConst<P>::PINV) & Fu<P>::M;   // x.v[0] < 2^B exactly: the low limb never receives a carry
-    if (j > 16) return false;
+    if (j > 32) return false;      // (values up to 32p: the G1 accumulation's Pp reaches 18p since its X lost the weak reduction)
     return fu_is_zero_modp_slow(x, j);
 }
 // the saturated field answers the same questions trivially (canonical representation)
@@ -535,22 +538,23 @@ template <class P> ZK_HD Fe2<P> fu_x3_numerator(const Fe2<P>& rr, const Fe2<P>& 
 // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: two sums of two products, each reduced once
 // (the same 4 x N^2 + 2 x N^2 multiply-adds as Karatsuba's three full products, but one negation instead of five
 // additions, and results that stay below 2p whatever the operands)
-template <class P>
+template <class P, bool LOOSE = false>
 ZK_HD Fu2<P> fu2_mul_inl(const Fu2<P>& a, const Fu2<P>& b) {
     // 8p - b1 without its carry round (limbs < 2^(B+1) + 2^B): it is multiplied at once, in a column of two products whose other
     // operands are TIGHT — N (2^(2B) + 2^(2B+1.6)) + N 2^(2B) stays below 2^64 for both limb widths (ZK_CHECK_OVERFLOW builds check)
     Fu<P> nb1;
     ZK_LAZY_TOP_CHECK(P, UConst<P>::nbias8(Fu<P>::N - 1), b.c1.v[Fu<P>::N - 1], "fu2_mul_inl");
     ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) nb1.v[i] = UConst<P>::nbias8(i) - b.c1.v[i];
-    return {fu_mul2_inl(a.c0, b.c0, a.c1, nb1), fu_mul2_inl(a.c0, b.c1, a.c1, b.c0)};
+    return {fu_mul2_inl<P, LOOSE>(a.c0, b.c0, a.c1, nb1), fu_mul2_inl<P, LOOSE>(a.c0, b.c1, a.c1, b.c0)};
 }
 // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u: two single products.  Operands < 6p keep (a0 + a1) < 12p and
 // (a0 + 8p - a1) < 14p, so the result stays below 12*14/169 + 1 < 2p.
-template <class P>
+template <class P, bool LOOSE = false>
 ZK_HD Fu2<P> fu2_sqr_inl(const Fu2<P>& a) {
     // (the sum and the doubled limb are multiplied at once by a TIGHT operand: no carry round for them)
     Fu<P> d0;
     ZK_UNROLL for (int i = 0; i < Fu<P>::N; ++i) d0.v[i] = a.c0.v[i] << 1;
+    if (LOOSE) return {fu_mul_loose(fe_add_lazy(a.c0, a.c1), fe_sub_k<8>(a.c0, a.c1)), fu_mul_loose(d0, a.c1)};
     return {fu_mul_inl(fe_add_lazy(a.c0, a.c1), fe_sub_k<8>(a.c0, a.c1)), fu_mul_inl(d0, a.c1)};
 }
 // The same product with THREE limb products instead of four (Karatsuba on the columns, before any reduction):
@@ -605,16 +609,16 @@ ZK_HD Fu2<P> fu2_mul_kara(const Fu2<P>& a, const Fu2<P>& b) {
     return r;
 }
 // a*b - c*d in Fq2 with one reduction per component (four limb products each): the tail of the mixed addition's Y3
-template <class P>
+template <class P, bool LOOSE = false>
 ZK_HD Fu2<P> fu2_mulsub_inl(const Fu2<P>& a, const Fu2<P>& b, const Fu2<P>& c, const Fu2<P>& d) {
     // c0 = a0 b0 - a1 b1 - c0 d0 + c1 d1;  c1 = a0 b1 + a1 b0 - c0 d1 - c1 d0      (negations as 8p - x)
     const Fu<P> nb1 = fe_sub_k<8>(Fu<P>::zero(), b.c1), nd0 = fe_sub_k<8>(Fu<P>::zero(), d.c0), nd1 = fe_sub_k<8>(Fu<P>::zero(), d.c1);
-    return {fu_mul4_inl(a.c0, b.c0, a.c1, nb1, c.c0, nd0, c.c1, d.c1), fu_mul4_inl(a.c0, b.c1, a.c1, b.c0, c.c0, nd1, c.c1, nd0)};
+    return {fu_mul4_inl<P, LOOSE>(a.c0, b.c0, a.c1, nb1, c.c0, nd0, c.c1, d.c1), fu_mul4_inl<P, LOOSE>(a.c0, b.c1, a.c1, b.c0, c.c0, nd1, c.c1, nd0)};
 }
-template <class P> ZK_HD_CALL Fu2<P> fu2_mul_call(const Fu2<P> a, const Fu2<P> b) { return fu2_mul_inl(a, b); }
-template <class P> ZK_HD_CALL Fu2<P> fu2_sqr_call(const Fu2<P> a) { return fu2_sqr_inl(a); }
-template <class P> ZK_HD Fu2<P> ec_mul(const Fu2<P>& a, const Fu2<P>& b) { return UCfg<P>::FQ2_INLINE ? fu2_mul_inl(a, b) : fu2_mul_call(a, b); }
-template <class P> ZK_HD Fu2<P> ec_sqr(const Fu2<P>& a) { return UCfg<P>::FQ2_INLINE ? fu2_sqr_inl(a) : fu2_sqr_call(a); }
+template <class P> ZK_HD_CALL Fu2<P> fu2_mul_call(const Fu2<P> a, const Fu2<P> b) { return fu2_mul_inl<P>(a, b); }
+template <class P> ZK_HD_CALL Fu2<P> fu2_sqr_call(const Fu2<P> a) { return fu2_sqr_inl<P>(a); }
+template <class P> ZK_HD Fu2<P> ec_mul(const Fu2<P>& a, const Fu2<P>& b) { return UCfg<P>::FQ2_INLINE ? fu2_mul_inl<P>(a, b) : fu2_mul_call(a, b); }
+template <class P> ZK_HD Fu2<P> ec_sqr(const Fu2<P>& a) { return UCfg<P>::FQ2_INLINE ? fu2_sqr_inl<P>(a) : fu2_sqr_call(a); }
 
 // ---- inversion (Fermat) on the unsaturated form: x^(p-2), one squaring per exponent bit and a product per set bit ----
 // For the kernels that invert once per work-item (the window-multiple tables at key load): 254 + ~127 Comba products

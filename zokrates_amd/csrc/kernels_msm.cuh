@@ -422,6 +422,12 @@ __device__ __forceinline__ void zk_pin_words(T& obj) {
 #ifndef ZK_ACCUM_FENCE
 #define ZK_ACCUM_FENCE 0
 #endif
+// X of the G1 running sum without its weak reduction (values < 10p, subtractions against 16p): 45 instructions fewer on paper, 34
+// scratch accesses more in the compiled loop (2 424 instructions with them against 2 427 without: tools/isa_mix.py g1
+// -DZK_ACCUM_X_UNREDUCED=1) — off
+#ifndef ZK_ACCUM_X_UNREDUCED
+#define ZK_ACCUM_X_UNREDUCED 0
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_SCHED_FENCE(on) do { if (on) __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -531,7 +537,12 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
         // and the others add.
         const bool pinf = pt.is_inf();
         const F ys = fe_cneg(pt.y, neg);
-        const F Pp = fe_sub_k<4>(ecm_k<true>(get_zz(0), pt.x), get_xy(0));     // X1 < 3p;  Pp < 6p
+        // (base field: X1 is kept as the numerator of X3 — TIGHT, value < 10p — without the weak reduction: it only ever meets a
+        // product (Q = X1 PP) or a subtraction with a large enough multiple of p; bounds below.  Fq2 keeps the reduction: the
+        // square of Pp in its (a0 + a1)(a0 - a1) form has no room for components of 18p.)
+        constexpr bool XWIDE = ZK_ACCUM_X_UNREDUCED && !MsmTuning<F>::IS_EXT;
+        constexpr int KX = XWIDE ? 16 : 4;
+        const F Pp = fe_sub_k<KX>(ecm_k<true>(get_zz(0), pt.x), get_xy(0));    // X1 < 3p (10p);  Pp < 6p (18p: PP < 3p, PPP, Q, ZZ3 < 2p all the same)
         const F R = fe_sub_k<4>(ecm_k<true>(get_zz(1), ys), get_xy(1));        // Y1 < 4p;  R < 6p
         const bool special = SKIP_INF ? (!pinf && !first && fe_is_zero_modp(Pp)) : (pinf || (!first && fe_is_zero_modp(Pp)));
         if (ZK_WAVE_ANY(special)) {
@@ -541,6 +552,7 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
             aff_load_words<F>(bases, e_cur & 0x7fffffffu, wg);
             const Aff<F> pg = aff_unpack<F>(wg);
             Xyzz<F> t = first ? Xyzz<F>::inf() : whole();
+            if (XWIDE) t.x = fe_relax(t.x);         // (the general addition expects X1 < 4p)
             if (!pinf) {
                 if (ZK_ACCUM_COLD_CALL) t = xyzz_madd_cold(t, Aff<F>{pg.x, fe_cneg(pg.y, neg)});
                 else xyzz_madd_acc<true>(t, Aff<F>{pg.x, fe_cneg(pg.y, neg)});
@@ -566,9 +578,10 @@ __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const 
             ZK_SCHED_FENCE(FENCE);
             const F Q = ecm_k<true>(get_xy(0), PP);
             ZK_SCHED_FENCE(FENCE);
-            const F X3 = fe_relax(fu_x3_numerator(ecs<true>(R), PPP, Q));     // R^2 - PPP - 2Q: < 10p before, < 3p after
+            const F X3n = fu_x3_numerator(ecs<true>(R), PPP, Q);              // R^2 - PPP - 2Q: TIGHT, < 10p
+            const F X3 = XWIDE ? X3n : fe_relax(X3n);                          // (< 3p after the weak reduction)
             ZK_SCHED_FENCE(FENCE);
-            put_xy(1, ec_mulsub<true>(R, fe_sub_k<4>(Q, X3), get_xy(1), PPP));  // one reduction: < 3p (G1 fused: < 2p)
+            put_xy(1, ec_mulsub<true>(R, fe_sub_k<KX>(Q, X3), get_xy(1), PPP));  // R < 6p times < 6p (18p) + Y1 (< 2p) PPP: one reduction, < 2p (Fq2: < 3p)
             put_xy(0, X3);
             ZK_SCHED_FENCE(FENCE);
         }
