@@ -327,6 +327,24 @@ int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes);
 int32_t zkhip_pk_export(const zkhip_pk* pk, uint8_t* out, uint64_t cap);
 int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk** out);
 
+/* ---- a resident prover's key: bound to its constraint system ----
+ * The reference turns the evaluations of a, b, c into the coefficients of h = (ab - c)/Z with seven transforms per proof
+ * ([UPSTREAM] ark-groth16 0.3.0 `LibsnarkReduction::witness_map`, reached from `Groth16::prove`,
+ * /root/reference/zokrates_ark/src/groth16.rs:44), only to pair the coefficients with `h_query`.  Those transforms are linear,
+ * so a prover that keeps a key resident can apply them to the key's BASES once: zkhip_pk_bind_r1cs computes
+ *   H'_j = sum_i (g^-i / N) w^(-ij) h_query[i]           (pairs with a(g w^j) b(g w^j) / Z(g), the quotient's evaluations) and
+ *   L'_v = l_query[v] + sum_k C[k][v] H''_k              (c's inverse transform and its mat-vec, folded into the l bases)
+ * and keeps them beside the key's own tables.  From then on zkhip_prove_g16* with THIS key and THIS constraint system takes four
+ * transforms and the mat-vec of A and B only; the proof's group elements — hence its bytes — are the same (the same holds for an
+ * assignment that does not satisfy the system: what the reference's MSM over h[..N-1] ignores, the bound bases ignore).  Any
+ * other constraint system, and every call after zkhip_pk_unbind, takes the key's own tables.  Costs two size-N transforms
+ * over G1 points (seconds at 2^20) and two more MSM tables of device memory (ZKHIP_ERR_NOMEM when they do not fit; the key stays
+ * usable, unbound).  Groth16 keys loaded whole only (not a shard, not GM17).  zkhip_pk_is_bound: 1 if proofs over `r1cs` would
+ * take the bound tables, else 0. */
+int32_t zkhip_pk_bind_r1cs(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* r1cs);
+int32_t zkhip_pk_unbind(zkhip_pk* pk);
+int32_t zkhip_pk_is_bound(const zkhip_pk* pk, const zkhip_r1cs* r1cs);
+
 /* ---- "next" row N1: ZoKrates' own input files (host only: no context, no device work) ----
  * zkhip_prog_parse replaces `ProgEnum::deserialize` (/root/reference/zokrates_ast/src/ir/serialize.rs:306-390: header,
  * sections, per-statement CBOR) followed by `Computation::generate_constraints`

@@ -40,6 +40,10 @@ extern "C" {
     pub fn zkhip_pk_export_size(pk: *const zkhip_pk, bytes: *mut u64) -> i32;
     pub fn zkhip_pk_export(pk: *const zkhip_pk, out: *mut u8, cap: u64) -> i32;
     pub fn zkhip_pk_import(ctx: *mut zkhip_ctx, bytes: *const u8, len: usize, out: *mut *mut zkhip_pk) -> i32;
+    // a resident prover binds its key to its constraint system once (four transforms per proof instead of six, no c)
+    pub fn zkhip_pk_bind_r1cs(ctx: *mut zkhip_ctx, pk: *mut zkhip_pk, r1cs: *const zkhip_r1cs) -> i32;
+    pub fn zkhip_pk_unbind(pk: *mut zkhip_pk) -> i32;
+    pub fn zkhip_pk_is_bound(pk: *const zkhip_pk, r1cs: *const zkhip_r1cs) -> i32;
     // one proof across several GPUs of this process
     pub fn zkhip_ctx_create_multi(devices: *const i32, n: i32, out: *mut *mut zkhip_multi) -> i32;
     pub fn zkhip_multi_free(m: *mut zkhip_multi);

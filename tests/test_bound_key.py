@@ -1,0 +1,173 @@
+"""A proving key bound to its constraint system (zkhip_pk_bind_r1cs, csrc/bind.cuh): the transforms that lead from the quotient's
+evaluations to h's coefficients are applied to the key's bases once, a proof takes four transforms instead of six and never touches
+the C matrix — and the proof bytes must not move.  Here on the TEST-ONLY emulator (same kernel sources) against the oracle; the
+`-m gpu` copies of these checks are in test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu
+from oracle import groth16 as g16
+from oracle.fields import BN254, BLS12_381
+from zokrates_amd import native
+
+from emu_util import emu_library
+
+CURVES = [BN254, BLS12_381]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = native.Context(0, emu_library())
+    assert "EMULATOR" in c.describe()
+    yield c
+    c.close()
+
+
+def bound_key_checks(ctx, curve, oc, seeds=((0x1234567, 0x89abcdef0123), (0, 77), (5, 0))):
+    """Every entry point of the prover, unbound and bound, against the closed-form trapdoor proof."""
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    opk = cpu.ProvingKey.setup(oc, tox)
+    z = oc.assignment()
+    cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, curve.curve_id, opk.serialize())
+    want = [cpu.trapdoor(oc, tox, z, r % curve.r, s % curve.r) for r, s in seeds]
+    rs = [(r % curve.r, s % curve.r) for r, s in seeds]
+    assert not pk.is_bound(cs)
+    assert [native.prove_g16(ctx, pk, cs, z, r, s) for r, s in rs] == want
+    pk.bind(cs)
+    assert pk.is_bound(cs)
+    assert [native.prove_g16(ctx, pk, cs, z, r, s) for r, s in rs] == want
+    za = native.Assignment(ctx, cs, z)
+    assert native.prove_g16_resident(ctx, pk, cs, za, *rs[0]) == want[0]
+    proofs, _ = native.prove_g16_resident_batch(ctx, pk, cs, [za] * len(rs), rs)
+    assert proofs == want
+    proofs, _ = native.prove_g16_batch(ctx, pk, cs, np.concatenate([z] * len(rs)), rs)
+    assert proofs == want
+    # another copy of the same system is another system: the key's own tables serve it (same bytes, the unbound way)
+    cs2 = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    assert not pk.is_bound(cs2)
+    assert native.prove_g16(ctx, pk, cs2, z, *rs[0]) == want[0]
+    # binding again (to the copy), unbinding, and the key is as it was loaded
+    pk.bind(cs2)
+    assert pk.is_bound(cs2) and not pk.is_bound(cs)
+    assert native.prove_g16(ctx, pk, cs2, z, *rs[0]) == want[0]
+    assert native.prove_g16(ctx, pk, cs, z, *rs[0]) == want[0]
+    pk.unbind()
+    assert not pk.is_bound(cs2)
+    assert native.prove_g16(ctx, pk, cs2, z, *rs[0]) == want[0]
+    return pk, cs, z, tox
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("kind", ["dense", "sha"])
+def test_bound_key_proves_the_same_bytes(ctx, curve, kind):
+    n = 14 if kind == "dense" else 29
+    oc = cpu.Circuit.synth(curve.curve_id, n, 0x5EED0040, kind)
+    bound_key_checks(ctx, curve, oc)
+
+
+def test_bound_key_with_an_unsatisfying_assignment(ctx):
+    """What the reference computes for an assignment that does NOT satisfy the system (ark's witness_map divides anyway and the MSM
+    ignores the top coefficient) is what the bound key computes: the algorithmic oracle on a corrupted assignment."""
+    curve = BN254
+    oc = cpu.Circuit.synth(0, 30, 0x5EED0041)
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    opk = cpu.ProvingKey.setup(oc, tox)
+    z = np.array(oc.assignment(), copy=True)
+    z[32 * 7] ^= 1                                            # one bit of one witness value
+    want, _ = cpu.prove(oc, opk, z, 11, 13)
+    cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, 0, opk.serialize())
+    assert native.prove_g16(ctx, pk, cs, z, 11, 13) == want
+    pk.bind(cs)
+    assert native.prove_g16(ctx, pk, cs, z, 11, 13) == want
+
+
+def test_bound_key_over_two_and_three_pass_domains():
+    """The bases come out of the key's sigma order (whatever the split of the context's plan is) and H' pairs with NATURAL-order
+    evaluations: two passes (sigma order of two digits) and three."""
+    for sub, logn in ((2, 4), (2, 6), (3, 7)):
+        c2 = native.Context(0, emu_library())
+        c2.tune("ntt_max_sublog", sub)
+        if logn <= 2 * sub:
+            c2.tune("ntt_single_max_log", 1)
+        try:
+            oc = cpu.Circuit.synth(0, (1 << logn) - 2, 0x5EED0050 + logn)
+            assert oc.N == 1 << logn
+            bound_key_checks(c2, BN254, oc, seeds=((3, 4),))
+        finally:
+            c2.close()
+
+
+def test_bound_key_with_heavy_columns_and_general_coefficients(ctx):
+    """C with a variable that occurs in most rows (its products meet in the workgroup's tree), coefficients other than +-1 (the
+    scalar multiplication of the per-entry products), a public variable in C (L' is finite where l_query is padding) and an
+    empty column."""
+    curve = BN254
+    r = curve.r
+    l, w, n = 3, 9, 70                                         # ONE, two public inputs; N = 128
+    m = l + w
+    import random
+    rnd = random.Random(99)
+    zv = [1] + [rnd.randrange(r) for _ in range(m - 1)]
+    rows = [[], [], []]
+    for k in range(n):
+        a = {rnd.randrange(m): rnd.randrange(1, r) for _ in range(2)}
+        b = {rnd.randrange(m): rnd.randrange(1, r) for _ in range(2)}
+        av = sum(c * zv[v] for v, c in a.items()) % r
+        bv = sum(c * zv[v] for v, c in b.items()) % r
+        # c: the heavy column 0 (ONE) in every row, variable 1 (public) with a large coefficient in some, a +-1 entry, never variable m-1
+        c = {0: 0}
+        if k % 3 == 0:
+            c[1] = rnd.randrange(2, r)
+        v = 3 + rnd.randrange(m - 4)
+        c[v] = 1 if k % 2 else r - 1
+        rest = (av * bv - sum(cf * zv[u] for u, cf in c.items())) % r
+        c[0] = rest                                            # ONE carries whatever is missing: the row holds
+        rows[0].append(a); rows[1].append(b); rows[2].append(c)
+    mats = []
+    for mat in rows:
+        rp, col, val = [0], [], []
+        for row in mat:
+            for v in sorted(row):
+                col.append(v); val.append(row[v])
+            rp.append(len(col))
+        mats.append((np.array(rp, dtype=np.uint64), np.array(col, dtype=np.uint32),
+                     np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in val), dtype=np.uint8)))
+    oc = cpu.Circuit.from_csr(0, n, l, w, mats)
+    z = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in zv), dtype=np.uint8)
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    opk = cpu.ProvingKey.setup(oc, tox)
+    want = cpu.trapdoor(oc, tox, z, 21, 22)
+    assert cpu.prove(oc, opk, z, 21, 22)[0] == want
+    cs = native.ConstraintSystem(ctx, 0, n, l, w, mats)
+    pk = native.ProvingKey(ctx, 0, opk.serialize())
+    assert native.prove_g16(ctx, pk, cs, z, 21, 22) == want
+    pk.bind(cs)
+    assert native.prove_g16(ctx, pk, cs, z, 21, 22) == want
+
+
+def test_what_does_not_bind(ctx):
+    curve = BN254
+    oc = cpu.Circuit.synth(0, 13, 0x5EED0042)
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    raw = cpu.ProvingKey.setup(oc, tox).serialize()
+    cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    shard = native.ProvingKey(ctx, 0, raw, rank=0, world=2)
+    with pytest.raises(native.ZkhipError):
+        shard.bind(cs)
+    other = cpu.Circuit.synth(0, 40, 0x5EED0043)
+    cs_other = native.ConstraintSystem(ctx, 0, other.n, other.l, other.w, [other.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, 0, raw)
+    with pytest.raises(native.ZkhipError):
+        pk.bind(cs_other)                                      # another domain
+    assert not pk.is_bound(cs_other) and not pk.is_bound(cs)
+    t4 = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    tb17 = t4[:96] + t4[128:160]
+    pk17 = native.ProvingKey(ctx, 0, cpu.Gm17ProvingKey.setup(oc, tb17).serialize(), scheme="gm17")
+    with pytest.raises(native.ZkhipError):
+        pk17.bind(cs)
+    z = oc.assignment()
+    assert native.prove_g16(ctx, pk, cs, z, 1, 2) == cpu.trapdoor(oc, tox, z, 1, 2)      # the refusals left the context usable

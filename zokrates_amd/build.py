@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libzkhip.so")
 UNITS = ["bls381_g2", "bls381_g1", "bn254_g2", "bn254_g1", "curve_bn254", "curve_bls381", "zkhip_api", "ingest"]   # slowest first
-HEADERS = ["core.cuh", "devrt.h", "ec.cuh", "field.cuh", "fieldu.cuh", "kernels_msm.cuh", "kernels_ntt.cuh", "setup.cuh", "gm17.cuh", "group.cuh", "ingest.h"]
+HEADERS = ["core.cuh", "devrt.h", "ec.cuh", "field.cuh", "fieldu.cuh", "kernels_msm.cuh", "kernels_ntt.cuh", "setup.cuh", "gm17.cuh", "group.cuh", "bind.cuh", "ingest.h"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

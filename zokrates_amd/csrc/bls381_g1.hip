@@ -2,4 +2,5 @@
 #include "group.cuh"
 namespace zk {
 ZK_INSTANTIATE_GROUP(Fe<Bls381Fq>)
+ZK_INSTANTIATE_BIND(Fe<Bls381Fq>)
 }  // namespace zk

@@ -2,4 +2,5 @@
 #include "group.cuh"
 namespace zk {
 ZK_INSTANTIATE_GROUP(Fe<Bn254Fq>)
+ZK_INSTANTIATE_BIND(Fe<Bn254Fq>)
 }  // namespace zk

@@ -7,6 +7,7 @@
 // `Groth16::prove` (:44).  SURVEY.md §8(a) rows a7, a8, K1-K9.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <memory>
@@ -600,6 +601,20 @@ u64 count_infinite(zkhip_ctx* ctx, const void* d_table, u64 count);
 template <class F>
 void mark_finite(zkhip_ctx* ctx, const void* d_table, u64 count, u32* d_bitmap);
 template <class F> static constexpr size_t packed_point_bytes() { return sizeof(AffPacked<typename Unsat<F>::type>); }
+// binding a key to a constraint system (bind.cuh: the kernels; group.cuh: these launchers, instantiated for G1 only).  `x`: two
+// vectors of N XYZZ points (bind_xyzz_bytes each); everything on ctx->stream.
+template <class F>
+size_t bind_xyzz_bytes();
+template <class F>
+void bind_scale(zkhip_ctx* ctx, const void* d_h_table, u64 N, u64 n_src, u32 n1, u32 n2, u32 n3, const u32* d_scal, const u32* d_konst, int nw, void* d_x);
+template <class F>
+void bind_fft(zkhip_ctx* ctx, void* d_x, u64 N, const u32* d_tw, int nw);
+template <class F>
+void bind_h_finish(zkhip_ctx* ctx, const void* d_x, u64 N, int logN, void* d_out);
+template <class F>
+void bind_cmul(zkhip_ctx* ctx, const void* d_x, int logN, const u32* d_row, const u32* d_val, int nw, const u32* d_minus_one, u64 nnz, void* d_prod);
+template <class F>
+void bind_l_finish(zkhip_ctx* ctx, const void* d_prod, const u64* d_cptr, const void* d_l_table, u64 m, void* d_out);
 // fixed-base tables / multiplications for setup (N3); also per-group code
 template <class F>
 void fixed_base_table(zkhip_ctx* ctx, const Aff<F>* h_pj, int nwin, DBuf& tbl);
@@ -682,9 +697,23 @@ struct zkhip_pk {
     // splits differently (ZKHIP_TUNE_NTT_SINGLE_MAX_LOG changed after the key was loaded, or an image written under
     // another setting) would pair h with the wrong bases, so the provers and zkhip_pk_import refuse the mismatch
     int ntt_log1 = -1;
+    // Bound to one constraint system (zkhip_pk_bind_r1cs, PkLoader::bind): H' = the coset inverse transform applied to h_query
+    // (natural order: it pairs with the quotient's EVALUATIONS on the coset), L' = l_query with c's share of the quotient folded in
+    // per variable.  Proofs over the system `bound_uid` names take four transforms and two mat-vecs; any other system, and every
+    // sharded / GM17 key, takes the tables above.  0 = not bound.
+    DBuf h_bound, l_bound;
+    u64 bound_uid = 0;
+    bool inf_many_bound[2] = {true, true};   // (L', H'): as inf_many
 };
 
+// every constraint system of a process has a number of its own (a key remembers WHICH system it was bound to: an address can be
+// handed out again after zkhip_r1cs_free)
+static inline u64 zk_next_uid() {
+    static std::atomic<u64> next{1};
+    return next.fetch_add(1);
+}
 struct zkhip_r1cs {
+    u64 uid = zk_next_uid();
     int curve;
     zkhip_ctx* ctx;
     u64 n, l, w, N;
@@ -893,6 +922,110 @@ struct PkLoader {
         msm_table_levels<Fq>(ctx, pk->h_sigma.p, pk->h_n, shh.level_bits(), (int)shh.levels);
         count_points_at_infinity(ctx, pk);
     }
+    // ---- zkhip_pk_bind_r1cs: H' and L' for ONE constraint system (bind.cuh has the algebra) ----
+    static void unbind(zkhip_pk* pk) {
+        pk->bound_uid = 0;
+        pk->h_bound.release();
+        pk->l_bound.release();
+    }
+    static void bind(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* cs) {
+        typedef typename C::Fr Fr;
+        require(pk->scheme == 0, ZKHIP_ERR_BAD_ARG, "only a Groth16 key binds to a constraint system");
+        require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "a shard of a multi-GPU key does not bind");
+        require(pk->curve == C::ID && cs->curve == C::ID, ZKHIP_ERR_BAD_ARG, "curve mismatch between key and constraint system");
+        require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
+                "proving key does not match the constraint system (m, w or domain size)");
+        require(pk->N >= 2 && pk->hlen + 1 == pk->N, ZKHIP_ERR_BAD_ARG, "domain too small to bind");
+        unbind(pk);
+        NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
+        require(pl->split() == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's h bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
+        const u64 N = pk->N, m = pk->m, me = m + 2, nnz = cs->nnz[2];
+        const int logN = pk->logN;
+        constexpr int NW = Fr::N;
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
+        require(pk->z_n == me && pk->h_n == N, ZKHIP_ERR_BAD_ARG, "internal: an unsharded key covers the whole index range");
+        const u64 g1 = packed_point_bytes<Fq>(), xb = bind_xyzz_bytes<Fq>();
+        {   // two more tables stay; the transforms' points and C's products are transient, like the levels' workspace
+            size_t free_b = 0, total_b = 0;
+            dev_mem_info(&free_b, &total_b);
+            const u64 need = N * shh.levels * g1 + me * shz.levels * g1 + 2 * N * xb + nnz * (xb + 4 + 32) + N * 48 + ((u64)3 << 30);
+            require(need < free_b, ZKHIP_ERR_NOMEM, "not enough device memory to bind the key (two more MSM tables and the transforms' workspace)");
+        }
+        Stream s = ctx->stream;
+        const unsigned T = 256;
+        // canonical-integer scalars: g^-i / N (what the bases of H' are scaled by), w^-e (the transform's roots), -1 / (N Z(g)), p - 1
+        DBuf d_scal, d_tw, d_k;
+        d_scal.ensure(N * sizeof(Fr));
+        d_tw.ensure(std::max<u64>(N / 2, 1) * sizeof(Fr));
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(N, T)), dim3(T), 0, s, ptr<Fr>(d_scal), pl->g_inv, pl->n_inv, N, 0u, 0u, 0, 1u);
+        ZK_LAUNCH((k_from_mont<Fr>), dim3(blocks_for(N, T)), dim3(T), 0, s, ptr<Fr>(d_scal), ptr<Fr>(d_scal), N);
+        ZK_LAUNCH((k_pow_table<Fr>), dim3(blocks_for(N / 2, T)), dim3(T), 0, s, ptr<Fr>(d_tw), pl->omega_inv, Fr::one(), N / 2, 0u, 0u, 0, 1u);
+        ZK_LAUNCH((k_from_mont<Fr>), dim3(blocks_for(N / 2, T)), dim3(T), 0, s, ptr<Fr>(d_tw), ptr<Fr>(d_tw), N / 2);
+        Fr konst[2];
+        konst[0] = fe_from_mont(fe_neg(fe_mul(pl->n_inv, pl->zinv)));
+        konst[1] = fe_from_mont(fe_neg(Fr::one()));
+        d_k.ensure(sizeof(konst));
+        dev_h2d(d_k.p, konst, sizeof(konst), s);
+        stream_sync(s);                                // (konst is on this frame)
+        // the two transforms over the bases: vector 0 -> H' (coset), vector 1 -> H'' (what C's columns are summed against)
+        DBuf x;
+        x.ensure(2 * N * xb);
+        bind_scale<Fq>(ctx, pk->h_sigma.p, N, pk->hlen, pl->N1, pl->N2, pl->N3, ptr<u32>(d_scal), ptr<u32>(d_k), NW, x.p);
+        bind_fft<Fq>(ctx, x.p, N, ptr<u32>(d_tw), NW);
+        pk->h_bound.ensure(N * (u64)shh.levels * g1);
+        bind_h_finish<Fq>(ctx, x.p, N, logN, pk->h_bound.p);
+        stream_sync(s);
+        d_scal.release();
+        d_tw.release();
+        msm_table_levels<Fq>(ctx, pk->h_bound.p, N, shh.level_bits(), (int)shh.levels);
+        // C by columns: D_v = sum_k C[k][v] H''_k
+        std::vector<u64> rp(cs->n + 1), cptr(m + 1, 0);
+        std::vector<u32> col(nnz), crow(nnz);
+        std::vector<uint8_t> val(nnz * 32), cval(nnz * 32);
+        dev_d2h(rp.data(), cs->rp[2].p, (cs->n + 1) * 8, s);
+        if (nnz) {
+            dev_d2h(col.data(), cs->col[2].p, nnz * 4, s);
+            dev_d2h(val.data(), cs->val[2].p, nnz * 32, s);
+        }
+        stream_sync(s);
+        for (u64 e = 0; e < nnz; ++e) {
+            require(col[e] < m, ZKHIP_ERR_BAD_ARG, "internal: column index out of range");
+            ++cptr[col[e] + 1];
+        }
+        for (u64 v = 0; v < m; ++v) cptr[v + 1] += cptr[v];
+        {
+            std::vector<u64> cur(cptr.begin(), cptr.end() - 1);
+            for (u64 k = 0; k < cs->n; ++k)
+                for (u64 e = rp[k]; e < rp[k + 1]; ++e) {
+                    const u64 at = cur[col[e]]++;
+                    crow[at] = (u32)k;
+                    memcpy(&cval[at * 32], &val[e * 32], 32);
+                }
+        }
+        DBuf d_cptr, d_crow, d_cval, prod;
+        d_cptr.ensure((m + 1) * 8);
+        d_crow.ensure(std::max<u64>(nnz, 1) * 4);
+        d_cval.ensure(std::max<u64>(nnz, 1) * 32);
+        prod.ensure(std::max<u64>(nnz, 1) * xb);
+        dev_h2d(d_cptr.p, cptr.data(), (m + 1) * 8, s);
+        if (nnz) {
+            dev_h2d(d_crow.p, crow.data(), nnz * 4, s);
+            dev_h2d(d_cval.p, cval.data(), nnz * 32, s);
+            ZK_LAUNCH((k_from_mont<Fr>), dim3(blocks_for(nnz, T)), dim3(T), 0, s, ptr<Fr>(d_cval), ptr<Fr>(d_cval), nnz);   // resident values: Montgomery form
+            bind_cmul<Fq>(ctx, (const uint8_t*)x.p + N * xb, logN, ptr<u32>(d_crow), ptr<u32>(d_cval), NW, ptr<u32>(d_k) + NW, nnz, prod.p);
+        }
+        pk->l_bound.ensure(me * (u64)shz.levels * g1);
+        dev_memset((uint8_t*)pk->l_bound.p + m * g1, 0, 2 * g1, s);          // the (delta, r) and (delta, s) slots: infinity in l's table
+        bind_l_finish<Fq>(ctx, prod.p, ptr<u64>(d_cptr), pk->l_ext.p, m, pk->l_bound.p);
+        stream_sync(s);                                // (the host vectors were the copies' sources)
+        x.release();
+        prod.release();
+        msm_table_levels<Fq>(ctx, pk->l_bound.p, me, shz.level_bits(), (int)shz.levels);
+        pk->inf_many_bound[0] = count_infinite<Fq>(ctx, pk->l_bound.p, me) * 2048 > me;
+        pk->inf_many_bound[1] = count_infinite<Fq>(ctx, pk->h_bound.p, N) * 2048 > N;
+        pk->bound_uid = cs->uid;
+    }
     static void count_points_at_infinity(zkhip_ctx* ctx, zkhip_pk* pk) {
         const u64 cnt[5] = {count_infinite<Fq>(ctx, pk->a_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->b1_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->l_ext.p, pk->z_n),
                             count_infinite<Fq2>(ctx, pk->b2_ext.p, pk->z_n), count_infinite<Fq>(ctx, pk->h_sigma.p, pk->h_n)};
@@ -952,10 +1085,13 @@ struct Prover {
     static CsrDev csr(const zkhip_r1cs* cs, int k) { return CsrDev{ptr<u64>(cs->rp[k]), ptr<u32>(cs->col[k]), cs->val[k].p}; }
 
     // K1: a = A z, b = B z, c = C z over rows [0, n) (+ the l instance rows of A), zero-filled up to N
-    static void matvec(zkhip_ctx* ctx, const zkhip_r1cs* cs, const Fr* zmont, Fr* a, Fr* b, Fr* c, u64 n, u64 l, u64 N) {
+    // (`nmat` = 2: A and B only — a key bound to the system carries c's share in its bases; the long rows of C, if any, still
+    // land in the c vector, which nothing reads then)
+    static void matvec(zkhip_ctx* ctx, const zkhip_r1cs* cs, const Fr* zmont, Fr* a, Fr* b, Fr* c, u64 n, u64 l, u64 N, int nmat = 3) {
         int g[3];
         for (int k = 0; k < 3; ++k) g[k] = matvec_group(cs->nnz_short[k], cs->n);
-        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), 3), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
+        if (nmat < 3) g[2] = 1;
+        ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), nmat), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
                   l, N, g[0], g[1], g[2], cs->l + cs->w);
         if (cs->n_long)
             ZK_LAUNCH((k_matvec_long<Fr>), dim3(blocks_for(cs->n_long, 4)), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c,
@@ -965,13 +1101,24 @@ struct Prover {
 
     // K1-K4 on the device: leaves h (canonical integers, sigma order) in ctx->cur->va.  The three vectors a, b, c live
     // back to back in va and go through every pass together (one launch per pass, grid.y = 3).
-    static void witness_map(zkhip_ctx* ctx, const zkhip_r1cs* cs, NttPlan<C>* pl) {
+    // `bound`: the key is bound to this system (PkLoader::bind) — the transforms that lead from the quotient's evaluations to h's
+    // coefficients, and everything c needs, were applied to the key's bases once: what is left per proof is a and b to their
+    // coefficients and on to the coset (FOUR transforms), and U_j = a_j b_j / Z(g) as canonical integers in NATURAL order in va.
+    static void witness_map(zkhip_ctx* ctx, const zkhip_r1cs* cs, NttPlan<C>* pl, bool bound = false) {
         Stream s = ctx->ws;
         const u64 N = pl->N;
         ctx->cur->va.ensure(3 * N * sizeof(Fr));
         Fr *a = ptr<Fr>(ctx->cur->va), *b = a + N, *c = b + N;
-        matvec(ctx, cs, ptr<Fr>(ctx->cur->zmont), a, b, c, cs->n, cs->l, N);
+        matvec(ctx, cs, ptr<Fr>(ctx->cur->zmont), a, b, c, cs->n, cs->l, N, bound ? 2 : 3);
         event_record(ctx->cur->ntt_b, s);
+        if (bound) {
+            ntt_kind_a<C>(ctx, pl, a, true, ptr<Fr>(pl->s_coset), 2, N);    // a, b: ifft, then * g^i
+            ntt_kind_b<C>(ctx, pl, a, false, nullptr, 2, N);                 // a, b: evaluations on g<w>, natural order
+            // (a plain-integer factor takes an R'-form product out of the Montgomery domain: canonical integers, the MSM's digits)
+            ZK_LAUNCH((k_quotient<typename Fr::Params>), dim3(blocks_for(N, 256)), dim3(256), 0, s, a, b, fe_from_mont(pl->zinv), a, N);
+            event_record(ctx->cur->ntt_e, s);
+            return;
+        }
         // SIX transforms (the reference's witness_map runs seven): a and b go to the coset and back as a product; c only needs
         // its coefficients — ((ab - c)/Z)'s coefficients are coset_ifft(ab / Z) - c_coeffs / Z, because the coset transform pair is
         // the identity on the c term — so c takes ONE inverse transform whose exit factor carries 1/(N Z) and leaves canonical
@@ -1020,6 +1167,7 @@ struct Prover {
         require(!sl.busy, ZKHIP_ERR_DEVICE, "internal: proof slot still in flight");
         slot_init(ctx, sl);
         const u64 m = pk->m, N = pk->N;
+        const bool bound = pk->bound_uid != 0 && pk->bound_uid == cs->uid && pk->world == 1;   // (zkhip_pk_bind_r1cs)
         Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
@@ -1074,7 +1222,7 @@ struct Prover {
         stream_wait_event(wn, sl.ev[0]);
         event_record(sl.ev[1], wn);
         ctx->ws = wn;
-        witness_map(ctx, cs, pl);
+        witness_map(ctx, cs, pl, bound);
         ctx->ws = ctx->stream;
         event_record(sl.ev[2], wn);
 
@@ -1082,7 +1230,7 @@ struct Prover {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
                 msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
-            run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready);
+            run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready, bound);
         } else {
             empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
         }
@@ -1090,7 +1238,9 @@ struct Prover {
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
         if (pk->h_n) {
             msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
-            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, with_inf(shh, pk->inf_many[4]), ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+            // (a bound key: U in natural order against H' — the same MSM machinery, other bases)
+            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], bound ? pk->h_bound.p : pk->h_sigma.p, with_inf(shh, bound ? pk->inf_many_bound[1] : pk->inf_many[4]),
+                        ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
         } else {
             empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
         }
@@ -1099,10 +1249,11 @@ struct Prover {
     }
 
     // ---- A, B1, L: the three G1 MSMs over the sorted assignment (window sums to ws1 + {0, 1, 2} * Wmax)
-    static void run_z_g1(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const MsmShape& shz, Xyzz<Fq>* ws1, int Wmax, Event h_ready) {
-        const void* tab[3] = {pk->a_ext.p, pk->b1_ext.p, pk->l_ext.p};
-        auto thin = [&](int k) { return (pk->thin_mask >> k) & 1u; };
-        auto inf_many = [&](int k) { return thin(k) ? pk->inf_many_thin[k] : pk->inf_many[k]; };
+    // (`bound`: L' in l's place, on the common list whatever l's family is — its public entries are finite)
+    static void run_z_g1(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const MsmShape& shz, Xyzz<Fq>* ws1, int Wmax, Event h_ready, bool bound = false) {
+        const void* tab[3] = {pk->a_ext.p, pk->b1_ext.p, bound ? pk->l_bound.p : pk->l_ext.p};
+        auto thin = [&](int k) { return (bound && k == 2) ? 0u : (pk->thin_mask >> k) & 1u; };
+        auto inf_many = [&](int k) { return (bound && k == 2) ? pk->inf_many_bound[0] : thin(k) ? pk->inf_many_thin[k] : pk->inf_many[k]; };
         if (!ctx->fuse_z) {
             for (int k = 0; k < 3; ++k)
                 msm_run<Fq>(ctx, sl.lanes[k], thin(k) ? sl.sorts[2] : sl.sorts[0], tab[k], with_inf(shz, inf_many(k)), ws1 + k * Wmax, sl.acc_b[k], sl.acc_e[k], h_ready);
@@ -1552,6 +1703,7 @@ namespace zk {
 struct CurveOps {
     void (*pk_load)(zkhip_ctx*, const uint8_t*, size_t, zkhip_pk*);
     void (*pk_table_levels)(zkhip_ctx*, zkhip_pk*);
+    void (*pk_bind)(zkhip_ctx*, zkhip_pk*, const zkhip_r1cs*);
     void (*r1cs_load)(zkhip_ctx*, zkhip_r1cs*, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]);
     void (*prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*prove_resident)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, void*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
@@ -1605,6 +1757,7 @@ static CurveOps make_curve_ops() {
     o.ntt_log1 = &ntt_log1_of<C>;
     o.pk_load = &PkLoader<C>::load;
     o.pk_table_levels = &PkLoader<C>::table_levels;
+    o.pk_bind = &PkLoader<C>::bind;
     o.r1cs_load = &Prover<C>::r1cs_load;
     o.prove = &Prover<C>::prove_host;
     o.prove_resident = &Prover<C>::prove_resident;

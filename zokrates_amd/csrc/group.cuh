@@ -2,6 +2,7 @@
 // translation unit of their own (bn254_g1.hip, bn254_g2.hip, bls381_g1.hip, bls381_g2.hip).
 #pragma once
 #include "core.cuh"
+#include "bind.cuh"
 
 namespace zk {
 
@@ -148,6 +149,44 @@ template <class F>
 void fixed_base_mul(zkhip_ctx* ctx, const DBuf& tbl, int nwin, const u32* d_scalars, u64 count, Aff<F>* d_out) {
     ZK_LAUNCH((k_fixed_base_mul<F>), dim3(blocks_for(count, 64)), dim3(64), 0, ctx->stream, d_scalars, count, ptr<Aff<F>>(tbl), nwin, d_out);
 }
+
+// ---- binding a key to a constraint system (bind.cuh): launchers, G1 only ----
+template <class FS>
+size_t bind_xyzz_bytes() { return sizeof(Xyzz<typename Unsat<FS>::type>); }
+template <class FS>
+void bind_scale(zkhip_ctx* ctx, const void* d_h_table, u64 N, u64 n_src, u32 n1, u32 n2, u32 n3, const u32* d_scal, const u32* d_konst, int nw, void* d_x) {
+    typedef typename Unsat<FS>::type F;
+    ZK_LAUNCH((k_bind_scale<F>), dim3(blocks_for(N, 256), 2), dim3(256), 0, ctx->stream, (const AffPacked<F>*)d_h_table, N, n_src, n1, n2, n3, d_scal, d_konst, nw,
+              (Xyzz<F>*)d_x);
+}
+template <class FS>
+void bind_fft(zkhip_ctx* ctx, void* d_x, u64 N, const u32* d_tw, int nw) {
+    typedef typename Unsat<FS>::type F;
+    for (u64 q = N / 2; q >= 1; q >>= 1)
+        ZK_LAUNCH((k_bind_fft_stage<F>), dim3(blocks_for(N / 2, 256), 2), dim3(256), 0, ctx->stream, (Xyzz<F>*)d_x, N, q, d_tw, nw);
+}
+template <class FS>
+void bind_h_finish(zkhip_ctx* ctx, const void* d_x, u64 N, int logN, void* d_out) {
+    typedef typename Unsat<FS>::type F;
+    ZK_LAUNCH((k_bind_h_finish<F>), dim3(blocks_for(N, 256)), dim3(256), 0, ctx->stream, (const Xyzz<F>*)d_x, N, logN, (AffPacked<F>*)d_out);
+}
+template <class FS>
+void bind_cmul(zkhip_ctx* ctx, const void* d_x, int logN, const u32* d_row, const u32* d_val, int nw, const u32* d_minus_one, u64 nnz, void* d_prod) {
+    typedef typename Unsat<FS>::type F;
+    ZK_LAUNCH((k_bind_cmul<F>), dim3(blocks_for(nnz, 256)), dim3(256), 0, ctx->stream, (const Xyzz<F>*)d_x, logN, d_row, d_val, nw, d_minus_one, nnz, (Xyzz<F>*)d_prod);
+}
+template <class FS>
+void bind_l_finish(zkhip_ctx* ctx, const void* d_prod, const u64* d_cptr, const void* d_l_table, u64 m, void* d_out) {
+    typedef typename Unsat<FS>::type F;
+    ZK_LAUNCH((k_bind_l_finish<F>), dim3((unsigned)m), dim3(64), 0, ctx->stream, (const Xyzz<F>*)d_prod, d_cptr, (const AffPacked<F>*)d_l_table, m, (AffPacked<F>*)d_out);
+}
+#define ZK_INSTANTIATE_BIND(F)                                                                                          \
+    template size_t bind_xyzz_bytes<F>();                                                                               \
+    template void bind_scale<F>(zkhip_ctx*, const void*, u64, u64, u32, u32, u32, const u32*, const u32*, int, void*);  \
+    template void bind_fft<F>(zkhip_ctx*, void*, u64, const u32*, int);                                                 \
+    template void bind_h_finish<F>(zkhip_ctx*, const void*, u64, int, void*);                                           \
+    template void bind_cmul<F>(zkhip_ctx*, const void*, int, const u32*, const u32*, int, const u32*, u64, void*);      \
+    template void bind_l_finish<F>(zkhip_ctx*, const void*, const u64*, const void*, u64, void*);
 
 #define ZK_INSTANTIATE_GROUP(F)                                                                                         \
     template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event, Event);   \

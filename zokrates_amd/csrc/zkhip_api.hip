@@ -250,6 +250,33 @@ int32_t zkhip_pk_load_g16_shard(zkhip_ctx* ctx, int32_t curve, const uint8_t* by
     });
 }
 void zkhip_pk_free(zkhip_pk* pk) { delete pk; }
+int32_t zkhip_pk_bind_r1cs(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* r1cs) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    const int32_t rc = guarded(ctx, [&] {
+        require(pk && r1cs, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
+        for (auto& sl : ctx->slots) require(!sl.busy, ZKHIP_ERR_BAD_ARG, "a proof is in flight in this context");
+        ops_for(pk->curve)->pk_bind(ctx, pk, r1cs);
+    });
+    if (rc != ZKHIP_OK && pk) {   // whatever failed half-way: the key is as it was loaded
+        pk->bound_uid = 0;
+        pk->h_bound.release();
+        pk->l_bound.release();
+    }
+    return rc;
+}
+int32_t zkhip_pk_unbind(zkhip_pk* pk) {
+    if (!pk) return ZKHIP_ERR_BAD_ARG;
+    if (pk->ctx) dev_set(pk->ctx->device);
+    pk->bound_uid = 0;
+    pk->h_bound.release();
+    pk->l_bound.release();
+    return ZKHIP_OK;
+}
+int32_t zkhip_pk_is_bound(const zkhip_pk* pk, const zkhip_r1cs* r1cs) {
+    if (!pk || !r1cs) return 0;
+    return pk->bound_uid != 0 && pk->bound_uid == r1cs->uid && pk->world == 1 ? 1 : 0;
+}
 int32_t zkhip_pk_dims(const zkhip_pk* pk, uint64_t out[4]) {
     if (!pk || !out) return ZKHIP_ERR_BAD_ARG;
     out[0] = pk->m; out[1] = pk->hlen; out[2] = pk->w; out[3] = pk->l;

@@ -59,6 +59,7 @@ class Library:
         "zkhip_prog_parse", "zkhip_prog_free", "zkhip_prog_dims", "zkhip_prog_matrix", "zkhip_prog_variable_order",
         "zkhip_prog_r1cs_load", "zkhip_prog_assignment", "zkhip_prog_write_bound", "zkhip_prog_write",
         "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import",
+        "zkhip_pk_bind_r1cs", "zkhip_pk_unbind", "zkhip_pk_is_bound",
         "zkhip_ctx_tune",
         "zkhip_ctx_create_multi", "zkhip_multi_free", "zkhip_multi_size", "zkhip_multi_ctx", "zkhip_multi_last_error", "zkhip_multi_r1cs_load",
         "zkhip_multi_pk_load_g16", "zkhip_multi_pk_load_gm17", "zkhip_prove_g16_multi", "zkhip_prove_gm17_multi",
@@ -128,6 +129,9 @@ class Library:
         L.zkhip_pk_export_size.restype = i32; L.zkhip_pk_export_size.argtypes = [vp, vp]
         L.zkhip_pk_export.restype = i32; L.zkhip_pk_export.argtypes = [vp, vp, u64]
         L.zkhip_pk_import.restype = i32; L.zkhip_pk_import.argtypes = [vp, vp, sz, pp]
+        L.zkhip_pk_bind_r1cs.restype = i32; L.zkhip_pk_bind_r1cs.argtypes = [vp, vp, vp]
+        L.zkhip_pk_unbind.restype = i32; L.zkhip_pk_unbind.argtypes = [vp]
+        L.zkhip_pk_is_bound.restype = i32; L.zkhip_pk_is_bound.argtypes = [vp, vp]
         L.zkhip_prog_parse.restype = i32; L.zkhip_prog_parse.argtypes = [vp, sz, pp]
         L.zkhip_prog_free.restype = None; L.zkhip_prog_free.argtypes = [vp]
         L.zkhip_prog_dims.restype = i32; L.zkhip_prog_dims.argtypes = [vp, vp]
@@ -273,6 +277,17 @@ class ProvingKey:
         ctx._check(ctx.lib.L.zkhip_pk_import(ctx.h, _ptr(image), image.size, C.byref(self.h)))
         self._dims()
         return self
+
+    def bind(self, cs):
+        """`zkhip_pk_bind_r1cs`: apply the quotient's transforms to this key's bases once, for the constraint system `cs` — proofs
+        over (this key, cs) then take four transforms instead of six and skip c; the proof bytes do not change."""
+        self.ctx._check(self.ctx.lib.L.zkhip_pk_bind_r1cs(self.ctx.h, self.h, cs.h))
+
+    def unbind(self):
+        self.ctx._check(self.ctx.lib.L.zkhip_pk_unbind(self.h))
+
+    def is_bound(self, cs):
+        return bool(self.ctx.lib.L.zkhip_pk_is_bound(self.h, cs.h))
 
     def close(self):
         if self.h:
