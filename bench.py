@@ -322,6 +322,10 @@ def main():
     ap.add_argument("--members", type=int, default=0,
                     help="after the timed region, prove ONE proof across this many members inside the library (zkhip_prove_*_multi); "
                          "members take the visible GPUs in turn, sharing them when there are fewer (0 = skip; N > 1 ranks: rank 0 drives all GPUs)")
+    ap.add_argument("--bind", type=int, default=1,
+                    help="Groth16: bind the resident key to the resident constraint system before the timed region (zkhip_pk_bind_r1cs: four "
+                         "transforms per proof instead of six, no C mat-vec, same proof bytes — checked here against an unbound proof; the line "
+                         "also times one region with the key unbound again).  0 = the key as loaded")
     args = ap.parse_args()
 
     timeline = {}
@@ -405,6 +409,29 @@ def main():
     else:
         prove_one = lambda a, rnd: (native.prove_g16_resident if isinstance(a, native.Assignment) else native.prove_g16)(ctx, pk, cs, a, *rnd, want_timings=True)
         prove_many = lambda aa, rnds: native.prove_g16_resident_batch(ctx, pk, cs, aa, rnds)
+    # The resident prover's key, bound to its system (include/zkhip.h: zkhip_pk_bind_r1cs).  Self-checking: the bound key must
+    # reproduce an unbound proof byte for byte, or the run goes on with the key as loaded and says so.
+    bound, bound_rnd0 = {"bound": False}, None
+    if args.bind and not gm17:
+        try:
+            ref_proof = native.prove_g16_resident(ctx, pk, cs, resident[0], *rs(0))
+            t0 = time.time()
+            pk.bind(cs)
+            bound["bind_ms"] = 1000 * (time.time() - t0)
+            same = native.prove_g16_resident(ctx, pk, cs, resident[0], *rs(0)) == ref_proof
+            bound["proof_identical_to_unbound"] = bool(same)
+            bound["bound"] = bool(same)
+            if same:
+                bound_rnd0 = native.prove_g16_resident(ctx, pk, cs, resident[0], 1000, 2000)   # (held against the CPU baseline's proof below)
+            else:
+                pk.unbind()
+        except native.ZkhipError as e:
+            bound["error"] = str(e)
+            try:
+                pk.unbind()
+            except native.ZkhipError:
+                pass
+        mark("key_bound")
     single = []
     if args.warmup:
         # The W warm-up steps run the way the timed steps do — through the pipelined batch call — so that the timed region starts
@@ -456,6 +483,20 @@ def main():
         tms = [prove_one(resident[i % nw], rs(400 + i))[1] for i in range(args.serial_proofs + 1)][1:]
         ctx.tune("serial", 0)
         serial = {k: sum(t[k] for t in tms) / len(tms) for k in tms[0]}
+
+    # the same region once more with the key UNBOUND (six transforms, three mat-vecs): the same-box figure the binding is worth
+    if bound["bound"]:
+        pk.unbind()
+        prove_many([resident[i % nw] for i in range(4)], [rs(500 + i) for i in range(4)])
+        barrier_sync()
+        t0 = time.perf_counter()
+        prove_many([resident[j % nw] for j in steps], [rs(j + 7000) for j in steps])
+        barrier_sync()
+        bound["unbound_ms_per_step"] = 1000.0 * ranks.max_over_ranks(time.perf_counter() - t0) / args.steps
+        bound["unbound_single_proof_ms"] = min(prove_one(resident[i % nw], rs(600 + i))[1]["total_ms"] for i in range(3))
+        bound["note"] = ("`value` is measured with the key bound to the constraint system (4 transforms + 2 mat-vecs per proof); unbound_* repeat the "
+                         "region and the isolated proof with the key as loaded (6 transforms + 3 mat-vecs; the reference's schedule has 7)")
+        mark("unbound_region_done")
 
     avg = {k: v / args.steps for k, v in acc.items()}
     # ---- roofline of the dominant kernel (HIP events on the library's streams)
@@ -523,7 +564,7 @@ def main():
     # the NTT passes: 2 * N * 32 B per pass and vector; Groth16 runs 12 pass-vectors per proof (6 transforms: c
     # needs only its coefficients; the reference runs 7), GM17 8 (4 transforms; the reference 5); the interval also
     # holds the pointwise quotient kernel
-    passes = 8 if gm17 else 12
+    passes = 8 if (gm17 or bound["bound"]) else 12
     if N <= 1 << 10:
         passes //= 2
     ntt_bytes = passes * 2 * N * 32
@@ -551,7 +592,7 @@ def main():
          f"synthetic R1CS {args.kind}, n = {circ.n} constraints (QAP domain 2^{args.log_domain})"
          + (" [stand-in for BASELINE configs[0], stdlib sha256/512bitPacked.zok: the ZoKrates compiler cannot run here, so the wire "
             "statistics of a SHA-256 circuit (90 % boolean) are generated directly], " if args.kind == "sha" else ", "))
-        + f"{args.curve} Groth16, 6 NTTs + 5 MSMs per proof")
+        + f"{args.curve} Groth16, " + ("4 NTTs + 5 MSMs per proof (key bound to the constraint system)" if bound["bound"] else "6 NTTs + 5 MSMs per proof"))
     out = {
         "metric": "gm17_proofs_per_sec" if gm17 else "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
@@ -576,6 +617,7 @@ def main():
                     "note": "`value` / `ms_per_step` are the FIRST region; every region is K steps over the same K resident witnesses"},
         "under_load": sampler.summary(idle_reading),
         "per_rank": per_rank,
+        "bound_key": bound,
     }
     # ---- optional legs (latency mode): a watchdog guarantees that the throughput line is printed even if one of them hangs
     # (a collective after an asymmetric failure; the in-library path on hardware this container cannot test)
@@ -631,6 +673,8 @@ def main():
         gpu_proof = prove_one(resident[0], rnd0)[0]
         batch_proof = prove_many([resident[0]] * 3, [rnd0] * 3)[0]
         out["cpu_baseline"]["gpu_proof_identical"] = bool(gpu_proof == cpu_proof and all(p == cpu_proof for p in batch_proof))
+        if bound_rnd0 is not None:
+            out["cpu_baseline"]["gpu_bound_key_proof_identical"] = bool(bound_rnd0 == cpu_proof)
         out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
     elif rank == 0:
         out["cpu_baseline"] = None   # N > 1 or --cpu-seconds 0

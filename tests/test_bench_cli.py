@@ -50,6 +50,12 @@ def test_single_rank_contract(args, metric):
     assert rp["regions"] == 3 and len(rp["ms_per_step"]) == 3 and abs(rp["ms_per_step"][0] - d["ms_per_step"]) < 1e-9 and rp["spread"] >= 0
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and abs(d["per_rank"][0]["ms_per_step"] - d["ms_per_step"]) < 1e-6
     assert "under_load" in d                            # (no sysfs view of a GPU here: the sampler says so instead of inventing numbers)
+    b = d["bound_key"]                                  # Groth16 runs with the key bound to its system, checked against an unbound proof and the CPU's
+    if metric == "groth16_proofs_per_sec":
+        assert b["bound"] is True and b["proof_identical_to_unbound"] is True and b["bind_ms"] > 0 and b["unbound_ms_per_step"] > 0, b
+        assert c["gpu_bound_key_proof_identical"] is True and "4 NTTs" in d["config"]["workload"]
+    else:
+        assert b == {"bound": False} and "gpu_bound_key_proof_identical" not in c
     if not with_cli_leg:
         return
     e = d["cli_end_to_end_ms"]                         # the reference-shaped flow: files -> proof.json, one process per proof

@@ -169,6 +169,22 @@ def test_prove_matches_oracle(ctx, curve, logn, kind):
     assert proofs == [cpu.trapdoor(oc, tox, z, a, b) for a, b in rs[:3]]
     # determinism: same (pk, z, r, s) -> same bytes (cf. zokrates_js/tests/tests.js:248-267)
     assert native.prove_g16(ctx, pk, cs, z, r_, s_) == got
+    # the key bound to this system (zkhip_pk_bind_r1cs: four transforms per proof, c folded into the bases): the same bytes from
+    # every entry point, and the key as loaded again after unbind
+    pk.bind(cs)
+    assert pk.is_bound(cs)
+    assert native.prove_g16(ctx, pk, cs, z, r_, s_) == want
+    assert native.prove_g16(ctx, pk, cs, z, 0, 0) == cpu.trapdoor(oc, tox, z, 0, 0)
+    assert native.prove_g16_resident(ctx, pk, cs, za, 3, 4) == cpu.trapdoor(oc, tox, z, 3, 4)
+    proofs, _ = native.prove_g16_resident_batch(ctx, pk, cs, [za] * len(rs), rs)
+    assert proofs == [cpu.trapdoor(oc, tox, z, a, b) for a, b in rs]
+    zbad = np.array(z, copy=True)
+    zbad[32 * (oc.l + 1)] ^= 1                                    # an assignment that does not satisfy the system: what ark computes for it
+    if logn <= 14:
+        assert native.prove_g16(ctx, pk, cs, zbad, 5, 6) == cpu.prove(oc, opk, zbad, 5, 6)[0]
+    pk.unbind()
+    assert not pk.is_bound(cs)
+    assert native.prove_g16(ctx, pk, cs, z, r_, s_) == want
 
 
 def test_schedule_does_not_change_proofs(ctx):
@@ -256,7 +272,14 @@ def test_full_size_properties(ctx):
     oc = cpu.Circuit.from_csr(0, circ.n, circ.l, circ.w, circ.mats())
     tb = b"".join(int(v).to_bytes(32, "little") for v in tox)
     r_, s_ = 0xDEADBEEF12345678, 0xCAFEBABE87654321
-    assert native.prove_g16(ctx, pk, cs, z, r_, s_) == cpu.trapdoor(oc, tb, z, r_, s_)
+    want = cpu.trapdoor(oc, tb, z, r_, s_)
+    assert native.prove_g16(ctx, pk, cs, z, r_, s_) == want
+    # (1b) the same with the key bound to the system (two 2^20-point transforms over G1 at bind time, H' and L' in the MSMs)
+    pk.bind(cs)
+    assert native.prove_g16(ctx, pk, cs, z, r_, s_) == want
+    z2 = circ.assignment(0x5EED0002)
+    assert native.prove_g16(ctx, pk, cs, z2, 7, 0) == cpu.trapdoor(oc, tb, z2, 7, 0)
+    pk.unbind()
     # (2) linearity on the key's own a_query bases
     nb = 32
     off = 2 * nb + 3 * 4 * nb + 8 + circ.l * 2 * nb + 2 * 2 * nb + 8

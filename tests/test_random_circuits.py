@@ -76,6 +76,10 @@ def run(ctx, curve, seed, n, l, extra):
     assert got == cpu.trapdoor(oc, tb, zb, r_, s_)
     assert got == cpu.prove(oc, cpu.ProvingKey.parse(curve.curve_id, raw), zb, r_, s_)[0]
     assert dcs.witness_map(zb).tobytes() == cpu.witness_map(oc, zb).tobytes()
+    pk.bind(dcs)                                            # the key bound to the system (zkhip_pk_bind_r1cs): the same bytes
+    assert native.prove_g16(ctx, pk, dcs, zb, r_, s_) == got
+    assert native.prove_g16(ctx, pk, dcs, zb, 0, s_) == cpu.trapdoor(oc, tb, zb, 0, s_)
+    pk.unbind()
     # GM17
     t17 = gm17.Toxic.from_seed(curve, seed)
     tb17 = cpu.gm17_toxic_bytes(t17)
@@ -144,6 +148,15 @@ def _check_row_lengths(ctx, curve):
     dcs = native.ConstraintSystem(ctx, curve.curve_id, len(lengths), cs.l, cs.w, mats)
     oc = cpu.Circuit.from_csr(curve.curve_id, len(lengths), cs.l, cs.w, mats)
     assert dcs.witness_map(zb).tobytes() == cpu.witness_map(oc, zb).tobytes()
+    # a bound key over the same system: long rows in C (whose mat-vec a bound proof skips, k_matvec_long's share included) and
+    # columns of C with hundreds of entries (the per-variable sums of zkhip_pk_bind_r1cs)
+    tox = g16.Toxic.from_seed(curve, 5)
+    tb = cpu.toxic_bytes(tox)
+    pk = native.ProvingKey(ctx, curve.curve_id, native.setup_g16(ctx, dcs, (tox.alpha, tox.beta, tox.gamma, tox.delta, tox.tau)))
+    want = cpu.trapdoor(oc, tb, zb, 12, 34)
+    assert native.prove_g16(ctx, pk, dcs, zb, 12, 34) == want
+    pk.bind(dcs)
+    assert native.prove_g16(ctx, pk, dcs, zb, 12, 34) == want
 
 
 @pytest.mark.parametrize("curve", [BN254, BLS12_381], ids=lambda c: c.name)
