@@ -150,6 +150,8 @@ def test_measuring_process_that_dies_is_reported_and_retried():
     d = json.loads(lines[0])
     assert d["value"] > 0 and len(d["attempts"]) == 2
     assert d["attempts"][0]["signal"] == 6 and d["attempts"][0]["last_stage"] == "context_created" and d["attempts"][1]["exit_status"] == 0
+    assert d["bound_key"]["bound"] is False and "second attempt" in d["bound_key"]["note"]      # the retry leaves the key as loaded
+    assert "6 NTTs" in d["config"]["workload"]
     lines = run_bench(args, extra_env={"ZKHIP_BENCH_TEST_DIE": "*"}, expect_rc=1)
     assert len(lines) == 1
     d = json.loads(lines[0])
