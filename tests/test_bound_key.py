@@ -171,3 +171,66 @@ def test_what_does_not_bind(ctx):
         pk17.bind(cs)
     z = oc.assignment()
     assert native.prove_g16(ctx, pk, cs, z, 1, 2) == cpu.trapdoor(oc, tox, z, 1, 2)      # the refusals left the context usable
+
+
+def _bound_proof(c2, curve, oc, raw, cs, z, r_, s_, via_image=False):
+    pk = native.ProvingKey(c2, curve.curve_id, raw)
+    if via_image:
+        pk = native.ProvingKey.from_image(c2, curve.curve_id, pk.export_image())
+    pk.bind(cs)
+    assert pk.is_bound(cs)
+    return pk, native.prove_g16(c2, pk, cs, z, r_, s_)
+
+
+def test_bound_key_under_every_table_and_list_setting():
+    """The binding builds its two tables with the key's own shape and rides on the prover's other choices: thinned tables (every
+    2nd / 3rd multiple, several bucket sets), 17-bit windows, a key that came from an image, the b family on a list of its own
+    (L' leaves that list whatever l's family was: its public entries are finite), both ways of meeting bases at infinity, the
+    unfused launches, one stream — same bytes everywhere."""
+    c2 = native.Context(0, emu_library())
+    try:
+        curve = BN254
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        cases = []
+        for kind, n in (("dense", 40), ("sha", 45)):
+            oc = cpu.Circuit.synth(0, n, 0x5EED0060 + n, kind)
+            raw = cpu.ProvingKey.setup(oc, tox).serialize()
+            cs = native.ConstraintSystem(c2, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+            z = oc.assignment()
+            cases.append((oc, raw, cs, z, cpu.trapdoor(oc, tox, z, 11, 13)))
+        from zokrates_amd import poseidon
+        ch = poseidon.chain(0, 1)                                 # a compiler-shaped circuit: a third of its variables never occur in B
+        oc = cpu.Circuit.from_csr(0, ch.n, ch.l, ch.w, ch.mats())
+        z = ch.assignment(3)
+        cases.append((oc, cpu.ProvingKey.setup(oc, tox).serialize(), native.ConstraintSystem(c2, 0, ch.n, ch.l, ch.w, ch.mats()), z,
+                      cpu.trapdoor(oc, tox, z, 11, 13)))
+        settings = [{}, {"msm_sets": 2}, {"msm_sets": 3}, {"msm_sets": 64}, {"msm_c": 17}, {"b_sort": 1}, {"b_sort": 2}, {"skip_inf": 1}, {"skip_inf": 2},
+                    {"fuse_z": 0}, {"serial": 1}, {"z_gate": 0}, {"z_gate": 2}, {"slots": 1}]
+        defaults = {"msm_sets": 0, "msm_c": 0, "b_sort": 0, "skip_inf": 0, "fuse_z": 1, "serial": 0, "z_gate": 1, "slots": 3}
+        for st in settings:
+            for k, v in st.items():
+                c2.tune(k, v)
+            for i, (oc, raw, cs, z, want) in enumerate(cases):
+                if st.get("msm_c") == 17 and i == 2:
+                    continue                                      # (2^16 buckets x a few hundred variables: slow here, nothing new)
+                pk, got = _bound_proof(c2, curve, oc, raw, cs, z, 11, 13, via_image=bool(st.get("msm_sets") == 2 or not st))
+                assert got == want, (st, i)
+                proofs, _ = native.prove_g16_batch(c2, pk, cs, np.concatenate([z, z]), [(11, 13), (11, 13)])
+                assert proofs == [want, want], (st, i)
+                pk.close()
+            for k in st:
+                c2.tune(k, defaults[k])
+    finally:
+        c2.close()
+
+
+def test_bound_key_on_bls12_381_with_a_sparse_b(ctx):
+    """BLS12-381 (14-limb base field, 255-bit scalars: 16 windows) over a circuit most of whose variables never occur in B."""
+    curve = BLS12_381
+    oc = cpu.Circuit.synth(curve.curve_id, 30, 0x5EED0070, "sha")
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    raw = cpu.ProvingKey.setup(oc, tox).serialize()
+    cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    z = oc.assignment()
+    pk, got = _bound_proof(ctx, curve, oc, raw, cs, z, 21, 22)
+    assert got == cpu.trapdoor(oc, tox, z, 21, 22) == cpu.prove(oc, cpu.ProvingKey.parse(curve.curve_id, raw), z, 21, 22)[0]
