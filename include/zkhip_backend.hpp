@@ -129,6 +129,27 @@ class Program {
     uint64_t n_ = 0, l_ = 0, w_ = 0;
 };
 
+// A program's constraint system resident on the GPU (zkhip_prog_r1cs_load).  `Backend::generate_proof` consumes its program
+// and the one-call form below uploads the system for every proof, as the reference rebuilds its ConstraintSystem for every proof
+// (zokrates_ark/src/lib.rs:80-129); a caller that proves many witnesses of one program — zokrates_js calls generate_proof many
+// times per process, zokrates_js/src/lib.rs:380-452 — keeps a System next to its Key and may bind the two (Hip::bind).
+class System {
+  public:
+    System() = default;
+    ~System();
+    System(System&& o) noexcept : cs_(o.cs_), prog_(o.prog_) { o.cs_ = nullptr; o.prog_ = nullptr; }
+    System& operator=(System&& o) noexcept;
+    System(const System&) = delete;
+    System& operator=(const System&) = delete;
+    zkhip_r1cs* get() const { return cs_; }
+    const Program& program() const { return *prog_; }     // (the Program must outlive the System)
+
+  private:
+    friend class Hip;
+    zkhip_r1cs* cs_ = nullptr;
+    const Program* prog_ = nullptr;
+};
+
 // NonUniversalBackend::setup's result (zokrates_proof_systems/src/lib.rs:59-65,113-118): the verification key as the text of
 // `verification.key` (scheme/groth16.rs:18-25, scheme/gm17.rs:19-27) and the proving key in ark's serialize_unchecked bytes
 struct SetupKeypair {
@@ -163,6 +184,14 @@ class Hip {
     Key import_key_image(const uint8_t* bytes, size_t len);            // zkhip_pk_import
     std::vector<uint8_t> export_key_image(const Key& key) const;      // zkhip_pk_export (compact: level 0 of the tables)
     Proof prove(Scheme scheme, const Program& program, const uint8_t* witness, size_t witness_len, const Key& key, StdRng& rng,
+                Timings* timings = nullptr);
+    // a long-lived prover: the constraint system uploaded once, the Groth16 key bound to it (zkhip_pk_bind_r1cs: the quotient's
+    // inverse transforms applied to the key's bases once, four transforms per proof afterwards, the same proof).  bind returns
+    // false when the device has no room for the two extra tables: the key then proves as it was loaded.
+    System load_system(const Program& program);
+    bool bind(Key& key, const System& system);
+    bool is_bound(const Key& key, const System& system) const;
+    Proof prove(Scheme scheme, const System& system, const uint8_t* witness, size_t witness_len, const Key& key, StdRng& rng,
                 Timings* timings = nullptr);
     // NonUniversalBackend<T, S>::setup(program, rng) -> SetupKeypair: toxic waste = five non-zero `Fr::rand` draws (alpha, beta,
     // gamma, delta, tau; GM17: gamma = 1 as in ark-gm17), standard group generators (ark samples random ones from the RNG: a

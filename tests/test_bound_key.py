@@ -211,8 +211,8 @@ def test_bound_key_under_every_table_and_list_setting():
             for k, v in st.items():
                 c2.tune(k, v)
             for i, (oc, raw, cs, z, want) in enumerate(cases):
-                if st.get("msm_c") == 17 and i == 2:
-                    continue                                      # (2^16 buckets x a few hundred variables: slow here, nothing new)
+                if i == 2 and not ("b_sort" in st or "skip_inf" in st or not st):
+                    continue                                      # (the Poseidon circuit where its sparse B matters: lists and infinities)
                 pk, got = _bound_proof(c2, curve, oc, raw, cs, z, 11, 13, via_image=bool(st.get("msm_sets") == 2 or not st))
                 assert got == want, (st, i)
                 proofs, _ = native.prove_g16_batch(c2, pk, cs, np.concatenate([z, z]), [(11, 13), (11, 13)])

@@ -28,6 +28,7 @@ def test_kernels_keep_every_column_inside_64_bits(tmp_path):
     # (test_bound_key.py: the two transforms over G1 points of zkhip_pk_bind_r1cs — negated XYZZ points, the two-bit ladder, general
     # additions of stored sums — run their products through the same check)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_emu_kernels.py"), os.path.join(HERE, "test_bound_key.py"), "-x", "-q", "-k",
-                        "test_prove_matches_oracle or test_msm_skewed_scalars or test_ntt_three_passes or test_bound_key", "-p", "no:cacheprovider"],
+                        "test_prove_matches_oracle or test_msm_skewed_scalars or test_ntt_three_passes or test_bound_key_proves_the_same_bytes or "
+                        "test_bound_key_with_heavy_columns or test_bound_key_over_two_and_three", "-p", "no:cacheprovider"],
                        env=dict(os.environ, ZKHIP_EMU_LIBRARY=lib), capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and "overflows 64 bits" not in p.stderr + p.stdout, (p.stdout[-2000:], p.stderr[-2000:])

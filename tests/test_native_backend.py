@@ -123,6 +123,30 @@ def test_native_cli_equals_python_cli_on_emulator(tmp_path, curve, scheme):
     _both_clis(_files(tmp_path, curve, lib, scheme), scheme, exe, dict(os.environ, ZKHIP_LIBRARY=EMU_LIB))
 
 
+@pytest.mark.parametrize("curve,scheme", [(BN254, "g16"), (BLS12_381, "g16"), (BN254, "gm17")], ids=lambda v: getattr(v, "name", v))
+def test_long_lived_prover_of_the_cpp_host_layer_on_emulator(tmp_path, curve, scheme):
+    """zokrates_js calls generate_proof many times per process (zokrates_js/src/lib.rs:380-452): the compiled host side keeps the
+    constraint system resident (System) next to the key and binds the Groth16 key to it (Hip::bind = zkhip_pk_bind_r1cs).  Same
+    proof.json text before and after the binding, through the one-call form, and from the `generate-proof` executable."""
+    from emu_util import emu_library
+    lib = emu_library()
+    paths = _files(tmp_path, curve, lib, scheme)
+    exe = str(tmp_path / "resident_prover")
+    emu_dir = os.path.join(HERE, "_emu")
+    host = os.path.join(ROOT, "zokrates_amd", "csrc", "host")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", os.path.join(HERE, "host", "resident_prover.cpp"), os.path.join(host, "backend.cpp"),
+                           os.path.join(host, "verify.cpp"), "-L" + emu_dir, "-lzkhip_emu", "-Wl,-rpath," + emu_dir, "-o", exe])
+    r = subprocess.run([exe, paths["out"], paths["witness"], paths["proving.key"], "same entropy", scheme], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    head, same, text = r.stdout.split("\n", 2)
+    assert same == "same=1"
+    assert head == ("bound=1 refused=0 is_bound=1" if scheme == "g16" else "bound=0 refused=1 is_bound=0")
+    cli = subprocess.run([os.path.join(emu_dir, "zkhip-cli-emu"), "generate-proof", "-i", paths["out"], "-w", paths["witness"], "-p", paths["proving.key"],
+                          "-s", scheme, "--entropy", "same entropy", "-j", paths["proof_cpp.json"]], capture_output=True, text=True)
+    assert cli.returncode == 0, cli.stderr
+    assert json.loads(open(paths["proof_cpp.json"]).read()) == json.loads(text)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve,scheme", [(BN254, "g16"), (BLS12_381, "gm17")], ids=lambda v: getattr(v, "name", str(v)))
 def test_native_cli_equals_python_cli_on_gpu(tmp_path, curve, scheme):

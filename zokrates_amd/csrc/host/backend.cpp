@@ -251,7 +251,41 @@ double ms_since(std::chrono::steady_clock::time_point t0) {
 }
 }  // namespace
 
+System::~System() { if (cs_) zkhip_r1cs_free(cs_); }
+System& System::operator=(System&& o) noexcept {
+    if (this != &o) {
+        if (cs_) zkhip_r1cs_free(cs_);
+        cs_ = o.cs_; prog_ = o.prog_;
+        o.cs_ = nullptr; o.prog_ = nullptr;
+    }
+    return *this;
+}
+System Hip::load_system(const Program& program) {
+    System s;
+    check(zkhip_prog_r1cs_load(ctx_, program.get(), &s.cs_));
+    s.prog_ = &program;
+    return s;
+}
+bool Hip::bind(Key& key, const System& system) {
+    const int32_t rc = zkhip_pk_bind_r1cs(ctx_, key.get(), system.get());
+    if (rc == ZKHIP_ERR_NOMEM) return false;
+    check(rc);
+    return true;
+}
+bool Hip::is_bound(const Key& key, const System& system) const { return zkhip_pk_is_bound(key.get(), system.get()) == 1; }
+
 Proof Hip::prove(Scheme scheme, const Program& program, const uint8_t* witness, size_t witness_len, const Key& key, StdRng& rng, Timings* tm) {
+    // the constraint system on the device, for this one proof
+    auto t0 = std::chrono::steady_clock::now();
+    const System system = load_system(program);
+    const double upload = ms_since(t0);
+    Proof p = prove(scheme, system, witness, witness_len, key, rng, tm);
+    if (tm) tm->r1cs_upload = upload;
+    return p;
+}
+
+Proof Hip::prove(Scheme scheme, const System& system, const uint8_t* witness, size_t witness_len, const Key& key, StdRng& rng, Timings* tm) {
+    const Program& program = system.program();
     const int32_t curve = program.curve();
     const size_t fq = curve == ZKHIP_CURVE_BN128 ? 32 : 48;
     // (1) the assignment in ark order and the public inputs as the ark backend computes them (groth16.rs:33-38)
@@ -263,11 +297,9 @@ Proof Hip::prove(Scheme scheme, const Program& program, const uint8_t* witness, 
     int32_t rc = zkhip_prog_assignment(program.get(), witness, witness_len, z.data(), inputs.data(), cap, &n_inputs);
     if (rc != ZKHIP_OK) throw Error(rc, zkhip_last_error(nullptr));
     if (tm) tm->witness_to_assignment = ms_since(t0);
-    // (2) the constraint system on the device
-    t0 = std::chrono::steady_clock::now();
-    zkhip_r1cs* cs = nullptr;
-    check(zkhip_prog_r1cs_load(ctx_, program.get(), &cs));
-    if (tm) tm->r1cs_upload = ms_since(t0);
+    // (2) the constraint system: resident
+    zkhip_r1cs* cs = system.get();
+    if (tm) tm->r1cs_upload = 0;
     // (3) the blinding scalars: the first draws ark makes from the caller's RNG; (4) the GPU
     t0 = std::chrono::steady_clock::now();
     std::vector<uint8_t> raw(8 * fq + 3);
@@ -279,7 +311,6 @@ Proof Hip::prove(Scheme scheme, const Program& program, const uint8_t* witness, 
         const std::array<uint8_t, 32> r = fr_rand(rng, curve), s = fr_rand(rng, curve);
         rc = zkhip_prove_g16(ctx_, key.get(), cs, z.data(), r.data(), s.data(), raw.data(), nullptr);
     }
-    zkhip_r1cs_free(cs);
     check(rc);
     if (tm) tm->prove = ms_since(t0);
     // (5) raw little-endian coordinates -> big-endian hex; a point at infinity is printed as ark's zero() = (0, 1)
