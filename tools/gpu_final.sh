@@ -36,18 +36,18 @@ ZKHIP_DIST_BACKEND=gloo ZKHIP_BENCH_DEVICE=0 timeout 600 python -m torch.distrib
 # given up.  Last, so that a profiler pass that hangs (one did: 900 s) cannot cost the bench lines.
 [ -z "${SKIP_PMC:-}" ] && ( cd /tmp && export TMPDIR=/tmp ZKHIP_BENCH_CHILD=1
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    ZKHIP_SERIAL=1 timeout 200 rocprofv3 --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0 > "$out/prof_pmc_$ctr.log" 2>&1
+    ZKHIP_SERIAL=1 timeout 200 rocprofv3 --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --bind 0 --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0 > "$out/prof_pmc_$ctr.log" 2>&1
     db=$(find "$out/prof_pmc_$ctr" -name "*.db" 2>/dev/null | head -1)
     [ -n "$db" ] && python "$root/tools/pmc_stats.py" "$db" "$out/${tag}_pmc_$ctr.md" > /dev/null
   done
   f=$(find "$out/prof_pmc_FETCH_SIZE" -name "*.db" 2>/dev/null | head -1); w=$(find "$out/prof_pmc_WRITE_SIZE" -name "*.db" 2>/dev/null | head -1)
   if [ -n "$f" ] && [ -n "$w" ]; then
-    python "$root/tools/pmc_traffic.py" "$f" "$w" "$out/pmc_traffic.json" "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate runs), ZKHIP_SERIAL=1 python bench.py --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0; profiles/${tag}_pmc_FETCH_SIZE.md, ${tag}_pmc_WRITE_SIZE.md" > /dev/null \
+    python "$root/tools/pmc_traffic.py" "$f" "$w" "$out/pmc_traffic.json" "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate runs), ZKHIP_SERIAL=1 python bench.py --bind 0 --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0; profiles/${tag}_pmc_FETCH_SIZE.md, ${tag}_pmc_WRITE_SIZE.md" > /dev/null \
       && cp "$out/pmc_traffic.json" "$root/profiles/pmc_traffic.json" && echo "pmc_traffic.json refreshed"
   else echo "PMC passes incomplete: profiles/pmc_traffic.json unchanged"; fi
   # VALU issue occupation of the same kernels -> pmc_valu.json (tools/pmc_valu.py)
   ZKHIP_SERIAL=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d "$out/prof_pmc_VALU" -o pmc -- \
-    python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0 > "$out/prof_pmc_VALU.log" 2>&1
+    python "$root/bench.py" --bind 0 --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0 > "$out/prof_pmc_VALU.log" 2>&1
   db=$(find "$out/prof_pmc_VALU" -name "*.db" 2>/dev/null | head -1)
   [ -n "$db" ] && python "$root/tools/pmc_valu.py" "$db" "$out/${tag}_pmc_VALU.md" > /dev/null && cp "$out/${tag}_pmc_VALU.json" "$out/pmc_valu.json" && echo "pmc_valu.json written"
   find "$out" -name "*.db" -size +8M -delete )

@@ -46,7 +46,7 @@ def main():
                 agg.setdefault(k, {}).setdefault(c, e)      # (a counter present in both passes: the first pass's)
     want = ("k_msm_accum<", "k_ntt_cols", "k_ntt_rows", "k_msm_fold", "k_msm_place", "k_msm_count", "k_matvec")
     rows = []
-    js = {"source": "rocprofv3 --pmc (two passes, --kernel-trace only) over ZKHIP_SERIAL=1 python bench.py --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0 --e2e 0",
+    js = {"source": "rocprofv3 --pmc (two passes, --kernel-trace only) over ZKHIP_SERIAL=1 python bench.py --bind 0 --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0 --e2e 0",
           "definition": "shares of SQ_WAVE_CYCLES (quad-cycles summed over waves): wait_any = parked on s_waitcnt/barrier, wait_inst_any = ready but not issued, "
                         "active_inst_* = issuing; l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS); waves_per_simd = SQ_LEVEL_WAVES / SQ_BUSY_CU_CYCLES / 4 where available", "kernels": {}}
     for k, cs in agg.items():

@@ -40,7 +40,7 @@ lines = ["| kernel | launches | avg us | VALU wave-instructions per launch | GPU
 for _, k, n, dur, insts, cyc, ghz, cpi, util in sorted(rows, reverse=True)[:20]:
     lines.append("| `%s` | %d | %.1f | %.3g | %.3g | %.2f | %.2f | %.0f |" % (k, n, dur, insts, cyc, ghz, cpi, util))
 import json
-js = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, ZKHIP_SERIAL=1 python bench.py --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0 (tools/gpu_pmc_valu.sh)",
+js = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, ZKHIP_SERIAL=1 python bench.py --bind 0 --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0 (tools/gpu_pmc_valu.sh)",
       "definition": "cycles = GRBM_GUI_ACTIVE / %d XCDs; cycles_per_valu_instruction_per_simd = cycles * %d SIMDs / SQ_INSTS_VALU; issue_utilisation = 4 / that (one wave64 VALU instruction per 4 cycles per 16-lane SIMD)" % (xcds, simds)}
 for _, k, n, dur, insts, cyc, ghz, cpi, util in rows:
     for tag, needle in (("G1", "k_msm_accum<Fu<"), ("G2", "k_msm_accum<Fu2<"), ("NTT_cols", "k_ntt_cols"), ("NTT_rows", "k_ntt_rows")):

@@ -30,13 +30,13 @@ db=$(find "$out/prof_serial" -name "*.db" | head -1)
 [ -n "$db" ] && python "$root/tools/rocpd_stats.py" "$db" "$out/${tag}_g16_serial_kernel_stats.md" > /dev/null
 # 3. / 4. counters (their own runs: --pmc with the kernel trace only); SKIP_PMC=1: tools/gpu_final.sh took them already
 for ctr in ${SKIP_PMC:+} $([ -z "${SKIP_PMC:-}" ] && echo FETCH_SIZE WRITE_SIZE); do
-  run pmc_$ctr --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0
+  run pmc_$ctr --pmc $ctr --kernel-trace -d "$out/prof_pmc_$ctr" -o pmc -- python "$root/bench.py" --bind 0 --cpu-seconds 0 --steps 4 --warmup 1 --serial-proofs 0 --e2e 0
   db=$(find "$out/prof_pmc_$ctr" -name "*.db" | head -1)
   [ -n "$db" ] && python "$root/tools/pmc_stats.py" "$db" "$out/${tag}_pmc_$ctr.md" > /dev/null
 done
 f=$(find "$out/prof_pmc_FETCH_SIZE" -name "*.db" | head -1); w=$(find "$out/prof_pmc_WRITE_SIZE" -name "*.db" | head -1)
 [ -n "$f" ] && [ -n "$w" ] && python "$root/tools/pmc_traffic.py" "$f" "$w" "$out/pmc_traffic.json" \
-  "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate runs), ZKHIP_SERIAL=1 python bench.py --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0; profiles/${tag}_pmc_FETCH_SIZE.md, ${tag}_pmc_WRITE_SIZE.md" > /dev/null
+  "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate runs), ZKHIP_SERIAL=1 python bench.py --bind 0 --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0; profiles/${tag}_pmc_FETCH_SIZE.md, ${tag}_pmc_WRITE_SIZE.md" > /dev/null
 unset ZKHIP_SERIAL
 # 5. GM17
 run gm17 --kernel-trace --stats -d "$out/prof_gm17" -o gm17 -- python "$root/bench.py" --cpu-seconds 0 --scheme gm17 --steps 16 --serial-proofs 0 --e2e 0
