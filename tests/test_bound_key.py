@@ -234,3 +234,62 @@ def test_bound_key_on_bls12_381_with_a_sparse_b(ctx):
     z = oc.assignment()
     pk, got = _bound_proof(ctx, curve, oc, raw, cs, z, 21, 22)
     assert got == cpu.trapdoor(oc, tox, z, 21, 22) == cpu.prove(oc, cpu.ProvingKey.parse(curve.curve_id, raw), z, 21, 22)[0]
+
+
+def _csr_from_rows(rows):
+    rp, col, val = [0], [], []
+    for row in rows:
+        for v, c in row:                                          # (kept in the order given: duplicates and zeros stay what they are)
+            col.append(v); val.append(c)
+        rp.append(len(col))
+    return (np.array(rp, dtype=np.uint64), np.array(col, dtype=np.uint32),
+            np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in val), dtype=np.uint8) if val else np.zeros(0, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("shape", ["empty_c", "zero_and_duplicate_entries", "one_constraint", "c_on_one_only"])
+def test_bound_key_edge_shapes_of_c(ctx, shape):
+    """What the per-variable sums of the binding meet at the edges: a C matrix with no entry at all (every product a * b is 0), entries
+    with coefficient 0 and the same (row, variable) twice, a single constraint (domain 2), C on the constant ONE only."""
+    curve = BN254
+    r = curve.r
+    import random
+    rnd = random.Random({"empty_c": 1, "zero_and_duplicate_entries": 2, "one_constraint": 3, "c_on_one_only": 4}[shape])
+    l = 2
+    if shape == "one_constraint":
+        zv = [1, 5, 7, 35]
+        A, B, C = [[(1, 1)]], [[(2, 1)]], [[(3, 1)]]
+    else:
+        n, w = 11, 6
+        zv = [1] + [rnd.randrange(1, r) for _ in range(l - 1 + w)]
+        A, B, C = [], [], []
+        for k in range(n):
+            a = [(rnd.randrange(len(zv)), rnd.randrange(1, r))]
+            av = a[0][1] * zv[a[0][0]] % r
+            if shape == "empty_c":
+                b, c = [], []                                     # b = 0: a * 0 = 0
+            elif shape == "c_on_one_only":
+                b = [(rnd.randrange(len(zv)), rnd.randrange(1, r))]
+                c = [(0, av * (b[0][1] * zv[b[0][0]] % r) % r)]
+            else:
+                b = [(rnd.randrange(len(zv)), rnd.randrange(1, r))]
+                prod = av * (b[0][1] * zv[b[0][0]] % r) % r
+                v = 2 + rnd.randrange(len(zv) - 2)
+                half = rnd.randrange(r)
+                inv = pow(zv[v], r - 2, r)
+                # prod = (half + rest) * z_v, the variable listed twice, next to an entry with coefficient 0
+                c = [(v, half), (1, 0), (v, (prod * inv - half) % r)]
+            A.append(a); B.append(b); C.append(c)
+    n = len(A)
+    w = len(zv) - l
+    mats = [_csr_from_rows(A), _csr_from_rows(B), _csr_from_rows(C)]
+    oc = cpu.Circuit.from_csr(0, n, l, w, mats)
+    z = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in zv), dtype=np.uint8)
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    opk = cpu.ProvingKey.setup(oc, tox)
+    want = cpu.prove(oc, opk, z, 31, 32)[0]
+    assert want == cpu.trapdoor(oc, tox, z, 31, 32)
+    cs = native.ConstraintSystem(ctx, 0, n, l, w, mats)
+    pk = native.ProvingKey(ctx, 0, opk.serialize())
+    assert native.prove_g16(ctx, pk, cs, z, 31, 32) == want
+    pk.bind(cs)
+    assert pk.is_bound(cs) and native.prove_g16(ctx, pk, cs, z, 31, 32) == want
