@@ -328,7 +328,7 @@ def main():
     ap.add_argument("--bind", type=int, default=1,
                     help="Groth16: bind the resident key to the resident constraint system before the timed region (zkhip_pk_bind_r1cs: four "
                          "transforms per proof instead of six, no C mat-vec, same proof bytes — checked here against an unbound proof; the line "
-                         "also times one region with the key unbound again).  0 = the key as loaded")
+                         "also times one region with the key unbound again).  0 = the key as loaded; 2 = bound, without the unbound region")
     args = ap.parse_args()
 
     timeline = {}
@@ -490,7 +490,7 @@ def main():
         serial = {k: sum(t[k] for t in tms) / len(tms) for k in tms[0]}
 
     # the same region once more with the key UNBOUND (six transforms, three mat-vecs): the same-box figure the binding is worth
-    if bound["bound"]:
+    if bound["bound"] and args.bind == 1:          # (--bind 2: bound throughout — a trace of the bound pipeline only)
         pk.unbind()
         prove_many([resident[i % nw] for i in range(4)], [rs(500 + i) for i in range(4)])
         barrier_sync()

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Overlap analysis of a rocprofv3 rocpd database (--kernel-trace) of a pipelined bench run:
 how much of the timed window has an accumulation kernel in flight, how much only small kernels, how much nothing.
-Usage: timeline.py results.db [first_fraction_to_skip=0.5]"""
+Usage: timeline.py results.db [first_fraction_to_skip=0.5]
+       timeline.py results.db --proofs A B     the window from the A-th to the B-th launch of k_quotient (one per Groth16 proof: a run
+                                               whose trace also holds key set-up, a bind or other legs picks its steady state by proof)"""
 import re
 import sqlite3
 import sys
@@ -15,10 +17,17 @@ def main():
     scol = "stream_id" if "stream_id" in cols else None
     sel = "name, start, end" + ("," + qcol if qcol else "") + ("," + scol if scol else "")
     rows = sorted(cur.execute("select %s from kernels" % sel), key=lambda r: r[1])
-    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
-    t0, t1 = rows[0][1], max(r[2] for r in rows)
-    lo = t0 + (t1 - t0) * skip
-    rows = [r for r in rows if r[1] >= lo]
+    if len(sys.argv) > 4 and sys.argv[2] == "--proofs":
+        marks = [r[1] for r in rows if "k_quotient" in r[0]]
+        a, b = int(sys.argv[3]), int(sys.argv[4])
+        lo, hi = marks[a], marks[b]
+        print("proofs %d..%d of %d (k_quotient launches)" % (a, b, len(marks)))
+        rows = [r for r in rows if r[1] >= lo and r[1] < hi]
+    else:
+        skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+        t0, t1 = rows[0][1], max(r[2] for r in rows)
+        lo = t0 + (t1 - t0) * skip
+        rows = [r for r in rows if r[1] >= lo]
     t0, t1 = rows[0][1], max(r[2] for r in rows)
     ev = []
     for r in rows:
