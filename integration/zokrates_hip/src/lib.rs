@@ -148,6 +148,41 @@ fn prove_raw<T: Field + ArkFieldExtensions>(flat: &Flat, pk_bytes: &[u8], gm17: 
     raw
 }
 
+/// A prover that lives across calls (zokrates_js calls `generate_proof` many times per process, zokrates_js/src/lib.rs:380-452): the
+/// context, the key and the constraint system stay on the GPU, and the Groth16 key is bound to the system once
+/// (`zkhip_pk_bind_r1cs`: the quotient's inverse transforms applied to the key's bases, four transforms per proof afterwards, the
+/// same proof bytes).  The C++ twin is `zokrates_hip::System` + `Hip::bind` (include/zkhip_backend.hpp).
+pub struct Resident { ctx: *mut ffi::zkhip_ctx, pk: *mut ffi::zkhip_pk, cs: *mut ffi::zkhip_r1cs, fq: usize }
+
+impl Resident {
+    /// `flat`: the walk of one witness of the program (only its matrices are kept); `pk_bytes`: the `proving.key` file
+    fn new<T: Field + ArkFieldExtensions>(flat: &Flat, pk_bytes: &[u8]) -> Self {
+        let (curve, fq) = curve_id::<T>();
+        unsafe {
+            let (mut ctx, mut pk, mut cs) = (null_mut(), null_mut(), null_mut());
+            check(null(), ffi::zkhip_ctx_create(0, &mut ctx));
+            check(ctx, ffi::zkhip_pk_load_g16(ctx, curve, pk_bytes.as_ptr(), pk_bytes.len(), &mut pk));
+            check(ctx, ffi::zkhip_r1cs_load(ctx, curve, flat.n, flat.l, flat.w,
+                flat.a.rp.as_ptr(), flat.a.col.as_ptr(), flat.a.val.as_ptr(),
+                flat.b.rp.as_ptr(), flat.b.col.as_ptr(), flat.b.val.as_ptr(),
+                flat.c.rp.as_ptr(), flat.c.col.as_ptr(), flat.c.val.as_ptr(), &mut cs));
+            // not enough device memory for the two extra tables (-3): the key proves as it was loaded
+            let rc = ffi::zkhip_pk_bind_r1cs(ctx, pk, cs);
+            if rc != 0 && rc != -3 { check(ctx, rc) }
+            Resident { ctx, pk, cs, fq }
+        }
+    }
+    /// one proof over the resident pair: `z` the assignment in ark order (Flat::build's), r and s drawn by the caller as ark draws them
+    fn prove(&self, z: &[u8], r: &[u8], s: &[u8]) -> Vec<u8> {
+        let mut raw = vec![0u8; 8 * self.fq + 3];
+        check(self.ctx, unsafe { ffi::zkhip_prove_g16(self.ctx, self.pk, self.cs, z.as_ptr(), r.as_ptr(), s.as_ptr(), raw.as_mut_ptr(), null_mut()) });
+        raw
+    }
+}
+impl Drop for Resident {
+    fn drop(&mut self) { unsafe { ffi::zkhip_r1cs_free(self.cs); ffi::zkhip_pk_free(self.pk); ffi::zkhip_ctx_free(self.ctx) } }
+}
+
 impl<T: Field + ArkFieldExtensions> Backend<T, G16> for Hip {
     fn generate_proof<'a, I: IntoIterator<Item = Statement<'a, T>>, R: Read, G: RngCore + CryptoRng>(
         program: ProgIterator<'a, T, I>, witness: Witness<T>, mut proving_key: R, rng: &mut G,
