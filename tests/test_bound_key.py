@@ -295,3 +295,32 @@ def test_bound_key_edge_shapes_of_c(ctx, shape):
     assert native.prove_g16(ctx, pk, cs, z, 31, 32) == want
     pk.bind(cs)
     assert pk.is_bound(cs) and native.prove_g16(ctx, pk, cs, z, 31, 32) == want
+
+
+@pytest.mark.parametrize("setting", ["0", "1", "2"])
+def test_lone_proofs_hold_their_g1_lanes_for_the_g2_accumulation(setting):
+    """ZKHIP_G2_HEAD_START (0 never, 1 over a bound key, 2 always): where the G2 accumulation runs one wave per SIMD (BLS12-381) a LONE
+    proof's G1 lanes also wait for the end of that accumulation.  A scheduling rule: the same proofs at every setting, bound and as
+    loaded, single and batched (the emulator runs the streams in order — the GPU copy of this check is in test_gpu_parity.py)."""
+    os.environ["ZKHIP_G2_HEAD_START"] = setting
+    try:
+        c2 = native.Context(0, emu_library())
+    finally:
+        os.environ.pop("ZKHIP_G2_HEAD_START")
+    try:
+        for curve in (BLS12_381, BN254):
+            oc = cpu.Circuit.synth(curve.curve_id, 21, 0x5EED0080, "sha")
+            tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+            raw = cpu.ProvingKey.setup(oc, tox).serialize()
+            cs = native.ConstraintSystem(c2, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+            z = oc.assignment()
+            want = cpu.trapdoor(oc, tox, z, 41, 42)
+            pk = native.ProvingKey(c2, curve.curve_id, raw)
+            za = native.Assignment(c2, cs, z)
+            assert native.prove_g16(c2, pk, cs, z, 41, 42) == want and native.prove_g16_resident(c2, pk, cs, za, 41, 42) == want
+            pk.bind(cs)
+            assert native.prove_g16(c2, pk, cs, z, 41, 42) == want and native.prove_g16_resident(c2, pk, cs, za, 41, 42) == want
+            proofs, _ = native.prove_g16_resident_batch(c2, pk, cs, [za] * 3, [(41, 42)] * 3)
+            assert proofs == [want] * 3
+    finally:
+        c2.close()

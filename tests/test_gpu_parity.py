@@ -325,3 +325,34 @@ def test_sharded_proof_virtual_ranks(ctx, world):
     za = native.Assignment(ctx, cs, z)
     parts = [native.prove_g16_partial(ctx, shards[k], cs, za, r_, s_) for k in range(world)]
     assert native.combine_g16(ctx, shards[0], parts, r_, s_) == want
+
+
+@pytest.mark.parametrize("setting", ["0", "1", "2"])
+def test_lone_proofs_hold_their_g1_lanes_for_the_g2_accumulation(setting):
+    """ZKHIP_G2_HEAD_START (0 never, 1 over a bound key — the default —, 2 always): on BLS12-381, whose G2 accumulation runs one wave
+    per SIMD, a lone proof's G1 lanes also wait for the end of that accumulation.  A scheduling rule on real streams: the same proof
+    bytes at every setting, bound and as loaded, single and pipelined."""
+    os.environ["ZKHIP_G2_HEAD_START"] = setting
+    try:
+        c2 = native.Context(0)
+    finally:
+        os.environ.pop("ZKHIP_G2_HEAD_START")
+    try:
+        for curve, logn in ((BLS12_381, 12), (BN254, 10)):
+            oc = cpu.Circuit.synth(curve.curve_id, (1 << logn) - 2, 0x5EED0090 + logn, "sha")
+            tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+            raw = cpu.ProvingKey.setup(oc, tox).serialize()
+            cs = native.ConstraintSystem(c2, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+            z = oc.assignment()
+            want = cpu.trapdoor(oc, tox, z, 41, 42)
+            pk = native.ProvingKey(c2, curve.curve_id, raw)
+            za = native.Assignment(c2, cs, z)
+            for bound in (False, True):
+                if bound:
+                    pk.bind(cs)
+                for _ in range(3):
+                    assert native.prove_g16(c2, pk, cs, z, 41, 42) == want and native.prove_g16_resident(c2, pk, cs, za, 41, 42) == want
+                proofs, _ = native.prove_g16_resident_batch(c2, pk, cs, [za] * 5, [(41, 42)] * 5)
+                assert proofs == [want] * 5
+    finally:
+        c2.close()

@@ -120,6 +120,7 @@ struct ProofSlot {
     Event ev[4] = {nullptr, nullptr, nullptr, nullptr};   // staged, MSMs over z issued, h ready, all done (copied out)
     Event acc_b[ZK_NLANES] = {}, acc_e[ZK_NLANES] = {};   // around each accumulation kernel
     Event ntt_b = nullptr, ntt_e = nullptr;               // around the transforms (7 for Groth16: 6 batched launches + 2; 5 for GM17)
+    Event g1_go = nullptr;                                // a lone proof's G1 lanes held for the G2 accumulation (Prover::enqueue, g2_head_start)
     bool ready = false;        // streams and events exist (slot_init)
     // the proof currently in flight in this slot
     bool busy = false;
@@ -154,6 +155,8 @@ struct zkhip_ctx {
     int msm_fused_waves = 0;  // accumulation waves per SIMD of that launch (0 = per point type)
     int msm_g1_waves = 0, msm_g2_waves = 0;   // slices per SIMD lane of a single-table G1 / G2 accumulation (0 = per point type)
     int z_gate = 1;           // which accumulations over z wait for the witness map of their proof: 0 none, 1 the G1 lanes, 2 all
+    int g2_head_start = 1;    // a LONE proof over a curve whose G2 accumulation runs one wave per SIMD: its G1 lanes also wait for the end of
+                              // that accumulation — 0 never, 1 over a bound key, 2 always (ZKHIP_G2_HEAD_START; Prover::enqueue)
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_max_sublog = 11;  // largest sub-transform of a pass (2^11 elements staged per sequence); domains above twice this take three passes
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
@@ -187,6 +190,7 @@ static inline void slot_init(zkhip_ctx* ctx, ProofSlot& sl) {
     for (auto& e : sl.ev) e = event_create();
     sl.ntt_b = event_create();
     sl.ntt_e = event_create();
+    sl.g1_go = event_create();
     sl.ready = true;
 }
 // streams made when they are first needed
@@ -1158,8 +1162,9 @@ struct Prover {
 
     // ---- enqueue: every kernel and copy of one proof, no host synchronisation
     // src_dev != nullptr: the assignment is already in HBM (copied device-to-device into the slot); else z is a host buffer
+    // `lone`: nothing else of this context is in flight beside this proof (the single-proof entry points; a batch pipelines)
     static void enqueue(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* src_dev,
-                        const uint8_t* r, const uint8_t* s_) {
+                        const uint8_t* r, const uint8_t* s_, bool lone = false) {
         require(pk->curve == C::ID && cs->curve == C::ID, ZKHIP_ERR_BAD_ARG, "curve mismatch between key and constraint system");
         require(pk->scheme == 0, ZKHIP_ERR_BAD_ARG, "this is a GM17 proving key: use zkhip_prove_gm17");
         require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
@@ -1230,7 +1235,21 @@ struct Prover {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
                 msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
-            run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready, bound);
+            // A G2 accumulation at one wave per SIMD (BLS12-381: the wave takes the SIMD's whole register file) shares no SIMD with a
+            // G1 wave: G1 workgroups that arrive while some of its workgroups are still waiting for a place take the places, and the
+            // G2 lane — the longest chain of such a proof — finishes that much later.  The witness map used to be the head start; a
+            // bound key's is a third shorter, and the lone Poseidon proof went from 6.9 to 8.1 ms
+            // (profiles/r5k_bound_key_single_proof_latency_ab.txt).  So a LONE proof holds its G1 lanes until the G2 accumulation is
+            // through; a batch has other proofs' kernels to fill the machine and is left alone.
+            Event g1_after = h_ready;
+            constexpr bool g2_owns_simds = MsmTuning<typename Unsat<Fq2>::type>::ACCUM_WPE == 1;
+            if (g2_owns_simds && lone && !ctx->serial && (ctx->g2_head_start == 2 || (ctx->g2_head_start == 1 && bound))) {
+                if (h_ready) stream_wait_event(st, h_ready);
+                stream_wait_event(st, sl.acc_e[4]);
+                event_record(sl.g1_go, st);
+                g1_after = sl.g1_go;
+            }
+            run_z_g1(ctx, sl, pk, shz, ws1, Wmax, g1_after, bound);
         } else {
             empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
         }
@@ -1497,12 +1516,12 @@ struct Prover {
     // one proof from a host assignment / from an assignment resident in HBM
     static void prove_host(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z, const uint8_t* r, const uint8_t* s_,
                            uint8_t* out, zkhip_timings* tm) {
-        enqueue(ctx, ctx->slots[0], pk, cs, z, nullptr, r, s_);
+        enqueue(ctx, ctx->slots[0], pk, cs, z, nullptr, r, s_, true);
         finish(ctx, ctx->slots[0], pk, out, tm);
     }
     static void prove_resident(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, void* d_scalars, const uint8_t* r, const uint8_t* s_,
                                uint8_t* out, zkhip_timings* tm) {
-        enqueue(ctx, ctx->slots[0], pk, cs, nullptr, d_scalars, r, s_);
+        enqueue(ctx, ctx->slots[0], pk, cs, nullptr, d_scalars, r, s_, true);
         finish(ctx, ctx->slots[0], pk, out, tm);
     }
     // `count` proofs, two in flight: while the GPU works on proof i the host finishes proof i-1 and enqueues proof i+1,

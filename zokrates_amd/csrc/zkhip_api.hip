@@ -126,6 +126,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         if (ctx->ntt_cols & (ctx->ntt_cols - 1)) ctx->ntt_cols = 2;   // the cols pass has no tail handling: a power of two only
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
+        ctx->g2_head_start = env_int("ZKHIP_G2_HEAD_START", 0, 2, 1);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
         ctx->heavy_runs = env_int("ZKHIP_MSM_HEAVY_RUNS", 0, 1, 1) != 0;
         { const int hg = env_int("ZKHIP_FOLD_HG", 1, 256, 32); ctx->fold_hg = 1 << ilog2_floor((u64)hg); }
@@ -177,6 +178,7 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
         for (auto& e : sl.ev) event_destroy(e);
         event_destroy(sl.ntt_b);
         event_destroy(sl.ntt_e);
+        event_destroy(sl.g1_go);
         host_free_pinned(sl.h_ws);
     }
     if (ctx->out_made) stream_destroy(ctx->out_stream);
