@@ -29,7 +29,10 @@ def _prove_like_the_cli(ctx, lib, case):
     if scheme == "gm17":
         raw = native.prove_gm17(ctx, pk, cs, z, *(rng.fr_rand(gen, prog.curve_id) for _ in range(3)))
     else:
-        raw = native.prove_g16(ctx, pk, cs, z, *(rng.fr_rand(gen, prog.curve_id) for _ in range(2)))
+        r_, s_ = (rng.fr_rand(gen, prog.curve_id) for _ in range(2))
+        raw = native.prove_g16(ctx, pk, cs, z, r_, s_)
+        pk.bind(cs)                               # the same bytes over the key bound to this system (zkhip_pk_bind_r1cs)
+        assert native.prove_g16(ctx, pk, cs, z, r_, s_) == raw, "the bound key's proof differs from the unbound one"
     return json.loads(formats.proof_json(prog.curve_id, raw, inputs, scheme=scheme))
 
 
