@@ -68,6 +68,22 @@ typedef struct zkhip_timings {
     float reserved[6];
 } zkhip_timings;
 
+/* ---- process-wide start options ---- */
+/* The library keeps ~20 HIP streams busy per context (a stream per proof slot and MSM, the transform pipeline, staging, copy-out);
+ * the HIP runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams that share a queue
+ * serialise: 8 queues measured +4 % proofs/s over 4, 16 another +1.5-2 %.  The runtime reads that setting ONCE, when it
+ * initialises (the first HIP call of the process) — so it is the HOST's decision, made explicitly here and nowhere else: the
+ * library itself never touches the process environment (rounds 1-5 did, in a load-time constructor: a drop-in loaded into someone
+ * else's process must not change HIP's behaviour for code that is not its own).
+ *   hw_queues > 0: ask the runtime for that many queues — GPU_MAX_HW_QUEUES is set unless the process has set it already;
+ *                  effective only BEFORE the first HIP call of the process (ZKHIP_ERR_BAD_ARG once this library has made one).
+ *                  8 is safe for any process; 16 only for a process with ONE resident prover (every queue reserves scratch
+ *                  for the largest kernel frame launched on it: a process with many contexts ran out at 16).
+ *   hw_queues = 0: nothing is changed; the call only reports (returns ZKHIP_OK).
+ * Not calling zkhip_init at all is legal: the runtime's own default applies.  Not thread-safe against concurrent getenv in other
+ * threads (setenv never is): call it from the thread that starts the process's GPU work, before the others exist. */
+int32_t zkhip_init(int32_t hw_queues);
+
 /* ---- context ---- */
 /* Number of usable HIP devices (0 if none / no runtime). */
 int32_t zkhip_device_count(void);
@@ -80,6 +96,12 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out);
 void zkhip_ctx_free(zkhip_ctx* ctx);
 /* Last error text of this context (or of the failed create when ctx == NULL). Never NULL. */
 const char* zkhip_last_error(const zkhip_ctx* ctx);
+/* Measurement aid: the shader clock the device actually runs at over the next `duration_us` microseconds, in GHz — ONE wavefront
+ * (a few registers, asleep between its two readings) compares the shader-cycle counter with the constant-rate wall clock, on a
+ * stream of its own, so that it can run BESIDE whatever else the device is doing: called from a second host thread on a second
+ * context of the same device while the first proves, it reads the clock the proving kernels run at (bench.py prices the
+ * accumulation's VALU issue limit with it instead of a clock derived from counters).  Blocks for the duration. */
+int32_t zkhip_ctx_clock_probe(zkhip_ctx* ctx, uint32_t duration_us, double* ghz_out);
 
 /* Development / measurement knobs of one context (none changes a result; all are plain fields read by the host code,
  * nothing consults the environment after zkhip_ctx_create).  ZKHIP_TUNE_MSM_C: window width of the MSM tables built by
@@ -307,13 +329,17 @@ int32_t zkhip_prove_gm17_multi(zkhip_multi* m, const uint8_t* z, const uint8_t* 
  * proofs_out: count x proof bytes) into one contiguous block per member and runs the members' pipelined batch calls on
  * one host thread each — no communication at all; what a long-lived prover service behind the trait would call. */
 int32_t zkhip_multi_pk_load_g16_replicas(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len);
+/* The members' keys (shards or replicas, Groth16 or GM17) bound to the members' constraint system — see zkhip_pk_bind_r1cs below;
+ * `key_bytes` = the key file the members were loaded from.  All members or none. */
+int32_t zkhip_multi_bind(zkhip_multi* m, const uint8_t* key_bytes, size_t len);
+int32_t zkhip_multi_unbind(zkhip_multi* m);
 int32_t zkhip_prove_g16_multi_batch(zkhip_multi* m, uint32_t count, const uint8_t* z, const uint8_t* rs, uint8_t* proofs_out,
                                     zkhip_timings* timings);
 
 /* ---- "next" row N2: proving-key cache ----
  * zkhip_pk_export writes the *resident* form of a loaded key (Groth16 or GM17, whole or one shard): packed Montgomery
  * points, MSM-ready order, the extended base vectors — the bytes the GPU holds, plus a small header.
- * zkhip_pk_import brings such an image back with five host-to-device copies and no parsing or conversion, taking
+ * zkhip_pk_import brings such an image back with five (a bound key: seven) host-to-device copies and no parsing or conversion, taking
  * `ProvingKey::deserialize_unchecked` (/root/reference/zokrates_ark/src/groth16.rs:40-42; one Fq multiplication per
  * coordinate and a single-threaded read in the reference) off the per-invocation path.
  * A resident key is a set of five MSM tables: level 0 = the key's points, the further levels their precomputed window
@@ -338,11 +364,23 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
  * transforms and the mat-vec of A and B only; the proof's group elements — hence its bytes — are the same (the same holds for an
  * assignment that does not satisfy the system: what the reference's MSM over h[..N-1] ignores, the bound bases ignore).  Any
  * other constraint system, and every call after zkhip_pk_unbind, takes the key's own tables.  Costs two size-N transforms
- * over G1 points (seconds at 2^20) and two more MSM tables of device memory (ZKHIP_ERR_NOMEM when they do not fit; the key stays
- * usable, unbound).  Groth16 keys loaded whole only (not a shard, not GM17).  zkhip_pk_is_bound: 1 if proofs over `r1cs` would
- * take the bound tables, else 0. */
+ * over G1 points (about a second at 2^20) and two more MSM tables of device memory (ZKHIP_ERR_NOMEM when they do not fit; the key stays
+ * usable, unbound).  A call that is refused for its arguments leaves an earlier binding untouched.
+ * GM17 keys bind the same way (/root/reference/zokrates_ark/src/gm17.rs:63: the SAP quotient (U^2 - W)/Z is linear in W and in the
+ * last transform): TWO transforms per proof instead of four on the twice-larger SAP domain, W's share on the c_query_1 bases.
+ * A SHARD of a multi-GPU key holds only its index ranges of the bases, and the transforms need every base once:
+ * zkhip_pk_bind_r1cs_shard takes the key FILE again (the bytes the shard was loaded from), computes H' / L' over the whole range
+ * and keeps this shard's ranges (works for a whole key as well); zkhip_multi_bind does it for the members of a zkhip_multi — one
+ * member computes, every member installs its ranges.
+ * A key image (zkhip_pk_export) of a bound key carries level 0 of H' / L' and a fingerprint of the constraint system
+ * (zkhip_r1cs_fingerprint: a position-keyed checksum of the resident matrices — a guard against mix-ups, not a commitment);
+ * zkhip_pk_bind_r1cs on the imported key attaches the tables when the fingerprint of `r1cs` agrees — a restart costs a read and a
+ * checksum, not the transforms.
+ * zkhip_pk_is_bound: 1 if proofs over `r1cs` would take the bound tables, else 0. */
 int32_t zkhip_pk_bind_r1cs(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* r1cs);
 int32_t zkhip_pk_unbind(zkhip_pk* pk);
+int32_t zkhip_pk_bind_r1cs_shard(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* key_bytes, size_t len);
+int32_t zkhip_r1cs_fingerprint(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, uint64_t out[2]);
 int32_t zkhip_pk_is_bound(const zkhip_pk* pk, const zkhip_r1cs* r1cs);
 
 /* ---- "next" row N1: ZoKrates' own input files (host only: no context, no device work) ----

@@ -157,20 +157,183 @@ def test_what_does_not_bind(ctx):
     cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
     shard = native.ProvingKey(ctx, 0, raw, rank=0, world=2)
     with pytest.raises(native.ZkhipError):
-        shard.bind(cs)
+        shard.bind(cs)                                         # a shard holds only its ranges of the bases: bind_shard takes the key file
     other = cpu.Circuit.synth(0, 40, 0x5EED0043)
     cs_other = native.ConstraintSystem(ctx, 0, other.n, other.l, other.w, [other.csr(k) for k in range(3)])
     pk = native.ProvingKey(ctx, 0, raw)
     with pytest.raises(native.ZkhipError):
         pk.bind(cs_other)                                      # another domain
     assert not pk.is_bound(cs_other) and not pk.is_bound(cs)
+    # a refused call leaves an earlier binding as it was (the argument checks come before anything of the key is touched)
+    pk.bind(cs)
+    with pytest.raises(native.ZkhipError):
+        pk.bind(cs_other)
+    assert pk.is_bound(cs)
+    z = oc.assignment()
+    assert native.prove_g16(ctx, pk, cs, z, 1, 2) == cpu.trapdoor(oc, tox, z, 1, 2)      # the refusals left the context usable
     t4 = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
     tb17 = t4[:96] + t4[128:160]
     pk17 = native.ProvingKey(ctx, 0, cpu.Gm17ProvingKey.setup(oc, tb17).serialize(), scheme="gm17")
     with pytest.raises(native.ZkhipError):
-        pk17.bind(cs)
-    z = oc.assignment()
-    assert native.prove_g16(ctx, pk, cs, z, 1, 2) == cpu.trapdoor(oc, tox, z, 1, 2)      # the refusals left the context usable
+        pk17.bind(cs_other)                                    # a GM17 key binds to ITS system only
+    with pytest.raises(native.ZkhipError):
+        pk.bind_shard(cs, cpu.Gm17ProvingKey.setup(oc, tb17).serialize())      # the key file of another scheme
+
+
+def _gm17_case(curve, n, kind="dense", seed=0x5EED0090):
+    oc = cpu.Circuit.synth(curve.curve_id, n, seed, kind)
+    t5 = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    tb17 = t5[:96] + t5[128:160]
+    return oc, tb17, cpu.Gm17ProvingKey.setup(oc, tb17), oc.assignment()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("kind,n", [("dense", 14), ("sha", 27), ("dense", 1)])
+def test_gm17_key_bound_to_its_system_proves_the_same_bytes(ctx, curve, kind, n):
+    """GM17 (/root/reference/zokrates_ark/src/gm17.rs:63): W's transform and its share of the quotient ride on the c_query_1 bases, the
+    last transform on g_gamma2_z_t — two transforms per proof instead of four, the same three group elements: against the oracle's
+    term-by-term restatement of ark-gm17 and its closed form, single and batched, and unbound again afterwards."""
+    oc, tb17, opk, z = _gm17_case(curve, n, kind)
+    cs = native.ConstraintSystem(ctx, curve.curve_id, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    pk = native.ProvingKey(ctx, curve.curve_id, opk.serialize(), scheme="gm17")
+    rnds = [(3, 5, 7), (0, 9, 0), (curve.r - 1, 1, 2)]
+    want = [cpu.gm17_prove(oc, opk, z, *rnd)[0] for rnd in rnds]
+    assert want[0] == cpu.gm17_trapdoor(oc, tb17, z, 3, 7)
+    assert [native.prove_gm17(ctx, pk, cs, z, *rnd) for rnd in rnds] == want
+    pk.bind(cs)
+    assert pk.is_bound(cs)
+    assert [native.prove_gm17(ctx, pk, cs, z, *rnd) for rnd in rnds] == want
+    za = native.Assignment(ctx, cs, z)
+    proofs, _ = native.prove_gm17_resident_batch(ctx, pk, cs, [za] * 3, rnds)
+    assert proofs == want
+    # an assignment that does NOT satisfy the system: the binding is linear, so bound and unbound agree there as well (what ark-gm17
+    # makes of such an assignment is another matter — it folds the blinding into the quotient before a division that is no longer
+    # exact, the device adds the blinding terms as group elements: INTEGRATION.md §7)
+    zbad = np.array(z, copy=True)
+    zbad[32 * (oc.l + 1)] ^= 1
+    bad_bound = native.prove_gm17(ctx, pk, cs, zbad, 3, 5, 7)
+    pk.unbind()
+    assert not pk.is_bound(cs) and native.prove_gm17(ctx, pk, cs, z, *rnds[0]) == want[0]
+    assert native.prove_gm17(ctx, pk, cs, zbad, 3, 5, 7) == bad_bound
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("scheme", ["g16", "gm17"])
+def test_shards_bind_from_the_key_file(ctx, world, scheme):
+    """A shard holds its index ranges of the bases; the binding's transforms need all of them once: zkhip_pk_bind_r1cs_shard takes the
+    key file, every shard keeps ITS ranges of H' / L' — the partial records of bound shards combine to the unsharded proof."""
+    curve = BN254
+    if scheme == "g16":
+        oc = cpu.Circuit.synth(0, 29, 0x5EED00A0, "sha")
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        raw = cpu.ProvingKey.setup(oc, tox).serialize()
+        z = oc.assignment()
+        want = cpu.trapdoor(oc, tox, z, 51, 52)
+    else:
+        oc, tb17, opk, z = _gm17_case(curve, 13)
+        raw = opk.serialize()
+        want = cpu.gm17_trapdoor(oc, tb17, z, 51, 52)
+    cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    shards = [native.ProvingKey(ctx, 0, raw, rank=k, world=world, scheme=scheme) for k in range(world)]
+    for bound in (False, True):
+        if bound:
+            for sh in shards:
+                sh.bind_shard(cs, raw)
+                assert sh.is_bound(cs)
+        if scheme == "g16":
+            parts = [native.prove_g16_partial(ctx, sh, cs, z, 51, 52) for sh in shards]
+            assert native.combine_g16(ctx, shards[0], parts, 51, 52) == want, bound
+        else:
+            parts = [native.prove_gm17_partial(ctx, sh, cs, z, 51, 0, 52) for sh in shards]
+            assert native.combine_gm17(ctx, shards[0], parts, 51, 0, 52) == want, bound
+    # a whole key binds through the same entry point, and an image of a bound shard comes back bound-able without the transforms
+    whole = native.ProvingKey(ctx, 0, raw, scheme=scheme)
+    whole.bind_shard(cs, raw)
+    prove = (lambda k: native.prove_g16(ctx, k, cs, z, 51, 52)) if scheme == "g16" else (lambda k: native.prove_gm17(ctx, k, cs, z, 51, 0, 52))
+    assert whole.is_bound(cs) and prove(whole) == want
+
+
+@pytest.mark.parametrize("scheme", ["g16", "gm17"])
+def test_key_image_carries_the_bound_tables(ctx, scheme):
+    """zkhip_pk_export of a bound key holds level 0 of H' / L' and the system's fingerprint; zkhip_pk_bind_r1cs on the imported key
+    attaches them when the fingerprint agrees (no transforms), and recomputes for any other system."""
+    curve = BN254
+    if scheme == "g16":
+        oc = cpu.Circuit.synth(0, 30, 0x5EED00B0)
+        tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+        raw = cpu.ProvingKey.setup(oc, tox).serialize()
+        z = oc.assignment()
+        want = cpu.trapdoor(oc, tox, z, 61, 62)
+        prove = lambda k, c: native.prove_g16(ctx, k, c, z, 61, 62)
+    else:
+        oc, tb17, opk, z = _gm17_case(curve, 14)
+        raw = opk.serialize()
+        want = cpu.gm17_trapdoor(oc, tb17, z, 61, 62)
+        prove = lambda k, c: native.prove_gm17(ctx, k, c, z, 61, 0, 62)
+    mats = [oc.csr(k) for k in range(3)]
+    cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, mats)
+    pk = native.ProvingKey(ctx, 0, raw, scheme=scheme)
+    plain = pk.export_image()
+    pk.bind(cs)
+    image = pk.export_image()
+    assert image.size > plain.size
+    pk.close()
+    back = native.ProvingKey.from_image(ctx, 0, image, scheme=scheme)
+    assert not back.is_bound(cs)                                   # tables present, not attached to a system yet
+    assert prove(back, cs) == want                                 # (the key's own tables)
+    cs_again = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, mats)     # the "restarted process": the same system loaded again
+    assert cs_again.fingerprint() == cs.fingerprint() and cs.fingerprint() != (0, 0)
+    back.bind(cs_again)
+    assert back.is_bound(cs_again) and prove(back, cs_again) == want
+    # the same dimensions, other coefficients: another fingerprint — the binding is recomputed, not trusted
+    rp, col, val = mats[2]
+    val2 = np.array(val, copy=True)
+    if val2.size:
+        val2[0] ^= 1
+    cs_other = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [mats[0], mats[1], (rp, col, val2)])
+    assert cs_other.fingerprint() != cs.fingerprint()
+    back.bind(cs_other)
+    assert back.is_bound(cs_other) and not back.is_bound(cs_again)
+    back.bind(cs_again)                                            # ... and back: recomputed, the same bytes
+    assert prove(back, cs_again) == want
+    # a truncated / inconsistent image is refused
+    with pytest.raises(native.ZkhipError):
+        native.ProvingKey.from_image(ctx, 0, image[:-5], scheme=scheme)
+
+
+def test_multi_members_bind_together(ctx):
+    """zkhip_multi_bind: one member computes the bound bases from the key file, every member installs its ranges; the members'
+    proof is the unsharded one, for both schemes, with the host exchange and the gathered one."""
+    curve = BN254
+    lib = emu_library()
+    for scheme in ("g16", "gm17"):
+        if scheme == "g16":
+            oc = cpu.Circuit.synth(0, 37, 0x5EED00C0)
+            tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+            raw = cpu.ProvingKey.setup(oc, tox).serialize()
+            z = oc.assignment()
+            want = cpu.trapdoor(oc, tox, z, 71, 72)
+        else:
+            oc, tb17, opk, z = _gm17_case(curve, 12)
+            raw = opk.serialize()
+            want = cpu.gm17_trapdoor(oc, tb17, z, 71, 72)
+        for members, rccl in ((3, False), (2, True)):
+            multi = native.Multi([0] * members, lib)
+            try:
+                if rccl:
+                    multi.use_rccl(True)
+                multi.load_constraint_system(0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+                multi.load_proving_key(0, raw, scheme=scheme)
+                for bound in (False, True):
+                    if bound:
+                        multi.bind(raw)
+                    got = multi.prove_g16(z, 71, 72) if scheme == "g16" else multi.prove_gm17(z, 71, 0, 72)
+                    assert got == want, (scheme, members, rccl, bound)
+                multi.unbind()
+                got = multi.prove_g16(z, 71, 72) if scheme == "g16" else multi.prove_gm17(z, 71, 0, 72)
+                assert got == want
+            finally:
+                multi.close()
 
 
 def _bound_proof(c2, curve, oc, raw, cs, z, r_, s_, via_image=False):

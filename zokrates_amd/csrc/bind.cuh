@@ -18,8 +18,8 @@
 //
 // Kernels (G1 only, the unsaturated field of fieldu.cuh, XYZZ points): k_bind_scale (bases -> scaled XYZZ, natural order),
 // k_bind_fft_stage (one radix-2 decimation-in-frequency stage over both vectors), k_bind_h_finish (bit-reversed XYZZ -> packed
-// affine level 0 of the H' table), k_bind_cmul (one product C[k][v] H''_k per non-zero of C, in column order), k_bind_l_finish (per
-// variable: the sum of its products + l_query[v] -> packed affine level 0 of the L' table).
+// affine level 0 of the H' table), k_bind_cmul (one product C[k][v] H''_k per non-zero of C, in column order), k_bind_l_sum_short / _long / k_bind_l_affine
+// (per variable: the sum of its products + l_query[v] -> packed affine level 0 of the L' table).
 #pragma once
 #include "kernels_msm.cuh"
 
@@ -38,26 +38,45 @@ ZK_HD Xyzz<F> xyzz_neg_u(const Xyzz<F>& p) {
     if (p.is_inf()) return p;
     return {p.x, fe_relax(fe_sub_k<4>(F::zero(), p.y)), p.zz, p.zzz};
 }
-// k * p for a canonical integer k of `nw` 32-bit words: two bits at a time against {p, 2p, 3p} (127 additions instead of the
-// ~254 slots a wavefront pays for a bit-by-bit ladder, whose lanes disagree at every bit).  Out of line, like every big cold routine.
+// k * p for a canonical integer k of `nw` 32-bit words (nw <= 12): signed four-bit windows against {p, 2p, ..., 8p} — 4 doublings and
+// one addition per window (15 of 16 digits are non-zero), 7 point operations for the table: ~3 270 field products for a 254-bit k
+// where round 5's two-bit form took ~4 060.  The table is indexed by a per-lane digit, so it lives in the kernel's private frame
+// (36 words per read against the ~3 000 instructions of the addition that follows).  Out of line, like every big cold routine.
 template <class F>
 ZK_HD_CALL Xyzz<F> xyzz_mul_words(const Xyzz<F> p, const u32* k, int nw) {
     Xyzz<F> r = Xyzz<F>::inf();
     if (p.is_inf()) return r;
-    Xyzz<F> tab[3];
+    Xyzz<F> tab[8];
     tab[0] = p;
     tab[1] = xyzz_dbl(p);
-    tab[2] = tab[1];
-    xyzz_add_acc_call(&tab[2], &p);
-    int top = nw * 16 - 1;                                       // highest non-zero two-bit digit
-    while (top >= 0 && ((k[top >> 4] >> ((top & 15) * 2)) & 3u) == 0) --top;
-    for (int i = top; i >= 0; --i) {
-        if (i != top) {
-            r = xyzz_dbl(r);
-            r = xyzz_dbl(r);
+    for (int t = 2; t < 8; ++t) {
+        tab[t] = tab[t - 1];
+        xyzz_add_acc_call(&tab[t], &p);
+    }
+    // recode from the low end: digit = nibble + carry, minus 16 (and a carry out) when that exceeds 8; magnitudes 0 .. 8 in four
+    // bits each, signs in a mask; one more digit (the last carry) on top
+    u32 mag[12];
+    u32 neg[3] = {0, 0, 0};
+    u32 carry = 0;
+    for (int w = 0; w < nw; ++w) {
+        u32 m = 0;
+        for (int q = 0; q < 8; ++q) {
+            u32 d = ((k[w] >> (4 * q)) & 15u) + carry;
+            carry = d > 8 ? 1u : 0u;
+            if (carry) { d = 16 - d; neg[(8 * w + q) >> 5] |= 1u << ((8 * w + q) & 31); }
+            m |= d << (4 * q);
         }
-        const u32 d = (k[i >> 4] >> ((i & 15) * 2)) & 3u;
-        if (d) xyzz_add_acc_call(&r, &tab[d - 1]);
+        mag[w] = m;
+    }
+    if (carry) r = p;                                              // the digit above the top nibble: 0 or 1
+    for (int i = 8 * nw - 1; i >= 0; --i) {
+        for (int b = 0; b < 4; ++b) r = xyzz_dbl(r);
+        const u32 d = (mag[i >> 3] >> (4 * (i & 7))) & 15u;
+        if (d) {
+            Xyzz<F> t = tab[d - 1];
+            if ((neg[i >> 5] >> (i & 31)) & 1u) t = xyzz_neg_u(t);
+            xyzz_add_acc_call(&r, &t);
+        }
     }
     return r;
 }
@@ -146,40 +165,62 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_bind_cmul(const
     prod[e] = is_one ? p : is_m1 ? xyzz_neg_u(p) : xyzz_mul_words<F>(p, k, nw);
 }
 
-// One workgroup of 64 per variable v: out[v] = affine(l[v] + sum of prod[cptr[v] .. cptr[v+1])), packed (level 0 of the L' table).
-// The work-items stride over the variable's products — a variable that occurs in every row of C (the constant ONE of a circuit full
-// of `x * y == k` rows) is 64 chains, not one — and meet in an LDS tree.
+// The per-variable sums S_v = l[v] + sum of prod[cptr[v] .. cptr[v+1]) in three stages (round 5 ran ONE workgroup of 64 per variable
+// whose lane 0 alone converted to affine form: 0.13 s at 2^20 with 63 lanes of 64 idle through a field inversion):
+//   k_bind_l_sum_short  one work-item per variable: columns of at most BIND_SHORT_COL entries (all but a handful in a compiled circuit)
+//   k_bind_l_sum_long   one workgroup per listed variable (the host lists the long columns: the constant ONE of a circuit full of
+//                       `x * y == k` rows occurs in every row of C): work-items stride over the products and meet in an LDS tree
+//   k_bind_l_affine     one work-item per variable: S_v -> packed affine (level 0 of the L' table), every lane inverting
 template <class F>
-__global__ void __launch_bounds__(64, MsmTuning<F>::COLD_WPE) k_bind_l_finish(const Xyzz<F>* __restrict__ prod, const u64* __restrict__ cptr, const AffPacked<F>* __restrict__ l,
-                                                      u64 m, AffPacked<F>* __restrict__ out) {
-    __shared__ Xyzz<F> sh[64];
-    const u64 v = blockIdx.x;
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_bind_l_sum_short(const Xyzz<F>* __restrict__ prod, const u64* __restrict__ cptr, const AffPacked<F>* __restrict__ l,
+                                                         u64 m, Xyzz<F>* __restrict__ sum) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= m) return;
+    const u64 b = cptr[v], e = cptr[v + 1];
+    if (e - b > BIND_SHORT_COL) return;              // k_bind_l_sum_long writes it
+    u32 w[2 * AffPacked<F>::NW];
+    aff_load_words<F>(l, v, w);
+    Xyzz<F> s = Xyzz<F>::from_affine(aff_unpack<F>(w));
+    for (u64 i = b; i < e; ++i) {
+        const Xyzz<F> t = prod[i];
+        xyzz_add_acc_call(&s, &t);
+    }
+    sum[v] = s;
+}
+template <class F>
+__global__ void __launch_bounds__(64, MsmTuning<F>::COLD_WPE) k_bind_l_sum_long(const Xyzz<F>* __restrict__ prod, const u64* __restrict__ cptr, const AffPacked<F>* __restrict__ l,
+                                                        const u32* __restrict__ cols, Xyzz<F>* __restrict__ sum) {
+    __shared__ Xyzz<F> sh[64];
+    const u64 v = cols[blockIdx.x];
     const u64 b = cptr[v], e = cptr[v + 1];
     Xyzz<F> s = Xyzz<F>::inf();
     for (u64 i = b + threadIdx.x; i < e; i += 64) {
         const Xyzz<F> t = prod[i];
         xyzz_add_acc_call(&s, &t);
     }
-    if (e - b > 1) {                 // (uniform over the workgroup)
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        for (unsigned st = 32; st > 0; st >>= 1) {
-            if (threadIdx.x < st && threadIdx.x + st < e - b) {
-                const Xyzz<F> o = sh[threadIdx.x + st];
-                xyzz_add_acc_call(&s, &o);
-                sh[threadIdx.x] = s;
-            }
-            __syncthreads();
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (unsigned st = 32; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const Xyzz<F> o = sh[threadIdx.x + st];
+            xyzz_add_acc_call(&s, &o);
+            sh[threadIdx.x] = s;
         }
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         u32 w[2 * AffPacked<F>::NW];
         aff_load_words<F>(l, v, w);
         const Xyzz<F> lv = Xyzz<F>::from_affine(aff_unpack<F>(w));
         xyzz_add_acc_call(&s, &lv);
-        aff_pack(xyzz_to_affine_u(s), out + v);
+        sum[v] = s;
     }
+}
+template <class F>
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_bind_l_affine(const Xyzz<F>* __restrict__ sum, u64 m, AffPacked<F>* __restrict__ out) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m) return;
+    aff_pack(xyzz_to_affine_u(sum[v]), out + v);
 }
 
 }  // namespace zk

@@ -618,7 +618,7 @@ void bind_h_finish(zkhip_ctx* ctx, const void* d_x, u64 N, int logN, void* d_out
 template <class F>
 void bind_cmul(zkhip_ctx* ctx, const void* d_x, int logN, const u32* d_row, const u32* d_val, int nw, const u32* d_minus_one, u64 nnz, void* d_prod);
 template <class F>
-void bind_l_finish(zkhip_ctx* ctx, const void* d_prod, const u64* d_cptr, const void* d_l_table, u64 m, void* d_out);
+void bind_l_finish(zkhip_ctx* ctx, const void* d_prod, const u64* d_cptr, const void* d_l_table, u64 m, const u32* d_long_cols, u64 n_long, void* d_sum, void* d_out);
 // fixed-base tables / multiplications for setup (N3); also per-group code
 template <class F>
 void fixed_base_table(zkhip_ctx* ctx, const Aff<F>* h_pj, int nwin, DBuf& tbl);
@@ -703,10 +703,13 @@ struct zkhip_pk {
     int ntt_log1 = -1;
     // Bound to one constraint system (zkhip_pk_bind_r1cs, PkLoader::bind): H' = the coset inverse transform applied to h_query
     // (natural order: it pairs with the quotient's EVALUATIONS on the coset), L' = l_query with c's share of the quotient folded in
-    // per variable.  Proofs over the system `bound_uid` names take four transforms and two mat-vecs; any other system, and every
-    // sharded / GM17 key, takes the tables above.  0 = not bound.
+    // per variable.  Proofs over the system `bound_uid` names take four transforms and two mat-vecs (a GM17 key: two transforms); any
+    // other system takes the tables above.  A shard holds its index ranges of H' and L' (zkhip_pk_bind_r1cs_shard).  0 = not bound.
     DBuf h_bound, l_bound;
     u64 bound_uid = 0;
+    u64 bound_fp[2] = {0, 0};                // fingerprint of that system (PkLoader::r1cs_fingerprint): what a key image remembers of it — a key
+                                             // imported with its bound tables is attached by zkhip_pk_bind_r1cs when the fingerprints agree,
+                                             // without recomputing anything
     bool inf_many_bound[2] = {true, true};   // (L', H'): as inf_many
 };
 
@@ -727,6 +730,8 @@ struct zkhip_r1cs {
     u64 nnz_short[3];     // without the rows of more than MATVEC_LONG terms (what the lanes-per-row choice of k_matvec is made from)
     DBuf long_rows;       // those rows, matrix << 32 | row (k_matvec_long)
     u64 n_long = 0;
+    u64 fp[2] = {0, 0};   // PkLoader::r1cs_fingerprint, computed when first asked for
+    bool fp_made = false;
 };
 // the matrices of a resident constraint system back in host memory (setup, N3: key generation walks them on the host; the
 // prover never needs them there, so zkhip_r1cs_load keeps no host copy).  Values come back as they are resident:
@@ -826,33 +831,46 @@ struct PkLoader {
         lo = std::min<u64>((u64)rank * nominal, total);
         n = std::min<u64>(nominal, total - lo);
     }
-    static void load(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk* pk) {
+    // the layout of ark's `serialize_unchecked` of ark_groth16::ProvingKey
+    struct Parsed {
+        const uint8_t *alpha_g1, *beta_g2, *delta_g2, *beta_g1, *delta_g1, *a_q, *b1_q, *b2_q, *h_q, *l_q;
+        u64 m, w, l, hl, N;
+    };
+    static Parsed parse(const uint8_t* bytes, size_t len) {
         Rd rd{bytes, bytes + len};
-        const uint8_t* alpha_g1 = rd.take(G1B);
-        const uint8_t* beta_g2 = rd.take(G2B);
+        Parsed k;
+        k.alpha_g1 = rd.take(G1B);
+        k.beta_g2 = rd.take(G2B);
         rd.take(G2B);                                  // gamma_g2 (verifier only)
-        const uint8_t* delta_g2 = rd.take(G2B);
+        k.delta_g2 = rd.take(G2B);
         const u64 n_abc = rd.len(G1B);
         rd.take(n_abc * G1B);                          // gamma_abc_g1 (verifier only)
-        const uint8_t* beta_g1 = rd.take(G1B);
-        const uint8_t* delta_g1 = rd.take(G1B);
-        const u64 m = rd.len(G1B);
-        const uint8_t* a_q = rd.take(m * G1B);
+        k.beta_g1 = rd.take(G1B);
+        k.delta_g1 = rd.take(G1B);
+        k.m = rd.len(G1B);
+        k.a_q = rd.take(k.m * G1B);
         const u64 mb1 = rd.len(G1B);
-        const uint8_t* b1_q = rd.take(mb1 * G1B);
+        k.b1_q = rd.take(mb1 * G1B);
         const u64 mb2 = rd.len(G2B);
-        const uint8_t* b2_q = rd.take(mb2 * G2B);
-        const u64 hl = rd.len(G1B);
-        const uint8_t* h_q = rd.take(hl * G1B);
-        const u64 w = rd.len(G1B);
-        const uint8_t* l_q = rd.take(w * G1B);
+        k.b2_q = rd.take(mb2 * G2B);
+        k.hl = rd.len(G1B);
+        k.h_q = rd.take(k.hl * G1B);
+        k.w = rd.len(G1B);
+        k.l_q = rd.take(k.w * G1B);
         require(rd.p == rd.e, ZKHIP_ERR_PARSE, "trailing bytes after proving key");
-        require(m >= 1 && mb1 == m && mb2 == m && w <= m, ZKHIP_ERR_PARSE, "inconsistent query lengths in proving key");
-        const u64 l = m - w;
-        require(n_abc == l, ZKHIP_ERR_PARSE, "gamma_abc length != number of instance variables");
-        const u64 N = hl + 1;
-        require((N & (N - 1)) == 0, ZKHIP_ERR_PARSE, "h_query length + 1 is not a power of two");
-        require(m + 2 < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "too many variables");
+        require(k.m >= 1 && mb1 == k.m && mb2 == k.m && k.w <= k.m, ZKHIP_ERR_PARSE, "inconsistent query lengths in proving key");
+        k.l = k.m - k.w;
+        require(n_abc == k.l, ZKHIP_ERR_PARSE, "gamma_abc length != number of instance variables");
+        k.N = k.hl + 1;
+        require((k.N & (k.N - 1)) == 0, ZKHIP_ERR_PARSE, "h_query length + 1 is not a power of two");
+        require(k.m + 2 < ((u64)1 << 31), ZKHIP_ERR_BAD_ARG, "too many variables");
+        return k;
+    }
+    static void load(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk* pk) {
+        const Parsed k = parse(bytes, len);
+        const uint8_t *alpha_g1 = k.alpha_g1, *beta_g2 = k.beta_g2, *delta_g2 = k.delta_g2, *beta_g1 = k.beta_g1, *delta_g1 = k.delta_g1, *a_q = k.a_q,
+                      *b1_q = k.b1_q, *b2_q = k.b2_q, *h_q = k.h_q, *l_q = k.l_q;
+        const u64 m = k.m, w = k.w, l = k.l, hl = k.hl, N = k.N;
         pk->m = m; pk->w = w; pk->l = l; pk->hlen = hl; pk->N = N; pk->logN = ilog2_floor(N);
         NttPlan<C>* plan = get_plan<C>(ctx, pk->logN);
         pk->ntt_log1 = plan->split();
@@ -929,32 +947,128 @@ struct PkLoader {
     // ---- zkhip_pk_bind_r1cs: H' and L' for ONE constraint system (bind.cuh has the algebra) ----
     static void unbind(zkhip_pk* pk) {
         pk->bound_uid = 0;
+        pk->bound_fp[0] = pk->bound_fp[1] = 0;
         pk->h_bound.release();
         pk->l_bound.release();
     }
-    static void bind(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* cs) {
-        typedef typename C::Fr Fr;
-        require(pk->scheme == 0, ZKHIP_ERR_BAD_ARG, "only a Groth16 key binds to a constraint system");
-        require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "a shard of a multi-GPU key does not bind");
+    // position-keyed checksum of a resident constraint system (dimensions, the three matrices as they are resident): cached
+    static void r1cs_fingerprint(zkhip_ctx* ctx, const zkhip_r1cs* cs_, u64 fp[2]) {
+        zkhip_r1cs* cs = const_cast<zkhip_r1cs*>(cs_);
+        if (!cs->fp_made) {
+            DBuf d;
+            d.ensure(16);
+            Stream s = ctx->stream;
+            dev_memset(d.p, 0, 16, s);
+            for (int k = 0; k < 3; ++k) {
+                const u64 salt = 0xA5A5A5A5ull * (u64)(k + 1) + cs->n * 0x9E3779B97F4A7C15ull + cs->l * 0xC2B2AE3D27D4EB4Full + cs->w;
+                auto run = [&](const void* p, u64 bytes, u64 tag) {
+                    if (bytes) ZK_LAUNCH(k_fingerprint, dim3(1024), dim3(256), 0, s, (const u32*)p, bytes / 4, salt ^ (tag * 0x165667B19E3779F9ull), (unsigned long long*)d.p);
+                };
+                run(cs->rp[k].p, (cs->n + 1) * 8, 1);
+                run(cs->col[k].p, cs->nnz[k] * 4, 2);
+                run(cs->val[k].p, cs->nnz[k] * 32, 3);
+            }
+            dev_d2h(cs->fp, d.p, 16, s);
+            stream_sync(s);
+            cs->fp[0] ^= (u64)cs->curve + 1;           // (never all zero for an empty system either)
+            cs->fp_made = true;
+        }
+        fp[0] = cs->fp[0];
+        fp[1] = cs->fp[1];
+    }
+    // the quotient's domain, the bases it pairs with and the variable range of either scheme
+    struct BindShape {
+        u64 N, n_src, me, mcols;    // domain; h bases that are not the padding; entries of the l table; variables (columns of W)
+        int logN;
+    };
+    static BindShape bind_shape(const zkhip_pk* pk) {
+        BindShape b;
+        b.N = pk->N; b.logN = pk->logN; b.mcols = pk->m; b.me = pk->m + 2;
+        b.n_src = pk->scheme == 0 ? pk->hlen : pk->N;     // Groth16: h_query has N - 1 entries; GM17: g_gamma2_z_t[0 .. D)
+        return b;
+    }
+    // everything a refusal can depend on, BEFORE anything of the key is touched (zkhip_pk_bind_r1cs)
+    static void bind_check(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs) {
         require(pk->curve == C::ID && cs->curve == C::ID, ZKHIP_ERR_BAD_ARG, "curve mismatch between key and constraint system");
-        require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
-                "proving key does not match the constraint system (m, w or domain size)");
-        require(pk->N >= 2 && pk->hlen + 1 == pk->N, ZKHIP_ERR_BAD_ARG, "domain too small to bind");
-        unbind(pk);
+        if (pk->scheme == 0) {
+            require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
+                    "proving key does not match the constraint system (m, w or domain size)");
+            require(pk->N >= 2 && pk->hlen + 1 == pk->N, ZKHIP_ERR_BAD_ARG, "domain too small to bind");
+        } else {
+            const u64 M = 1 + 2 * (cs->l - 1) + cs->w + cs->n, D0 = 2 * cs->n + 2 * (cs->l - 1) + 1;
+            require(pk->m == M && pk->l == cs->l && pk->N == ((u64)1 << ilog2_ceil(D0)) && pk->N >= 2, ZKHIP_ERR_BAD_ARG,
+                    "GM17 proving key does not match the constraint system (SAP variables, instance size or domain)");
+        }
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
         require(pl->split() == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's h bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
-        const u64 N = pk->N, m = pk->m, me = m + 2, nnz = cs->nnz[2];
-        const int logN = pk->logN;
+    }
+    // W — the matrix whose product with the assignment the quotient subtracts (Groth16: C; GM17: the SAP's) — by COLUMNS, on the
+    // host: crow[cptr[v] .. cptr[v+1]) = the rows variable v occurs in, cval the coefficients (saturated Montgomery form, as the
+    // matrices are resident), long_cols the variables with more than BIND_SHORT_COL entries
+    struct WCols {
+        std::vector<u64> cptr;
+        std::vector<u32> crow, long_cols;
+        std::vector<uint8_t> cval;
+        u64 nnz() const { return crow.size(); }
+    };
+    // `extra[v]`: entries variable v gets besides C's (GM17); each C entry lands on row row_mul * k with its value times val_mul4 ? 4 : 1
+    struct WExtra { u32 col, row; int four; };
+    static void w_columns(zkhip_ctx* ctx, const zkhip_r1cs* cs, u64 mcols, u32 row_mul, bool val_mul4, const std::vector<WExtra>& extra, WCols& W) {
+        typedef typename C::Fr Fr;
+        static_assert(sizeof(Fr) == 32 && Fr::N <= 12, "the binding's scalar routines take up to 12 words; Fr is 32 bytes on both curves");
+        Stream s = ctx->stream;
+        const u64 nnz = cs->nnz[2];
+        std::vector<u64> rp(cs->n + 1);
+        std::vector<u32> col(nnz);
+        std::vector<uint8_t> val(nnz * sizeof(Fr));
+        dev_d2h(rp.data(), cs->rp[2].p, (cs->n + 1) * 8, s);
+        if (nnz) {
+            dev_d2h(col.data(), cs->col[2].p, nnz * 4, s);
+            dev_d2h(val.data(), cs->val[2].p, nnz * sizeof(Fr), s);
+        }
+        stream_sync(s);
+        W.cptr.assign(mcols + 1, 0);
+        for (u64 e = 0; e < nnz; ++e) {
+            require(col[e] < mcols, ZKHIP_ERR_BAD_ARG, "internal: column index out of range");
+            ++W.cptr[col[e] + 1];
+        }
+        for (const WExtra& x : extra) ++W.cptr[x.col + 1];
+        for (u64 v = 0; v < mcols; ++v) W.cptr[v + 1] += W.cptr[v];
+        const u64 total = W.cptr[mcols];
+        W.crow.resize(total);
+        W.cval.resize(total * sizeof(Fr));
+        std::vector<u64> cur(W.cptr.begin(), W.cptr.end() - 1);
+        for (u64 k = 0; k < cs->n; ++k)
+            for (u64 e = rp[k]; e < rp[k + 1]; ++e) {
+                const u64 at = cur[col[e]]++;
+                W.crow[at] = (u32)(k * row_mul);
+                Fr v;
+                memcpy(v.v, &val[e * sizeof(Fr)], sizeof(Fr));
+                if (val_mul4) v = fe_dbl(fe_dbl(v));
+                memcpy(&W.cval[at * sizeof(Fr)], v.v, sizeof(Fr));
+            }
+        const Fr one = Fr::one(), four = fe_dbl(fe_dbl(Fr::one()));
+        for (const WExtra& x : extra) {
+            const u64 at = cur[x.col]++;
+            W.crow[at] = x.row;
+            memcpy(&W.cval[at * sizeof(Fr)], (x.four ? four : one).v, sizeof(Fr));
+        }
+        W.long_cols.clear();
+        for (u64 v = 0; v < mcols; ++v)
+            if (W.cptr[v + 1] - W.cptr[v] > BIND_SHORT_COL) W.long_cols.push_back((u32)v);
+    }
+    // Level 0 of H' (N points, NATURAL order) and of L' (me points) from level 0 of the key's h table (sigma order, N entries, packed)
+    // and of its padded l table (me entries, packed), both covering the WHOLE index range, on this context's device.
+    static void bind_level0(zkhip_ctx* ctx, NttPlan<C>* pl, const BindShape& b, const void* d_h0, const void* d_l0, const WCols& W, DBuf& h_out, DBuf& l_out) {
+        typedef typename C::Fr Fr;
         constexpr int NW = Fr::N;
-        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
-        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
-        require(pk->z_n == me && pk->h_n == N, ZKHIP_ERR_BAD_ARG, "internal: an unsharded key covers the whole index range");
+        const u64 N = b.N, nnz = W.nnz();
         const u64 g1 = packed_point_bytes<Fq>(), xb = bind_xyzz_bytes<Fq>();
-        {   // two more tables stay; the transforms' points and C's products are transient, like the levels' workspace
+        {   // the transforms' points and W's products are transient, like the levels' workspace
             size_t free_b = 0, total_b = 0;
             dev_mem_info(&free_b, &total_b);
-            const u64 need = N * shh.levels * g1 + me * shz.levels * g1 + 2 * N * xb + nnz * (xb + 4 + 32) + N * 48 + ((u64)3 << 30);
-            require(need < free_b, ZKHIP_ERR_NOMEM, "not enough device memory to bind the key (two more MSM tables and the transforms' workspace)");
+            const u64 need = (N + b.me) * g1 + 2 * N * xb + nnz * (xb + 4 + 32) + b.mcols * (xb + 8) + N * 48 + ((u64)1 << 30);
+            require(need < free_b, ZKHIP_ERR_NOMEM, "not enough device memory to bind the key (the transforms' workspace)");
         }
         Stream s = ctx->stream;
         const unsigned T = 256;
@@ -972,62 +1086,183 @@ struct PkLoader {
         d_k.ensure(sizeof(konst));
         dev_h2d(d_k.p, konst, sizeof(konst), s);
         stream_sync(s);                                // (konst is on this frame)
-        // the two transforms over the bases: vector 0 -> H' (coset), vector 1 -> H'' (what C's columns are summed against)
+        // the two transforms over the bases: vector 0 -> H' (coset), vector 1 -> H'' (what W's columns are summed against)
         DBuf x;
         x.ensure(2 * N * xb);
-        bind_scale<Fq>(ctx, pk->h_sigma.p, N, pk->hlen, pl->N1, pl->N2, pl->N3, ptr<u32>(d_scal), ptr<u32>(d_k), NW, x.p);
+        bind_scale<Fq>(ctx, d_h0, N, b.n_src, pl->N1, pl->N2, pl->N3, ptr<u32>(d_scal), ptr<u32>(d_k), NW, x.p);
         bind_fft<Fq>(ctx, x.p, N, ptr<u32>(d_tw), NW);
-        pk->h_bound.ensure(N * (u64)shh.levels * g1);
-        bind_h_finish<Fq>(ctx, x.p, N, logN, pk->h_bound.p);
+        h_out.ensure(N * g1);
+        bind_h_finish<Fq>(ctx, x.p, N, b.logN, h_out.p);
         stream_sync(s);
         d_scal.release();
         d_tw.release();
-        msm_table_levels<Fq>(ctx, pk->h_bound.p, N, shh.level_bits(), (int)shh.levels);
-        // C by columns: D_v = sum_k C[k][v] H''_k
-        std::vector<u64> rp(cs->n + 1), cptr(m + 1, 0);
-        std::vector<u32> col(nnz), crow(nnz);
-        std::vector<uint8_t> val(nnz * 32), cval(nnz * 32);
-        dev_d2h(rp.data(), cs->rp[2].p, (cs->n + 1) * 8, s);
-        if (nnz) {
-            dev_d2h(col.data(), cs->col[2].p, nnz * 4, s);
-            dev_d2h(val.data(), cs->val[2].p, nnz * 32, s);
-        }
-        stream_sync(s);
-        for (u64 e = 0; e < nnz; ++e) {
-            require(col[e] < m, ZKHIP_ERR_BAD_ARG, "internal: column index out of range");
-            ++cptr[col[e] + 1];
-        }
-        for (u64 v = 0; v < m; ++v) cptr[v + 1] += cptr[v];
-        {
-            std::vector<u64> cur(cptr.begin(), cptr.end() - 1);
-            for (u64 k = 0; k < cs->n; ++k)
-                for (u64 e = rp[k]; e < rp[k + 1]; ++e) {
-                    const u64 at = cur[col[e]]++;
-                    crow[at] = (u32)k;
-                    memcpy(&cval[at * 32], &val[e * 32], 32);
-                }
-        }
-        DBuf d_cptr, d_crow, d_cval, prod;
-        d_cptr.ensure((m + 1) * 8);
+        // W by columns: D_v = sum_k W[k][v] H''_k, added to the l base of v
+        DBuf d_cptr, d_crow, d_cval, d_long, prod, sum;
+        d_cptr.ensure((b.mcols + 1) * 8);
         d_crow.ensure(std::max<u64>(nnz, 1) * 4);
         d_cval.ensure(std::max<u64>(nnz, 1) * 32);
+        d_long.ensure(std::max<u64>(W.long_cols.size(), 1) * 4);
         prod.ensure(std::max<u64>(nnz, 1) * xb);
-        dev_h2d(d_cptr.p, cptr.data(), (m + 1) * 8, s);
+        sum.ensure(std::max<u64>(b.mcols, 1) * xb);
+        dev_h2d(d_cptr.p, W.cptr.data(), (b.mcols + 1) * 8, s);
+        if (!W.long_cols.empty()) dev_h2d(d_long.p, W.long_cols.data(), W.long_cols.size() * 4, s);
         if (nnz) {
-            dev_h2d(d_crow.p, crow.data(), nnz * 4, s);
-            dev_h2d(d_cval.p, cval.data(), nnz * 32, s);
+            dev_h2d(d_crow.p, W.crow.data(), nnz * 4, s);
+            dev_h2d(d_cval.p, W.cval.data(), nnz * 32, s);
             ZK_LAUNCH((k_from_mont<Fr>), dim3(blocks_for(nnz, T)), dim3(T), 0, s, ptr<Fr>(d_cval), ptr<Fr>(d_cval), nnz);   // resident values: Montgomery form
-            bind_cmul<Fq>(ctx, (const uint8_t*)x.p + N * xb, logN, ptr<u32>(d_crow), ptr<u32>(d_cval), NW, ptr<u32>(d_k) + NW, nnz, prod.p);
+            bind_cmul<Fq>(ctx, (const uint8_t*)x.p + N * xb, b.logN, ptr<u32>(d_crow), ptr<u32>(d_cval), NW, ptr<u32>(d_k) + NW, nnz, prod.p);
         }
-        pk->l_bound.ensure(me * (u64)shz.levels * g1);
-        dev_memset((uint8_t*)pk->l_bound.p + m * g1, 0, 2 * g1, s);          // the (delta, r) and (delta, s) slots: infinity in l's table
-        bind_l_finish<Fq>(ctx, prod.p, ptr<u64>(d_cptr), pk->l_ext.p, m, pk->l_bound.p);
+        l_out.ensure(b.me * g1);
+        dev_d2d((uint8_t*)l_out.p + b.mcols * g1, (const uint8_t*)d_l0 + b.mcols * g1, (b.me - b.mcols) * g1, s);   // the slots behind the variables: as in l's table
+        bind_l_finish<Fq>(ctx, prod.p, ptr<u64>(d_cptr), d_l0, b.mcols, ptr<u32>(d_long), W.long_cols.size(), sum.p, l_out.p);
         stream_sync(s);                                // (the host vectors were the copies' sources)
-        x.release();
-        prod.release();
-        msm_table_levels<Fq>(ctx, pk->l_bound.p, me, shz.level_bits(), (int)shz.levels);
-        pk->inf_many_bound[0] = count_infinite<Fq>(ctx, pk->l_bound.p, me) * 2048 > me;
-        pk->inf_many_bound[1] = count_infinite<Fq>(ctx, pk->h_bound.p, N) * 2048 > N;
+    }
+    // this key's index ranges of H' / L' as MSM tables (level 0 from `h_src` / `l_src`: this key's RANGES, h_n / z_n points, on the
+    // host or — `on_device` — on this device), the window multiples behind them, the counts the accumulation kernel is chosen from
+    static void install_bound(zkhip_ctx* ctx, zkhip_pk* pk, const void* h_src, const void* l_src, bool on_device, const u64 fp[2]) {
+        typedef typename C::Fr Fr;
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
+        const u64 g1 = packed_point_bytes<Fq>();
+        {
+            size_t free_b = 0, total_b = 0;
+            dev_mem_info(&free_b, &total_b);
+            const u64 need = pk->h_n * shh.levels * g1 + pk->z_n * shz.levels * g1 + ((u64)2 << 30);
+            require(need < free_b, ZKHIP_ERR_NOMEM, "not enough device memory to bind the key (two more MSM tables)");
+        }
+        Stream s = ctx->stream;
+        pk->h_bound.ensure(std::max<u64>(pk->h_n, 1) * (u64)shh.levels * g1);
+        pk->l_bound.ensure(std::max<u64>(pk->z_n, 1) * (u64)shz.levels * g1);
+        auto put = [&](DBuf& dst, const void* src, u64 bytes) {
+            if (!bytes) return;
+            if (on_device) dev_d2d(dst.p, src, bytes, s);
+            else dev_h2d_fill(dst.p, bytes, 64, s, [src](char* out, size_t off, size_t len) { memcpy(out, (const char*)src + off, len); });
+        };
+        put(pk->h_bound, h_src, pk->h_n * g1);
+        put(pk->l_bound, l_src, pk->z_n * g1);
+        stream_sync(s);
+        msm_table_levels<Fq>(ctx, pk->h_bound.p, pk->h_n, shh.level_bits(), (int)shh.levels);
+        msm_table_levels<Fq>(ctx, pk->l_bound.p, pk->z_n, shz.level_bits(), (int)shz.levels);
+        pk->inf_many_bound[0] = count_infinite<Fq>(ctx, pk->l_bound.p, pk->z_n) * 2048 > pk->z_n;
+        pk->inf_many_bound[1] = count_infinite<Fq>(ctx, pk->h_bound.p, pk->h_n) * 2048 > pk->h_n;
+        pk->bound_fp[0] = fp[0];
+        pk->bound_fp[1] = fp[1];
+    }
+    static void w_columns_for(zkhip_ctx* ctx, int scheme, const zkhip_r1cs* cs, u64 mcols, WCols& W) {
+        if (scheme == 0) { w_columns(ctx, cs, mcols, 1, false, {}, W); return; }
+        // GM17: W = the SAP's right-hand sides (gm17.cuh: rows 2k: 4 C_k + e_k, 2k+1: e_k, 2n: 1, 2n+2i-1: 4 x_i + f_i, 2n+2i: f_i)
+        const u64 n = cs->n, l = cs->l, m = cs->l + cs->w;
+        std::vector<WExtra> extra;
+        extra.reserve(2 * n + 3 * l);
+        extra.push_back({0u, (u32)(2 * n), 0});
+        for (u64 i = 1; i < l; ++i) extra.push_back({(u32)i, (u32)(2 * n + 2 * i - 1), 1});
+        for (u64 k = 0; k < n; ++k) { extra.push_back({(u32)(m + k), (u32)(2 * k), 0}); extra.push_back({(u32)(m + k), (u32)(2 * k + 1), 0}); }
+        for (u64 i = 1; i < l; ++i) { extra.push_back({(u32)(m + n - 1 + i), (u32)(2 * n + 2 * i - 1), 0}); extra.push_back({(u32)(m + n - 1 + i), (u32)(2 * n + 2 * i), 0}); }
+        w_columns(ctx, cs, mcols, 2, true, extra, W);
+    }
+    // zkhip_pk_bind_r1cs on a key that covers the whole index range (or one whose imported bound tables only need attaching)
+    static void bind(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* cs) {
+        bind_check(ctx, pk, cs);
+        u64 fp[2];
+        r1cs_fingerprint(ctx, cs, fp);
+        if (pk->h_bound.p && pk->l_bound.p && pk->bound_fp[0] == fp[0] && pk->bound_fp[1] == fp[1] && (fp[0] | fp[1])) {
+            pk->bound_uid = cs->uid;                    // the tables are there already (an imported image, or the same system loaded again)
+            return;
+        }
+        require(pk->world == 1, ZKHIP_ERR_BAD_ARG,
+                "a shard of a multi-GPU key binds through zkhip_pk_bind_r1cs_shard / zkhip_multi_bind (the transforms need every base of the key once)");
+        unbind(pk);
+        NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
+        const BindShape b = bind_shape(pk);
+        require(pk->z_n == b.me && pk->h_n == b.N, ZKHIP_ERR_BAD_ARG, "internal: an unsharded key covers the whole index range");
+        WCols W;
+        w_columns_for(ctx, pk->scheme, cs, b.mcols, W);
+        DBuf h0, l0;
+        bind_level0(ctx, pl, b, pk->h_sigma.p, pk->l_ext.p, W, h0, l0);
+        install_bound(ctx, pk, h0.p, l0.p, true, fp);
+        pk->bound_uid = cs->uid;
+    }
+    // Level 0 of H' and L' over the WHOLE index range, from the key FILE (a shard holds only its ranges of the bases; the transforms
+    // need all of them once), left in host memory: every member of a multi-GPU prover then installs its own ranges
+    // (zkhip_multi_bind: one member computes, all install; zkhip_pk_bind_r1cs_shard: a rank of a multi-process prover does both).
+    static void bound_level0_from_file(zkhip_ctx* ctx, int scheme, const zkhip_r1cs* cs, const uint8_t* bytes, size_t len, std::vector<uint8_t>& h_host,
+                                       std::vector<uint8_t>& l_host, u64 fp[2]) {
+        zkhip_pk tmp;                                   // dimensions and level 0 of the two tables only
+        tmp.curve = C::ID; tmp.scheme = scheme; tmp.ctx = ctx;
+        DBuf h_aff, l_aff;
+        if (scheme == 0) {
+            const Parsed k = parse(bytes, len);
+            tmp.m = k.m; tmp.w = k.w; tmp.l = k.l; tmp.hlen = k.hl; tmp.N = k.N; tmp.logN = ilog2_floor(k.N);
+            upload_decoded<2>(ctx, l_aff, k.m + 2, k.l_q, k.w, k.l, nullptr, 0);
+            upload_decoded<2>(ctx, h_aff, std::max<u64>(k.hl, 1), k.h_q, k.hl, 0, nullptr, 0);
+        } else {
+            gm17_level0_sources(ctx, bytes, len, &tmp, h_aff, l_aff);
+        }
+        NttPlan<C>* pl = get_plan<C>(ctx, tmp.logN);
+        tmp.ntt_log1 = pl->split();
+        bind_check(ctx, &tmp, cs);
+        const BindShape b = bind_shape(&tmp);
+        const u64 g1 = packed_point_bytes<Fq>();
+        DBuf h_sig, h0p, l0p;
+        h_sig.ensure(b.N * G1B);
+        ZK_LAUNCH((k_sigma_gather_points<Aff<Fq>>), dim3(blocks_for(b.N, 256)), dim3(256), 0, ctx->stream, ptr<Aff<Fq>>(h_aff), ptr<Aff<Fq>>(h_sig), b.N, b.n_src,
+                  pl->N1, pl->N2, pl->N3);
+        h0p.ensure(b.N * g1);
+        l0p.ensure(b.me * g1);
+        points_to_packed<Fq>(ctx, ptr<Aff<Fq>>(h_sig), h0p.p, b.N);
+        points_to_packed<Fq>(ctx, ptr<Aff<Fq>>(l_aff), l0p.p, b.me);
+        stream_sync(ctx->stream);
+        h_aff.release(); l_aff.release(); h_sig.release();
+        WCols W;
+        w_columns_for(ctx, scheme, cs, b.mcols, W);
+        DBuf h0, l0;
+        bind_level0(ctx, pl, b, h0p.p, l0p.p, W, h0, l0);
+        h_host.resize(b.N * g1);
+        l_host.resize(b.me * g1);
+        dev_d2h(h_host.data(), h0.p, h_host.size(), ctx->stream);
+        dev_d2h(l_host.data(), l0.p, l_host.size(), ctx->stream);
+        stream_sync(ctx->stream);
+        r1cs_fingerprint(ctx, cs, fp);
+    }
+    // ark_gm17::ProvingKey: the quotient's bases g_gamma2_z_t[0 .. D) and the padded c_query_1 table (gm17.cuh Gm17::load's lane 2)
+    static void gm17_level0_sources(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_pk* dims, DBuf& h_aff, DBuf& l_aff) {
+        Rd rd{bytes, bytes + len};
+        rd.take(G2B); rd.take(G1B); rd.take(G2B); rd.take(G1B); rd.take(G2B);
+        const u64 l = rd.len(G1B);
+        rd.take(l * G1B);
+        const u64 M = rd.len(G1B);
+        rd.take(M * G1B);
+        const u64 Mb = rd.len(G2B);
+        rd.take(Mb * G2B);
+        const u64 n1 = rd.len(G1B);
+        const uint8_t* c1_q = rd.take(n1 * G1B);
+        const u64 Mc2 = rd.len(G1B);
+        rd.take(Mc2 * G1B);
+        rd.take(G1B); rd.take(G2B);
+        const uint8_t* g_ab_gamma_z = rd.take(G1B);
+        rd.take(G1B);
+        const u64 tl = rd.len(G1B);
+        const uint8_t* t_q = rd.take(tl * G1B);
+        require(rd.p == rd.e, ZKHIP_ERR_PARSE, "trailing bytes after proving key");
+        require(l >= 1 && M >= l && Mb == M && Mc2 == M && n1 == M - l && tl >= 2 && ((tl - 1) & (tl - 2)) == 0 && M + 2 < ((u64)1 << 31), ZKHIP_ERR_PARSE,
+                "inconsistent query lengths in GM17 proving key");
+        const u64 D = tl - 1;
+        dims->m = M; dims->w = n1; dims->l = l; dims->hlen = tl; dims->N = D; dims->logN = ilog2_floor(D);
+        upload_decoded<2>(ctx, l_aff, M + 2, c1_q, n1, l, g_ab_gamma_z, M);
+        upload_decoded<2>(ctx, h_aff, D, t_q, D, 0, nullptr, 0);
+    }
+    // a member's share of a binding computed elsewhere: its ranges of the whole-range level-0 arrays
+    static void install_bound_ranges(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* h_full, size_t h_len, const uint8_t* l_full, size_t l_len,
+                                     const u64 fp[2]) {
+        bind_check(ctx, pk, cs);
+        const BindShape b = bind_shape(pk);
+        const u64 g1 = packed_point_bytes<Fq>();
+        require(h_len == b.N * g1 && l_len == b.me * g1, ZKHIP_ERR_BAD_ARG, "internal: bound level-0 arrays of another key");
+        u64 have[2];
+        r1cs_fingerprint(ctx, cs, have);
+        require(have[0] == fp[0] && have[1] == fp[1], ZKHIP_ERR_BAD_ARG, "internal: the binding was computed for another constraint system");
+        unbind(pk);
+        install_bound(ctx, pk, h_full + pk->h_lo * g1, l_full + pk->z_lo * g1, false, fp);
         pk->bound_uid = cs->uid;
     }
     static void count_points_at_infinity(zkhip_ctx* ctx, zkhip_pk* pk) {
@@ -1172,7 +1407,7 @@ struct Prover {
         require(!sl.busy, ZKHIP_ERR_DEVICE, "internal: proof slot still in flight");
         slot_init(ctx, sl);
         const u64 m = pk->m, N = pk->N;
-        const bool bound = pk->bound_uid != 0 && pk->bound_uid == cs->uid && pk->world == 1;   // (zkhip_pk_bind_r1cs)
+        const bool bound = pk->bound_uid != 0 && pk->bound_uid == cs->uid;   // (zkhip_pk_bind_r1cs; a shard: its ranges of H' / L')
         Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
@@ -1723,6 +1958,11 @@ struct CurveOps {
     void (*pk_load)(zkhip_ctx*, const uint8_t*, size_t, zkhip_pk*);
     void (*pk_table_levels)(zkhip_ctx*, zkhip_pk*);
     void (*pk_bind)(zkhip_ctx*, zkhip_pk*, const zkhip_r1cs*);
+    void (*pk_bind_check)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*);
+    void (*bound_level0_from_file)(zkhip_ctx*, int scheme, const zkhip_r1cs*, const uint8_t*, size_t, std::vector<uint8_t>&, std::vector<uint8_t>&, u64 fp[2]);
+    void (*install_bound_ranges)(zkhip_ctx*, zkhip_pk*, const zkhip_r1cs*, const uint8_t*, size_t, const uint8_t*, size_t, const u64 fp[2]);
+    void (*install_bound)(zkhip_ctx*, zkhip_pk*, const void*, const void*, bool on_device, const u64 fp[2]);
+    void (*r1cs_fingerprint)(zkhip_ctx*, const zkhip_r1cs*, u64 fp[2]);
     void (*r1cs_load)(zkhip_ctx*, zkhip_r1cs*, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]);
     void (*prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*prove_resident)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, void*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
@@ -1777,6 +2017,11 @@ static CurveOps make_curve_ops() {
     o.pk_load = &PkLoader<C>::load;
     o.pk_table_levels = &PkLoader<C>::table_levels;
     o.pk_bind = &PkLoader<C>::bind;
+    o.pk_bind_check = &PkLoader<C>::bind_check;
+    o.bound_level0_from_file = &PkLoader<C>::bound_level0_from_file;
+    o.install_bound_ranges = &PkLoader<C>::install_bound_ranges;
+    o.install_bound = &PkLoader<C>::install_bound;
+    o.r1cs_fingerprint = &PkLoader<C>::r1cs_fingerprint;
     o.r1cs_load = &Prover<C>::r1cs_load;
     o.prove = &Prover<C>::prove_host;
     o.prove_resident = &Prover<C>::prove_resident;

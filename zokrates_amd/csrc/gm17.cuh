@@ -40,18 +40,21 @@ __global__ void k_sap_rows(const Fe<P>* __restrict__ ra, const Fe<P>* __restrict
     typedef Fe<P> F;
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + l) return;
+    // (sc == nullptr: a key bound to the system carries W's share in its bases — rc is not read, sc not written)
     if (i < n) {
         const F a = ra[i], b = rb[i];
         const F d = fe_sub(a, b);
         const F e = rp_sqr(d);
         sa[2 * i] = fe_add(a, b);
         sa[2 * i + 1] = d;
-        sc[2 * i] = fe_add(fe_dbl(fe_dbl(rc[i])), e);
-        sc[2 * i + 1] = e;
+        if (sc) {
+            sc[2 * i] = fe_add(fe_dbl(fe_dbl(rc[i])), e);
+            sc[2 * i + 1] = e;
+        }
         ext[m + i] = rp_to_plain(e);
     } else if (i == n) {
         sa[2 * n] = rp_one<P>();
-        sc[2 * n] = rp_one<P>();
+        if (sc) sc[2 * n] = rp_one<P>();
     } else {
         const u64 j = i - n;   // 1 <= j < l
         const F x = z[j], one = rp_one<P>();
@@ -59,8 +62,10 @@ __global__ void k_sap_rows(const Fe<P>* __restrict__ ra, const Fe<P>* __restrict
         const F f = rp_sqr(d);
         sa[2 * n + 2 * j - 1] = fe_add(x, one);
         sa[2 * n + 2 * j] = d;
-        sc[2 * n + 2 * j - 1] = fe_add(fe_dbl(fe_dbl(x)), f);
-        sc[2 * n + 2 * j] = f;
+        if (sc) {
+            sc[2 * n + 2 * j - 1] = fe_add(fe_dbl(fe_dbl(x)), f);
+            sc[2 * n + 2 * j] = f;
+        }
         ext[m + n - 1 + j] = rp_to_plain(f);
     }
 }
@@ -184,6 +189,7 @@ struct Gm17 {
         Fr dd = fe_from_bytes_canon<Fr>(d1), rr = fe_from_bytes_canon<Fr>(r);
         require(canon_lt_mod(dd) && canon_lt_mod(rr), ZKHIP_ERR_BAD_ARG, "d1 or r not a canonical field element");
         const Fr rho = add_mod(dd, rr);
+        const bool bound = pk->bound_uid != 0 && pk->bound_uid == cs->uid;   // (zkhip_pk_bind_r1cs: W's share and the last transform live in the bases)
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
         require(pl->split() == pk->ntt_log1, ZKHIP_ERR_BAD_ARG, "the key's quotient bases were ordered for another NTT split (NTT_SINGLE_MAX_LOG changed): reload the key");
         sl.t_start = std::chrono::steady_clock::now();
@@ -219,12 +225,13 @@ struct Gm17 {
         const u64 D0 = 2 * n + 2 * (l - 1) + 1;
         if (D0 < D) {
             dev_memset(sa + D0, 0, (D - D0) * sizeof(Fr), st);
-            dev_memset(sc + D0, 0, (D - D0) * sizeof(Fr), st);
+            if (!bound) dev_memset(sc + D0, 0, (D - D0) * sizeof(Fr), st);
         }
         sl.vc.ensure(3 * std::max<u64>(n, 1) * sizeof(Fr));      // the three row-product vectors
         Fr *ra = ptr<Fr>(sl.vc), *rb = ra + n, *rc = rb + n;
-        if (n) P::matvec(ctx, cs, ptr<Fr>(sl.zmont), ra, rb, rc, n, 0, n);
-        ZK_LAUNCH((k_sap_rows<typename Fr::Params>), dim3(blocks_for(n + l, 256)), dim3(256), 0, st, ra, rb, rc, ptr<Fr>(sl.zmont), sa, sc, (Fr*)d_scalars, n, l, m);
+        if (n) P::matvec(ctx, cs, ptr<Fr>(sl.zmont), ra, rb, rc, n, 0, n, bound ? 2 : 3);
+        ZK_LAUNCH((k_sap_rows<typename Fr::Params>), dim3(blocks_for(n + l, 256)), dim3(256), 0, st, ra, rb, rc, ptr<Fr>(sl.zmont), sa, bound ? (Fr*)nullptr : sc,
+                  (Fr*)d_scalars, n, l, m);
         event_record(sl.ev[1], st);
 
         // ---- the four MSMs over S = [ext_0..ext_{M-1}, rho, 0] share one digit/sort pass
@@ -254,12 +261,21 @@ struct Gm17 {
         stream_wait_event(wn, sl.ev[1]);
         ctx->ws = wn;
         event_record(sl.ntt_b, wn);
-        // four transforms (ark-gm17's witness_map runs five): W only needs its coefficients, as c in the Groth16 prover
-        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_coset), 1, 0);
-        ntt_kind_a<C>(ctx, pl, sc, true, ptr<Fr>(pl->s_cexit), 1, 0, 1);
-        ntt_kind_b<C>(ctx, pl, sa, false, nullptr, 1, 0);
-        ZK_LAUNCH((k_sap_quotient<typename Fr::Params>), dim3(blocks_for(D, 256)), dim3(256), 0, wn, sa, pl->zinv_rp, sa, D);
-        ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_cosetinv_canon), 1, 0, 1, sc);
+        if (bound) {
+            // TWO transforms: U to its coefficients and on to the coset; U^2 / Z(g) there, as canonical integers in NATURAL order (a
+            // plain-integer factor takes the R'-form product out of the Montgomery domain), pairs with G' = the coset inverse transform
+            // applied to g_gamma2_z_t once (PkLoader::bind) — and W's share rides on the c_query_1 lane's bases
+            ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_coset), 1, 0);
+            ntt_kind_b<C>(ctx, pl, sa, false, nullptr, 1, 0);
+            ZK_LAUNCH((k_sap_quotient<typename Fr::Params>), dim3(blocks_for(D, 256)), dim3(256), 0, wn, sa, fe_from_mont(pl->zinv), sa, D);
+        } else {
+            // four transforms (ark-gm17's witness_map runs five): W only needs its coefficients, as c in the Groth16 prover
+            ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_coset), 1, 0);
+            ntt_kind_a<C>(ctx, pl, sc, true, ptr<Fr>(pl->s_cexit), 1, 0, 1);
+            ntt_kind_b<C>(ctx, pl, sa, false, nullptr, 1, 0);
+            ZK_LAUNCH((k_sap_quotient<typename Fr::Params>), dim3(blocks_for(D, 256)), dim3(256), 0, wn, sa, pl->zinv_rp, sa, D);
+            ntt_kind_a<C>(ctx, pl, sa, true, ptr<Fr>(pl->s_cosetinv_canon), 1, 0, 1, sc);
+        }
         ctx->ws = ctx->stream;
         event_record(sl.ntt_e, wn);
         event_record(sl.ev[2], wn);
@@ -268,15 +284,16 @@ struct Gm17 {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
                 msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
-            P::run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready);
+            P::run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready, bound);
         } else {
             P::empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
         }
 
-        // ---- G = MSM(g_gamma2_z_t, h0)
+        // ---- G = MSM(g_gamma2_z_t, h0)   (a bound key: U^2 / Z(g) in natural order against G')
         if (pk->h_n) {
             msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
-            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], pk->h_sigma.p, with_inf(shh, pk->inf_many[4]), ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+            msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], bound ? pk->h_bound.p : pk->h_sigma.p, with_inf(shh, bound ? pk->inf_many_bound[1] : pk->inf_many[4]),
+                        ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
         } else {
             P::empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
         }

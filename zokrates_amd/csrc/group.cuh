@@ -176,9 +176,12 @@ void bind_cmul(zkhip_ctx* ctx, const void* d_x, int logN, const u32* d_row, cons
     ZK_LAUNCH((k_bind_cmul<F>), dim3(blocks_for(nnz, 256)), dim3(256), 0, ctx->stream, (const Xyzz<F>*)d_x, logN, d_row, d_val, nw, d_minus_one, nnz, (Xyzz<F>*)d_prod);
 }
 template <class FS>
-void bind_l_finish(zkhip_ctx* ctx, const void* d_prod, const u64* d_cptr, const void* d_l_table, u64 m, void* d_out) {
+void bind_l_finish(zkhip_ctx* ctx, const void* d_prod, const u64* d_cptr, const void* d_l_table, u64 m, const u32* d_long_cols, u64 n_long, void* d_sum, void* d_out) {
     typedef typename Unsat<FS>::type F;
-    ZK_LAUNCH((k_bind_l_finish<F>), dim3((unsigned)m), dim3(64), 0, ctx->stream, (const Xyzz<F>*)d_prod, d_cptr, (const AffPacked<F>*)d_l_table, m, (AffPacked<F>*)d_out);
+    ZK_LAUNCH((k_bind_l_sum_short<F>), dim3(blocks_for(m, 256)), dim3(256), 0, ctx->stream, (const Xyzz<F>*)d_prod, d_cptr, (const AffPacked<F>*)d_l_table, m, (Xyzz<F>*)d_sum);
+    if (n_long)
+        ZK_LAUNCH((k_bind_l_sum_long<F>), dim3((unsigned)n_long), dim3(64), 0, ctx->stream, (const Xyzz<F>*)d_prod, d_cptr, (const AffPacked<F>*)d_l_table, d_long_cols, (Xyzz<F>*)d_sum);
+    ZK_LAUNCH((k_bind_l_affine<F>), dim3(blocks_for(m, 256)), dim3(256), 0, ctx->stream, (const Xyzz<F>*)d_sum, m, (AffPacked<F>*)d_out);
 }
 #define ZK_INSTANTIATE_BIND(F)                                                                                          \
     template size_t bind_xyzz_bytes<F>();                                                                               \
@@ -186,7 +189,7 @@ void bind_l_finish(zkhip_ctx* ctx, const void* d_prod, const u64* d_cptr, const 
     template void bind_fft<F>(zkhip_ctx*, void*, u64, const u32*, int);                                                 \
     template void bind_h_finish<F>(zkhip_ctx*, const void*, u64, int, void*);                                           \
     template void bind_cmul<F>(zkhip_ctx*, const void*, int, const u32*, const u32*, int, const u32*, u64, void*);      \
-    template void bind_l_finish<F>(zkhip_ctx*, const void*, const u64*, const void*, u64, void*);
+    template void bind_l_finish<F>(zkhip_ctx*, const void*, const u64*, const void*, u64, const u32*, u64, void*, void*);
 
 #define ZK_INSTANTIATE_GROUP(F)                                                                                         \
     template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event, Event);   \

@@ -101,6 +101,7 @@ static constexpr int MSM_MAX_TABLES = 3;
 struct MsmTables {
     const void* p[MSM_MAX_TABLES];
 };
+static constexpr u32 BIND_SHORT_COL = 16;   // bind.cuh: columns of W of at most this many entries are summed by one work-item (the host lists the others)
 static constexpr u32 MSM_MIN_SLICE = 8;   // default for the finest cut of the sorted list (small inputs leave work-items idle)
 
 // The kernels below work on points over the UNSATURATED field types of fieldu.cuh (Fu / Fu2); only the window sums

@@ -92,6 +92,24 @@ __global__ void k_check_canonical(const F* __restrict__ x, u64 n, u32* __restric
     }
     if (!lt) atomicOr(flag, 1u);
 }
+// Position-keyed checksum of `nwords` 32-bit words: out[0], out[1] += two independent 64-bit mixes of (word, index, salt) summed over
+// the array.  What a proving-key image remembers of the constraint system its bound tables were made for (zkhip_pk::bound_fp): a
+// guard against pairing them with another system by accident, not a cryptographic commitment.
+static __global__ void k_fingerprint(const u32* __restrict__ data, u64 nwords, u64 salt, unsigned long long* __restrict__ out) {
+    u64 a = 0, b = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (u64)gridDim.x * blockDim.x) {
+        u64 x = ((u64)data[i] << 32 | (u32)i) ^ (salt + (i >> 32) * 0xD6E8FEB86659FD93ull);
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        a += x;
+        b += (x * 0x9E3779B97F4A7C15ull) ^ (x >> 17);
+    }
+    if (a | b) {
+        atomicAdd(&out[0], (unsigned long long)a);
+        atomicAdd(&out[1], (unsigned long long)b);
+    }
+}
 // op: 0 add, 1 sub, 2 mul — operands and result in Montgomery form
 template <class F>
 __global__ void k_field_op(const F* __restrict__ a, const F* __restrict__ b, F* __restrict__ out, u64 n, int op) {

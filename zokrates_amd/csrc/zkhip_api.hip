@@ -65,22 +65,33 @@ static int32_t guarded_host(Fn&& fn) {
         return ZKHIP_ERR_PARSE;
     }
 }
+// whether this library has made a HIP call in this process (after which GPU_MAX_HW_QUEUES is no longer read by the runtime)
+static std::atomic<bool> g_hip_touched{false};
 #ifndef ZK_EMU
-// The library keeps ~20 HIP streams busy per context (a stream per proof slot and MSM, the transform pipeline, staging, copy-out);
-// the runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams that share a queue
-// serialise: 8 queues measured +4 % proofs/s over 4, 16 another +1.5-2 % (profiles/r5d_scheduling_knobs.txt).  The runtime reads
-// the variable when it initialises (the first HIP call of the process), so the library sets it when it is loaded — unless the
-// process, or a HIP user that initialised the runtime earlier, has decided already.  EIGHT, not sixteen: every queue reserves
-// scratch for the largest frame launched on it, and a process that drives many contexts and both curves through 16 queues ran out
-// of that resource (HSA_STATUS_ERROR_OUT_OF_RESOURCES with 264 GB of device memory free: three of five runs of the GPU suite's
-// one process, profiles/r5_q16_suite_abort.txt; never at 4 or 8).  A process with ONE resident prover can ask for 16 itself
-// (bench.py does: a few hundred runs, no failure).
-__attribute__((constructor)) static void zkhip_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// one wavefront: shader cycles against the constant-rate wall clock over `ticks` wall-clock ticks (zkhip_ctx_clock_probe)
+static __global__ void k_clock_probe(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    while (wall_clock64() - w0 < ticks) __builtin_amdgcn_s_sleep(64);
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
 #endif
 
 extern "C" {
 
-int32_t zkhip_device_count(void) { return dev_count(); }
+int32_t zkhip_init(int32_t hw_queues) {
+    if (hw_queues < 0 || hw_queues > 64) { g_create_err = "hw_queues out of range (0 .. 64)"; return ZKHIP_ERR_BAD_ARG; }
+    if (hw_queues == 0) return ZKHIP_OK;
+#ifndef ZK_EMU
+    if (g_hip_touched.load()) { g_create_err = "zkhip_init after the library's first HIP call: the runtime has read its settings already"; return ZKHIP_ERR_BAD_ARG; }
+    char buf[16];
+    snprintf(buf, sizeof(buf), "%d", (int)hw_queues);
+    setenv("GPU_MAX_HW_QUEUES", buf, 0);      // (0: a value the process set itself stands)
+#endif
+    return ZKHIP_OK;
+}
+
+int32_t zkhip_device_count(void) { g_hip_touched.store(true); return dev_count(); }
 
 int32_t zkhip_device_pci_bus_id(int32_t device, char* out, size_t cap) {
     if (!out || cap < 13) { g_create_err = "out is NULL or shorter than 13 bytes"; return ZKHIP_ERR_BAD_ARG; }
@@ -94,6 +105,7 @@ int32_t zkhip_device_pci_bus_id(int32_t device, char* out, size_t cap) {
 int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
     if (!out) { g_create_err = "out is NULL"; return ZKHIP_ERR_BAD_ARG; }
     *out = nullptr;
+    g_hip_touched.store(true);
     return guarded(nullptr, [&] {
         // ZKHIP_INIT_PROFILE=1: where the start of a process goes (stderr; a one-proof CLI run is mostly this)
         const bool prof = getenv("ZKHIP_INIT_PROFILE") != nullptr;
@@ -186,6 +198,29 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
     stream_destroy(ctx->stream);
     delete ctx;
 }
+int32_t zkhip_ctx_clock_probe(zkhip_ctx* ctx, uint32_t duration_us, double* ghz_out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(ghz_out && duration_us >= 1 && duration_us <= 10000000, ZKHIP_ERR_BAD_ARG, "null output or duration out of range (1 us .. 10 s)");
+        *ghz_out = 0.0;
+#ifndef ZK_EMU
+        int khz = 0;
+        ZK_HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+        require(khz > 0, ZKHIP_ERR_DEVICE, "the device reports no wall-clock rate");
+        unsigned long long* h = (unsigned long long*)host_alloc_pinned(16);
+        h[0] = h[1] = 0;
+        DBuf d;
+        d.ensure(16);
+        Stream s = stream_create_high_priority();      // (a stream of its own: it runs beside the context's proofs, not behind them)
+        hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, (unsigned long long)duration_us * (unsigned long long)khz / 1000ull, (unsigned long long*)d.p);
+        ZK_HIP_CHECK(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, s));
+        stream_sync(s);
+        stream_destroy(s);
+        if (h[1]) *ghz_out = (double)h[0] / ((double)h[1] / ((double)khz * 1e3)) / 1e9;
+        host_free_pinned(h);
+#endif
+    });
+}
 int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
     return guarded(ctx, [&] {
@@ -254,30 +289,62 @@ int32_t zkhip_pk_load_g16_shard(zkhip_ctx* ctx, int32_t curve, const uint8_t* by
 void zkhip_pk_free(zkhip_pk* pk) { delete pk; }
 int32_t zkhip_pk_bind_r1cs(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* r1cs) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    // the argument checks come first and never touch the key: a call that is refused leaves an earlier binding (seconds of work)
+    // as it was; only a failure INSIDE the rebuild — which starts by dropping the old tables — leaves the key as loaded
+    bool started = false;
     const int32_t rc = guarded(ctx, [&] {
         require(pk && r1cs, ZKHIP_ERR_BAD_ARG, "null argument");
         require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
         for (auto& sl : ctx->slots) require(!sl.busy, ZKHIP_ERR_BAD_ARG, "a proof is in flight in this context");
+        ops_for(pk->curve)->pk_bind_check(ctx, pk, r1cs);
+        started = true;
         ops_for(pk->curve)->pk_bind(ctx, pk, r1cs);
     });
-    if (rc != ZKHIP_OK && pk) {   // whatever failed half-way: the key is as it was loaded
-        pk->bound_uid = 0;
-        pk->h_bound.release();
-        pk->l_bound.release();
-    }
+    if (rc != ZKHIP_OK && pk && started) zkhip_pk_unbind(pk);   // whatever failed half-way: the key is as it was loaded
     return rc;
 }
 int32_t zkhip_pk_unbind(zkhip_pk* pk) {
     if (!pk) return ZKHIP_ERR_BAD_ARG;
-    if (pk->ctx) dev_set(pk->ctx->device);
-    pk->bound_uid = 0;
-    pk->h_bound.release();
-    pk->l_bound.release();
-    return ZKHIP_OK;
+    return guarded(pk->ctx, [&] {
+        pk->bound_uid = 0;
+        pk->bound_fp[0] = pk->bound_fp[1] = 0;
+        pk->h_bound.release();
+        pk->l_bound.release();
+    });
+}
+// a shard of a multi-GPU key (or a whole key): the binding computed from the key FILE — the transforms need every base once — of
+// which this key keeps its own index ranges
+int32_t zkhip_pk_bind_r1cs_shard(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* key_bytes, size_t len) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    bool started = false;
+    const int32_t rc = guarded(ctx, [&] {
+        require(pk && r1cs && key_bytes, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "key / constraint system belong to another context");
+        for (auto& sl : ctx->slots) require(!sl.busy, ZKHIP_ERR_BAD_ARG, "a proof is in flight in this context");
+        const CurveOps* ops = ops_for(pk->curve);
+        ops->pk_bind_check(ctx, pk, r1cs);
+        std::vector<uint8_t> h_host, l_host;
+        u64 fp[2];
+        ops->bound_level0_from_file(ctx, pk->scheme, r1cs, key_bytes, len, h_host, l_host, fp);
+        started = true;
+        ops->install_bound_ranges(ctx, pk, r1cs, h_host.data(), h_host.size(), l_host.data(), l_host.size(), fp);
+    });
+    if (rc != ZKHIP_OK && pk && started) zkhip_pk_unbind(pk);
+    return rc;
+}
+int32_t zkhip_r1cs_fingerprint(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, uint64_t out[2]) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(r1cs && out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "constraint system belongs to another context");
+        u64 fp[2];
+        ops_for(r1cs->curve)->r1cs_fingerprint(ctx, r1cs, fp);
+        out[0] = fp[0]; out[1] = fp[1];
+    });
 }
 int32_t zkhip_pk_is_bound(const zkhip_pk* pk, const zkhip_r1cs* r1cs) {
     if (!pk || !r1cs) return 0;
-    return pk->bound_uid != 0 && pk->bound_uid == r1cs->uid && pk->world == 1 ? 1 : 0;
+    return pk->bound_uid != 0 && pk->bound_uid == r1cs->uid ? 1 : 0;
 }
 int32_t zkhip_pk_dims(const zkhip_pk* pk, uint64_t out[4]) {
     if (!pk || !out) return ZKHIP_ERR_BAD_ARG;
@@ -522,7 +589,7 @@ int32_t zkhip_prog_r1cs_load(zkhip_ctx* ctx, const zkhip_prog* prog, zkhip_r1cs*
 // An image holds level 0 of the five base tables; the window multiples are recomputed on the device at import (~0.1 s for a
 // 2^20 key — less than reading the 6 GiB they occupy from any disk: measured in round 3, which is why the image that carried
 // every level is gone).
-static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '4'};
+static const char PK_IMAGE_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'P', 'K', '5'};
 struct PkImageHeader {
     char magic[8];
     int32_t curve, scheme;
@@ -532,6 +599,11 @@ struct PkImageHeader {
     int32_t ntt_split, reserved;      // the NTT split h_sigma is ordered for (zkhip_pk::ntt_log1 = NttPlan::split())
     uint64_t z_lo, z_n, h_lo, h_n;
     uint64_t len_delta, len_g2z2, len_buf[5];
+    // version 5: level 0 of the bound tables H' / L' (this key's index ranges) when the key was bound at export, and the fingerprint
+    // of the constraint system they were made for — zkhip_pk_bind_r1cs on the imported key attaches them when the system's
+    // fingerprint agrees and costs a checksum instead of the transforms (0 / 0: the key was not bound)
+    uint64_t len_bound[2];            // H', L'
+    uint64_t bound_fp[2];
 };
 static DBuf* pk_bufs(zkhip_pk* pk, int k) { DBuf* b[5] = {&pk->a_ext, &pk->b1_ext, &pk->l_ext, &pk->b2_ext, &pk->h_sigma}; return b[k]; }
 static int pk_levels(int curve, int c, int sets) {
@@ -548,6 +620,7 @@ int32_t zkhip_pk_export_size(const zkhip_pk* pk, uint64_t* bytes) {
     if (!pk || !bytes) return ZKHIP_ERR_BAD_ARG;
     uint64_t t = sizeof(PkImageHeader) + pk->delta_g1_canon.size() + pk->g_gamma2_z2_canon.size();
     for (int k = 0; k < 5; ++k) t += pk_table_bytes(pk->curve, k, pk->z_n, pk->h_n, 1);
+    if (pk->h_bound.p && pk->l_bound.p) t += pk_table_bytes(pk->curve, 4, pk->z_n, pk->h_n, 1) + pk_table_bytes(pk->curve, 2, pk->z_n, pk->h_n, 1);
     *bytes = t;
     return ZKHIP_OK;
 }
@@ -570,6 +643,12 @@ int32_t zkhip_pk_export(const zkhip_pk* pk_, uint8_t* out, uint64_t cap) {
         h.z_lo = pk->z_lo; h.z_n = pk->z_n; h.h_lo = pk->h_lo; h.h_n = pk->h_n;
         h.len_delta = pk->delta_g1_canon.size(); h.len_g2z2 = pk->g_gamma2_z2_canon.size();
         for (int k = 0; k < 5; ++k) h.len_buf[k] = pk_table_bytes(pk->curve, k, pk->z_n, pk->h_n, 1);
+        const bool with_bound = pk->h_bound.p && pk->l_bound.p;
+        if (with_bound) {
+            h.len_bound[0] = pk_table_bytes(pk->curve, 4, pk->z_n, pk->h_n, 1);
+            h.len_bound[1] = pk_table_bytes(pk->curve, 2, pk->z_n, pk->h_n, 1);
+            h.bound_fp[0] = pk->bound_fp[0]; h.bound_fp[1] = pk->bound_fp[1];
+        }
         uint8_t* p = out;
         memcpy(p, &h, sizeof(h)); p += sizeof(h);
         memcpy(p, pk->delta_g1_canon.data(), h.len_delta); p += h.len_delta;
@@ -577,6 +656,10 @@ int32_t zkhip_pk_export(const zkhip_pk* pk_, uint8_t* out, uint64_t cap) {
         for (int k = 0; k < 5; ++k) {
             dev_d2h(p, pk_bufs(pk, k)->p, h.len_buf[k], ctx->stream);     // level 0 leads every table
             p += h.len_buf[k];
+        }
+        if (with_bound) {
+            dev_d2h(p, pk->h_bound.p, h.len_bound[0], ctx->stream); p += h.len_bound[0];
+            dev_d2h(p, pk->l_bound.p, h.len_bound[1], ctx->stream); p += h.len_bound[1];
         }
         stream_sync(ctx->stream);
     });
@@ -593,7 +676,7 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         const CurveOps* ops = ops_for(h.curve);   // (validates the curve id)
         require(h.scheme == 0 || h.scheme == 1, ZKHIP_ERR_PARSE, "key image: unknown scheme");
         uint64_t total = sizeof(PkImageHeader), rest = len - sizeof(PkImageHeader);
-        const uint64_t parts[7] = {h.len_delta, h.len_g2z2, h.len_buf[0], h.len_buf[1], h.len_buf[2], h.len_buf[3], h.len_buf[4]};
+        const uint64_t parts[9] = {h.len_delta, h.len_g2z2, h.len_buf[0], h.len_buf[1], h.len_buf[2], h.len_buf[3], h.len_buf[4], h.len_bound[0], h.len_bound[1]};
         for (uint64_t part : parts) {
             require(part <= rest, ZKHIP_ERR_PARSE, "key image truncated");
             rest -= part;
@@ -609,6 +692,10 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         bool sizes_ok = h.m + 2 < ((uint64_t)1 << 31) && h.z_lo <= h.m + 2 && h.z_n <= h.m + 2 - h.z_lo && h.h_lo <= h.N && h.h_n <= h.N - h.h_lo &&
                         h.len_delta <= 4096 && h.len_g2z2 <= 4096;
         for (int k = 0; k < 5 && sizes_ok; ++k) sizes_ok = h.len_buf[k] == pk_table_bytes(h.curve, k, h.z_n, h.h_n, 1);
+        const bool with_bound = h.len_bound[0] || h.len_bound[1];
+        if (with_bound)
+            sizes_ok = sizes_ok && h.len_bound[0] == pk_table_bytes(h.curve, 4, h.z_n, h.h_n, 1) && h.len_bound[1] == pk_table_bytes(h.curve, 2, h.z_n, h.h_n, 1) &&
+                       (h.bound_fp[0] | h.bound_fp[1]) != 0;
         require(sizes_ok, ZKHIP_ERR_PARSE, "key image: array sizes do not match the header");
         require(ops->ntt_log1(ctx, h.logN) == h.ntt_split, ZKHIP_ERR_PARSE,
                 "key image: written under another NTT split (NTT_SINGLE_MAX_LOG / NTT_MAX_SUBLOG) than this context uses; re-import the proving key");
@@ -649,6 +736,10 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
         }
         stream_sync(ctx->stream);
         ops->pk_table_levels(ctx, pk.get());       // recompute the window multiples behind level 0
+        if (with_bound) {                          // ... and behind level 0 of H' / L'; attached to a system by zkhip_pk_bind_r1cs (fingerprint)
+            ops->install_bound(ctx, pk.get(), p, p + h.len_bound[0], false, h.bound_fp);
+            p += h.len_bound[0] + h.len_bound[1];
+        }
         *out = pk.release();
     });
 }
@@ -898,6 +989,32 @@ int32_t zkhip_multi_pk_load_gm17(zkhip_multi* m, int32_t curve, const uint8_t* b
     const int32_t rc = multi_each(m, [&](size_t k) { return zkhip_pk_load_gm17_shard(m->ctx[k], curve, bytes, len, (uint32_t)k, world, &m->pk[k]); });
     if (rc == ZKHIP_OK) m->scheme = 1; else multi_drop_keys(m);
     return rc;
+}
+// The members' keys bound to the members' constraint system: member 0 computes level 0 of H' / L' over the whole index range from
+// the key file (the same bytes the key was loaded from), every member installs its own ranges (replicas: all of it).
+int32_t zkhip_multi_bind(zkhip_multi* m, const uint8_t* key_bytes, size_t len) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    if (!key_bytes) { m->err = "null argument"; return ZKHIP_ERR_BAD_ARG; }
+    if (m->scheme < 0 || !multi_loaded(m)) { m->err = "load the constraint system and a proving key first"; return ZKHIP_ERR_BAD_ARG; }
+    std::vector<uint8_t> h_host, l_host;
+    u64 fp[2] = {0, 0};
+    const CurveOps* ops = nullptr;
+    int32_t rc = guarded(m->ctx[0], [&] {
+        ops = ops_for(m->pk[0]->curve);
+        for (size_t k = 0; k < m->ctx.size(); ++k) ops->pk_bind_check(m->ctx[k], m->pk[k], m->cs[k]);
+        ops->bound_level0_from_file(m->ctx[0], m->scheme, m->cs[0], key_bytes, len, h_host, l_host, fp);
+    });
+    if (rc != ZKHIP_OK) { m->err = std::string("member 0: ") + zkhip_last_error(m->ctx[0]); return rc; }
+    rc = multi_each(m, [&](size_t k) {
+        return guarded(m->ctx[k], [&] { ops->install_bound_ranges(m->ctx[k], m->pk[k], m->cs[k], h_host.data(), h_host.size(), l_host.data(), l_host.size(), fp); });
+    });
+    if (rc != ZKHIP_OK) for (auto* p : m->pk) zkhip_pk_unbind(p);      // all members or none
+    return rc;
+}
+int32_t zkhip_multi_unbind(zkhip_multi* m) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    for (auto* p : m->pk) if (p) zkhip_pk_unbind(p);
+    return ZKHIP_OK;
 }
 // throughput mode: the whole key on every member; zkhip_prove_g16_multi_batch deals independent proofs round-robin
 int32_t zkhip_multi_pk_load_g16_replicas(zkhip_multi* m, int32_t curve, const uint8_t* bytes, size_t len) {

@@ -59,8 +59,8 @@ class Library:
         "zkhip_prog_parse", "zkhip_prog_free", "zkhip_prog_dims", "zkhip_prog_matrix", "zkhip_prog_variable_order",
         "zkhip_prog_r1cs_load", "zkhip_prog_assignment", "zkhip_prog_write_bound", "zkhip_prog_write",
         "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import",
-        "zkhip_pk_bind_r1cs", "zkhip_pk_unbind", "zkhip_pk_is_bound",
-        "zkhip_ctx_tune",
+        "zkhip_pk_bind_r1cs", "zkhip_pk_unbind", "zkhip_pk_is_bound", "zkhip_pk_bind_r1cs_shard", "zkhip_r1cs_fingerprint",
+        "zkhip_ctx_tune", "zkhip_init", "zkhip_ctx_clock_probe", "zkhip_multi_bind", "zkhip_multi_unbind",
         "zkhip_ctx_create_multi", "zkhip_multi_free", "zkhip_multi_size", "zkhip_multi_ctx", "zkhip_multi_last_error", "zkhip_multi_r1cs_load",
         "zkhip_multi_pk_load_g16", "zkhip_multi_pk_load_gm17", "zkhip_prove_g16_multi", "zkhip_prove_gm17_multi",
         "zkhip_multi_pk_load_g16_replicas", "zkhip_prove_g16_multi_batch", "zkhip_multi_use_rccl", "zkhip_multi_exchange",
@@ -132,6 +132,12 @@ class Library:
         L.zkhip_pk_bind_r1cs.restype = i32; L.zkhip_pk_bind_r1cs.argtypes = [vp, vp, vp]
         L.zkhip_pk_unbind.restype = i32; L.zkhip_pk_unbind.argtypes = [vp]
         L.zkhip_pk_is_bound.restype = i32; L.zkhip_pk_is_bound.argtypes = [vp, vp]
+        L.zkhip_pk_bind_r1cs_shard.restype = i32; L.zkhip_pk_bind_r1cs_shard.argtypes = [vp, vp, vp, vp, sz]
+        L.zkhip_r1cs_fingerprint.restype = i32; L.zkhip_r1cs_fingerprint.argtypes = [vp, vp, vp]
+        L.zkhip_init.restype = i32; L.zkhip_init.argtypes = [i32]
+        L.zkhip_ctx_clock_probe.restype = i32; L.zkhip_ctx_clock_probe.argtypes = [vp, u32, vp]
+        L.zkhip_multi_bind.restype = i32; L.zkhip_multi_bind.argtypes = [vp, vp, sz]
+        L.zkhip_multi_unbind.restype = i32; L.zkhip_multi_unbind.argtypes = [vp]
         L.zkhip_prog_parse.restype = i32; L.zkhip_prog_parse.argtypes = [vp, sz, pp]
         L.zkhip_prog_free.restype = None; L.zkhip_prog_free.argtypes = [vp]
         L.zkhip_prog_dims.restype = i32; L.zkhip_prog_dims.argtypes = [vp, vp]
@@ -142,6 +148,13 @@ class Library:
         L.zkhip_prog_write.restype = i32; L.zkhip_prog_write.argtypes = [i32, u64, u64] + [vp] * 9 + [vp, vp, vp, u64, u32, vp, u64, vp]
         L.zkhip_prog_assignment.restype = i32; L.zkhip_prog_assignment.argtypes = [vp, vp, sz, vp, vp, u64, vp]
         self.L = L
+
+    def init(self, hw_queues):
+        """`zkhip_init`: the host's explicit request for `hw_queues` HIP hardware queues (GPU_MAX_HW_QUEUES, unless the process set it),
+        BEFORE the first HIP call of the process.  The library never touches the environment by itself."""
+        rc = self.L.zkhip_init(int(hw_queues))
+        if rc != 0:
+            raise ZkhipError(rc, self.L.zkhip_last_error(None).decode(errors="replace"))
 
     def device_count(self):
         return int(self.L.zkhip_device_count())
@@ -184,6 +197,14 @@ class Context:
         return buf.value.decode()
 
     TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7, "ntt_cols": 8, "slots": 9, "z_gate": 10, "fuse_z": 11, "msm_fused_waves": 12, "stream_jitter": 13, "ntt_max_sublog": 16, "msm_sets": 17, "skip_inf": 18, "b_sort": 19, "heavy_runs": 20}
+
+    def clock_probe(self, duration_us=2000):
+        """`zkhip_ctx_clock_probe`: the shader clock (GHz) the device runs at over the next `duration_us` microseconds — one wavefront
+        comparing the cycle counter with the wall clock beside whatever else the device is doing (call it on a SECOND context from a
+        second thread while the first proves).  Blocks for the duration."""
+        out = C.c_double()
+        self._check(self.lib.L.zkhip_ctx_clock_probe(self.h, int(duration_us), C.byref(out)))
+        return out.value
 
     def tune(self, name, value):
         """`zkhip_ctx_tune`: development / measurement knobs (window width, slices, fold form, serial streams ...)."""
@@ -283,6 +304,12 @@ class ProvingKey:
         over (this key, cs) then take four transforms instead of six and skip c; the proof bytes do not change."""
         self.ctx._check(self.ctx.lib.L.zkhip_pk_bind_r1cs(self.ctx.h, self.h, cs.h))
 
+    def bind_shard(self, cs, key_bytes):
+        """`zkhip_pk_bind_r1cs_shard`: the same for a SHARD (or a whole key) from the key file — the transforms need every base of
+        the key once; this key keeps its index ranges of the bound tables."""
+        data = _u8(key_bytes)
+        self.ctx._check(self.ctx.lib.L.zkhip_pk_bind_r1cs_shard(self.ctx.h, self.h, cs.h, _ptr(data), data.size))
+
     def unbind(self):
         self.ctx._check(self.ctx.lib.L.zkhip_pk_unbind(self.h))
 
@@ -320,6 +347,12 @@ class ConstraintSystem:
             args += [_ptr(rp), _ptr(col), _ptr(val)]
         self.h = C.c_void_p()
         ctx._check(ctx.lib.L.zkhip_r1cs_load(ctx.h, curve_id, n, l, w, *args, C.byref(self.h)))
+
+    def fingerprint(self):
+        """`zkhip_r1cs_fingerprint`: the checksum a key image remembers of the system its bound tables were made for."""
+        out = np.zeros(2, dtype=np.uint64)
+        self.ctx._check(self.ctx.lib.L.zkhip_r1cs_fingerprint(self.ctx.h, self.h, _ptr(out)))
+        return int(out[0]), int(out[1])
 
     def witness_map(self, z):
         N = 1
@@ -690,6 +723,15 @@ class Multi:
         b = _u8(pk_bytes)
         self._check(self.lib.L.zkhip_multi_pk_load_g16_replicas(self.h, curve_id, _ptr(b), b.size))
         self.curve_id = curve_id
+
+    def bind(self, pk_bytes):
+        """`zkhip_multi_bind`: the members' keys bound to the members' constraint system (one member computes the bound bases from
+        the key file, every member installs its index ranges)."""
+        b = _u8(pk_bytes)
+        self._check(self.lib.L.zkhip_multi_bind(self.h, _ptr(b), b.size))
+
+    def unbind(self):
+        self._check(self.lib.L.zkhip_multi_unbind(self.h))
 
     def prove_g16_batch(self, zs, rss):
         """Independent proofs dealt over the members (`zkhip_prove_g16_multi_batch`): zs = list of host assignments,
