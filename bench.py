@@ -39,8 +39,6 @@ import sys
 import time
 
 T_PROCESS_START = time.time()
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts: the library drives ~20 streams per context and asks for 8
-                                                    # queues by itself; ONE resident prover per process can afford 16 (+1.5-2 %, zkhip_api.hip)
 
 
 def supervise():
@@ -329,7 +327,18 @@ def main():
                     help="Groth16: bind the resident key to the resident constraint system before the timed region (zkhip_pk_bind_r1cs: four "
                          "transforms per proof instead of six, no C mat-vec, same proof bytes — checked here against an unbound proof; the line "
                          "also times one region with the key unbound again).  0 = the key as loaded; 2 = bound, without the unbound region")
+    ap.add_argument("--oracle", default="auto", choices=["auto", "algorithmic", "trapdoor", "none"],
+                    help="what the device proof is held to: `algorithmic` = the cpu_baseline leg's proof (the C++ restatement of ark's prover, "
+                         "needs --cpu-seconds > 0), `trapdoor` = the closed form from the setup's toxic waste (oracle/c, independent of every "
+                         "transform and MSM; seconds at any size), auto = algorithmic when the CPU leg runs, else none")
+    ap.add_argument("--configs", type=int, default=-1,
+                    help="after everything else, run BASELINE.json's other configurations as short legs (GM17 2^20, Poseidon chain on BLS12-381, "
+                         "stdlib SHA-256 2^20, 2^22 on one GPU and as 8 members), each checked against the oracle's closed form, and append them as "
+                         "the LAST key of the line (`configs`).  -1 = only for the default workload on one GPU; 0 = never; 1 = always")
     args = ap.parse_args()
+    # the host's explicit choice of HIP hardware queues (zkhip_init; the library never touches the environment itself): 16 for a process
+    # with ONE resident prover, 8 as soon as it will hold several contexts (--members: every queue reserves scratch for the largest frame)
+    native.default_library().init(8 if args.members else 16)
 
     timeline = {}
 
@@ -415,19 +424,20 @@ def main():
     # The resident prover's key, bound to its system (include/zkhip.h: zkhip_pk_bind_r1cs).  Self-checking: the bound key must
     # reproduce an unbound proof byte for byte, or the run goes on with the key as loaded and says so.
     bound, bound_rnd0 = {"bound": False}, None
-    if args.bind and not gm17 and os.environ.get("ZKHIP_BENCH_BIND") == "0":
+    rnd0 = (1000, 3000, 2000) if gm17 else (1000, 2000)      # the randomness of the proof that is held against the oracle
+    if args.bind and os.environ.get("ZKHIP_BENCH_BIND") == "0":
         bound["note"] = "second attempt after a measuring process that died: the key is left as loaded"
-    elif args.bind and not gm17:
+    elif args.bind:
         try:
-            ref_proof = native.prove_g16_resident(ctx, pk, cs, resident[0], *rs(0))
+            ref_proof = prove_one(resident[0], rs(0))[0]
             t0 = time.time()
             pk.bind(cs)
             bound["bind_ms"] = 1000 * (time.time() - t0)
-            same = native.prove_g16_resident(ctx, pk, cs, resident[0], *rs(0)) == ref_proof
+            same = prove_one(resident[0], rs(0))[0] == ref_proof
             bound["proof_identical_to_unbound"] = bool(same)
             bound["bound"] = bool(same)
             if same:
-                bound_rnd0 = native.prove_g16_resident(ctx, pk, cs, resident[0], 1000, 2000)   # (held against the CPU baseline's proof below)
+                bound_rnd0 = prove_one(resident[0], rnd0)[0]   # (held against the oracle's proof below)
             else:
                 pk.unbind()
         except native.ZkhipError as e:
@@ -453,6 +463,8 @@ def main():
     sampler = LoadSampler(pci)
     idle_reading = sampler.read_once()
     sampler.start()
+    clock = ClockProbe(device)            # a second context's one-wave probe: the shader clock the proving kernels actually run at
+    clock.start()
     barrier_sync()
     t_begin = time.perf_counter()
     proofs, acc = prove_many([resident[j % nw] for j in steps], [rs(j) for j in steps])
@@ -469,6 +481,7 @@ def main():
         barrier_sync()
         region_ms.append(1000.0 * ranks.max_over_ranks(time.perf_counter() - t0) / args.steps)
     sampler.stop()
+    clock_regions = clock.window(t_begin, time.perf_counter())
     mark("repeats_done")
     per_rank = gather_per_rank(ranks, device, pci, placement, args.steps, elapsed_local)
     # isolated single-proof latency (not part of the timed region): resident assignment, then from host memory
@@ -483,14 +496,18 @@ def main():
         from_host.append(1000.0 * (time.perf_counter() - t0))
     # one-stream leg: the same proofs with every kernel on ONE stream -> un-overlapped kernel durations
     serial = None
+    clock_serial = None
     if args.serial_proofs > 0:
         ctx.tune("serial", 1)
+        t_s0 = time.perf_counter()
         tms = [prove_one(resident[i % nw], rs(400 + i))[1] for i in range(args.serial_proofs + 1)][1:]
+        clock_serial = clock.window(t_s0, time.perf_counter())
         ctx.tune("serial", 0)
         serial = {k: sum(t[k] for t in tms) / len(tms) for k in tms[0]}
+    clock.stop()
 
     # the same region once more with the key UNBOUND (six transforms, three mat-vecs): the same-box figure the binding is worth
-    if bound["bound"] and args.bind == 1:          # (--bind 2: bound throughout — a trace of the bound pipeline only)
+    if bound["bound"] and args.bind == 1 and args.repeats > 1:          # (--bind 2: bound throughout — a trace of the bound pipeline only)
         pk.unbind()
         prove_many([resident[i % nw] for i in range(4)], [rs(500 + i) for i in range(4)])
         barrier_sync()
@@ -499,10 +516,18 @@ def main():
         barrier_sync()
         bound["unbound_ms_per_step"] = 1000.0 * ranks.max_over_ranks(time.perf_counter() - t0) / args.steps
         bound["unbound_single_proof_ms"] = min(prove_one(resident[i % nw], rs(600 + i))[1]["total_ms"] for i in range(3))
-        bound["note"] = ("`value` is measured with the key bound to the constraint system (4 transforms + 2 mat-vecs per proof); unbound_* repeat the "
-                         "region and the isolated proof with the key as loaded (6 transforms + 3 mat-vecs; the reference's schedule has 7)")
+        bound["note"] = ("`value` is measured with the key bound to the constraint system (Groth16: 4 transforms + 2 mat-vecs per proof; GM17: 2 transforms); "
+                         "unbound_* repeat the region and the isolated proof with the key as loaded (6 transforms + 3 mat-vecs, GM17 4; the reference's "
+                         "schedules have 7 and 5)")
         mark("unbound_region_done")
 
+    value_first = world * args.steps / elapsed
+    if bound["bound"]:
+        value_bound, value_unbound = value_first, (world * 1000.0 / bound["unbound_ms_per_step"]) if bound.get("unbound_ms_per_step") else None
+        key_state = "bound to the constraint system (zkhip_pk_bind_r1cs: one-time bind_ms outside the timed region, two extra tables resident)"
+    else:
+        value_bound, value_unbound = None, value_first
+        key_state = "as loaded" + (" — FALLBACK: " + bound["note"] if os.environ.get("ZKHIP_BENCH_BIND") == "0" and args.bind else "")
     avg = {k: v / args.steps for k, v in acc.items()}
     # ---- roofline of the dominant kernel (HIP events on the library's streams)
     m, N = circ.m, circ.N
@@ -520,43 +545,58 @@ def main():
     achieved = bytes_all / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) — measured offline, same workload
-    traffic, traffic_ntt = None, None
+    traffic, traffic_ntt, traffic_cal = None, None, None
     default_workload = args.log_domain == 20 and args.curve == "bn128" and args.kind == "dense" and not gm17
     evidence = offline_evidence() if default_workload else {"traffic": None, "valu": None, "stale": False}
     pmc = evidence["traffic"]
     if pmc:
         ent = pmc.get("G2" if "G2" in name else "G1", {})
         traffic = ent.get("traffic_bytes_per_launch")
+        traffic_cal = {"fetch_factor": ent.get("fetch_factor"), "pattern": ent.get("pattern"), "calibration": pmc.get("calibration")}
         if traffic and "G1" in name:
             # the file averages over the accumulation launches of its run; re-average if that run cut a proof's G1 work
             # into a different number of launches than this build (the per-proof total is what was measured)
             lpp = ent.get("launches_per_proof") or (ent["launches_fetch_pass"] / pmc["NTT"]["proofs"] if pmc.get("NTT", {}).get("proofs") else launches)
             traffic = int(traffic * lpp / launches)
         traffic_ntt = pmc.get("NTT", {}).get("traffic_bytes_per_pass")
-    # the honest bound of this kernel: mixed additions per second against the multiplier-limited rate of the same
-    # kernel on synthetic data (tools/accum_bench.hip); one mixed addition per non-zero signed digit, W digits per scalar
+    # The honest bound of this kernel is VALU ISSUE (Montgomery products are multiply-adds; one wave64 instruction per 4 cycles and SIMD):
+    #   peak = the kernel's own VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of this build, profiles/pmc_valu.json)
+    #          issued by 1 024 SIMDs at the shader clock MEASURED IN THIS RUN beside the kernels (zkhip_ctx_clock_probe)
+    # expressed as mixed additions per second (one per non-zero signed digit, W digits per scalar).
     W = msm_windows(synth.FR_BITS[curve_id], m + 2) if args.log_domain >= 15 else None
     compute = None
+    pv = evidence["valu"]
     if W and args.curve == "bn128" and args.kind == "dense":   # (sparse / boolean witnesses drop their zero digits: no fixed addition count)
         madds = (((m + 2) if "G2" in name else (3 * (m + 2) + N)) * W)
-        peak = 5.57e9 if "G2" in name else 13.4e9
-        compute = {"unit": "mixed additions/s", "achieved": madds / (ms * 1e-3), "peak": peak, "frac": madds / (ms * 1e-3) / peak, "windows": W,
-                   "peak_source": "tools/accum_bench.hip on MI355X (this round's kernel on synthetic sorted lists with equal buckets, best slicing: profiles/r5a_accum_bench.txt)"}
-        if serial and serial[key] > 0:
-            compute["frac_serial"] = madds / (serial[key] * 1e-3) / peak
-    # VALU issue occupation of the same kernel from the committed counter pass (tools/pmc_valu.py)
-    pv = evidence["valu"]
-    if compute is not None and pv:
-        ent = pv.get("G2" if "G2" in name else "G1")
-        if ent:
-            compute["valu_issue_utilisation"] = ent["issue_utilisation"]
-            compute["valu_cycles_per_instruction_per_simd"] = ent["cycles_per_valu_instruction_per_simd"]
-            compute["clock_ghz_under_load"] = ent["clock_ghz"]
-            compute["valu_source"] = "OFFLINE: rocprofv3 --pmc pass of this workload on this build, profiles/pmc_valu.json (not measured in this run)"
-    if compute is not None and "valu_issue_utilisation" in compute and world == 1 and not gm17:
-        compute["pipeline_issue_bound"] = pipeline_issue_bound(pv, 1000.0 * elapsed / args.steps, 8 if bound["bound"] else 12)
+        group = "G2" if "G2" in name else "G1"
+        ghz = clock_regions.get("mean_ghz") or (pv or {}).get(group, {}).get("clock_ghz")
+        ghz_serial = (clock_serial or {}).get("mean_ghz") or ghz
+        ent = (pv or {}).get(group)
+        static = STATIC_VALU_PER_ADDITION.get(group)
+        # wave-instructions of one proof's launches of this kernel: counted (fresh counter file) or, failing that, the static count of the
+        # hot loop (profiles/r5_accum_isa_mix.txt) times the additions
+        instr = ent["valu_wave_instructions_per_launch"] * launches if ent else (madds * static / 64.0 if static else None)
+        compute = {"unit": "mixed additions/s", "achieved": madds / (ms * 1e-3), "windows": W,
+                   "valu_wave_instructions_per_proof": instr,
+                   "instructions_source": ("rocprofv3 SQ_INSTS_VALU of this build (profiles/pmc_valu.json: OFFLINE, fingerprinted)" if ent else
+                                           "static count of the hot loop x additions (no fresh counter file for this build)"),
+                   "shader_clock_ghz": ghz, "shader_clock_ghz_serial_leg": ghz_serial,
+                   "clock_source": "zkhip_ctx_clock_probe: one wavefront beside the kernels, shader cycles / wall clock (LIVE)" if clock_regions.get("mean_ghz") else
+                                   "derived from the counter pass (no live probe)",
+                   "kernel_on_synthetic_lists": {"additions_per_s": 5.57e9 if "G2" in name else 13.4e9, "source": "tools/accum_bench.hip, profiles/r5a_accum_bench.txt (round 5's `peak`: the kernel against itself)"}}
+        if instr and ghz:
+            t_issue_ms = instr / (1024 * ghz * 1e9 / 4) * 1e3                  # per proof, this kernel alone at the issue limit
+            compute["peak"] = madds / (t_issue_ms * 1e-3)
+            compute["peak_source"] = "VALU issue limit: 1024 SIMDs x shader clock / 4 cycles per wave64 instruction / the kernel's instructions per proof"
+            compute["frac"] = compute["achieved"] / compute["peak"]
+            if serial and serial[key] > 0 and ghz_serial:
+                compute["frac_serial"] = (instr / (1024 * ghz_serial * 1e9 / 4) * 1e3) / serial[key]
+        if world == 1 and not gm17 and pv:
+            compute["pipeline_issue_bound"] = pipeline_issue_bound(pv, 1000.0 * elapsed / args.steps, 8 if bound["bound"] else 12, ghz)
     roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_ratio": (traffic / (bytes_all / launches)) if traffic else None,
+                "traffic_calibration": traffic_cal,
                 "traffic_source": ("offline rocprofv3 --pmc passes of this workload, " + PMC_TRAFFIC_FILE) if traffic else None,
                 "frac_serial": (bytes_all / (serial[key] * 1e-3) / 1e9 / HBM_PEAK_GBS) if serial and serial[key] > 0 else None,
                 "bytes_per_launch": bytes_all / launches, "ms_per_launch": ms / launches,
@@ -575,7 +615,7 @@ def main():
     ntt_bytes = passes * 2 * N * 32
     roofline_ntt = {"bound": "hbm", "kernel": "ntt_cols / ntt_rows (%d pass-vectors of 2^%d elements per proof)" % (passes, int(np.log2(N))),
                     "achieved": ntt_bytes / (avg["kernel_ntt_ms"] * 1e-3) / 1e9 if avg.get("kernel_ntt_ms", 0) > 0 else None,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic_ntt,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic_ntt, "traffic_ratio": (traffic_ntt / (2.0 * N * 32)) if traffic_ntt else None,
                     "traffic_source": ("offline rocprofv3 --pmc passes of this workload, " + PMC_TRAFFIC_FILE) if traffic_ntt else None,
                     "bytes_per_pass": 2 * N * 32}
     if roofline_ntt["achieved"]:
@@ -599,7 +639,8 @@ def main():
             "statistics of a SHA-256 circuit (90 % boolean) are generated directly], " if args.kind == "sha" else ", "))
         + f"{args.curve} Groth16, " + ("4 NTTs + 5 MSMs per proof (key bound to the constraint system)" if bound["bound"] else "6 NTTs + 5 MSMs per proof"))
     out = {
-        "metric": "gm17_proofs_per_sec" if gm17 else "groth16_proofs_per_sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
+        "metric": "gm17_proofs_per_sec" if gm17 else "groth16_proofs_per_sec", "value": value_first, "unit": "proofs/s",
+        "value_is": "value_bound" if bound["bound"] else "value_unbound", "value_bound": value_bound, "value_unbound": value_unbound, "key_state": key_state,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": workload, "curve": args.curve, "constraints": circ.n,
@@ -608,7 +649,8 @@ def main():
                    "process_group": ranks.describe(),
                    "launcher": ("bench.py --gpus N started the ranks itself" if os.environ.get("ZKHIP_BENCH_LAUNCHED") == "self" else
                                 "external launcher (torch.distributed.run)" if world > 1 else "single process")},
-        "single_proof_ms": single_ms, "single_proof_from_host_ms": min(from_host), "phases_ms": avg, "phases_ms_serial": serial,
+        "single_proof_ms": single_ms, "single_proof_unbound_ms": bound.get("unbound_single_proof_ms"),
+        "single_proof_from_host_ms": min(from_host), "phases_ms": avg, "phases_ms_serial": serial,
         "whole_proof_hbm": {"algorithmic_bytes": b_alg, "achieved_GBs": b_alg / (elapsed / args.steps) / 1e9,
                             "frac": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         "roofline": roofline, "roofline_ntt": roofline_ntt,
@@ -621,6 +663,8 @@ def main():
                     "value_of_median": world * 1000.0 / float(np.median(region_ms)),
                     "note": "`value` / `ms_per_step` are the FIRST region; every region is K steps over the same K resident witnesses"},
         "under_load": sampler.summary(idle_reading),
+        "shader_clock": {"timed_regions": clock_regions, "serial_leg": clock_serial,
+                         "source": "zkhip_ctx_clock_probe on a second context of the same device, 2 ms readings back to back (shader cycles / wall clock of one sleeping wavefront)"},
         "per_rank": per_rank,
         "bound_key": bound,
     }
@@ -665,32 +709,133 @@ def main():
     if os.environ.get("ZKHIP_BENCH_TEST_STALL"):      # tests/test_bench_cli.py: an optional leg that never returns
         time.sleep(3600)
     if rank == 0 and members >= 1:
-        out["multi_single_proof"] = multi_leg(ctx, circ, curve_id, pk_bytes, zs[0], members, gm17, prove_one)
+        out["multi_single_proof"] = multi_leg(ctx, circ, curve_id, pk_bytes, zs[0], members, gm17, prove_one,
+                                              oracle=(lambda rnd: trapdoor_proof(circ, curve_id, zs[0], rnd, gm17)) if args.oracle == "trapdoor" else None)
     if world > 1:
         ranks.host_barrier()      # the other ranks idle (on the host: no collective kernel parked on their GPUs) while rank 0
                                   # drives every GPU through the library
     watchdog.cancel()
+    oracle_kind = args.oracle if args.oracle != "auto" else ("algorithmic" if (world == 1 and args.cpu_seconds > 0) else "none")
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         base, cpu_proof = cpu_baseline(circ, pk_bytes, zs[0], args.cpu_seconds, gm17)
         out["cpu_baseline"] = base
         # same inputs -> byte-identical proof (the CPU leg doubles as a full-size parity check)
-        rnd0 = (1000, 3000, 2000) if gm17 else (1000, 2000)
         gpu_proof = prove_one(resident[0], rnd0)[0]
         batch_proof = prove_many([resident[0]] * 3, [rnd0] * 3)[0]
         out["cpu_baseline"]["gpu_proof_identical"] = bool(gpu_proof == cpu_proof and all(p == cpu_proof for p in batch_proof))
         if bound_rnd0 is not None:
             out["cpu_baseline"]["gpu_bound_key_proof_identical"] = bool(bound_rnd0 == cpu_proof)
-        out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
+        # like for like: the CPU baseline runs the reference's schedule on the key as loaded, so the ratio is quoted on the UNBOUND region
+        # when this run has one (the bound figure amortises a one-time bind of `bind_ms` over the prover's lifetime)
+        out["speedup_vs_cpu_baseline"] = (out.get("value_unbound") or out["value"]) / base["value"]
+        out["speedup_vs_cpu_baseline_is"] = "value_unbound / cpu_baseline.value" if out.get("value_unbound") else "value / cpu_baseline.value (no unbound region in this run)"
+        if oracle_kind == "algorithmic":
+            out["identical_to_oracle"] = bool(out["cpu_baseline"]["gpu_proof_identical"] and (bound_rnd0 is None or bound_rnd0 == cpu_proof))
+            out["oracle"] = "algorithmic restatement of ark's prover (oracle/c), the cpu_baseline leg's proof"
     elif rank == 0:
         out["cpu_baseline"] = None   # N > 1 or --cpu-seconds 0
+    if rank == 0 and oracle_kind == "trapdoor":
+        # the closed form from the toxic waste of this run's own setup (oracle/c orc_trapdoor / orc_gm17_trapdoor): no transform, no MSM
+        try:
+            t0 = time.time()
+            want = trapdoor_proof(circ, curve_id, zs[0], rnd0, gm17)
+            gpu_proof = prove_one(resident[0], rnd0)[0]
+            batch_proof = prove_many([resident[0]] * 3, [rnd0] * 3)[0]
+            ok = gpu_proof == want and all(p == want for p in batch_proof) and (bound_rnd0 is None or bound_rnd0 == want)
+            out["identical_to_oracle"] = bool(ok)
+            out["oracle"] = "closed-form trapdoor proof (oracle/c), %.1f s" % (time.time() - t0)
+        except Exception as e:
+            out["identical_to_oracle"] = None
+            out["oracle"] = "trapdoor check failed to run: %r" % (e,)
     if rank == 0 and world == 1 and args.e2e:
         out["cli_end_to_end_ms"] = cli_end_to_end(circ, curve_id, pk_bytes, zs[0], args.scheme, ctx, pk, cs)
     if rank == 0 and world == 1:
         out["box_probe"] = box_probe()
         out["rocm_smi"] = rocm_smi()
+    want_configs = args.configs == 1 or (args.configs == -1 and default_workload and world == 1 and not os.environ.get("ZKHIP_BENCH_LEG"))
+    if rank == 0 and want_configs:
+        del resident[:]                      # this process's share of the device: the legs are processes of their own
+        for obj in (pk, cs):
+            try:
+                obj.close()
+            except Exception:
+                pass
+        out["configs"] = config_legs(args)   # LAST key of the line on purpose: it survives a reader that keeps the tail
     if rank == 0:
         print(json.dumps(out), flush=True)
     ranks.close()
+
+
+def trapdoor_proof(circ, curve_id, z, rnd, gm17):
+    """The proof the toxic waste of make_proving_key's setup determines in closed form (oracle/c: three fixed-base products of
+    field expressions — no transform, no MSM; test infrastructure, used here as the checker only)."""
+    from oracle import cpu
+    oc = cpu.Circuit.from_csr(curve_id, circ.n, circ.l, circ.w, circ.mats())
+    tox = synth.toxic_waste(curve_id, 0xC0FFEE)
+    if gm17:
+        tb = b"".join(int(v).to_bytes(32, "little") for v in (tox[0], tox[1], tox[2], tox[4]))
+        return cpu.gm17_trapdoor(oc, tb, z, rnd[0], rnd[2])
+    tb = b"".join(int(v).to_bytes(32, "little") for v in tox)
+    return cpu.trapdoor(oc, tb, z, rnd[0], rnd[1])
+
+
+CONFIG_LEGS = [
+    # (key, BASELINE.json config, bench.py arguments)
+    ("gm17_2e20", "configs[4]: GM17 on the 2^20-constraint BN254 circuit", ["--scheme", "gm17"]),
+    ("poseidon_chain_bls12_381_2e18", "configs[3]: stdlib Poseidon hash chain (depth 1024), BLS12-381", ["--curve", "bls12_381", "--log-domain", "18", "--kind", "poseidon"]),
+    ("sha256_stdlib_2e20", "configs[0] at the size of configs[1]: stdlib sha256/512bitPacked.zok side by side up to a 2^20 domain", ["--kind", "sha256", "--log-domain", "20"]),
+    ("dense_2e22_and_8_members", "configs[2]: 2^22 constraints, one GPU whole and as 8 members of one proof", ["--log-domain", "22", "--members", "8"]),
+]
+
+
+def config_legs(args, budget_s=None):
+    """BASELINE.json's other configurations as short runs of THIS script (a process each: a leg that dies or stalls costs its own entry,
+    not the line): >= 8 timed steps after 2 warm-up steps, the key bound as a resident prover would, the device proof — single, batched,
+    bound — held to the oracle's closed form.  Compact records; `wall_s` is the leg's whole process."""
+    import subprocess
+    budget_s = budget_s or float(os.environ.get("ZKHIP_BENCH_CONFIGS_BUDGET_S", "95"))
+    t_all = time.time()
+    res = {}
+    legs = CONFIG_LEGS
+    if os.environ.get("ZKHIP_BENCH_TEST_LEGS"):      # tests/test_bench_cli.py: the same four legs at toy size (the emulator build)
+        legs = [(k, w, {"gm17_2e20": ["--scheme", "gm17", "--log-domain", "5"], "poseidon_chain_bls12_381_2e18": ["--curve", "bls12_381", "--log-domain", "8", "--kind", "poseidon"],
+                        "sha256_stdlib_2e20": ["--kind", "sha", "--log-domain", "6"], "dense_2e22_and_8_members": ["--log-domain", "6", "--members", "2"]}[k])
+                for k, w, _ in CONFIG_LEGS]
+        budget_s = 1200
+    for key, what, extra in legs:
+        left = budget_s - (time.time() - t_all)
+        if left < 15:
+            res[key] = {"config": what, "skipped": "time budget of the configs block (%.0f s) spent" % budget_s}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--witnesses", "2", "--cpu-seconds", "0", "--e2e", "0",
+               "--serial-proofs", "0", "--repeats", "2", "--oracle", "trapdoor", "--configs", "0"] + extra
+        env = dict(os.environ, ZKHIP_BENCH_CHILD="1", ZKHIP_BENCH_LEG="1", ZKHIP_BENCH_STAGES="")
+        env.pop("ZKHIP_BENCH_STAGES")
+        t0 = time.time()
+        rec = {"config": what}
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=left if os.environ.get("ZKHIP_BENCH_TEST_LEGS") else min(left, 75.0))
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not lines:
+                rec["error"] = "exit status %d: %s" % (p.returncode, (p.stderr or "")[-300:])
+            else:
+                d = json.loads(lines[-1])
+                rec.update({"proofs_per_s": d["value"], "ms_per_step": d["ms_per_step"], "single_proof_ms": d["single_proof_ms"],
+                            "identical_to_oracle": d.get("identical_to_oracle"), "oracle": d.get("oracle"),
+                            "key_bound": d["bound_key"].get("bound"), "bind_ms": d["bound_key"].get("bind_ms"),
+                            "proofs_per_s_unbound": d.get("value_unbound"), "single_proof_unbound_ms": d.get("single_proof_unbound_ms"),
+                            "steps": d["steps"], "constraints": d["config"]["constraints"], "domain": d["config"]["domain"], "curve": d["config"]["curve"]})
+                mm = d.get("multi_single_proof")
+                if mm:
+                    rec["members"] = {k: mm.get(k) for k in ("members", "distinct_gpus", "ms", "ms_unbound", "identical_to_unsharded", "identical_to_oracle", "key_bound",
+                                                               "bind_ms", "kernel_ntt_ms", "error") if k in mm}
+        except subprocess.TimeoutExpired:
+            rec["error"] = "timed out"
+        except Exception as e:
+            rec["error"] = repr(e)[:200]
+        rec["wall_s"] = round(time.time() - t0, 1)
+        res[key] = rec
+    return res
 
 
 def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
@@ -771,22 +916,27 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
                     rec["verified"] = "verified against the verification key" in p.stdout
             res[name] = rec
 
-        if os.access(native_exe, os.X_OK):
+        # three runs of the compiled executable (csrc/host: the drop-in's own front end): from the proving.key; the first run with a key
+        # cache (writes the device-layout image); from that image.  ZKHIP_BENCH_CLI_ALL=1 adds round 5's other legs (the self check by
+        # the compiled verifier, the full tables, the Python shim's three) — tests/test_bench_cli.py runs them at toy size.
+        have_native = os.access(native_exe, os.X_OK)
+        if have_native:
             paths["cache_native"] = os.path.join(d, "cache_native")
             run("native_from_proving_key", [], native_exe)
             run("native_first_run_with_key_cache", ["--key-cache", paths["cache_native"]], native_exe)
             run("native_from_key_image", ["--key-cache", paths["cache_native"]], native_exe)
-            # the same once more with the self check: the proof of the 2^20 circuit against the verification key at the head of its
-            # proving key, by the compiled verifier on the host CPU (csrc/host/verify.cpp) — "verify_ms" and "verified" in the record
-            run("native_from_key_image_with_verify", ["--key-cache", paths["cache_native"], "--verify"], native_exe)
-            # what the same process pays when it builds the window-multiple tables a RESIDENT prover works with (the CLI does not:
-            # one proof per process, `tables` in the record says which)
-            run("native_from_proving_key_full_tables", ["--full-tables"], native_exe)
-        run("from_proving_key", [])
-        run("first_run_with_key_cache", ["--key-cache", paths["cache"]])
-        run("from_key_image", ["--key-cache", paths["cache"]])
-        res["file_bytes"]["key_image"] = sum(os.path.getsize(os.path.join(paths["cache"], f)) for f in os.listdir(paths["cache"]))
-        ing = res["from_proving_key"].get("parse_program_ms")
+            res["file_bytes"]["key_image"] = sum(os.path.getsize(os.path.join(paths["cache_native"], f)) for f in os.listdir(paths["cache_native"]))
+            ing = res["native_from_proving_key"].get("parse_program_ms")
+        if os.environ.get("ZKHIP_BENCH_CLI_ALL") or not have_native:
+            if have_native:
+                run("native_from_key_image_with_verify", ["--key-cache", paths["cache_native"], "--verify"], native_exe)
+                run("native_from_proving_key_full_tables", ["--full-tables"], native_exe)
+            run("from_proving_key", [])
+            run("first_run_with_key_cache", ["--key-cache", paths["cache"]])
+            run("from_key_image", ["--key-cache", paths["cache"]])
+            if not have_native:
+                res["file_bytes"]["key_image"] = sum(os.path.getsize(os.path.join(paths["cache"], f)) for f in os.listdir(paths["cache"]))
+                ing = res["from_proving_key"].get("parse_program_ms")
         if ing:
             res["ingest_constraints_per_s"] = circ.n / (ing * 1e-3)
     except Exception as e:   # the throughput line must survive a failure of this leg
@@ -796,10 +946,11 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
     return res
 
 
-def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one):
+def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one, oracle=None):
     """ONE proof across `members` members inside the library (zkhip_ctx_create_multi / zkhip_prove_*_multi: a host thread per
     member, canonical partial records gathered in host memory — no Python, no collective library): the latency mode a caller
-    behind the reference's trait gets."""
+    behind the reference's trait gets.  First with the members' shards as loaded, then bound to the system (zkhip_multi_bind: one
+    member computes the bound bases, every member installs its index ranges) — `ms` is the bound figure when the binding took."""
     try:
         ndev = ctx.lib.device_count()
         devices = [k % ndev for k in range(members)]
@@ -814,12 +965,34 @@ def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one):
         multi.load_proving_key(curve_id, pk_bytes, scheme="gm17" if gm17 else "g16")
         t_load = time.time() - t0
         rnd = (31, 59, 4242) if gm17 else (4242, 777)
-        times, phases = [], None
-        for i in range(5):
-            t0 = time.perf_counter()
-            proof, phases = (multi.prove_gm17 if gm17 else multi.prove_g16)(z, *rnd, want_timings=True)
-            times.append(1000.0 * (time.perf_counter() - t0))
         whole = prove_one(z, rnd)[0]
+
+        def timed(count=5):
+            times, phases, proof = [], None, None
+            for i in range(count):
+                t0 = time.perf_counter()
+                proof, phases = (multi.prove_gm17 if gm17 else multi.prove_g16)(z, *rnd, want_timings=True)
+                times.append(1000.0 * (time.perf_counter() - t0))
+            return min(times[1:]), phases, proof
+        ms_unbound, phases_unbound, proof = timed()
+        same = proof == whole
+        rec = {"members": members, "devices": devices, "distinct_gpus": len(set(devices)), "key_load_ms": 1000.0 * t_load,
+               "ms_unbound": ms_unbound, "ms": ms_unbound, "key_bound": False}
+        try:
+            t0 = time.time()
+            multi.bind(pk_bytes)
+            rec["bind_ms"] = 1000.0 * (time.time() - t0)
+            ms_bound, phases, proof_b = timed()
+            same = same and proof_b == whole
+            rec.update({"ms": ms_bound, "key_bound": True, "slowest_member_phases_ms": phases, "kernel_ntt_ms": phases.get("kernel_ntt_ms"),
+                        "kernel_ntt_ms_unbound": phases_unbound.get("kernel_ntt_ms")})
+            multi.unbind()
+        except native.ZkhipError as e:
+            rec["bind_error"] = str(e)
+            rec["slowest_member_phases_ms"] = phases_unbound
+        rec["identical_to_unsharded"] = bool(same)
+        if oracle is not None:
+            rec["identical_to_oracle"] = bool(same and whole == oracle(rnd))
         replicas = None
         if not gm17:
             # throughput mode of the same members: whole key on each, independent proofs dealt over them
@@ -831,12 +1004,10 @@ def multi_leg(ctx, circ, curve_id, pk_bytes, z, members, gm17, prove_one):
             proofs, _ = multi.prove_g16_batch(zs, rss)
             dt = time.perf_counter() - t0
             replicas = {"proofs": count, "proofs_per_s": count / dt, "first_identical_to_unsharded": bool(proofs[0] == whole)}
-        exchange = multi.exchange()
+        rec["replicas_batch"] = replicas
+        rec["exchange"] = multi.exchange()
         multi.close()
-        return {"ms": min(times[1:]), "members": members, "devices": devices, "distinct_gpus": len(set(devices)),
-                "identical_to_unsharded": bool(proof == whole), "key_load_ms": 1000.0 * t_load,
-                "slowest_member_phases_ms": phases, "replicas_batch": replicas,
-                "exchange": exchange}
+        return rec
     except Exception as e:   # the throughput line must survive a failure of the optional leg
         return {"error": repr(e)}
 
@@ -987,25 +1158,85 @@ def offline_evidence(root=ROOT, pkg=None):
     return out
 
 
-def pipeline_issue_bound(pv, ms_per_step, pass_vectors=12):
+def pipeline_issue_bound(pv, ms_per_step, pass_vectors=12, clock_ghz=None):
     """The proof rate against the issue limit of the pipeline's own instruction stream: the VALU wavefront instructions the
     committed counter pass (profiles/pmc_valu.json) counted for the kernels that fill the machine — two G1 accumulation launches,
     one G2, four column and four row transform launches per Groth16 proof (two thirds of the latter over a bound key); sort, fold and
-    mat-vec add < 3 % —, divided by what
-    1024 SIMDs issue at one instruction per 4 cycles at the clock the chip held during that pass.  OFFLINE instruction counts,
-    this run's time.  None if the file does not hold what is needed."""
+    mat-vec add < 3 % —, divided by what 1024 SIMDs issue at one instruction per 4 cycles at `clock_ghz`: the shader clock measured
+    LIVE beside the kernels (zkhip_ctx_clock_probe), or — without a probe — the clock the counter pass derived.  OFFLINE instruction
+    counts, this run's time and clock.  None if the file does not hold what is needed."""
     try:
         # (the counter passes run with the key as loaded, `--bind 0`: 12 pass-vectors in four column and four row launches; a proof
         # over a bound key runs `pass_vectors` = 8 of the same)
         per_proof = {"G1": 2, "G2": 1, "NTT_cols": 4 * pass_vectors / 12.0, "NTT_rows": 4 * pass_vectors / 12.0}
         instr = sum(n * pv[k]["valu_wave_instructions_per_launch"] for k, n in per_proof.items())
-        clock = pv["G1"]["clock_ghz"]
+        clock = clock_ghz or pv["G1"]["clock_ghz"]
         ms = instr / (1024 * clock * 1e9 / 4) * 1e3
-        return {"valu_wave_instructions_per_proof": instr, "clock_ghz_under_load": clock, "ms_per_proof_at_issue_limit": ms,
+        return {"valu_wave_instructions_per_proof": instr, "clock_ghz_under_load": clock, "clock_is_live": bool(clock_ghz),
+                "ms_per_proof_at_issue_limit": ms,
                 "frac_of_ms_per_step": ms / ms_per_step if ms_per_step > 0 else None,
-                "source": "OFFLINE instruction counts (profiles/pmc_valu.json), this run's ms_per_step"}
+                "source": "OFFLINE instruction counts (profiles/pmc_valu.json), this run's ms_per_step and shader clock"}
     except Exception:
         return None
+
+
+# instructions of the accumulation's hot loop per sorted entry (tools/isa_mix.py on the build of profiles/r5_accum_isa_mix.txt): the
+# fallback of compute_bound when no counter file of THIS build is at hand
+STATIC_VALU_PER_ADDITION = {"G1": 2427, "G2": 6506}
+
+
+class ClockProbe:
+    """The shader clock under the bench's own load: a SECOND context on the rank's device runs zkhip_ctx_clock_probe — one wavefront
+    that compares the shader-cycle counter with the constant-rate wall clock over 2 ms, asleep in between — in a host thread, back to
+    back, while the first context proves (the calls release the GIL).  window(t0, t1) averages the readings that ended inside."""
+
+    def __init__(self, device, period_us=2000):
+        import threading
+        self.samples = []
+        self.period_us = period_us
+        self._stop = threading.Event()
+        self._thread = None
+        self.ctx = None
+        self.error = None
+        try:
+            self.ctx = native.Context(device)
+            self.ctx.clock_probe(200)
+        except Exception as e:      # (an older library, the emulator: no probe, no figure)
+            self.error = repr(e)[:160]
+            self.ctx = None
+
+    def start(self):
+        import threading
+        if self.ctx is None:
+            return
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    ghz = self.ctx.clock_probe(self.period_us)
+                except Exception as e:
+                    self.error = repr(e)[:160]
+                    return
+                self.samples.append((time.perf_counter(), ghz))
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def window(self, t0, t1):
+        vals = [g for t, g in self.samples if t0 <= t <= t1 and g > 0.3]      # (< 0.3 GHz: a counter that does not tick at the shader clock)
+        if not vals:
+            return {"mean_ghz": None, "samples": 0, "note": self.error or "no reading inside the window"}
+        return {"mean_ghz": sum(vals) / len(vals), "min_ghz": min(vals), "max_ghz": max(vals), "samples": len(vals)}
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2)
+        if self.ctx is not None:
+            try:
+                self.ctx.close()
+            except Exception:
+                pass
+            self.ctx = None
 
 
 def box_probe():

@@ -140,6 +140,10 @@ int32_t zkhip_ctx_clock_probe(zkhip_ctx* ctx, uint32_t duration_us, double* ghz_
 #define ZKHIP_TUNE_B_SORT 19          /* keys loaded from now on: the MSMs over b_query (G2, and G1 of a Groth16 key) on a sorted list of
                                       * their own that leaves out the variables whose B bases are the point at infinity — 0 = when a tenth
                                       * of them are (real circuits: every variable that does not occur in B), 1 = always, 2 = never       */
+#define ZKHIP_TUNE_LONE_SCHED 21      /* how a LONE proof (the single-proof entry points) is laid out on the device, bits: 1 = its G2 accumulation
+                                      * takes one workgroup per CU at raised wave priority, so that the short kernels of the witness map and the
+                                      * sorts find room beside it; 2 = its G1 lanes over the assignment also wait for the sort of h.  Batches are
+                                      * untouched; no setting changes a result. */
 #define ZKHIP_TUNE_HEAVY_RUNS 20      /* 1 (default): the partials of a bucket spread over many slices (the ones of a witness of bits) are
                                       * first summed run by run by a kernel of their own; 0: by the one workgroup of the bucket's row      */
 #define ZKHIP_TUNE_NTT_MAX_SUBLOG 16 /* log2 of the longest sub-transform of an NTT pass (2..11; default 11): domains above 2^(2 x this)

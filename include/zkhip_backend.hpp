@@ -168,6 +168,11 @@ class Hip {
   public:
     explicit Hip(int32_t device = 0);
     ~Hip();
+    // Process-wide, BEFORE the first Hip object (and before any other HIP user of the process starts the runtime): ask the HIP
+    // runtime for `hw_queues` hardware queues (zkhip_init).  A resident prover keeps ~20 streams busy and wants 8 (16 if it is the
+    // only context of its process); a one-proof process runs on one stream and need not call this.  The library never changes the
+    // process environment on its own.
+    static void init(int32_t hw_queues = 8);
     // One proof per process (what `generate-proof` is): keys loaded from now on skip the precomputed window multiples — building
     // them costs ten times what they save a single proof (0.15 s of kernels at 2^20 against ~5 ms of proof time) — and the MSMs
     // fold one bucket set per window instead (ZKHIP_TUNE_MSM_SETS).  A resident prover keeps the default.

@@ -33,7 +33,8 @@ def run_bench(args, extra_env=None, timeout=900, expect_rc=0):
 ])
 def test_single_rank_contract(args, metric):
     with_cli_leg = "--scheme" not in args and "--kind" not in args      # the CLI-shaped leg (seven subprocesses) once is enough
-    lines = run_bench(args + ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"] + ([] if with_cli_leg else ["--e2e", "0"]))
+    lines = run_bench(args + ["--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"] + ([] if with_cli_leg else ["--e2e", "0"]),
+                      extra_env={"ZKHIP_BENCH_CLI_ALL": "1"})
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in REQUIRED:
@@ -50,12 +51,16 @@ def test_single_rank_contract(args, metric):
     assert rp["regions"] == 3 and len(rp["ms_per_step"]) == 3 and abs(rp["ms_per_step"][0] - d["ms_per_step"]) < 1e-9 and rp["spread"] >= 0
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and abs(d["per_rank"][0]["ms_per_step"] - d["ms_per_step"]) < 1e-6
     assert "under_load" in d                            # (no sysfs view of a GPU here: the sampler says so instead of inventing numbers)
-    b = d["bound_key"]                                  # Groth16 runs with the key bound to its system, checked against an unbound proof and the CPU's
+    b = d["bound_key"]                                  # either scheme runs with the key bound to its system, checked against an unbound proof and the CPU's
+    assert b["bound"] is True and b["proof_identical_to_unbound"] is True and b["bind_ms"] > 0 and b["unbound_ms_per_step"] > 0, b
+    assert c["gpu_bound_key_proof_identical"] is True
     if metric == "groth16_proofs_per_sec":
-        assert b["bound"] is True and b["proof_identical_to_unbound"] is True and b["bind_ms"] > 0 and b["unbound_ms_per_step"] > 0, b
-        assert c["gpu_bound_key_proof_identical"] is True and "4 NTTs" in d["config"]["workload"]
-    else:
-        assert b == {"bound": False} and "gpu_bound_key_proof_identical" not in c
+        assert "4 NTTs" in d["config"]["workload"]
+    # which figure `value` is, both figures side by side, the CPU ratio on the like-for-like (unbound) schedule
+    assert d["value_is"] == "value_bound" and abs(d["value_bound"] - d["value"]) < 1e-9 and d["value_unbound"] > 0 and "bound" in d["key_state"]
+    assert abs(d["speedup_vs_cpu_baseline"] - d["value_unbound"] / c["value"]) < 1e-6 * d["speedup_vs_cpu_baseline"]
+    assert d["identical_to_oracle"] is True and "algorithmic" in d["oracle"]
+    assert "configs" not in d                           # (the other BASELINE configurations ride on the default workload only)
     if not with_cli_leg:
         return
     e = d["cli_end_to_end_ms"]                         # the reference-shaped flow: files -> proof.json, one process per proof
@@ -152,6 +157,7 @@ def test_measuring_process_that_dies_is_reported_and_retried():
     assert d["attempts"][0]["signal"] == 6 and d["attempts"][0]["last_stage"] == "context_created" and d["attempts"][1]["exit_status"] == 0
     assert d["bound_key"]["bound"] is False and "second attempt" in d["bound_key"]["note"]      # the retry leaves the key as loaded
     assert "6 NTTs" in d["config"]["workload"]
+    assert d["value_is"] == "value_unbound" and d["value_bound"] is None and "FALLBACK" in d["key_state"]      # ... and the line says so at top level
     lines = run_bench(args, extra_env={"ZKHIP_BENCH_TEST_DIE": "*"}, expect_rc=1)
     assert len(lines) == 1
     d = json.loads(lines[0])
@@ -235,3 +241,19 @@ def test_bench_window_count_mirrors_the_library_rule():
     exec(src[start:src.index("def numa_placement(")], ns)
     assert ns["msm_windows"](254, (1 << 20) + 2) == 15 and ns["msm_windows"](255, (1 << 20) + 2) == 16
     assert ns["msm_windows"](254, 1 << 10) == (254 + 1 + 10) // 11 and ns["msm_windows"](254, 1 << 24) == 15
+
+
+def test_config_legs_of_the_default_line():
+    """The default line carries BASELINE.json's other configurations as its LAST key: short runs of the same script, each bound and
+    held to the oracle's closed form.  Here at toy size through the hook that overrides the legs' arguments."""
+    lines = run_bench(["--log-domain", "5", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--e2e", "0", "--configs", "1"],
+                      extra_env={"ZKHIP_BENCH_TEST_LEGS": "1"}, timeout=1500)
+    d = json.loads(lines[0])
+    assert list(d.keys())[-2:] == ["configs", "attempts"] or list(d.keys())[-1] == "configs", list(d.keys())[-3:]
+    cfg = d["configs"]
+    assert set(cfg) == {"gm17_2e20", "poseidon_chain_bls12_381_2e18", "sha256_stdlib_2e20", "dense_2e22_and_8_members"}
+    for k, rec in cfg.items():
+        assert "error" not in rec and "skipped" not in rec, (k, rec)
+        assert rec["identical_to_oracle"] is True and rec["proofs_per_s"] > 0 and rec["single_proof_ms"] > 0 and rec["key_bound"] is True, (k, rec)
+    mm = cfg["dense_2e22_and_8_members"]["members"]
+    assert mm["members"] == 2 and mm["identical_to_unsharded"] is True and mm["identical_to_oracle"] is True and mm["key_bound"] is True, mm

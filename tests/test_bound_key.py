@@ -304,8 +304,11 @@ def test_key_image_carries_the_bound_tables(ctx, scheme):
 def test_multi_members_bind_together(ctx):
     """zkhip_multi_bind: one member computes the bound bases from the key file, every member installs its ranges; the members'
     proof is the unsharded one, for both schemes, with the host exchange and the gathered one."""
+    multi_bind_checks(emu_library(), gathered=True)
+
+
+def multi_bind_checks(lib, gathered):
     curve = BN254
-    lib = emu_library()
     for scheme in ("g16", "gm17"):
         if scheme == "g16":
             oc = cpu.Circuit.synth(0, 37, 0x5EED00C0)
@@ -317,7 +320,7 @@ def test_multi_members_bind_together(ctx):
             oc, tb17, opk, z = _gm17_case(curve, 12)
             raw = opk.serialize()
             want = cpu.gm17_trapdoor(oc, tb17, z, 71, 72)
-        for members, rccl in ((3, False), (2, True)):
+        for members, rccl in ((3, False), (2, True)) if gathered else ((3, False), (8, False)):
             multi = native.Multi([0] * members, lib)
             try:
                 if rccl:

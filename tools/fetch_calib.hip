@@ -46,6 +46,28 @@ __global__ void k_gather(const uint4* __restrict__ tbl, u64 nrec_mask, u64 count
     }
     if (acc == 0x12345u) sink[0] = acc;
 }
+// the rows pass of the NTT (csrc/kernels_ntt.cuh ntt_load): lane i reads the two uint4 of element i — 16 B at a 32-byte stride per
+// instruction, two instructions per element, over a contiguous run
+__global__ void k_pair16(const uint4* __restrict__ src, u64 nelem, u32* __restrict__ sink) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 acc = 0;
+    for (; i < nelem; i += stride) { const uint4 lo = src[2 * i], hi = src[2 * i + 1]; acc ^= lo.x ^ lo.w ^ hi.y ^ hi.z; }
+    if (acc == 0x12345u) sink[0] = acc;
+}
+// the cols pass: C adjacent 32-byte elements per row (64 bytes at C = 2, 128 at C = 4), rows `row_elems` elements apart; a workgroup
+// walks the rows of its C columns, every lane reading the two uint4 of one element
+template <int C>
+__global__ void k_segments(const uint4* __restrict__ src, u64 row_elems, u64 rows, u32* __restrict__ sink) {
+    const u64 c0 = (u64)blockIdx.x * C;                 // first column of this workgroup
+    u32 acc = 0;
+    for (u64 e = threadIdx.x; e < rows * C; e += blockDim.x) {
+        const u64 a = e / C, j = e % C, g = a * row_elems + c0 + j;
+        const uint4 lo = src[2 * g], hi = src[2 * g + 1];
+        acc ^= lo.x ^ lo.w ^ hi.y ^ hi.z;
+    }
+    if (acc == 0x12345u) sink[0] = acc;
+}
 __global__ void k_fill(uint4* p, u64 n16) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -78,6 +100,15 @@ int main() {
         printf("gather128  requested %llu bytes  %.3f ms  %.0f GB/s\n", want, ms, want / ms / 1e6);
         ms = time_it([&] { hipLaunchKernelGGL(k_gather<2>, G, T, 0, 0, (const uint4*)tbl, table_bytes / 32 - 1, want / 32, sink); });
         printf("gather32   requested %llu bytes  %.3f ms  %.0f GB/s\n", want, ms, want / ms / 1e6);
+        ms = time_it([&] { hipLaunchKernelGGL(k_pair16, G, T, 0, 0, (const uint4*)tbl, want / 32, sink); });
+        printf("pair16     requested %llu bytes  %.3f ms  %.0f GB/s\n", want, ms, want / ms / 1e6);
+        {   // a 2^13 x 2^13 matrix of 32-byte elements (2 GiB): every column group once
+            const u64 n = 1 << 13;
+            ms = time_it([&] { hipLaunchKernelGGL(k_segments<2>, dim3((unsigned)(n / 2)), dim3(512), 0, 0, (const uint4*)tbl, n, n, sink); });
+            printf("seg64      requested %llu bytes  %.3f ms  %.0f GB/s\n", n * n * 32, ms, n * n * 32 / ms / 1e6);
+            ms = time_it([&] { hipLaunchKernelGGL(k_segments<4>, dim3((unsigned)(n / 4)), dim3(512), 0, 0, (const uint4*)tbl, n, n, sink); });
+            printf("seg128     requested %llu bytes  %.3f ms  %.0f GB/s\n", n * n * 32, ms, n * n * 32 / ms / 1e6);
+        }
     }
     return 0;
 }

@@ -107,6 +107,8 @@ struct MsmLane {
     bool high_priority = false;
     DBuf lane_key, heavy, partial, bucket, rows, cols;
     Event done = nullptr;
+    bool share_cu = false;    // THIS launch of the lane: one accumulation workgroup per CU (LDS padding) at raised wave priority — a lone proof's
+                              // G2 lane (zkhip_ctx::lone_sched); reset by msm_run_tables
 };
 static constexpr int ZK_NLANES = 5;   // A, B1, L (G1), B2 (G2) over z; H over h
 static constexpr int ZK_NSLOTS = 4;   // most proofs in flight (zkhip_prove_g16*_batch pipelines consecutive proofs; ctx->nslots of them are used)
@@ -155,6 +157,14 @@ struct zkhip_ctx {
     int msm_fused_waves = 0;  // accumulation waves per SIMD of that launch (0 = per point type)
     int msm_g1_waves = 0, msm_g2_waves = 0;   // slices per SIMD lane of a single-table G1 / G2 accumulation (0 = per point type)
     int z_gate = 1;           // which accumulations over z wait for the witness map of their proof: 0 none, 1 the G1 lanes, 2 all
+    int lone_sched = 0;       // how a LONE proof (the single-proof entry points; nothing else of the context in flight) is laid out — bits:
+                              // 1: its G2 accumulation takes ONE workgroup per CU (dynamic LDS padded to more than half a CU's) at raised wave
+                              //    priority: the short kernels of the witness map and of the sorts find a place at once instead of waiting for a
+                              //    round of accumulation workgroups to retire (a 0.65 ms witness map took 3.4 ms beside a machine-filling G2
+                              //    accumulation, the h sort 3.3 ms instead of 0.5: profiles/r6a_lone_bound_proof_gantt.txt);
+                              // 2: its G1 lanes over z wait for the h SORT as well (else for the witness map only): that sort then runs beside
+                              //    the G2 lane alone, and the H accumulation can start with the others
+                              // (ZKHIP_LONE_SCHED / ZKHIP_TUNE_LONE_SCHED; batches are untouched)
     int g2_head_start = 1;    // a LONE proof over a curve whose G2 accumulation runs one wave per SIMD: its G1 lanes also wait for the end of
                               // that accumulation — 0 never, 1 over a bound key, 2 always (ZKHIP_G2_HEAD_START; Prover::enqueue)
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
@@ -588,12 +598,14 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
 // Runs on lane.stream after so.ready; lane.done is recorded behind the last kernel.
 // `d_table` holds packed affine points (AffPacked, level-major when it carries window multiples); the sums come back in
 // the saturated Montgomery form.
+// `h_window_sums` (may be null): the pinned host mirror of d_window_sums — the lane copies its sums out itself, behind its fold and
+// before `done`, so that the host can take each MSM's result as it arrives (Prover::finish) instead of all of them after the last
 template <class F>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<F>* d_window_sums,
-             Event ev_begin, Event ev_end, Event accum_after = nullptr);
+             Event ev_begin, Event ev_end, Event accum_after = nullptr, Xyzz<F>* h_window_sums = nullptr);
 template <class F>
 void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* const* d_tables, int nt, const MsmShape& sh, Xyzz<F>* d_window_sums,
-                    u32 sum_stride, Event ev_begin, Event ev_end, Event accum_after);
+                    u32 sum_stride, Event ev_begin, Event ev_end, Event accum_after, Xyzz<F>* h_window_sums = nullptr);
 // affine points, saturated Montgomery form -> packed working form of the MSM kernels (level 0 of a table); on ctx->stream
 template <class F>
 void points_to_packed(zkhip_ctx* ctx, const Aff<F>* d_in, void* d_out, u64 n);
@@ -1442,6 +1454,10 @@ struct Prover {
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));   // 4 G1 MSMs + 1 G2 MSM
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
+        host_sums(sl, Wmax);
+        Xyzz<Fq>* hs1 = (Xyzz<Fq>*)sl.h_ws;                    // the host mirrors of ws1 / ws2: every lane copies its own sums out
+        Xyzz<Fq2>* hs2 = (Xyzz<Fq2>*)((uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
+        const int lone_sched = (lone && !ctx->serial) ? ctx->lone_sched : 0;
         // An accumulation kernel is sized to fill the machine, saturates the integer multiplier and nothing preempts it:
         // whatever arrives beside it waits for a place or crawls (kernel traces, profiles/r2_single_proof_traces.md: a
         // 0.14 ms mat-vec took 4 ms, a 0.2 ms transform pass 3 ms), h arrives late and the H MSM trails alone behind
@@ -1453,8 +1469,10 @@ struct Prover {
         if (pk->z_n) {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
             if (pk->thin_mask) msm_prepare(ctx, st, sl.sorts[2], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n, ptr<u32>(pk->thin_keep), &sl.sorts[0]);
-            if (gate < 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
+            if (gate < 2) {
+                sl.lanes[3].share_cu = (lone_sched & 1) != 0;
+                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], nullptr, hs2);   // longest first
+            }
         }
 
         // ---- K1-K4 and the h-sort, on the NTT stream: the main stream is free for the next proof's staging and z-sort
@@ -1466,10 +1484,13 @@ struct Prover {
         ctx->ws = ctx->stream;
         event_record(sl.ev[2], wn);
 
+        // (lone_sched bit 2: the h sort goes out BEFORE the G1 lanes over z, which then wait for it — it runs beside the G2 lane alone)
+        const bool h_sort_first = (lone_sched & 2) != 0 && pk->h_n && gate;
+        if (h_sort_first) msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
         if (pk->z_n) {
-            const Event h_ready = gate ? sl.ev[2] : nullptr;
+            const Event h_ready = !gate ? nullptr : h_sort_first ? sl.sorts[1].ready : sl.ev[2];
             if (gate >= 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
+                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready, hs2);
             // A G2 accumulation at one wave per SIMD (BLS12-381: the wave takes the SIMD's whole register file) shares no SIMD with a
             // G1 wave: G1 workgroups that arrive while some of its workgroups are still waiting for a place take the places, and the
             // G2 lane — the longest chain of such a proof — finishes that much later.  The witness map used to be the head start; a
@@ -1484,17 +1505,17 @@ struct Prover {
                 event_record(sl.g1_go, st);
                 g1_after = sl.g1_go;
             }
-            run_z_g1(ctx, sl, pk, shz, ws1, Wmax, g1_after, bound);
+            run_z_g1(ctx, sl, pk, shz, ws1, Wmax, g1_after, bound, hs1);
         } else {
             empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
         }
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
         if (pk->h_n) {
-            msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
+            if (!h_sort_first) msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
             // (a bound key: U in natural order against H' — the same MSM machinery, other bases)
             msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], bound ? pk->h_bound.p : pk->h_sigma.p, with_inf(shh, bound ? pk->inf_many_bound[1] : pk->inf_many[4]),
-                        ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+                        ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3], nullptr, hs1 + 3 * Wmax);
         } else {
             empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
         }
@@ -1504,13 +1525,15 @@ struct Prover {
 
     // ---- A, B1, L: the three G1 MSMs over the sorted assignment (window sums to ws1 + {0, 1, 2} * Wmax)
     // (`bound`: L' in l's place, on the common list whatever l's family is — its public entries are finite)
-    static void run_z_g1(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const MsmShape& shz, Xyzz<Fq>* ws1, int Wmax, Event h_ready, bool bound = false) {
+    static void run_z_g1(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const MsmShape& shz, Xyzz<Fq>* ws1, int Wmax, Event h_ready, bool bound = false,
+                         Xyzz<Fq>* hs1 = nullptr) {
         const void* tab[3] = {pk->a_ext.p, pk->b1_ext.p, bound ? pk->l_bound.p : pk->l_ext.p};
         auto thin = [&](int k) { return (bound && k == 2) ? 0u : (pk->thin_mask >> k) & 1u; };
         auto inf_many = [&](int k) { return (bound && k == 2) ? pk->inf_many_bound[0] : thin(k) ? pk->inf_many_thin[k] : pk->inf_many[k]; };
         if (!ctx->fuse_z) {
             for (int k = 0; k < 3; ++k)
-                msm_run<Fq>(ctx, sl.lanes[k], thin(k) ? sl.sorts[2] : sl.sorts[0], tab[k], with_inf(shz, inf_many(k)), ws1 + k * Wmax, sl.acc_b[k], sl.acc_e[k], h_ready);
+                msm_run<Fq>(ctx, sl.lanes[k], thin(k) ? sl.sorts[2] : sl.sorts[0], tab[k], with_inf(shz, inf_many(k)), ws1 + k * Wmax, sl.acc_b[k], sl.acc_e[k], h_ready,
+                            hs1 ? hs1 + k * Wmax : nullptr);
             return;
         }
         // One launch per sorted list: the tables on the common list together, the tables on the thinned list together (up to three
@@ -1527,7 +1550,7 @@ struct Prover {
             // destination slots: lead, then every `step` slots (any subset of {0, 1, 2} is an arithmetic progression)
             const int step = nm > 1 ? member[1] - member[0] : 1;
             msm_run_tables<Fq>(ctx, sl.lanes[lead], which ? sl.sorts[2] : sl.sorts[0], tabs, nm, with_inf(shz, many), ws1 + lead * Wmax, (u32)(step * Wmax),
-                               sl.acc_b[lead], sl.acc_e[lead], h_ready);
+                               sl.acc_b[lead], sl.acc_e[lead], h_ready, hs1 ? hs1 + lead * Wmax : nullptr);
             Stream s0 = ctx->serial ? ctx->stream : lane_stream(sl.lanes[lead]);
             for (int q = 1; q < nm; ++q) {
                 event_record(sl.acc_b[member[q]], s0);
@@ -1537,12 +1560,8 @@ struct Prover {
         }
     }
 
-    // ---- window sums to the host, on a stream of their own so that the main stream can start the next proof
-    static void copy_out(zkhip_ctx* ctx, ProofSlot& sl, int Wmax) {
-        Stream st = ctx->stream;
-        Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
-        Stream so = ctx->serial ? st : ctx_out_stream(ctx);
-        for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(so, sl.lanes[k].done);
+    // the slot's pinned host copy of the window sums (4 G1 MSMs, the G2 MSM, the verdict word of the canonical check)
+    static void host_sums(ProofSlot& sl, int Wmax) {
         const size_t b1 = (size_t)4 * Wmax * sizeof(Xyzz<Fq>), b2 = (size_t)Wmax * sizeof(Xyzz<Fq2>);
         if (sl.h_ws_cap < b1 + b2 + 4) {
             host_free_pinned(sl.h_ws);
@@ -1550,8 +1569,15 @@ struct Prover {
             sl.h_ws = host_alloc_pinned(b1 + b2 + 4);
             sl.h_ws_cap = b1 + b2 + 4;
         }
-        dev_d2h_pinned(sl.h_ws, ws1, b1, so);                         // (h_ws is the slot's own pinned buffer: truly asynchronous)
-        dev_d2h_pinned((uint8_t*)sl.h_ws + b1, sl.ws2.p, b2, so);
+    }
+    // ---- the end of a proof's device work: every lane has copied its window sums out behind its fold (msm_run_tables) and recorded
+    // `done`; a stream of its own — the main stream is free for the next proof — waits for all of them, fetches the verdict of the
+    // canonical check and records "all done"
+    static void copy_out(zkhip_ctx* ctx, ProofSlot& sl, int Wmax) {
+        Stream st = ctx->stream;
+        Stream so = ctx->serial ? st : ctx_out_stream(ctx);
+        for (int k = 0; k < ZK_NLANES; ++k) stream_wait_event(so, sl.lanes[k].done);
+        const size_t b1 = (size_t)4 * Wmax * sizeof(Xyzz<Fq>), b2 = (size_t)Wmax * sizeof(Xyzz<Fq2>);
         sl.zflag.ensure(4);
         dev_d2h_pinned((uint8_t*)sl.h_ws + b1 + b2, sl.zflag.p, 4, so);   // written on the main stream before ev[0], which every lane waits for
         event_record(sl.ev[3], so);
@@ -1562,8 +1588,14 @@ struct Prover {
     // bookkeeping of the slot stays uniform
     static void empty_msm(zkhip_ctx* ctx, ProofSlot& sl, Xyzz<Fq>* ws1, size_t n1, Xyzz<Fq2>* ws2, size_t n2, int lane_from, int lane_to) {
         Stream st = ctx->stream;
-        if (n1) dev_memset(ws1, 0, n1 * sizeof(Xyzz<Fq>), st);
-        if (n2) dev_memset(ws2, 0, n2 * sizeof(Xyzz<Fq2>), st);
+        if (n1) {
+            dev_memset(ws1, 0, n1 * sizeof(Xyzz<Fq>), st);
+            memset((uint8_t*)sl.h_ws + ((const uint8_t*)ws1 - (const uint8_t*)sl.ws1.p), 0, n1 * sizeof(Xyzz<Fq>));     // (the host mirror: nothing is in flight for these slots)
+        }
+        if (n2) {
+            dev_memset(ws2, 0, n2 * sizeof(Xyzz<Fq2>), st);
+            memset((uint8_t*)sl.h_ws + (size_t)4 * n2 * sizeof(Xyzz<Fq>) + ((const uint8_t*)ws2 - (const uint8_t*)sl.ws2.p), 0, n2 * sizeof(Xyzz<Fq2>));   // (n2 = Wmax: the G2 sums follow the 4 x Wmax G1 sums)
+        }
         for (int k = lane_from; k < lane_to; ++k) {
             const int e = k == 3 ? 4 : k == 4 ? 3 : k;   // lane 3 (B2) times with event pair 4, lane 4 (H) with pair 3
             event_record(sl.acc_b[e], st);
@@ -1603,29 +1635,32 @@ struct Prover {
     }
     // ---- K9: C = s*A + r*B1 - rs*delta_1 + L + H   (App. A.3; alpha/beta/delta terms already inside A, B1, B2)
     static void assemble(const zkhip_pk* pk, const Sums& g, const uint8_t* r, const uint8_t* s_, uint8_t* out) {
-        const Xyzz<Fq>&gA = g.a, &gB1 = g.b1, &gL = g.l, &gH = g.h;
-        const Xyzz<Fq2>& gB2 = g.b2;
-        Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
-        Fr rs = fe_from_mont(fe_mul(fe_to_mont(rr), fe_to_mont(ss)));
-        uint8_t dec[2 * FQB];
-        decode_point<FQB, 2>(pk->delta_g1_canon.data(), dec);
-        Aff<Fq> d1;
-        memcpy(&d1, dec, sizeof(d1));
-        d1 = PkLoader<C>::to_mont_point(d1);
+        const Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         // three independent 254-bit scalar multiplications
         Xyzz<Fq> sA, rB1, rsD;
         {
             HostThreads th;
-            th.run([&] { sA = xyzz_mul_limbs(gA, ss.v, Fr::N); });
-            th.run([&] { rB1 = xyzz_mul_limbs(gB1, rr.v, Fr::N); });
-            rsD = xyzz_mul_limbs(Xyzz<Fq>::from_affine(d1), rs.v, Fr::N);
+            th.run([&] { sA = xyzz_mul_limbs(g.a, ss.v, Fr::N); });
+            th.run([&] { rB1 = xyzz_mul_limbs(g.b1, rr.v, Fr::N); });
+            rsD = rs_delta(pk, rr, ss);
         }
+        assemble_tail(g, sA, rB1, rsD, out);
+    }
+    static void assemble_tail(const Sums& g, const Xyzz<Fq>& sA, const Xyzz<Fq>& rB1, const Xyzz<Fq>& rsD, uint8_t* out) {
+        const Xyzz<Fq>&gA = g.a, &gL = g.l, &gH = g.h;
+        const Xyzz<Fq2>& gB2 = g.b2;
         Xyzz<Fq> gC = xyzz_add(sA, rB1);
         gC = xyzz_add(gC, xyzz_neg(rsD));
         gC = xyzz_add(gC, gL);
         gC = xyzz_add(gC, gH);
-        Aff<Fq> pa = xyzz_to_affine(gA), pc = xyzz_to_affine(gC);
-        Aff<Fq2> pb = xyzz_to_affine(gB2);
+        Aff<Fq> pa, pc;
+        Aff<Fq2> pb;
+        {
+            HostThreads th;               // three inversions: one thread each
+            th.run([&] { pa = xyzz_to_affine(gA); });
+            th.run([&] { pc = xyzz_to_affine(gC); });
+            pb = xyzz_to_affine(gB2);
+        }
         memset(out, 0, 8 * FQB + 3);
         if (!gA.is_inf()) { write_fe(pa.x, out); write_fe(pa.y, out + FQB); }
         if (!gB2.is_inf()) {
@@ -1651,12 +1686,56 @@ struct Prover {
             tm->kernel_msm_accum_g2_ms = event_elapsed_ms(sl.acc_b[4], sl.acc_e[4]);
         }
     }
+    // ---- the host's share of a proof, taken in the order the lanes deliver: r s delta_1 needs nothing of the device, s A and r B1 wait
+    // for the lanes over z only — three 254-bit scalar multiplications (0.2 ms) that used to start after the LAST lane and now run
+    // beside the H MSM's tail; what is left behind the last event is two group additions and three conversions to affine form
     static void finish(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, uint8_t* out, zkhip_timings* tm) {
         require(pk->world == 1, ZKHIP_ERR_BAD_ARG, "this proving key is one shard of a multi-GPU key: use zkhip_prove_g16_partial + zkhip_combine_g16");
-        const Sums g = collect(ctx, sl, pk);
-        const auto t_fin = std::chrono::steady_clock::now();
-        assemble(pk, g, sl.r, sl.s, out);
+        require(sl.busy, ZKHIP_ERR_DEVICE, "internal: no proof in flight in this slot");
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
+        const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
+        const Xyzz<Fq>* h_ws1 = (const Xyzz<Fq>*)sl.h_ws;
+        const Xyzz<Fq2>* h_ws2 = (const Xyzz<Fq2>*)((const uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
+        const Fr rr = fe_from_bytes_canon<Fr>(sl.r), ss = fe_from_bytes_canon<Fr>(sl.s);
+        Sums g;
+        Xyzz<Fq> sA, rB1, rsD;
+        std::chrono::steady_clock::time_point t_fin;
+        try {
+            HostThreads th;
+            th.run([&] { rsD = rs_delta(pk, rr, ss); });
+            event_sync(sl.lanes[3].done);
+            g.b2 = msm_combine(h_ws2, shz);
+            for (int k = 0; k < 3; ++k) event_sync(sl.lanes[k].done);
+            g.a = msm_combine(&h_ws1[0 * Wmax], shz);
+            g.b1 = msm_combine(&h_ws1[1 * Wmax], shz);
+            th.run([&] { sA = xyzz_mul_limbs(g.a, ss.v, Fr::N); });
+            th.run([&] { rB1 = xyzz_mul_limbs(g.b1, rr.v, Fr::N); });
+            g.l = msm_combine(&h_ws1[2 * Wmax], shz);
+            event_sync(sl.lanes[4].done);
+            t_fin = std::chrono::steady_clock::now();
+            g.h = msm_combine(&h_ws1[3 * Wmax], shh);
+            event_sync(sl.ev[3]);
+            th.join();
+        } catch (...) {
+            sl.busy = false;
+            throw;
+        }
+        sl.busy = false;
+        u32 zflag;
+        memcpy(&zflag, (const uint8_t*)(h_ws2 + Wmax), 4);
+        require_canonical(zflag);
+        assemble_tail(g, sA, rB1, rsD, out);
         fill_timings(sl, tm, t_fin);
+    }
+    static Xyzz<Fq> rs_delta(const zkhip_pk* pk, const Fr& rr, const Fr& ss) {
+        const Fr rs = fe_from_mont(fe_mul(fe_to_mont(rr), fe_to_mont(ss)));
+        uint8_t dec[2 * FQB];
+        decode_point<FQB, 2>(pk->delta_g1_canon.data(), dec);
+        Aff<Fq> d1;
+        memcpy(&d1, dec, sizeof(d1));
+        d1 = PkLoader<C>::to_mont_point(d1);
+        return xyzz_mul_limbs(Xyzz<Fq>::from_affine(d1), rs.v, Fr::N);
     }
     // The canonical representative of a group element as an XYZZ record: affine coordinates with ZZ = ZZZ = 1 (Montgomery
     // one), infinity all-zero.  The projective coordinates an MSM leaves depend on the order in which the bucket sort's

@@ -243,6 +243,9 @@ struct Gm17 {
         sl.ws1.ensure((size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         sl.ws2.ensure((size_t)Wmax * sizeof(Xyzz<Fq2>));
         Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
+        P::host_sums(sl, Wmax);
+        Xyzz<Fq>* hs1 = (Xyzz<Fq>*)sl.h_ws;                    // the host mirrors of ws1 / ws2: every lane copies its own sums out
+        Xyzz<Fq2>* hs2 = (Xyzz<Fq2>*)((uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
         // (a sharded key covers only its index range of the bases and pairs them with the same range of the scalars)
         // (the G1 lanes wait for the transforms, as in Prover::enqueue: the G2 lane starts at once)
         const int gate = z_gate(ctx);
@@ -252,7 +255,7 @@ struct Gm17 {
             msm_prepare(ctx, st, sl.sorts[0], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n);
             if (pk->thin_mask) msm_prepare(ctx, st, sl.sorts[2], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n, ptr<u32>(pk->thin_keep), &sl.sorts[0]);
             if (gate < 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4]);   // longest first
+                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], nullptr, hs2);   // longest first
         }
 
         // ---- quotient h0 = (U^2 - W)/Z: iNTT + coset NTT of U, pointwise square, coset iNTT minus W's coefficients / Z (sigma order, canonical)
@@ -283,8 +286,8 @@ struct Gm17 {
         if (pk->z_n) {
             const Event h_ready = gate ? sl.ev[2] : nullptr;
             if (gate >= 2)
-                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready);
-            P::run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready, bound);
+                msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready, hs2);
+            P::run_z_g1(ctx, sl, pk, shz, ws1, Wmax, h_ready, bound, hs1);
         } else {
             P::empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
         }
@@ -293,7 +296,7 @@ struct Gm17 {
         if (pk->h_n) {
             msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
             msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], bound ? pk->h_bound.p : pk->h_sigma.p, with_inf(shh, bound ? pk->inf_many_bound[1] : pk->inf_many[4]),
-                        ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3]);
+                        ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3], nullptr, hs1 + 3 * Wmax);
         } else {
             P::empty_msm(ctx, sl, ws1 + 3 * Wmax, Wmax, nullptr, 0, 4, 5);
         }

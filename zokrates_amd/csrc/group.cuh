@@ -35,7 +35,7 @@ void msm_table_levels(zkhip_ctx* ctx, void* d_table, u64 count, int c, int W) {
 // (three separate accumulations pack five waves per SIMD and leave no room for a 128-register fold wave).
 template <class FS>
 void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* const* d_tables, int nt, const MsmShape& sh, Xyzz<FS>* d_window_sums,
-                    u32 sum_stride, Event ev_begin, Event ev_end, Event accum_after) {
+                    u32 sum_stride, Event ev_begin, Event ev_end, Event accum_after, Xyzz<FS>* h_window_sums) {
     typedef typename Unsat<FS>::type F;   // the kernels run on the unsaturated field
     require(nt >= 1 && nt <= MSM_MAX_TABLES, ZKHIP_ERR_BAD_ARG, "internal: number of tables of one MSM launch");
     MsmTables tables{};
@@ -49,7 +49,9 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     const int wpe = ctx->msm_waves ? ctx->msm_waves : (nt > 1 ? std::max(1, (ctx->msm_fused_waves ? ctx->msm_fused_waves : MsmTuning<F>::FUSED_WPE)) : single);
     const u64 machine = ctx->msm_lanes ? (u64)ctx->msm_lanes : (u64)ctx->cus * 4 * 64 * wpe / (nt > 1 && !ctx->msm_waves ? nt : 1);
     const u32 nlanes = (u32)std::max<u64>(1, std::min<u64>(machine, (sh.n * (u64)sh.W + ctx->msm_min_slice - 1) / ctx->msm_min_slice));
-    const MsmCut cut{nlanes, ctx->msm_min_slice, (u32)std::min<u64>(sh.n * (u64)sh.levels, 0x7fffffffu)};
+    const bool share = lane.share_cu && !ctx->serial;
+    lane.share_cu = false;
+    const MsmCut cut{nlanes, ctx->msm_min_slice, (u32)std::min<u64>(sh.n * (u64)sh.levels, 0x7fffffffu), share ? 1u : 0u};
     const u64 partial_stride = (u64)sh.nkeys + nlanes;
     lane.heavy.ensure(((size_t)sh.nkeys + 1) * 4);            // [0] = count, [1..] = keys
     lane.lane_key.ensure((size_t)nlanes * 4);
@@ -68,7 +70,9 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
               ptr<u32>(lane.heavy));
     if (accum_after && !ctx->serial) stream_wait_event(s, accum_after);   // (the slicing above only needs the sort)
     if (ev_begin) event_record(ev_begin, s);
-    constexpr size_t acc_lds = msm_accum_lds_bytes<F>();      // the coordinates of the running sums that live in LDS (kernels_msm.cuh)
+    // (share: padded beyond half of the CU's 160 KiB, so that a second workgroup of this launch does not fit beside the first — the
+    // other half of the LDS and of the registers stays free for whatever else arrives)
+    const size_t acc_lds = share ? std::max<size_t>(msm_accum_lds_bytes<F>(), (size_t)84 * 1024) : msm_accum_lds_bytes<F>();
     if (ctx->skip_inf_mode == 1 || (ctx->skip_inf_mode == 0 && sh.skip_inf)) {
         if (acc_lds > 64 * 1024) lds_opt_in(ctx, (const void*)k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, true>);
         ZK_LAUNCH((k_msm_accum<F, MsmTuning<F>::ACCUM_WPE, true>), dim3(blocks_for(nlanes, T), nt), dim3(T), acc_lds, s, tables, ptr<u32>(so.off), ptr<u32>(so.sorted),
@@ -108,6 +112,9 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
         ZK_LAUNCH((k_msm_fold_final<F, FS>), dim3(sh.sets, nt), dim3(TF), TF * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols), sh.Lw,
                   sh.H, d_window_sums, sum_stride);
     }
+    if (h_window_sums)          // the lane's own copy-out (pinned host memory of the proof slot: truly asynchronous)
+        for (int t = 0; t < nt; ++t)
+            dev_d2h_pinned(h_window_sums + (size_t)t * sum_stride, d_window_sums + (size_t)t * sum_stride, (size_t)sh.nsums() * sizeof(Xyzz<FS>), s);
     event_record(lane.done, s);
 }
 // number of points at infinity among the first `count` entries (level 0) of a packed table; synchronises ctx->stream
@@ -132,8 +139,8 @@ void mark_finite(zkhip_ctx* ctx, const void* d_table, u64 count, u32* d_bitmap) 
 }
 template <class FS>
 void msm_run(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void* d_table, const MsmShape& sh, Xyzz<FS>* d_window_sums,
-             Event ev_begin, Event ev_end, Event accum_after) {
-    msm_run_tables<FS>(ctx, lane, so, &d_table, 1, sh, d_window_sums, 0, ev_begin, ev_end, accum_after);
+             Event ev_begin, Event ev_end, Event accum_after, Xyzz<FS>* h_window_sums) {
+    msm_run_tables<FS>(ctx, lane, so, &d_table, 1, sh, d_window_sums, 0, ev_begin, ev_end, accum_after, h_window_sums);
 }
 
 template <class F>
@@ -192,8 +199,8 @@ void bind_l_finish(zkhip_ctx* ctx, const void* d_prod, const u64* d_cptr, const 
     template void bind_l_finish<F>(zkhip_ctx*, const void*, const u64*, const void*, u64, const u32*, u64, void*, void*);
 
 #define ZK_INSTANTIATE_GROUP(F)                                                                                         \
-    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event, Event);   \
-    template void msm_run_tables<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void* const*, int, const MsmShape&, Xyzz<F>*, u32, Event, Event, Event); \
+    template void msm_run<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void*, const MsmShape&, Xyzz<F>*, Event, Event, Event, Xyzz<F>*);   \
+    template void msm_run_tables<F>(zkhip_ctx*, MsmLane&, const MsmSort&, const void* const*, int, const MsmShape&, Xyzz<F>*, u32, Event, Event, Event, Xyzz<F>*); \
     template void points_to_packed<F>(zkhip_ctx*, const Aff<F>*, void*, u64);                    \
     template void msm_table_levels<F>(zkhip_ctx*, void*, u64, int, int);                         \
     template u64 count_infinite<F>(zkhip_ctx*, const void*, u64);                                \

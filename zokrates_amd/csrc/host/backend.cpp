@@ -204,6 +204,10 @@ Hip::Hip(int32_t device) {
     if (rc != ZKHIP_OK) throw Error(rc, zkhip_last_error(nullptr));
 }
 Hip::~Hip() { if (ctx_) zkhip_ctx_free(ctx_); }
+void Hip::init(int32_t hw_queues) {
+    const int32_t rc = zkhip_init(hw_queues);
+    if (rc != ZKHIP_OK) throw Error(rc, zkhip_last_error(nullptr));
+}
 // One proof, then the process ends: no window-multiple tables (ten times what they would save one proof), and every kernel on the
 // context's one stream — the ~20 streams a resident prover overlaps its proofs on cost ~10 ms of queue set-up each, ~90 ms of a
 // process whose proof takes 25 (profiles/r5_cli_start_profile.txt).

@@ -364,7 +364,8 @@ static __global__ void k_scan_add(u32* __restrict__ off, const u32* __restrict__
 // The list (length total = off[nkeys], known only on the device) is cut into nlanes slices of P = max(ceil(total / nlanes),
 // min_slice) entries: with nlanes = the number of work-items the machine holds, every work-item of the accumulation
 // kernel does the same number of additions in ONE round of workgroups, whatever the scalars look like.
-struct MsmCut { u32 nlanes, min_slice; u32 table_len; };   // table_len: entries of a base table (levels x points), for the checked build
+struct MsmCut { u32 nlanes, min_slice; u32 table_len; u32 prio; };   // table_len: entries of a base table (levels x points), for the checked build;
+                                                                      // prio: the accumulation's waves raise their issue priority (a lone proof's G2 lane: core.cuh lone_sched)
 static __device__ __forceinline__ u32 msm_slice_len(const u32* __restrict__ off, u32 nkeys, MsmCut cut) {
     const u32 total = off[nkeys];
     const u32 P = (total + cut.nlanes - 1) / cut.nlanes;
@@ -443,6 +444,9 @@ template <class F, int WPE, bool SKIP_INF>
 __global__ void __launch_bounds__(256, WPE) k_msm_accum(MsmTables tables, const u32* __restrict__ off, const u32* __restrict__ sorted,
                                                     const u32* __restrict__ lane_key, Xyzz<F>* __restrict__ partial, u64 partial_stride, u32 nkeys, MsmCut cut) {
     constexpr int NW2 = 2 * AffPacked<F>::NW;
+#ifndef ZK_EMU
+    if (cut.prio) __builtin_amdgcn_s_setprio(2);       // (wave-uniform: a kernel argument)
+#endif
     const AffPacked<F>* __restrict__ bases = (const AffPacked<F>*)tables.p[blockIdx.y];   // blockIdx.y: which MSM of the launch
     partial += (u64)blockIdx.y * partial_stride;
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;

@@ -139,6 +139,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
         ctx->g2_head_start = env_int("ZKHIP_G2_HEAD_START", 0, 2, 1);
+        ctx->lone_sched = env_int("ZKHIP_LONE_SCHED", 0, 3, 0);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
         ctx->heavy_runs = env_int("ZKHIP_MSM_HEAVY_RUNS", 0, 1, 1) != 0;
         { const int hg = env_int("ZKHIP_FOLD_HG", 1, 256, 32); ctx->fold_hg = 1 << ilog2_floor((u64)hg); }
@@ -240,6 +241,7 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_NTT_MAX_SUBLOG: in(2, NTT_MAX_SUBLOG); dev_sync_all(); ctx->ntt_max_sublog = value; ctx->plans.clear(); break;
             case ZKHIP_TUNE_SLOTS: in(1, ZK_NSLOTS); dev_sync_all(); ctx->nslots = value; break;
             case ZKHIP_TUNE_Z_GATE: in(0, 2); ctx->z_gate = value; break;
+            case ZKHIP_TUNE_LONE_SCHED: in(0, 3); ctx->lone_sched = value; break;
             case ZKHIP_TUNE_FUSE_Z: in(0, 1); ctx->fuse_z = value != 0; break;
             case ZKHIP_TUNE_MSM_FUSED_WAVES: in(0, 8); ctx->msm_fused_waves = value; break;
             case ZKHIP_TUNE_STREAM_JITTER: in(0, 5000); dev_sync_all(); jitter_state().max_us.store(value); break;
