@@ -790,7 +790,7 @@ CONFIG_LEGS = [
 
 def config_legs(args, budget_s=None):
     """BASELINE.json's other configurations as short runs of THIS script (a process each: a leg that dies or stalls costs its own entry,
-    not the line): >= 8 timed steps after 2 warm-up steps, the key bound as a resident prover would, the device proof — single, batched,
+    not the line): 16 timed steps after 4 warm-up steps, the key bound as a resident prover would, the device proof — single, batched,
     bound — held to the oracle's closed form.  Compact records; `wall_s` is the leg's whole process."""
     import subprocess
     budget_s = budget_s or float(os.environ.get("ZKHIP_BENCH_CONFIGS_BUDGET_S", "95"))
@@ -807,7 +807,7 @@ def config_legs(args, budget_s=None):
         if left < 15:
             res[key] = {"config": what, "skipped": "time budget of the configs block (%.0f s) spent" % budget_s}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--witnesses", "2", "--cpu-seconds", "0", "--e2e", "0",
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "16", "--warmup", "4", "--witnesses", "2", "--cpu-seconds", "0", "--e2e", "0",
                "--serial-proofs", "0", "--repeats", "2", "--oracle", "trapdoor", "--configs", "0"] + extra
         env = dict(os.environ, ZKHIP_BENCH_CHILD="1", ZKHIP_BENCH_LEG="1", ZKHIP_BENCH_STAGES="")
         env.pop("ZKHIP_BENCH_STAGES")

@@ -144,6 +144,8 @@ int32_t zkhip_ctx_clock_probe(zkhip_ctx* ctx, uint32_t duration_us, double* ghz_
                                       * takes one workgroup per CU at raised wave priority, so that the short kernels of the witness map and the
                                       * sorts find room beside it; 2 = its G1 lanes over the assignment also wait for the sort of h.  Batches are
                                       * untouched; no setting changes a result. */
+#define ZKHIP_TUNE_NTT_SKEW_US 22     /* start skew (microseconds, 0 = off) of the first round of workgroups of every transform pass: co-resident
+                                      * workgroups drift apart so that one's loads land under the other's butterflies (kernels_ntt.cuh NttSkew) */
 #define ZKHIP_TUNE_HEAVY_RUNS 20      /* 1 (default): the partials of a bucket spread over many slices (the ones of a witness of bits) are
                                       * first summed run by run by a kernel of their own; 0: by the one workgroup of the bucket's row      */
 #define ZKHIP_TUNE_NTT_MAX_SUBLOG 16 /* log2 of the longest sub-transform of an NTT pass (2..11; default 11): domains above 2^(2 x this)
@@ -337,6 +339,16 @@ int32_t zkhip_multi_pk_load_g16_replicas(zkhip_multi* m, int32_t curve, const ui
  * `key_bytes` = the key file the members were loaded from.  All members or none. */
 int32_t zkhip_multi_bind(zkhip_multi* m, const uint8_t* key_bytes, size_t len);
 int32_t zkhip_multi_unbind(zkhip_multi* m);
+/* The witness map of ONE proof split between the members (north_star: "NTT domain shard"): over keys bound to the
+ * system a proof needs a and b on the coset and nothing else of the witness map, so members of even rank transform a, members of odd
+ * rank b (two transforms each instead of four), partners copy each other's vector — N x 32 bytes device to device (xGMI peer copy
+ * between GPUs) — and every member forms the products of its own index range.  On by default for Groth16 members that are bound
+ * (zkhip_multi_bind) over domains of at least 2^18 (ZKHIP_SPLIT_MIN_LOG; below, two small transforms cost less than the exchange);
+ * every other case runs the whole map on every member, as SURVEY.md §8e recommends for it.  Same proof bytes either way.
+ * zkhip_multi_transform_split(m, 0 / 1) switches it (-1: leave it), returning the previous setting; zkhip_multi_last_split tells
+ * whether the last zkhip_prove_*_multi did split. */
+int32_t zkhip_multi_transform_split(zkhip_multi* m, int32_t on);
+int32_t zkhip_multi_last_split(const zkhip_multi* m);
 int32_t zkhip_prove_g16_multi_batch(zkhip_multi* m, uint32_t count, const uint8_t* z, const uint8_t* rs, uint8_t* proofs_out,
                                     zkhip_timings* timings);
 
@@ -384,6 +396,15 @@ int32_t zkhip_pk_import(zkhip_ctx* ctx, const uint8_t* bytes, size_t len, zkhip_
 int32_t zkhip_pk_bind_r1cs(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* r1cs);
 int32_t zkhip_pk_unbind(zkhip_pk* pk);
 int32_t zkhip_pk_bind_r1cs_shard(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* key_bytes, size_t len);
+/* The same split for ranks that are separate PROCESSES (one per GPU, torch.distributed / MPI around them): `begin` stages the
+ * assignment, starts this rank's MSMs over it and transforms ITS half of the witness map — half = 0: a, 1: b on the coset — into
+ * `half_out` (N x 32 bytes of host memory; N = the key's domain); the caller exchanges halves with a rank of the other parity;
+ * `end` takes the partner's half and leaves the rank's partial record (as zkhip_prove_g16_partial).  The key must be bound
+ * (zkhip_pk_bind_r1cs_shard).  zokrates_amd/parallel.py prove_sharded does exactly this over RCCL / gloo. */
+int32_t zkhip_prove_g16_split_begin(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z, zkhip_assignment* z_resident,
+                                    const uint8_t* r, const uint8_t* s, int32_t half, uint8_t* half_out);
+int32_t zkhip_prove_g16_split_end(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* other_half, uint8_t* partial_out,
+                                  zkhip_timings* timings);
 int32_t zkhip_r1cs_fingerprint(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, uint64_t out[2]);
 int32_t zkhip_pk_is_bound(const zkhip_pk* pk, const zkhip_r1cs* r1cs);
 

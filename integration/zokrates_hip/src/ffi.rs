@@ -14,6 +14,9 @@ pub const ZKHIP_CURVE_BN128: i32 = 0;
 pub const ZKHIP_CURVE_BLS12_381: i32 = 1;
 
 extern "C" {
+    /// process-wide, before the first context: ask the HIP runtime for `hw_queues` hardware queues (the library never sets
+    /// GPU_MAX_HW_QUEUES on its own; 8 for a resident prover, 16 if it is the only context of its process, 0 = leave it)
+    pub fn zkhip_init(hw_queues: i32) -> i32;
     pub fn zkhip_ctx_create(device: i32, out: *mut *mut zkhip_ctx) -> i32;
     pub fn zkhip_ctx_free(ctx: *mut zkhip_ctx);
     pub fn zkhip_last_error(ctx: *const zkhip_ctx) -> *const c_char;
@@ -44,6 +47,8 @@ extern "C" {
     pub fn zkhip_pk_bind_r1cs(ctx: *mut zkhip_ctx, pk: *mut zkhip_pk, r1cs: *const zkhip_r1cs) -> i32;
     pub fn zkhip_pk_unbind(pk: *mut zkhip_pk) -> i32;
     pub fn zkhip_pk_is_bound(pk: *const zkhip_pk, r1cs: *const zkhip_r1cs) -> i32;
+    /// a shard of a multi-GPU key (or a whole key, Groth16 or GM17) bound from the key FILE: the transforms need every base once
+    pub fn zkhip_pk_bind_r1cs_shard(ctx: *mut zkhip_ctx, pk: *mut zkhip_pk, r1cs: *const zkhip_r1cs, key_bytes: *const u8, len: usize) -> i32;
     // one proof across several GPUs of this process
     pub fn zkhip_ctx_create_multi(devices: *const i32, n: i32, out: *mut *mut zkhip_multi) -> i32;
     pub fn zkhip_multi_free(m: *mut zkhip_multi);
@@ -56,6 +61,11 @@ extern "C" {
         rp_c: *const u64, col_c: *const u32, val_c: *const u8) -> i32;
     pub fn zkhip_multi_pk_load_g16(m: *mut zkhip_multi, curve: i32, bytes: *const u8, len: usize) -> i32;
     pub fn zkhip_multi_pk_load_gm17(m: *mut zkhip_multi, curve: i32, bytes: *const u8, len: usize) -> i32;
+    /// the members' keys bound to the members' system (one member computes, all install their ranges); bound Groth16 members then
+    /// split a proof's witness map between them (zkhip_multi_transform_split, on by default)
+    pub fn zkhip_multi_bind(m: *mut zkhip_multi, key_bytes: *const u8, len: usize) -> i32;
+    pub fn zkhip_multi_unbind(m: *mut zkhip_multi) -> i32;
+    pub fn zkhip_multi_transform_split(m: *mut zkhip_multi, on: i32) -> i32;
     pub fn zkhip_prove_g16_multi(m: *mut zkhip_multi, z: *const u8, r: *const u8, s: *const u8, proof_out: *mut u8,
         timings: *mut zkhip_timings) -> i32;
     pub fn zkhip_prove_gm17_multi(m: *mut zkhip_multi, z: *const u8, d1_d2_r: *const u8, proof_out: *mut u8,

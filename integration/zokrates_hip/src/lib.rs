@@ -155,32 +155,46 @@ fn prove_raw<T: Field + ArkFieldExtensions>(flat: &Flat, pk_bytes: &[u8], gm17: 
 pub struct Resident { ctx: *mut ffi::zkhip_ctx, pk: *mut ffi::zkhip_pk, cs: *mut ffi::zkhip_r1cs, fq: usize }
 
 impl Resident {
-    /// `flat`: the walk of one witness of the program (only its matrices are kept); `pk_bytes`: the `proving.key` file
-    fn new<T: Field + ArkFieldExtensions>(flat: &Flat, pk_bytes: &[u8]) -> Self {
+    /// Process-wide, once, before the first `Resident` (and before anything else in the process starts the HIP runtime): the
+    /// hardware queues a resident prover wants (zkhip_init; the library never touches the environment by itself).
+    pub fn init(hw_queues: i32) { unsafe { check(null(), ffi::zkhip_init(hw_queues)) } }
+
+    /// `flat`: the walk of one witness of the program (only its matrices are kept); `pk_bytes`: the `proving.key` file.
+    /// The struct exists BEFORE the first call that can fail, so that a panic in `check` still frees what was made (Drop).
+    pub fn new<T: Field + ArkFieldExtensions>(flat: &Flat, pk_bytes: &[u8], gm17: bool) -> Self {
         let (curve, fq) = curve_id::<T>();
+        let mut me = Resident { ctx: null_mut(), pk: null_mut(), cs: null_mut(), fq };
         unsafe {
-            let (mut ctx, mut pk, mut cs) = (null_mut(), null_mut(), null_mut());
-            check(null(), ffi::zkhip_ctx_create(0, &mut ctx));
-            check(ctx, ffi::zkhip_pk_load_g16(ctx, curve, pk_bytes.as_ptr(), pk_bytes.len(), &mut pk));
-            check(ctx, ffi::zkhip_r1cs_load(ctx, curve, flat.n, flat.l, flat.w,
+            check(null(), ffi::zkhip_ctx_create(0, &mut me.ctx));
+            check(me.ctx, if gm17 { ffi::zkhip_pk_load_gm17(me.ctx, curve, pk_bytes.as_ptr(), pk_bytes.len(), &mut me.pk) }
+                          else { ffi::zkhip_pk_load_g16(me.ctx, curve, pk_bytes.as_ptr(), pk_bytes.len(), &mut me.pk) });
+            check(me.ctx, ffi::zkhip_r1cs_load(me.ctx, curve, flat.n, flat.l, flat.w,
                 flat.a.rp.as_ptr(), flat.a.col.as_ptr(), flat.a.val.as_ptr(),
                 flat.b.rp.as_ptr(), flat.b.col.as_ptr(), flat.b.val.as_ptr(),
-                flat.c.rp.as_ptr(), flat.c.col.as_ptr(), flat.c.val.as_ptr(), &mut cs));
-            // not enough device memory for the two extra tables (-3): the key proves as it was loaded
-            let rc = ffi::zkhip_pk_bind_r1cs(ctx, pk, cs);
-            if rc != 0 && rc != -3 { check(ctx, rc) }
-            Resident { ctx, pk, cs, fq }
+                flat.c.rp.as_ptr(), flat.c.col.as_ptr(), flat.c.val.as_ptr(), &mut me.cs));
+            // both schemes bind; not enough device memory for the two extra tables (-3): the key proves as it was loaded
+            let rc = ffi::zkhip_pk_bind_r1cs(me.ctx, me.pk, me.cs);
+            if rc != 0 && rc != -3 { check(me.ctx, rc) }
         }
+        me
     }
-    /// one proof over the resident pair: `z` the assignment in ark order (Flat::build's), r and s drawn by the caller as ark draws them
-    fn prove(&self, z: &[u8], r: &[u8], s: &[u8]) -> Vec<u8> {
+    /// one Groth16 proof over the resident pair: `z` the assignment in ark order (Flat::build's), r and s drawn by the caller as ark draws them
+    pub fn prove(&self, z: &[u8], r: &[u8], s: &[u8]) -> Vec<u8> {
         let mut raw = vec![0u8; 8 * self.fq + 3];
         check(self.ctx, unsafe { ffi::zkhip_prove_g16(self.ctx, self.pk, self.cs, z.as_ptr(), r.as_ptr(), s.as_ptr(), raw.as_mut_ptr(), null_mut()) });
         raw
     }
+    /// ... and a GM17 one (d1 | d2 | r, 96 bytes)
+    pub fn prove_gm17(&self, z: &[u8], d1_d2_r: &[u8]) -> Vec<u8> {
+        let mut raw = vec![0u8; 8 * self.fq + 3];
+        check(self.ctx, unsafe { ffi::zkhip_prove_gm17(self.ctx, self.pk, self.cs, z.as_ptr(), d1_d2_r.as_ptr(), raw.as_mut_ptr(), null_mut()) });
+        raw
+    }
 }
 impl Drop for Resident {
-    fn drop(&mut self) { unsafe { ffi::zkhip_r1cs_free(self.cs); ffi::zkhip_pk_free(self.pk); ffi::zkhip_ctx_free(self.ctx) } }
+    fn drop(&mut self) {          // (every free accepts a null handle: a Resident whose construction panicked half-way drops cleanly)
+        unsafe { ffi::zkhip_r1cs_free(self.cs); ffi::zkhip_pk_free(self.pk); ffi::zkhip_ctx_free(self.ctx) }
+    }
 }
 
 impl<T: Field + ArkFieldExtensions> Backend<T, G16> for Hip {

@@ -41,6 +41,13 @@ def main():
     z_common = circ.assignment(424242)
     sharded = parallel.prove_sharded(ranks, ctx, shard, cs, z_common, 31337, 271828)
     sharded_ok = ranks.sum_over_ranks(1.0 if sharded == cpu.trapdoor(oc, tb, z_common, 31337, 271828) else 0.0)
+    # ... and with the shards BOUND to the system and the witness map split between the ranks (even ranks transform a, odd ranks b,
+    # partners swap their halves over the process group): the same proof
+    raw16 = native.setup_g16(ctx, cs, tox)
+    shard.bind_shard(cs, raw16)
+    split = parallel.prove_sharded(ranks, ctx, shard, cs, z_common, 31337, 271828, transform_split=True)
+    whole_map = parallel.prove_sharded(ranks, ctx, shard, cs, z_common, 31337, 271828, transform_split=False)
+    split_ok = ranks.sum_over_ranks(1.0 if split == whole_map == cpu.trapdoor(oc, tb, z_common, 31337, 271828) else 0.0)
     # the same for the second scheme: GM17 key sharded over the ranks, one record each, combined on every rank
     t4 = (tox[0], tox[1], tox[2], tox[4])
     tb17 = b"".join(int(v).to_bytes(32, "little") for v in t4)
@@ -48,7 +55,7 @@ def main():
     sharded17 = parallel.prove_sharded(ranks, ctx, shard17, cs, z_common, 31337, None, d1_d2=(1414, 1732))
     sharded17_ok = ranks.sum_over_ranks(1.0 if sharded17 == cpu.gm17_trapdoor(oc, tb17, z_common, 1414, 31337) else 0.0)
     if ranks.rank == 0:
-        print(json.dumps({"sharded_gm17_ok": sharded17_ok, "sharded_ok": sharded_ok, "n_gpus": ranks.world, "steps": steps, "value": ranks.world * steps / elapsed, "ranks_ok": all_ok,
+        print(json.dumps({"sharded_bound_split_ok": split_ok, "sharded_gm17_ok": sharded17_ok, "sharded_ok": sharded_ok, "n_gpus": ranks.world, "steps": steps, "value": ranks.world * steps / elapsed, "ranks_ok": all_ok,
                           "distinct_witnesses_per_rank": distinct, "seed_sum": seeds, "scaling": "weak"}), flush=True)
     ranks.close()
 

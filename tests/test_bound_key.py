@@ -490,3 +490,79 @@ def test_lone_proofs_hold_their_g1_lanes_for_the_g2_accumulation(setting):
             assert proofs == [want] * 3
     finally:
         c2.close()
+
+
+def test_members_split_the_witness_map(monkeypatch):
+    """Bound members of a multi-GPU proof split its witness map — even members transform a, odd members b, partners copy each other's
+    vector (zkhip_multi_transform_split; north_star's "NTT domain shard") — and the proof is the unsharded one: 2, 3 (an odd member
+    without a partner of its own) and 8 members, the host exchange and the gathered one, split off again, domains of one, two and
+    three passes."""
+    monkeypatch.setenv("ZKHIP_SPLIT_MIN_LOG", "0")
+    split_checks(emu_library(), ((37, None), (60, 3), (200, 3)), gathered=True)
+
+
+def split_checks(lib, sizes, gathered):
+    curve = BN254
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    for n_con, sub in sizes:
+        oc = cpu.Circuit.synth(0, n_con, 0x5EED00E0 + n_con, "sha" if n_con == 60 else "dense")
+        raw = cpu.ProvingKey.setup(oc, tox).serialize()
+        z = oc.assignment()
+        want = cpu.trapdoor(oc, tox, z, 81, 82)
+        for members, rccl in (((2, False), (3, False), (8, False)) + (((2, True),) if gathered else ())) if sub is None else ((3, False),):
+            multi = native.Multi([0] * members, lib)
+            try:
+                if sub:
+                    for k in range(members):
+                        c = multi.member_context(k)
+                        c.tune("ntt_max_sublog", sub)
+                        c.tune("ntt_single_max_log", 1)
+                if rccl:
+                    multi.use_rccl(True)
+                multi.load_constraint_system(0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+                multi.load_proving_key(0, raw)
+                assert multi.prove_g16(z, 81, 82) == want and not multi.last_split()          # unbound: every member runs the whole map
+                multi.bind(raw)
+                assert multi.prove_g16(z, 81, 82) == want and multi.last_split(), (n_con, members, rccl)
+                assert multi.prove_g16(z, 81, 82) == want                                      # ... again: the slots are reusable
+                assert multi.transform_split(False) is True
+                assert multi.prove_g16(z, 81, 82) == want and not multi.last_split()
+                multi.transform_split(True)
+                multi.unbind()
+                assert multi.prove_g16(z, 81, 82) == want and not multi.last_split()
+            finally:
+                multi.close()
+
+
+def test_split_entry_points_for_ranks_in_separate_processes(monkeypatch):
+    """zkhip_prove_g16_split_begin / _end: what a rank of a multi-process prover calls around its exchange — here two contexts in one
+    process stand for two ranks: each transforms its half, they swap, both finish, the records combine to the unsharded proof."""
+    split_entry_point_checks(emu_library())
+
+
+def split_entry_point_checks(lib):
+    curve = BN254
+    oc = cpu.Circuit.synth(0, 29, 0x5EED00F0)
+    tox = cpu.toxic_bytes(g16.Toxic.from_seed(curve))
+    raw = cpu.ProvingKey.setup(oc, tox).serialize()
+    z = oc.assignment()
+    want = cpu.trapdoor(oc, tox, z, 91, 92)
+    ranks = []
+    for k in range(2):
+        c = native.Context(0, lib)
+        cs = native.ConstraintSystem(c, 0, oc.n, oc.l, oc.w, [oc.csr(q) for q in range(3)])
+        sh = native.ProvingKey(c, 0, raw, rank=k, world=2)
+        ranks.append((c, cs, sh))
+    with pytest.raises(native.ZkhipError):
+        native.prove_g16_split_begin(ranks[0][0], ranks[0][2], ranks[0][1], z, 91, 92, 0)      # not bound: nothing to split
+    for c, cs, sh in ranks:
+        sh.bind_shard(cs, raw)
+    halves = [native.prove_g16_split_begin(c, sh, cs, z, 91, 92, k) for k, (c, cs, sh) in enumerate(ranks)]
+    assert halves[0].tobytes() != halves[1].tobytes()
+    parts = [native.prove_g16_split_end(c, sh, cs, halves[1 - k]) for k, (c, cs, sh) in enumerate(ranks)]
+    assert native.combine_g16(ranks[0][0], ranks[0][2], parts, 91, 92) == want
+    # the same ranks prove the ordinary way afterwards
+    parts = [native.prove_g16_partial(c, sh, cs, z, 91, 92) for c, cs, sh in ranks]
+    assert native.combine_g16(ranks[0][0], ranks[0][2], parts, 91, 92) == want
+    for c, cs, sh in ranks:
+        sh.close(); c.close()

@@ -466,6 +466,16 @@ def test_three_pass_prove(logn, sub):
         c2.close()
 
 
+def test_witness_map_with_paired_tiles(ctx):
+    """A two-pass domain whose passes run 8 tiles per vector: the launches over a and b take the XCD-paired order (kernels_ntt.cuh
+    ntt_tile_of: workgroups L and L + 8 share a tile of the factor table) — an affinity only, the result is the oracle's h."""
+    oc = cpu.Circuit.synth(0, (1 << 13) - 2, 0x5EED0123)
+    assert oc.N == 1 << 13
+    z = oc.assignment()
+    cs = native.ConstraintSystem(ctx, 0, oc.n, oc.l, oc.w, [oc.csr(k) for k in range(3)])
+    assert cs.witness_map(z).tobytes() == cpu.witness_map(oc, z).tobytes()
+
+
 def test_error_paths(ctx):
     curve = BN254
     oc = cpu.Circuit.synth(0, 5, 1)

@@ -70,3 +70,16 @@ def test_gpu_lone_proof_layouts(sched):
                 assert proofs == [want] * 5
     finally:
         c2.close()
+
+
+def test_gpu_members_split_the_witness_map(monkeypatch):
+    """Even members transform a, odd members b, partners copy each other's vector on the device they share here (between GPUs: an xGMI
+    peer copy) — small domains forced to split, and one at the default threshold (2^18) with 8 members."""
+    monkeypatch.setenv("ZKHIP_SPLIT_MIN_LOG", "0")
+    T.split_checks(native.default_library(), ((37, None), (3000, None)), gathered=False)
+    monkeypatch.delenv("ZKHIP_SPLIT_MIN_LOG")
+    T.split_checks(native.default_library(), (((1 << 18) - 2, 11),), gathered=False)      # (sub = 11: the default plan) three members, 2^18
+
+
+def test_gpu_split_entry_points():
+    T.split_entry_point_checks(native.default_library())

@@ -23,6 +23,7 @@ def test_two_ranks_gloo():
     assert line["ranks_ok"] == 2.0                      # every rank's proofs equal the oracle's
     assert line["sharded_ok"] == 2.0                    # the proof sharded over both ranks equals the oracle's on both
     assert line["sharded_gm17_ok"] == 2.0               # and so does the GM17 proof
+    assert line["sharded_bound_split_ok"] == 2.0        # bound shards with the witness map split between the ranks: the same proof
     assert line["distinct_witnesses_per_rank"] == steps
     assert line["seed_sum"] == 2 * 0x5EED0000 + 1000    # ranks drew different witness seeds
     assert line["value"] > 0

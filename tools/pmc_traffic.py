@@ -56,7 +56,9 @@ nq, _ = pick(fetch, "k_quotient")
 ncf, cf = pick(fetch, "k_ntt_cols"); nrf, rf = pick(fetch, "k_ntt_rows")
 ncw, cw = pick(write, "k_ntt_cols"); nrw, rw = pick(write, "k_ntt_rows")
 if ncf and nrf and ncw and nrw and nq:
-    passes = 12   # pass-vectors per Groth16 proof with the key as loaded (6 transforms x 2 passes: c takes one); k_quotient runs once per proof
+    # pass-vectors per Groth16 proof: 12 with the key as loaded (6 transforms x 2 passes: c takes one), 8 over a bound key (`--bind 2`);
+    # k_quotient runs once per proof
+    passes = int(os.environ.get("ZKHIP_PMC_PASSES", "12"))
     cols_pat = os.environ.get("ZKHIP_NTT_COLS_PATTERN", "seg128")     # the cols pass reads C adjacent elements per row: seg64 at C = 2, seg128 at C = 4
     true_fetch = CAL[cols_pat] * 1024 * cf + CAL["pair16"] * 1024 * rf
     out["NTT"] = {"launches_fetch_pass": ncf + nrf, "proofs": nq, "fetch_kb_raw_per_proof": (cf + rf) / nq, "write_kb_raw_per_proof": (cw + rw) / nq,

@@ -123,6 +123,9 @@ struct ProofSlot {
     Event acc_b[ZK_NLANES] = {}, acc_e[ZK_NLANES] = {};   // around each accumulation kernel
     Event ntt_b = nullptr, ntt_e = nullptr;               // around the transforms (7 for Groth16: 6 batched launches + 2; 5 for GM17)
     Event g1_go = nullptr;                                // a lone proof's G1 lanes held for the G2 accumulation (Prover::enqueue, g2_head_start)
+    Event half_ready = nullptr;                           // a member of a multi-GPU proof: its half of the witness map (a or b on the coset) is in va
+    int half = -1;                                        // which half this proof's head computed (-1: the whole witness map)
+    bool lone = false;                                    // (enqueue_head -> enqueue_tail)
     bool ready = false;        // streams and events exist (slot_init)
     // the proof currently in flight in this slot
     bool busy = false;
@@ -167,9 +170,12 @@ struct zkhip_ctx {
                               // (ZKHIP_LONE_SCHED / ZKHIP_TUNE_LONE_SCHED; batches are untouched)
     int g2_head_start = 1;    // a LONE proof over a curve whose G2 accumulation runs one wave per SIMD: its G1 lanes also wait for the end of
                               // that accumulation — 0 never, 1 over a bound key, 2 always (ZKHIP_G2_HEAD_START; Prover::enqueue)
+    int split_min_log = 18;   // smallest domain (log2) whose witness map the members of a multi-GPU proof split between them (below: every
+                              // member runs all of it — two transforms of 2^17 elements cost less than the exchange; ZKHIP_SPLIT_MIN_LOG)
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_max_sublog = 11;  // largest sub-transform of a pass (2^11 elements staged per sequence); domains above twice this take three passes
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
+    int ntt_skew_us = 0;      // start skew of a transform pass's first round of workgroups (kernels_ntt.cuh NttSkew; ZKHIP_NTT_SKEW_US)
     u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
     int sort_kh_log = 15;     // log2 of the counters of one sort workgroup's LDS histogram (ZKHIP_SORT_KH_LOG: development knob — a smaller
                               // histogram leaves LDS to the kernels beside it and reads the digits once more per halving)
@@ -201,6 +207,7 @@ static inline void slot_init(zkhip_ctx* ctx, ProofSlot& sl) {
     sl.ntt_b = event_create();
     sl.ntt_e = event_create();
     sl.g1_go = event_create();
+    sl.half_ready = event_create();
     sl.ready = true;
 }
 // streams made when they are first needed
@@ -343,7 +350,7 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
             dev_h2d(d_src.p, src.data(), src.size() * 4, s);
             for (int inv = 0; inv < 2; ++inv) {
                 DBuf& dst = which == 0 ? pl->plan1[inv] : which == 1 ? pl->plan2[inv] : pl->plan3[inv];
-                dst.ensure((size_t)plen * Fu<typename Fr::Params>::N * 4);
+                dst.ensure((size_t)plen * NTT_PLAN_STRIDE * 4);
                 ZK_LAUNCH((k_ntt_plan_gather<typename Fr::Params>), dim3(blocks_for(plen, T)), dim3(T), 0, s, ptr<FrU>(inv ? pl->roots_inv : pl->roots_fwd),
                           (int)(pl->M >> lg), ptr<u32>(d_src), plen, ptr<u32>(dst));
             }
@@ -410,6 +417,12 @@ static NttPlan<C>* get_plan(zkhip_ctx* ctx, int logN) {
     return pl;
 }
 
+// the start skew of a pass whose workgroups take `smem` bytes of LDS each: the first round = as many workgroups as the device holds
+static inline NttSkew ntt_skew(const zkhip_ctx* ctx, size_t smem) {
+    if (ctx->ntt_skew_us <= 0) return NttSkew{0, 0};
+    const u32 per_cu = (u32)std::max<size_t>(1, std::min<size_t>(4, (size_t)160 * 1024 / std::max<size_t>(smem, 1)));
+    return NttSkew{(u32)ctx->ntt_skew_us * 100u, (u32)ctx->cus * per_cu};
+}
 // `nvec` vectors of N elements, vec_stride elements apart, go through one launch (grid.y)
 // the pass over N1: columns of the N1 x Nb matrix
 template <class C>
@@ -417,7 +430,7 @@ static void ntt_cols(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool 
                      int canon = 0, const typename C::Fr* minus = nullptr) {
     typedef typename C::Fr Fr;
     ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3((unsigned)(pl->Nb / pl->C_cols), nvec), dim3(pl->threads_cols), pl->smem_cols, ctx->ws, data, vec_stride,
-              pl->log1, (u32)pl->Nb, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon, minus, (u64)0, ~(u64)0);
+              pl->log1, (u32)pl->Nb, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon, minus, (u64)0, ~(u64)0, ntt_skew(ctx, pl->smem_cols));
 }
 // three passes only — the pass over N2: columns of the N2 x N3 matrix of every outer index (grid.z).  `post_mask`: Nb - 1 for
 // the per-block twiddles, all ones for a table as long as the vector.
@@ -425,7 +438,7 @@ template <class C>
 static void ntt_mid(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, u64 post_mask, int nvec, u64 vec_stride) {
     typedef typename C::Fr Fr;
     ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3(pl->N3 / pl->C_mid, nvec, pl->N1), dim3(pl->threads_mid), pl->smem_mid, ctx->ws, data, vec_stride,
-              pl->log2, pl->N3, pl->C_mid, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, 0, (const Fr*)nullptr, pl->Nb, post_mask);
+              pl->log2, pl->N3, pl->C_mid, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, 0, (const Fr*)nullptr, pl->Nb, post_mask, ntt_skew(ctx, pl->smem_mid));
 }
 // the pass over the last factor: contiguous sequences
 template <class C>
@@ -435,7 +448,8 @@ static void ntt_rows(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool 
     const bool three = pl->log3 > 0;
     const int lg = three ? pl->log3 : pl->log2;
     ZK_LAUNCH((k_ntt_rows<typename Fr::Params>), dim3((unsigned)((pl->N >> lg) / pl->R_rows), nvec), dim3(pl->threads_rows), pl->smem_rows, ctx->ws, data, vec_stride,
-              lg, pl->R_rows, ptr<u32>((three ? pl->plan3 : pl->plan2)[inverse ? 1 : 0]), three ? pl->plen3 : pl->plen2, post, canon, minus, post_mask);
+              lg, pl->R_rows, ptr<u32>((three ? pl->plan3 : pl->plan2)[inverse ? 1 : 0]), three ? pl->plen3 : pl->plen2, post, canon, minus, post_mask,
+              ntt_skew(ctx, pl->smem_rows));
 }
 // natural order in -> sigma order out
 template <class C>
@@ -1338,12 +1352,12 @@ struct Prover {
     // K1: a = A z, b = B z, c = C z over rows [0, n) (+ the l instance rows of A), zero-filled up to N
     // (`nmat` = 2: A and B only — a key bound to the system carries c's share in its bases; the long rows of C, if any, still
     // land in the c vector, which nothing reads then)
-    static void matvec(zkhip_ctx* ctx, const zkhip_r1cs* cs, const Fr* zmont, Fr* a, Fr* b, Fr* c, u64 n, u64 l, u64 N, int nmat = 3) {
+    // (`mat0`: the first matrix of the launch — a member of a multi-GPU proof that transforms b only runs mat0 = 1, nmat = 1)
+    static void matvec(zkhip_ctx* ctx, const zkhip_r1cs* cs, const Fr* zmont, Fr* a, Fr* b, Fr* c, u64 n, u64 l, u64 N, int nmat = 3, int mat0 = 0) {
         int g[3];
-        for (int k = 0; k < 3; ++k) g[k] = matvec_group(cs->nnz_short[k], cs->n);
-        if (nmat < 3) g[2] = 1;
+        for (int k = 0; k < 3; ++k) g[k] = (k >= mat0 && k < mat0 + nmat) ? matvec_group(cs->nnz_short[k], cs->n) : 1;
         ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), nmat), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
-                  l, N, g[0], g[1], g[2], cs->l + cs->w);
+                  l, N, g[0], g[1], g[2], cs->l + cs->w, mat0);
         if (cs->n_long)
             ZK_LAUNCH((k_matvec_long<Fr>), dim3(blocks_for(cs->n_long, 4)), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c,
                       ptr<u64>(cs->long_rows), cs->n_long, cs->l + cs->w);
@@ -1355,11 +1369,22 @@ struct Prover {
     // `bound`: the key is bound to this system (PkLoader::bind) — the transforms that lead from the quotient's evaluations to h's
     // coefficients, and everything c needs, were applied to the key's bases once: what is left per proof is a and b to their
     // coefficients and on to the coset (FOUR transforms), and U_j = a_j b_j / Z(g) as canonical integers in NATURAL order in va.
-    static void witness_map(zkhip_ctx* ctx, const zkhip_r1cs* cs, NttPlan<C>* pl, bool bound = false) {
+    static void witness_map(zkhip_ctx* ctx, const zkhip_r1cs* cs, NttPlan<C>* pl, bool bound = false, int half = -1) {
         Stream s = ctx->ws;
         const u64 N = pl->N;
         ctx->cur->va.ensure(3 * N * sizeof(Fr));
         Fr *a = ptr<Fr>(ctx->cur->va), *b = a + N, *c = b + N;
+        if (half >= 0) {
+            // ONE of the two vectors a bound key's proof needs on the coset (a member of a multi-GPU proof: its partner of the other
+            // parity computes the other, Prover::enqueue_tail multiplies them once both are here): two transforms instead of four
+            Fr* v = a + (u64)half * N;
+            matvec(ctx, cs, ptr<Fr>(ctx->cur->zmont), a, b, c, cs->n, cs->l, N, 1, half);
+            event_record(ctx->cur->ntt_b, s);
+            ntt_kind_a<C>(ctx, pl, v, true, ptr<Fr>(pl->s_coset), 1, 0);
+            ntt_kind_b<C>(ctx, pl, v, false, nullptr, 1, 0);
+            event_record(ctx->cur->ntt_e, s);
+            return;
+        }
         matvec(ctx, cs, ptr<Fr>(ctx->cur->zmont), a, b, c, cs->n, cs->l, N, bound ? 2 : 3);
         event_record(ctx->cur->ntt_b, s);
         if (bound) {
@@ -1412,6 +1437,19 @@ struct Prover {
     // `lone`: nothing else of this context is in flight beside this proof (the single-proof entry points; a batch pipelines)
     static void enqueue(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* src_dev,
                         const uint8_t* r, const uint8_t* s_, bool lone = false) {
+        enqueue_head(ctx, sl, pk, cs, z_host, src_dev, r, s_, lone, -1);
+        enqueue_tail(ctx, sl, pk, cs);
+    }
+    // whether a proof over (pk, cs) may be split between members: a bound key (its proof needs a and b on the coset and nothing else
+    // of the witness map) over a domain where two transforms cost more than the exchange
+    static bool can_split(const zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs) {
+        return pk->scheme == 0 && pk->bound_uid != 0 && pk->bound_uid == cs->uid && pk->logN >= ctx->split_min_log;
+    }
+    // the staged scalars, the sort of the assignment, the G2 lane and the witness map — all of it (`half` = -1) or the vector `half`
+    // (0: a, 1: b) of a bound key's, after which sl.half_ready is recorded and the caller brings the other vector into
+    // sl.va + (1 - half) * N before enqueue_tail
+    static void enqueue_head(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* src_dev,
+                             const uint8_t* r, const uint8_t* s_, bool lone, int half) {
         require(pk->curve == C::ID && cs->curve == C::ID, ZKHIP_ERR_BAD_ARG, "curve mismatch between key and constraint system");
         require(pk->scheme == 0, ZKHIP_ERR_BAD_ARG, "this is a GM17 proving key: use zkhip_prove_gm17");
         require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
@@ -1420,6 +1458,9 @@ struct Prover {
         slot_init(ctx, sl);
         const u64 m = pk->m, N = pk->N;
         const bool bound = pk->bound_uid != 0 && pk->bound_uid == cs->uid;   // (zkhip_pk_bind_r1cs; a shard: its ranges of H' / L')
+        require(half < 0 || (bound && half <= 1), ZKHIP_ERR_BAD_ARG, "internal: only a proof over a bound key splits its witness map");
+        sl.half = half;
+        sl.lone = lone;
         Fr rr = fe_from_bytes_canon<Fr>(r), ss = fe_from_bytes_canon<Fr>(s_);
         require(canon_lt_mod(rr) && canon_lt_mod(ss), ZKHIP_ERR_BAD_ARG, "r or s not a canonical field element");
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
@@ -1480,13 +1521,41 @@ struct Prover {
         stream_wait_event(wn, sl.ev[0]);
         event_record(sl.ev[1], wn);
         ctx->ws = wn;
-        witness_map(ctx, cs, pl, bound);
+        witness_map(ctx, cs, pl, bound, half);
         ctx->ws = ctx->stream;
+        if (half >= 0) event_record(sl.half_ready, wn);
+    }
+    // ... and the rest: (the product of the two halves,) the G1 lanes over z, the h sort and the H MSM, the copies out
+    static void enqueue_tail(zkhip_ctx* ctx, ProofSlot& sl, const zkhip_pk* pk, const zkhip_r1cs* cs) {
+        const u64 N = pk->N;
+        const bool bound = pk->bound_uid != 0 && pk->bound_uid == cs->uid, lone = sl.lone;
+        NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
+        ctx->cur = &sl;
+        Stream st = ctx->stream;
+        Stream wn = ctx->serial ? st : ctx_ntt_stream(ctx);
+        const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
+        const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
+        const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
+        Xyzz<Fq>* ws1 = ptr<Xyzz<Fq>>(sl.ws1);
+        Xyzz<Fq>* hs1 = (Xyzz<Fq>*)sl.h_ws;
+        Xyzz<Fq2>* hs2 = (Xyzz<Fq2>*)((uint8_t*)sl.h_ws + (size_t)4 * Wmax * sizeof(Xyzz<Fq>));
+        const int lone_sched = (lone && !ctx->serial) ? ctx->lone_sched : 0;
+        const int gate = z_gate(ctx);
+        const MsmSort& sort_b = (pk->thin_mask & 8) ? sl.sorts[2] : sl.sorts[0];
+        const bool inf_b2 = (pk->thin_mask & 8) ? pk->inf_many_thin[3] : pk->inf_many[3];
+        // where the H MSM's scalars are: the first vector — except for a split proof, whose product goes to the THIRD (c's, idle over a
+        // bound key): its own half stays as it is for the partner that may still be copying it
+        const u32* h_scalars = ptr<u32>(sl.va) + (sl.half >= 0 ? 2 * N * 8 : 0);
+        if (sl.half >= 0) {
+            // both vectors are on the coset now (the other one arrived on this stream): U_j = a_j b_j / Z(g), canonical integers
+            Fr* a = ptr<Fr>(sl.va);
+            ZK_LAUNCH((k_quotient<typename Fr::Params>), dim3(blocks_for(N, 256)), dim3(256), 0, wn, a, a + N, fe_from_mont(pl->zinv), a + 2 * N, N);
+        }
         event_record(sl.ev[2], wn);
 
         // (lone_sched bit 2: the h sort goes out BEFORE the G1 lanes over z, which then wait for it — it runs beside the G2 lane alone)
         const bool h_sort_first = (lone_sched & 2) != 0 && pk->h_n && gate;
-        if (h_sort_first) msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
+        if (h_sort_first) msm_prepare(ctx, wn, sl.sorts[1], h_scalars + pk->h_lo * 8, shh, pk->h_n);
         if (pk->z_n) {
             const Event h_ready = !gate ? nullptr : h_sort_first ? sl.sorts[1].ready : sl.ev[2];
             if (gate >= 2)
@@ -1512,7 +1581,7 @@ struct Prover {
 
         // ---- H = MSM(h_query, h) in sigma order (the zero-padded tail pairs with infinity bases)
         if (pk->h_n) {
-            if (!h_sort_first) msm_prepare(ctx, wn, sl.sorts[1], ptr<u32>(sl.va) + pk->h_lo * 8, shh, pk->h_n);
+            if (!h_sort_first) msm_prepare(ctx, wn, sl.sorts[1], h_scalars + pk->h_lo * 8, shh, pk->h_n);
             // (a bound key: U in natural order against H' — the same MSM machinery, other bases)
             msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], bound ? pk->h_bound.p : pk->h_sigma.p, with_inf(shh, bound ? pk->inf_many_bound[1] : pk->inf_many[4]),
                         ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3], nullptr, hs1 + 3 * Wmax);
@@ -1766,6 +1835,57 @@ struct Prover {
         canonicalise(g);
         memcpy(partial_out, &g, sizeof(g));
         fill_timings(ctx->slots[0], tm, t_fin);
+    }
+    // ---- a member's share of a proof whose witness map is SPLIT between the members (a bound key: the proof needs a and b on the
+    // coset; the members of even rank transform a, those of odd rank b, and partners exchange — north_star's "NTT domain shard"):
+    //   split_begin     the head with this member's half;
+    //   split_fetch*    the partner's half into this member's vectors (device to device across xGMI / from host memory);
+    //   split_half_out  this member's half to host memory (the multi-process exchange);
+    //   split_end_*     the tail, and the member's result as prove_partial / prove_device_sums leave it.
+    static void split_begin(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const uint8_t* z_host, const void* z_dev, const uint8_t* r,
+                            const uint8_t* s_, int half) {
+        require(pk->bound_uid != 0 && pk->bound_uid == cs->uid && pk->scheme == 0 && (half == 0 || half == 1), ZKHIP_ERR_BAD_ARG,
+                "only a Groth16 proof over a key bound to its constraint system splits its witness map (half = 0: a, 1: b)");
+        enqueue_head(ctx, ctx->slots[0], pk, cs, z_host, z_dev, r, s_, false, half);
+    }
+    static const void* split_half_ptr(zkhip_ctx* ctx, const zkhip_pk* pk, int half) { return ptr<Fr>(ctx->slots[0].va) + (u64)half * pk->N; }
+    static void split_fetch(zkhip_ctx* ctx, const zkhip_pk* pk, const void* src, int src_device, Event src_ready) {
+        ProofSlot& sl = ctx->slots[0];
+        require(sl.half >= 0, ZKHIP_ERR_BAD_ARG, "internal: no split proof in flight");
+        Stream wn = ctx->serial ? ctx->stream : ctx_ntt_stream(ctx);
+        if (src_ready) event_sync(src_ready);           // (the partner's stream, possibly on another device: waited for on the host)
+        dev_copy_between(ptr<Fr>(sl.va) + (u64)(1 - sl.half) * pk->N, ctx->device, src, src_device, pk->N * sizeof(Fr), wn);
+    }
+    static void split_fetch_host(zkhip_ctx* ctx, const zkhip_pk* pk, const uint8_t* other_half) {
+        ProofSlot& sl = ctx->slots[0];
+        require(sl.half >= 0, ZKHIP_ERR_BAD_ARG, "internal: no split proof in flight");
+        Stream wn = ctx->serial ? ctx->stream : ctx_ntt_stream(ctx);
+        dev_h2d(ptr<Fr>(sl.va) + (u64)(1 - sl.half) * pk->N, other_half, pk->N * sizeof(Fr), wn);
+    }
+    static void split_half_out(zkhip_ctx* ctx, const zkhip_pk* pk, uint8_t* out) {
+        ProofSlot& sl = ctx->slots[0];
+        require(sl.half >= 0, ZKHIP_ERR_BAD_ARG, "internal: no split proof in flight");
+        Stream wn = ctx->serial ? ctx->stream : ctx_ntt_stream(ctx);
+        dev_d2h(out, ptr<Fr>(sl.va) + (u64)sl.half * pk->N, pk->N * sizeof(Fr), wn);
+        stream_sync(wn);
+    }
+    static void split_end_partial(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, uint8_t* partial_out, zkhip_timings* tm) {
+        ProofSlot& sl = ctx->slots[0];
+        require(sl.half >= 0, ZKHIP_ERR_BAD_ARG, "internal: no split proof in flight");
+        enqueue_tail(ctx, sl, pk, cs);
+        Sums g = collect(ctx, sl, pk);
+        const auto t_fin = std::chrono::steady_clock::now();
+        canonicalise(g);
+        memcpy(partial_out, &g, sizeof(g));
+        fill_timings(sl, tm, t_fin);
+    }
+    static void split_end_device_sums(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* cs, const void** d_ws1, size_t* b1, const void** d_ws2, size_t* b2,
+                                      zkhip_timings* tm) {
+        ProofSlot& sl = ctx->slots[0];
+        require(sl.half >= 0, ZKHIP_ERR_BAD_ARG, "internal: no split proof in flight");
+        enqueue_tail(ctx, sl, pk, cs);
+        wait_device_sums(ctx, sl, pk, d_ws1, b1, d_ws2, b2);
+        fill_timings(sl, tm, std::chrono::steady_clock::now());
     }
     // one rank's share of a proof, left ON THE DEVICE: the raw bucket-set sums of its five MSMs (ws1: 4 G1 MSMs x Wmax XYZZ
     // sums, ws2: the G2 MSM), for an exchange that never touches host memory (zkhip_multi_use_rccl: RCCL all-gather over
@@ -2042,6 +2162,14 @@ struct CurveOps {
     void (*install_bound_ranges)(zkhip_ctx*, zkhip_pk*, const zkhip_r1cs*, const uint8_t*, size_t, const uint8_t*, size_t, const u64 fp[2]);
     void (*install_bound)(zkhip_ctx*, zkhip_pk*, const void*, const void*, bool on_device, const u64 fp[2]);
     void (*r1cs_fingerprint)(zkhip_ctx*, const zkhip_r1cs*, u64 fp[2]);
+    bool (*can_split)(const zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*);
+    void (*split_begin)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const void*, const uint8_t*, const uint8_t*, int half);
+    const void* (*split_half_ptr)(zkhip_ctx*, const zkhip_pk*, int half);
+    void (*split_fetch)(zkhip_ctx*, const zkhip_pk*, const void*, int, Event);
+    void (*split_fetch_host)(zkhip_ctx*, const zkhip_pk*, const uint8_t*);
+    void (*split_half_out)(zkhip_ctx*, const zkhip_pk*, uint8_t*);
+    void (*split_end_partial)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, uint8_t*, zkhip_timings*);
+    void (*split_end_device_sums)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const void**, size_t*, const void**, size_t*, zkhip_timings*);
     void (*r1cs_load)(zkhip_ctx*, zkhip_r1cs*, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]);
     void (*prove)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
     void (*prove_resident)(zkhip_ctx*, const zkhip_pk*, const zkhip_r1cs*, void*, const uint8_t*, const uint8_t*, uint8_t*, zkhip_timings*);
@@ -2101,6 +2229,14 @@ static CurveOps make_curve_ops() {
     o.install_bound_ranges = &PkLoader<C>::install_bound_ranges;
     o.install_bound = &PkLoader<C>::install_bound;
     o.r1cs_fingerprint = &PkLoader<C>::r1cs_fingerprint;
+    o.can_split = &Prover<C>::can_split;
+    o.split_begin = &Prover<C>::split_begin;
+    o.split_half_ptr = &Prover<C>::split_half_ptr;
+    o.split_fetch = &Prover<C>::split_fetch;
+    o.split_fetch_host = &Prover<C>::split_fetch_host;
+    o.split_half_out = &Prover<C>::split_half_out;
+    o.split_end_partial = &Prover<C>::split_end_partial;
+    o.split_end_device_sums = &Prover<C>::split_end_device_sums;
     o.r1cs_load = &Prover<C>::r1cs_load;
     o.prove = &Prover<C>::prove_host;
     o.prove_resident = &Prover<C>::prove_resident;

@@ -326,6 +326,13 @@ inline void dev_d2h(void* h, const void* d, size_t n, Stream s) {
     drain(q ^ 1);
 }
 inline void dev_d2d(void* d, const void* s_, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s)); }
+// device memory of `src_dev` -> device memory of `dst_dev` (the current device), on a stream of the latter: the members of a
+// multi-GPU proof exchange their halves of the witness map this way (xGMI peer copy; the same device: a plain copy)
+inline void dev_copy_between(void* d, int dst_dev, const void* s_, int src_dev, size_t n, Stream s) {
+    jitter_before(s);
+    if (dst_dev == src_dev) ZK_HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s));
+    else ZK_HIP_CHECK(hipMemcpyPeerAsync(d, dst_dev, s_, src_dev, n, s));
+}
 inline void dev_memset(void* d, int v, size_t n, Stream s) { jitter_before(s); ZK_HIP_CHECK(hipMemsetAsync(d, v, n, s)); }
 inline Stream stream_create() {
     Stream s;
@@ -438,6 +445,7 @@ inline void staging_drain() {}
 inline void dev_h2d_pinned(void* d, const void* h, size_t n, Stream) { memcpy(d, h, n); }
 inline void dev_d2h_pinned(void* h, const void* d, size_t n, Stream) { memcpy(h, d, n); }
 inline void dev_d2d(void* d, const void* s_, size_t n, Stream) { memcpy(d, s_, n); }
+inline void dev_copy_between(void* d, int, const void* s_, int, size_t n, Stream) { memcpy(d, s_, n); }
 inline void dev_memset(void* d, int v, size_t n, Stream) { memset(d, v, n); }
 inline Stream stream_create() { return 0; }
 inline Stream stream_create_high_priority() { return 0; }

@@ -177,10 +177,10 @@ struct CsrDev {
 static constexpr u32 MATVEC_LONG = 32;
 template <class F>
 __global__ void __launch_bounds__(256) k_matvec(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ oa, F* __restrict__ ob,
-                                                F* __restrict__ oc, u64 n, u64 l, u64 N, int gA, int gB, int gC, u64 m_vars) {
+                                                F* __restrict__ oc, u64 n, u64 l, u64 N, int gA, int gB, int gC, u64 m_vars, int mat0 = 0) {
     ZK_PRIO_HIGH();
     __shared__ F sh[256];
-    const int which = blockIdx.y;
+    const int which = blockIdx.y + mat0;
     const int G = which == 0 ? gA : which == 1 ? gB : gC;
     const u32 rows_per_block = blockDim.x / (u32)G;
     if ((u64)blockIdx.x * rows_per_block >= N) return;            // whole workgroup past the end (uniform)
@@ -293,17 +293,27 @@ static inline void ntt_plan_exponents(int logn, std::vector<u32>& src) {
     }
     src.push_back(n >> 2);
 }
+// Entry-major: entry i = NTT_PLAN_STRIDE consecutive words (the nine limbs and padding to three 16-byte loads) — one address
+// computation and three loads per factor.  (Round 5 kept the plan limb-major: nine 4-byte loads per factor, each with a 64-bit
+// address of its own — 27 loads and as many address additions per butterfly; the plan of a 1024-point sub-NTT is 48 KiB either way
+// and lives in the caches.)
+static constexpr u32 NTT_PLAN_STRIDE = 12;
 template <class P>
 __global__ void k_ntt_plan_gather(const Fu<P>* __restrict__ roots, int rstride, const u32* __restrict__ src, u32 plen, u32* __restrict__ plan) {
+    static_assert(Fu<P>::N <= (int)NTT_PLAN_STRIDE, "a plan entry holds the limbs of one factor");
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= plen) return;
     const Fu<P> w = roots[(size_t)src[i] * rstride];
-    ZK_UNROLL for (int l = 0; l < Fu<P>::N; ++l) plan[(size_t)l * plen + i] = w.v[l];
+    ZK_UNROLL for (int l = 0; l < (int)NTT_PLAN_STRIDE; ++l) plan[(size_t)i * NTT_PLAN_STRIDE + l] = l < Fu<P>::N ? w.v[l] : 0u;
 }
 template <class P>
 __device__ __forceinline__ Fu<P> ntt_plan_get(const u32* __restrict__ plan, u32 plen, u32 i) {
+    (void)plen;
+    const uint4* e = (const uint4*)(plan + (size_t)i * NTT_PLAN_STRIDE);
+    const uint4 a = e[0], b = e[1], c = e[2];
+    const u32 w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
     Fu<P> r;
-    ZK_UNROLL for (int l = 0; l < Fu<P>::N; ++l) r.v[l] = plan[(size_t)l * plen + i];
+    ZK_UNROLL for (int l = 0; l < Fu<P>::N; ++l) r.v[l] = w[l];
     return r;
 }
 
@@ -321,11 +331,12 @@ __device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn,
     if (logn >= 2) {
         const int per_seq = n >> 2, nbf = nseq * per_seq;
         u32 off = 0;
-        for (int L = n; L >= 4; L >>= 2) {
+        int logq = logn - 2;                      // log2 of q = L / 4 (every length is a power of two: shifts, no divisions)
+        for (int L = n; L >= 4; L >>= 2, logq -= 2) {
             const int q = L >> 2;
             for (int b = threadIdx.x; b < nbf; b += T) {
-                const int seq = b / per_seq, bb = b - seq * per_seq;
-                const int grp = bb / q, pos = bb - grp * q;
+                const int seq = b >> (logn - 2), bb = b & (per_seq - 1);
+                const int grp = bb >> logq, pos = bb & (q - 1);
                 const int base = seq * SS, i0 = grp * L + pos;
                 const int s0 = base + ntt_slot(i0), s1 = base + ntt_slot(i0 + q), s2 = base + ntt_slot(i0 + 2 * q), s3 = base + ntt_slot(i0 + 3 * q);
                 // ordered to keep few values alive: (b, d) first, each output stored as soon as it exists
@@ -360,7 +371,7 @@ __device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn,
     if (logn & 1) {   // the last radix-2 stage (pairs of neighbours, no twiddle)
         const int per_seq = n >> 1, nb2 = nseq * per_seq;
         for (int b = threadIdx.x; b < nb2; b += T) {
-            const int seq = b / per_seq, k = b - seq * per_seq;
+            const int seq = b >> (logn - 1), k = b & (per_seq - 1);
             const int s0 = seq * SS + ntt_slot(2 * k), s1 = seq * SS + ntt_slot(2 * k + 1);
             const U u = lds_get_u<P>(lds, PL, s0), v = lds_get_u<P>(lds, PL, s1);
             lds_put_u<P>(lds, PL, s0, fe_add(u, v));
@@ -377,6 +388,38 @@ __device__ __forceinline__ Fu<P> ntt_load(const uint4* __restrict__ data, size_t
     const uint4 lo = data[2 * g], hi = data[2 * g + 1];
     const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return fe_relax(fu_unpack<P>(w));
+}
+// The passes fetch in BATCHES: every work-item issues the loads of all (up to NTT_BATCH) elements it moves before it touches the
+// first — one memory latency per phase instead of one per element (round 5's loops loaded, waited and used element by element: four
+// elements per work-item, eight exposed latencies per workgroup between the tile's load, its factors and its store — a quarter of a
+// wavefront's cycles parked, profiles/r5a_stall_*.md).
+static constexpr int NTT_BATCH = 4;
+template <class P>
+__device__ __forceinline__ Fu<P> ntt_unpack_words(const uint4& lo, const uint4& hi) {
+    const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return fe_relax(fu_unpack<P>(w));
+}
+// as ntt_store below, the factor already in registers
+template <class P>
+__device__ __forceinline__ void ntt_store_with(uint4* __restrict__ data, size_t g, Fu<P> x, bool have_post, const uint4& plo, const uint4& phi, int canon,
+                                               const uint4* __restrict__ minus, size_t pg) {
+    if (have_post) {
+        const u32 w[8] = {plo.x, plo.y, plo.z, plo.w, phi.x, phi.y, phi.z, phi.w};
+        x = fu_mul_inl(x, fu_unpack<P>(w));
+    } else {
+        x = fe_relax(x);
+    }
+    Fe<P> o;
+    fu_pack(x, o.v);
+    if (canon) fe_reduce_once(o);
+    if (minus) {            // canonical exit only: o - minus[g] mod p, both canonical integers (the c term of the quotient)
+        const uint4 lo = minus[2 * pg], hi = minus[2 * pg + 1];
+        Fe<P> m;
+        m.v[0] = lo.x; m.v[1] = lo.y; m.v[2] = lo.z; m.v[3] = lo.w; m.v[4] = hi.x; m.v[5] = hi.y; m.v[6] = hi.z; m.v[7] = hi.w;
+        o = fe_sub(o, m);
+    }
+    data[2 * g] = make_uint4(o.v[0], o.v[1], o.v[2], o.v[3]);
+    data[2 * g + 1] = make_uint4(o.v[4], o.v[5], o.v[6], o.v[7]);
 }
 // x: TIGHT, value < 32p.  With a post factor the product is < 2p; without one fe_relax leaves < 2p; `canon` adds the
 // final conditional subtraction (the Montgomery exit of the last transform must leave canonical integers: MSM digits).
@@ -405,6 +448,43 @@ __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu
     data[2 * g + 1] = make_uint4(o.v[4], o.v[5], o.v[6], o.v[7]);
 }
 
+// Which (tile, vector) a workgroup of a pass takes.  A launch over TWO vectors (a and b of a proof go through every pass together)
+// reads the same element-wise factors for both: a workgroup's tile of the `post` table is as large as its tile of the data.  The
+// hardware deals consecutive workgroups round-robin over the 8 XCDs, each with an L2 of its own — in (x = tile, y = vector) order
+// the two users of a table tile are half a launch apart and the second read comes from HBM again (counted: 1.5 x the data).  So the
+// linear workgroup number is re-read as 16-blocks of (8 tiles x 2 vectors): workgroups L and L + 8 — the same XCD, back to back —
+// take the same tile of the two vectors, and the second finds the factors in that XCD's L2.  A speed-only affinity: any mapping
+// computes the same result.  (nvec != 2, or a tile count that is not a multiple of 8: the identity.)
+static __device__ __forceinline__ void ntt_tile_of(u32& tile, u32& vec) {
+    tile = blockIdx.x;
+    vec = blockIdx.y;
+    if (gridDim.y == 2 && (gridDim.x & 7u) == 0) {
+        const u32 L = blockIdx.x + gridDim.x * blockIdx.y;
+        const u32 g = L >> 4, r = L & 15u;
+        tile = g * 8 + (r & 7u);
+        vec = r >> 3;
+    }
+}
+// Start skew.  A pass is load -> five butterfly rounds -> store per workgroup, and a launch over a 2^20 domain is exactly TWO rounds
+// of workgroups (the machine's LDS holds half the elements): dispatched together, every workgroup of a round loads at the same time
+// (a 32 MiB burst: ~7 us with the multipliers idle), computes at the same time (HBM idle), stores at the same time — the memory
+// phases and the arithmetic of a pass add up instead of overlapping (46 us of VALU issue + 18 us of HBM time = the 64 us per
+// pass-vector of rounds 3-5).  So the workgroups of the FIRST round (linear number < first_round) wait a pseudo-random time below
+// `skew_ticks` (wall clock, 10 ns) before they load: co-resident workgroups drift apart, one's loads land under the other's
+// butterflies, and the drift carries into the second round.  A scheduling aid: 0 = off (ZKHIP_TUNE_NTT_SKEW_US), no effect on results.
+struct NttSkew { u32 ticks, first_round; };
+static __device__ __forceinline__ void ntt_start_skew(NttSkew sk) {
+#ifndef ZK_EMU
+    if (!sk.ticks) return;
+    const u32 L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (L >= sk.first_round) return;
+    const u32 d = ((L * 2654435761u) >> 12) % sk.ticks;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(4);
+#else
+    (void)sk;
+#endif
+}
 // "cols" pass: the matrix is n1 x n2 row-major; this workgroup owns columns [c0, c0 + C).  grid.y = vectors
 // (consecutive vectors are vec_stride elements apart).
 // workgroups of 512 work-items per CU the transform kernels are compiled for (4: 64 VGPRs, a few spilled; 3: 85 VGPRs)
@@ -417,28 +497,60 @@ __device__ __forceinline__ void ntt_store(uint4* __restrict__ data, size_t g, Fu
 template <class P>
 __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n1, u32 n2, int C, const u32* __restrict__ plan,
                                                      u32 plen, const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr,
-                                                     u64 batch_stride = 0, u64 post_mask = ~(u64)0) {
+                                                     u64 batch_stride = 0, u64 post_mask = ~(u64)0, NttSkew skew = NttSkew{0, 0}) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     static_assert(P::N == 8, "Fr is 8 x 32-bit words");
+    ntt_start_skew(skew);
     u32* lds = (u32*)smem;
+    u32 tile, vec;
+    ntt_tile_of(tile, vec);
     const size_t boff = (size_t)blockIdx.z * batch_stride;
-    uint4* data = (uint4*)(data_ + (size_t)blockIdx.y * vec_stride + boff);
+    uint4* data = (uint4*)(data_ + (size_t)vec * vec_stride + boff);
     const uint4* post = (const uint4*)post_;
     const int n1 = 1 << log_n1;
     const int SS = n1 + (n1 >> 5) + 1, PL = C * SS;
-    const u32 c0 = blockIdx.x * C;
+    const u32 c0 = tile * C;
     const int total = C * n1;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int a = e / C, j = e - a * C;
-        lds_put_u<P>(lds, PL, j * SS + ntt_slot(a), ntt_load<P>(data, (size_t)a * n2 + c0 + j));
+    const int logC = 31 - __clz(C);                 // (C is a power of two)
+    for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
+        uint4 lo[NTT_BATCH] = {}, hi[NTT_BATCH] = {};
+        ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+            const int e = e0 + q * blockDim.x;
+            if (e < total) {
+                const size_t g = (size_t)(e >> logC) * n2 + c0 + (e & (C - 1));
+                lo[q] = data[2 * g];
+                hi[q] = data[2 * g + 1];
+            }
+        }
+        ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+            const int e = e0 + q * blockDim.x;
+            if (e < total) lds_put_u<P>(lds, PL, (e & (C - 1)) * SS + ntt_slot(e >> logC), ntt_unpack_words<P>(lo[q], hi[q]));
+        }
     }
     __syncthreads();
     lds_ntt_dif4<P>(lds, PL, SS, log_n1, C, plan, plen);
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int k = e / C, j = e - k * C;
-        const size_t g = (size_t)k * n2 + c0 + j;
-        ntt_store<P>(data, g, lds_get_u<P>(lds, PL, j * SS + ntt_slot(bitrev_n(k, log_n1))), post, canon, (const uint4*)minus_, (boff + g) & post_mask);
+    for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
+        uint4 plo[NTT_BATCH] = {}, phi[NTT_BATCH] = {};
+        if (post) {
+            ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+                const int e = e0 + q * blockDim.x;
+                if (e < total) {
+                    const size_t pg = (boff + (size_t)(e >> logC) * n2 + c0 + (e & (C - 1))) & post_mask;
+                    plo[q] = post[2 * pg];
+                    phi[q] = post[2 * pg + 1];
+                }
+            }
+        }
+        ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+            const int e = e0 + q * blockDim.x;
+            if (e < total) {
+                const int k = e >> logC, j = e & (C - 1);
+                const size_t g = (size_t)k * n2 + c0 + j;
+                ntt_store_with<P>(data, g, lds_get_u<P>(lds, PL, j * SS + ntt_slot(bitrev_n(k, log_n1))), post != nullptr, plo[q], phi[q], canon, (const uint4*)minus_,
+                                  (boff + g) & post_mask);
+            }
+        }
     }
 }
 
@@ -446,25 +558,55 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __re
 template <class P>
 __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_rows(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n2, int R, const u32* __restrict__ plan, u32 plen,
                                                      const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr,
-                                                     u64 post_mask = ~(u64)0) {
+                                                     u64 post_mask = ~(u64)0, NttSkew skew = NttSkew{0, 0}) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
+    ntt_start_skew(skew);
     u32* lds = (u32*)smem;
-    uint4* data = (uint4*)(data_ + (size_t)blockIdx.y * vec_stride);
+    u32 tile, vec;
+    ntt_tile_of(tile, vec);
+    uint4* data = (uint4*)(data_ + (size_t)vec * vec_stride);
     const uint4* post = (const uint4*)post_;
     const int n2 = 1 << log_n2;
     const int SS = n2 + (n2 >> 5) + 1, PL = R * SS;
-    const size_t base = (size_t)blockIdx.x * R * n2;
+    const size_t base = (size_t)tile * R * n2;
     const int total = R * n2;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int r = e >> log_n2, i = e & (n2 - 1);
-        lds_put_u<P>(lds, PL, r * SS + ntt_slot(i), ntt_load<P>(data, base + e));
+    for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
+        uint4 lo[NTT_BATCH] = {}, hi[NTT_BATCH] = {};
+        ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+            const int e = e0 + q * blockDim.x;
+            if (e < total) {
+                lo[q] = data[2 * (base + e)];
+                hi[q] = data[2 * (base + e) + 1];
+            }
+        }
+        ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+            const int e = e0 + q * blockDim.x;
+            if (e < total) lds_put_u<P>(lds, PL, (e >> log_n2) * SS + ntt_slot(e & (n2 - 1)), ntt_unpack_words<P>(lo[q], hi[q]));
+        }
     }
     __syncthreads();
     lds_ntt_dif4<P>(lds, PL, SS, log_n2, R, plan, plen);
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int r = e >> log_n2, k = e & (n2 - 1);
-        ntt_store<P>(data, base + e, lds_get_u<P>(lds, PL, r * SS + ntt_slot(bitrev_n(k, log_n2))), post, canon, (const uint4*)minus_, (base + e) & post_mask);
+    for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
+        uint4 plo[NTT_BATCH] = {}, phi[NTT_BATCH] = {};
+        if (post) {
+            ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+                const int e = e0 + q * blockDim.x;
+                if (e < total) {
+                    const size_t pg = (base + e) & post_mask;
+                    plo[q] = post[2 * pg];
+                    phi[q] = post[2 * pg + 1];
+                }
+            }
+        }
+        ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+            const int e = e0 + q * blockDim.x;
+            if (e < total) {
+                const int r = e >> log_n2, k = e & (n2 - 1);
+                ntt_store_with<P>(data, base + e, lds_get_u<P>(lds, PL, r * SS + ntt_slot(bitrev_n(k, log_n2))), post != nullptr, plo[q], phi[q], canon,
+                                  (const uint4*)minus_, (base + e) & post_mask);
+            }
+        }
     }
 }
 

@@ -140,6 +140,8 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
         ctx->g2_head_start = env_int("ZKHIP_G2_HEAD_START", 0, 2, 1);
         ctx->lone_sched = env_int("ZKHIP_LONE_SCHED", 0, 3, 0);
+        ctx->split_min_log = env_int("ZKHIP_SPLIT_MIN_LOG", 0, 40, 18);
+        ctx->ntt_skew_us = env_int("ZKHIP_NTT_SKEW_US", 0, 200, 0);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
         ctx->heavy_runs = env_int("ZKHIP_MSM_HEAVY_RUNS", 0, 1, 1) != 0;
         { const int hg = env_int("ZKHIP_FOLD_HG", 1, 256, 32); ctx->fold_hg = 1 << ilog2_floor((u64)hg); }
@@ -242,6 +244,7 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_SLOTS: in(1, ZK_NSLOTS); dev_sync_all(); ctx->nslots = value; break;
             case ZKHIP_TUNE_Z_GATE: in(0, 2); ctx->z_gate = value; break;
             case ZKHIP_TUNE_LONE_SCHED: in(0, 3); ctx->lone_sched = value; break;
+            case ZKHIP_TUNE_NTT_SKEW_US: in(0, 200); ctx->ntt_skew_us = value; break;
             case ZKHIP_TUNE_FUSE_Z: in(0, 1); ctx->fuse_z = value != 0; break;
             case ZKHIP_TUNE_MSM_FUSED_WAVES: in(0, 8); ctx->msm_fused_waves = value; break;
             case ZKHIP_TUNE_STREAM_JITTER: in(0, 5000); dev_sync_all(); jitter_state().max_us.store(value); break;
@@ -333,6 +336,33 @@ int32_t zkhip_pk_bind_r1cs_shard(zkhip_ctx* ctx, zkhip_pk* pk, const zkhip_r1cs*
     });
     if (rc != ZKHIP_OK && pk && started) zkhip_pk_unbind(pk);
     return rc;
+}
+// One rank's share of a proof whose witness map is split between the ranks of a multi-PROCESS prover (one process per GPU): begin
+// computes this rank's half — `half` = 0: a, 1: b on the coset, N x 32 bytes (R'-form, packed) into `half_out` (host memory) — and
+// leaves the proof in flight; the ranks exchange halves (partners of the other parity); end takes the partner's and finishes.
+int32_t zkhip_prove_g16_split_begin(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* z, zkhip_assignment* z_resident, const uint8_t* r,
+                                    const uint8_t* s, int32_t half, uint8_t* half_out) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && (z || z_resident) && r && s && half_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
+        if (!z) require(z_resident->ctx == ctx && z_resident->curve == pk->curve && z_resident->m == r1cs->l + r1cs->w, ZKHIP_ERR_BAD_ARG,
+                        "assignment does not match the constraint system");
+        for (auto& sl : ctx->slots) require(!sl.busy, ZKHIP_ERR_BAD_ARG, "a proof is in flight in this context");
+        const CurveOps* ops = ops_for(pk->curve);
+        ops->split_begin(ctx, pk, r1cs, z, z ? nullptr : z_resident->scalars.p, r, s, half);
+        ops->split_half_out(ctx, pk, half_out);
+    });
+}
+int32_t zkhip_prove_g16_split_end(zkhip_ctx* ctx, const zkhip_pk* pk, const zkhip_r1cs* r1cs, const uint8_t* other_half, uint8_t* partial_out, zkhip_timings* timings) {
+    if (!ctx) return ZKHIP_ERR_BAD_ARG;
+    return guarded(ctx, [&] {
+        require(pk && r1cs && other_half && partial_out, ZKHIP_ERR_BAD_ARG, "null argument");
+        require(pk->ctx == ctx && r1cs->ctx == ctx, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
+        const CurveOps* ops = ops_for(pk->curve);
+        ops->split_fetch_host(ctx, pk, other_half);
+        ops->split_end_partial(ctx, pk, r1cs, partial_out, timings);
+    });
 }
 int32_t zkhip_r1cs_fingerprint(zkhip_ctx* ctx, const zkhip_r1cs* r1cs, uint64_t out[2]) {
     if (!ctx) return ZKHIP_ERR_BAD_ARG;
@@ -753,12 +783,14 @@ struct zkhip_multi {
     std::vector<zkhip_r1cs*> cs;     // replicas
     int scheme = -1;                 // of the loaded key: 0 Groth16, 1 GM17
     bool replicas = false;           // every member holds the WHOLE key (throughput mode) instead of shard k of n
+    bool transform_split = true;     // bound members split the witness map (even members transform a, odd ones b, partners exchange)
     std::string err;
     // the exchange step over RCCL (zkhip_multi_use_rccl): one communicator and one pair of device buffers per member
     bool rccl = false;
     std::vector<void*> comm;         // ncclComm_t per member
     std::vector<DBuf> gather1, gather2;   // all members' ws1 / ws2, rank-major, on every member's device
     std::string rccl_desc;
+    bool last_split = false;         // the last zkhip_prove_*_multi split its witness map
 };
 }  // extern "C"
 
@@ -1013,6 +1045,15 @@ int32_t zkhip_multi_bind(zkhip_multi* m, const uint8_t* key_bytes, size_t len) {
     if (rc != ZKHIP_OK) for (auto* p : m->pk) zkhip_pk_unbind(p);      // all members or none
     return rc;
 }
+// 1 / 0: let bound members split the witness map of a proof between them (default 1); returns what it was.  -1: only report.
+int32_t zkhip_multi_transform_split(zkhip_multi* m, int32_t on) {
+    if (!m) return ZKHIP_ERR_BAD_ARG;
+    const int32_t was = m->transform_split ? 1 : 0;
+    if (on >= 0) m->transform_split = on != 0;
+    return was;
+}
+// 1 if the last zkhip_prove_*_multi split its witness map between the members, else 0
+int32_t zkhip_multi_last_split(const zkhip_multi* m) { return m && m->last_split ? 1 : 0; }
 int32_t zkhip_multi_unbind(zkhip_multi* m) {
     if (!m) return ZKHIP_ERR_BAD_ARG;
     for (auto* p : m->pk) if (p) zkhip_pk_unbind(p);
@@ -1068,6 +1109,31 @@ static int32_t multi_prove(zkhip_multi* m, int scheme, const uint8_t* z, const u
     std::vector<uint8_t> records(n * rec);
     std::vector<zkhip_timings> tm(n);
     int32_t rc;
+    // The witness map SPLIT between the members (SURVEY.md §8e / north_star "NTT domain shard"): over keys bound to the system a proof
+    // needs a and b on the coset and nothing else — members of even rank transform a, those of odd rank b (two transforms instead
+    // of four each), partners copy each other's vector (N x 32 B over xGMI, or on the device they share) and every member multiplies.
+    // Unbound keys, GM17, one member, domains below 2^18: every member runs the whole map, as before.
+    const CurveOps* sops = ops_for(m->pk[0]->curve);
+    bool split = scheme == 0 && n >= 2 && m->transform_split;
+    for (size_t k = 0; k < n && split; ++k) split = sops->can_split(m->ctx[k], m->pk[k], m->cs[k]);
+    auto half_of = [](size_t k) { return (int)(k & 1); };
+    auto partner_of = [n](size_t k) { return (k ^ 1) < n ? (k ^ 1) : k - 1; };
+    auto fetch = [&](size_t k) {      // (inside guarded(m->ctx[k], ...))
+        const size_t p = partner_of(k);
+        sops->split_fetch(m->ctx[k], m->pk[k], sops->split_half_ptr(m->ctx[p], m->pk[p], half_of(p)), m->ctx[p]->device, m->ctx[p]->slots[0].half_ready);
+    };
+    m->last_split = split;
+    if (split) {
+        // phase A on every member before phase B on any: a member fetches its partner's half only when that half is enqueued
+        rc = multi_each(m, [&](size_t k) {
+            return guarded(m->ctx[k], [&] {
+                require(m->pk[k]->ctx == m->ctx[k] && m->cs[k]->ctx == m->ctx[k], ZKHIP_ERR_BAD_ARG, "handles belong to another context");
+                for (auto& sl : m->ctx[k]->slots) require(!sl.busy, ZKHIP_ERR_BAD_ARG, "a proof is in flight in this context");
+                sops->split_begin(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, s_, half_of(k));
+            });
+        });
+        if (rc != ZKHIP_OK) { for (auto* c : m->ctx) { try { dev_set(c->device); dev_sync_all(); } catch (...) {} } return rc; }
+    }
     if (m->rccl) {
         // every member leaves the bucket-set sums of its five partial MSMs on its device and all-gathers them (RCCL over
         // xGMI; in the test emulator: copies in member order); member 0's gathered copy is read back and combined
@@ -1078,7 +1144,8 @@ static int32_t multi_prove(zkhip_multi* m, int scheme, const uint8_t* z, const u
             return guarded(m->ctx[k], [&] {
                 zkhip_ctx* c = m->ctx[k];
                 require(m->pk[k]->ctx == c && m->cs[k]->ctx == c, ZKHIP_ERR_BAD_ARG, "handles belong to another context");
-                if (scheme == 0) ops->prove_device_sums(c, m->pk[k], m->cs[k], z, rnd, s_, &d1[k], &b1[k], &d2[k], &b2[k], &tm[k]);
+                if (split) { fetch(k); ops->split_end_device_sums(c, m->pk[k], m->cs[k], &d1[k], &b1[k], &d2[k], &b2[k], &tm[k]); }
+                else if (scheme == 0) ops->prove_device_sums(c, m->pk[k], m->cs[k], z, rnd, s_, &d1[k], &b1[k], &d2[k], &b2[k], &tm[k]);
                 else ops->gm17_prove_device_sums(c, m->pk[k], m->cs[k], z, rnd, &d1[k], &b1[k], &d2[k], &b2[k], &tm[k]);
                 m->gather1[k].ensure(n * b1[k]);
                 m->gather2[k].ensure(n * b2[k]);
@@ -1119,6 +1186,7 @@ static int32_t multi_prove(zkhip_multi* m, int scheme, const uint8_t* z, const u
         if (rc != ZKHIP_OK) { m->err = std::string("gather: ") + zkhip_last_error(m->ctx[0]); return rc; }
     } else {
         rc = multi_each(m, [&](size_t k) {
+            if (split) return guarded(m->ctx[k], [&] { fetch(k); sops->split_end_partial(m->ctx[k], m->pk[k], m->cs[k], &records[k * rec], &tm[k]); });
             return scheme == 0 ? zkhip_prove_g16_partial(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, s_, &records[k * rec], &tm[k])
                                : zkhip_prove_gm17_partial(m->ctx[k], m->pk[k], m->cs[k], z, nullptr, rnd, &records[k * rec], &tm[k]);
         });

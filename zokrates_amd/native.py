@@ -61,6 +61,7 @@ class Library:
         "zkhip_pk_export_size", "zkhip_pk_export", "zkhip_pk_import",
         "zkhip_pk_bind_r1cs", "zkhip_pk_unbind", "zkhip_pk_is_bound", "zkhip_pk_bind_r1cs_shard", "zkhip_r1cs_fingerprint",
         "zkhip_ctx_tune", "zkhip_init", "zkhip_ctx_clock_probe", "zkhip_multi_bind", "zkhip_multi_unbind",
+        "zkhip_multi_transform_split", "zkhip_multi_last_split", "zkhip_prove_g16_split_begin", "zkhip_prove_g16_split_end",
         "zkhip_ctx_create_multi", "zkhip_multi_free", "zkhip_multi_size", "zkhip_multi_ctx", "zkhip_multi_last_error", "zkhip_multi_r1cs_load",
         "zkhip_multi_pk_load_g16", "zkhip_multi_pk_load_gm17", "zkhip_prove_g16_multi", "zkhip_prove_gm17_multi",
         "zkhip_multi_pk_load_g16_replicas", "zkhip_prove_g16_multi_batch", "zkhip_multi_use_rccl", "zkhip_multi_exchange",
@@ -138,6 +139,10 @@ class Library:
         L.zkhip_ctx_clock_probe.restype = i32; L.zkhip_ctx_clock_probe.argtypes = [vp, u32, vp]
         L.zkhip_multi_bind.restype = i32; L.zkhip_multi_bind.argtypes = [vp, vp, sz]
         L.zkhip_multi_unbind.restype = i32; L.zkhip_multi_unbind.argtypes = [vp]
+        L.zkhip_multi_transform_split.restype = i32; L.zkhip_multi_transform_split.argtypes = [vp, i32]
+        L.zkhip_multi_last_split.restype = i32; L.zkhip_multi_last_split.argtypes = [vp]
+        L.zkhip_prove_g16_split_begin.restype = i32; L.zkhip_prove_g16_split_begin.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
+        L.zkhip_prove_g16_split_end.restype = i32; L.zkhip_prove_g16_split_end.argtypes = [vp, vp, vp, vp, vp, vp]
         L.zkhip_prog_parse.restype = i32; L.zkhip_prog_parse.argtypes = [vp, sz, pp]
         L.zkhip_prog_free.restype = None; L.zkhip_prog_free.argtypes = [vp]
         L.zkhip_prog_dims.restype = i32; L.zkhip_prog_dims.argtypes = [vp, vp]
@@ -196,7 +201,7 @@ class Context:
         self._check(self.lib.L.zkhip_describe(self.h, buf, 256))
         return buf.value.decode()
 
-    TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7, "ntt_cols": 8, "slots": 9, "z_gate": 10, "fuse_z": 11, "msm_fused_waves": 12, "stream_jitter": 13, "ntt_max_sublog": 16, "msm_sets": 17, "skip_inf": 18, "b_sort": 19, "heavy_runs": 20, "lone_sched": 21}
+    TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7, "ntt_cols": 8, "slots": 9, "z_gate": 10, "fuse_z": 11, "msm_fused_waves": 12, "stream_jitter": 13, "ntt_max_sublog": 16, "msm_sets": 17, "skip_inf": 18, "b_sort": 19, "heavy_runs": 20, "lone_sched": 21, "ntt_skew_us": 22}
 
     def clock_probe(self, duration_us=2000):
         """`zkhip_ctx_clock_probe`: the shader clock (GHz) the device runs at over the next `duration_us` microseconds — one wavefront
@@ -405,6 +410,29 @@ def prove_g16_resident(ctx, pk, cs, assignment, r, s, want_timings=False):
     tm = Timings()
     ctx._check(ctx.lib.L.zkhip_prove_g16_resident(ctx.h, pk.h, cs.h, assignment.h, _ptr(rb), _ptr(sb), _ptr(out), C.byref(tm)))
     return (out.tobytes(), tm.as_dict()) if want_timings else out.tobytes()
+
+
+def prove_g16_split_begin(ctx, pk_shard, cs, z, r, s, half):
+    """`zkhip_prove_g16_split_begin`: this rank's half (0: a, 1: b on the coset) of a split witness map, as uint8[N * 32]; the proof
+    stays in flight until prove_g16_split_end."""
+    n_dom = pk_shard.hlen + 1
+    out = np.zeros(n_dom * 32, dtype=np.uint8)
+    rb, sb = int(r).to_bytes(32, "little"), int(s).to_bytes(32, "little")
+    if isinstance(z, Assignment):
+        zp, za = None, z.h
+    else:
+        zp, za = _ptr(_u8(z, cs.m * 32)), None
+    ctx._check(ctx.lib.L.zkhip_prove_g16_split_begin(ctx.h, pk_shard.h, cs.h, zp, za, rb, sb, int(half), _ptr(out)))
+    return out
+
+
+def prove_g16_split_end(ctx, pk_shard, cs, other_half):
+    """`zkhip_prove_g16_split_end`: the partner's half in, this rank's partial record out."""
+    other = _u8(other_half, (pk_shard.hlen + 1) * 32)
+    out = np.zeros(partial_size(ctx, pk_shard.curve_id), dtype=np.uint8)
+    tm = Timings()
+    ctx._check(ctx.lib.L.zkhip_prove_g16_split_end(ctx.h, pk_shard.h, cs.h, _ptr(other), _ptr(out), C.byref(tm)))
+    return out
 
 
 def partial_size(ctx, curve_id):
@@ -732,6 +760,13 @@ class Multi:
 
     def unbind(self):
         self._check(self.lib.L.zkhip_multi_unbind(self.h))
+
+    def transform_split(self, on=None):
+        """`zkhip_multi_transform_split`: let bound members split a proof's witness map (None: only report).  Returns the previous setting."""
+        return bool(self.lib.L.zkhip_multi_transform_split(self.h, -1 if on is None else int(bool(on))))
+
+    def last_split(self):
+        return bool(self.lib.L.zkhip_multi_last_split(self.h))
 
     def prove_g16_batch(self, zs, rss):
         """Independent proofs dealt over the members (`zkhip_prove_g16_multi_batch`): zs = list of host assignments,

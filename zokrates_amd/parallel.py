@@ -98,6 +98,32 @@ class Ranks:
         self._dist.all_gather(out, mine)
         return [t.cpu().numpy() for t in out]
 
+    def exchange_bytes(self, partner, record):
+        """This rank's uint8 record to `partner`, the partner's back (a pairwise send / receive: RCCL over xGMI on GPUs, gloo in the
+        CPU tests) — the halves of a split witness map are N x 32 bytes each, an all-gather would move world / 2 copies of them."""
+        import numpy as np
+        record = np.ascontiguousarray(record, dtype=np.uint8)
+        if self._dist is None or partner == self.rank:
+            return record
+        torch, dist = self._torch, self._dist
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        mine = torch.from_numpy(record.copy()).to(dev)
+        theirs = torch.empty_like(mine)
+        ops = [dist.P2POp(dist.isend, mine, partner), dist.P2POp(dist.irecv, theirs, partner)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return theirs.cpu().numpy()
+
+    def send_bytes(self, to, record):
+        import numpy as np
+        t = self._torch.from_numpy(np.ascontiguousarray(record, dtype=np.uint8).copy()).to("cuda" if self.backend == "nccl" else "cpu")
+        self._dist.send(t, to)
+
+    def recv_bytes(self, src, size):
+        t = self._torch.empty(size, dtype=self._torch.uint8, device="cuda" if self.backend == "nccl" else "cpu")
+        self._dist.recv(t, src)
+        return t.cpu().numpy()
+
     def witness_seed(self, step):
         """Distinct witnesses per (rank, step): ranks never prove the same statement twice."""
         return 0x5EED0000 + self.rank * 1000 + step
@@ -108,7 +134,10 @@ class Ranks:
             self._dist = None
 
 
-def prove_sharded(ranks, ctx, pk_shard, cs, z, r, s, d1_d2=None):
+SPLIT_MIN_LOG = int(os.environ.get("ZKHIP_SPLIT_MIN_LOG", "18"))     # the library's own threshold (zkhip_ctx: split_min_log)
+
+
+def prove_sharded(ranks, ctx, pk_shard, cs, z, r, s, d1_d2=None, transform_split=None):
     """One proof across all ranks.  `pk_shard` = native.ProvingKey(..., rank=ranks.rank, world=ranks.world); z and the
     blinding scalars are the same on every rank (Groth16: r, s; GM17: d1_d2 = (d1, d2) and r, `s` ignored).  Every rank
     returns the (identical) proof bytes."""
@@ -117,6 +146,21 @@ def prove_sharded(ranks, ctx, pk_shard, cs, z, r, s, d1_d2=None):
         d1, d2 = d1_d2
         parts = ranks.all_gather_bytes(native.prove_gm17_partial(ctx, pk_shard, cs, z, d1, d2, r))
         return native.combine_gm17(ctx, pk_shard, parts, d1, d2, r)
-    part = native.prove_g16_partial(ctx, pk_shard, cs, z, r, s)
+    split = transform_split if transform_split is not None else (ranks.world >= 2 and pk_shard.is_bound(cs) and (pk_shard.hlen + 1) >= (1 << SPLIT_MIN_LOG))
+    if split and ranks.world >= 2:
+        # the witness map split between the ranks (bound shards: a and b on the coset are all a proof needs of it): even ranks
+        # transform a, odd ranks b, partners swap their halves
+        half = ranks.rank & 1
+        partner = ranks.rank ^ 1 if (ranks.rank ^ 1) < ranks.world else ranks.rank - 1
+        mine = native.prove_g16_split_begin(ctx, pk_shard, cs, z, r, s, half)
+        if (ranks.rank ^ 1) < ranks.world:
+            theirs = ranks.exchange_bytes(partner, mine)
+        else:      # the odd rank out (world is odd): it only receives — its partner has a partner of its own
+            theirs = ranks.recv_bytes(partner, mine.size)
+        if ranks.world % 2 == 1 and ranks.rank == ranks.world - 2:
+            ranks.send_bytes(ranks.world - 1, mine)          # ... which also serves the rank without one
+        part = native.prove_g16_split_end(ctx, pk_shard, cs, theirs)
+    else:
+        part = native.prove_g16_partial(ctx, pk_shard, cs, z, r, s)
     parts = ranks.all_gather_bytes(part)
     return native.combine_g16(ctx, pk_shard, parts, r, s)
