@@ -190,7 +190,7 @@ class Hip {
     std::vector<uint8_t> export_key_image(const Key& key) const;      // zkhip_pk_export (compact: level 0 of the tables)
     Proof prove(Scheme scheme, const Program& program, const uint8_t* witness, size_t witness_len, const Key& key, StdRng& rng,
                 Timings* timings = nullptr);
-    // a long-lived prover: the constraint system uploaded once, the Groth16 key bound to it (zkhip_pk_bind_r1cs: the quotient's
+    // a long-lived prover: the constraint system uploaded once, the key (Groth16 or GM17) bound to it (zkhip_pk_bind_r1cs: the quotient's
     // inverse transforms applied to the key's bases once, four transforms per proof afterwards, the same proof).  bind returns
     // false when the device has no room for the two extra tables: the key then proves as it was loaded.
     System load_system(const Program& program);

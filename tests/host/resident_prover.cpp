@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
         try {
             bound = hip.bind(key, sys);
         } catch (const Error&) {
-            refused = true;                                   // GM17 keys do not bind
+            refused = true;                                   // (a key that does not match its system: not in this program)
         }
         const std::string after = prove(false).to_json(), again = prove(false).to_json(), one = prove(true).to_json();
         printf("bound=%d refused=%d is_bound=%d\n", (int)bound, (int)refused, (int)hip.is_bound(key, sys));

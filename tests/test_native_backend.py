@@ -126,7 +126,7 @@ def test_native_cli_equals_python_cli_on_emulator(tmp_path, curve, scheme):
 @pytest.mark.parametrize("curve,scheme", [(BN254, "g16"), (BLS12_381, "g16"), (BN254, "gm17")], ids=lambda v: getattr(v, "name", v))
 def test_long_lived_prover_of_the_cpp_host_layer_on_emulator(tmp_path, curve, scheme):
     """zokrates_js calls generate_proof many times per process (zokrates_js/src/lib.rs:380-452): the compiled host side keeps the
-    constraint system resident (System) next to the key and binds the Groth16 key to it (Hip::bind = zkhip_pk_bind_r1cs).  Same
+    constraint system resident (System) next to the key and binds the key (Groth16 or GM17) to it (Hip::bind = zkhip_pk_bind_r1cs).  Same
     proof.json text before and after the binding, through the one-call form, and from the `generate-proof` executable."""
     from emu_util import emu_library
     lib = emu_library()
@@ -140,7 +140,7 @@ def test_long_lived_prover_of_the_cpp_host_layer_on_emulator(tmp_path, curve, sc
     assert r.returncode == 0, r.stderr
     head, same, text = r.stdout.split("\n", 2)
     assert same == "same=1"
-    assert head == ("bound=1 refused=0 is_bound=1" if scheme == "g16" else "bound=0 refused=1 is_bound=0")
+    assert head == "bound=1 refused=0 is_bound=1"          # both schemes bind (GM17: two transforms per proof afterwards)
     cli = subprocess.run([os.path.join(emu_dir, "zkhip-cli-emu"), "generate-proof", "-i", paths["out"], "-w", paths["witness"], "-p", paths["proving.key"],
                           "-s", scheme, "--entropy", "same entropy", "-j", paths["proof_cpp.json"]], capture_output=True, text=True)
     assert cli.returncode == 0, cli.stderr
