@@ -38,48 +38,32 @@ ZK_HD Xyzz<F> xyzz_neg_u(const Xyzz<F>& p) {
     if (p.is_inf()) return p;
     return {p.x, fe_relax(fe_sub_k<4>(F::zero(), p.y)), p.zz, p.zzz};
 }
-// k * p for a canonical integer k of `nw` 32-bit words (nw <= 12): signed four-bit windows against {p, 2p, ..., 8p} — 4 doublings and
-// one addition per window (15 of 16 digits are non-zero), 7 point operations for the table: ~3 270 field products for a 254-bit k
-// where round 5's two-bit form took ~4 060.  The table is indexed by a per-lane digit, so it lives in the kernel's private frame
-// (36 words per read against the ~3 000 instructions of the addition that follows).  Out of line, like every big cold routine.
+// k * p for a canonical integer k of `nw` 32-bit words: two bits at a time against {p, 2p, 3p} (127 additions instead of the
+// ~254 slots a wavefront pays for a bit-by-bit ladder, whose lanes disagree at every bit).  Out of line, like every big cold routine.
 template <class F>
 ZK_HD_CALL Xyzz<F> xyzz_mul_words(const Xyzz<F> p, const u32* k, int nw) {
     Xyzz<F> r = Xyzz<F>::inf();
     if (p.is_inf()) return r;
-    Xyzz<F> tab[8];
+    Xyzz<F> tab[3];
     tab[0] = p;
     tab[1] = xyzz_dbl(p);
-    for (int t = 2; t < 8; ++t) {
-        tab[t] = tab[t - 1];
-        xyzz_add_acc_call(&tab[t], &p);
-    }
-    // recode from the low end: digit = nibble + carry, minus 16 (and a carry out) when that exceeds 8; magnitudes 0 .. 8 in four
-    // bits each, signs in a mask; one more digit (the last carry) on top
-    u32 mag[12];
-    u32 neg[3] = {0, 0, 0};
-    u32 carry = 0;
-    for (int w = 0; w < nw; ++w) {
-        u32 m = 0;
-        for (int q = 0; q < 8; ++q) {
-            u32 d = ((k[w] >> (4 * q)) & 15u) + carry;
-            carry = d > 8 ? 1u : 0u;
-            if (carry) { d = 16 - d; neg[(8 * w + q) >> 5] |= 1u << ((8 * w + q) & 31); }
-            m |= d << (4 * q);
+    tab[2] = tab[1];
+    xyzz_add_acc_call(&tab[2], &p);
+    int top = nw * 16 - 1;                                       // highest non-zero two-bit digit
+    while (top >= 0 && ((k[top >> 4] >> ((top & 15) * 2)) & 3u) == 0) --top;
+    for (int i = top; i >= 0; --i) {
+        if (i != top) {
+            r = xyzz_dbl(r);
+            r = xyzz_dbl(r);
         }
-        mag[w] = m;
-    }
-    if (carry) r = p;                                              // the digit above the top nibble: 0 or 1
-    for (int i = 8 * nw - 1; i >= 0; --i) {
-        for (int b = 0; b < 4; ++b) r = xyzz_dbl(r);
-        const u32 d = (mag[i >> 3] >> (4 * (i & 7))) & 15u;
-        if (d) {
-            Xyzz<F> t = tab[d - 1];
-            if ((neg[i >> 5] >> (i & 31)) & 1u) t = xyzz_neg_u(t);
-            xyzz_add_acc_call(&r, &t);
-        }
+        const u32 d = (k[i >> 4] >> ((i & 15) * 2)) & 3u;
+        if (d) xyzz_add_acc_call(&r, &tab[d - 1]);
     }
     return r;
 }
+// (Round 6 tried signed four-bit windows against {p .. 8p} — 64 additions instead of ~95, ~20 % fewer field products on paper: the
+// stage kernel took 48.9 ms instead of 41.8 (profiles/r6h_bound_serial_kernel_stats.md: a 2 864-byte frame, digits and table entries
+// fetched through per-lane indices).  The two-bit form stays.)
 
 // out[vec * n + nat] = s * H_nat in XYZZ, H_nat = tbl[p] with nat = sigma_nat(p) (level 0 of the key's h table: sigma order);
 // natural indices >= n_src (the padding: N - 1) are the point at infinity.  vec 0: s = scal[nat] (g^-nat / N); vec 1: s = *konst.

@@ -97,6 +97,7 @@ struct NttPlanBase {
 // result of one classification / digit / counting-sort pass; shared (read-only) by every base set paired with those scalars
 struct MsmSort {
     DBuf dig, sorted, cnt, off, cursor, chunk_sum, grand;   // dig: the scalars' signed digits, window-major (k_msm_digits)
+    DBuf pairs, ccur, tile_off;                             // the two-level placement: (key & 255, entry) pairs by coarse bin, the bins' cursors, tiles per bin
     Event ready = nullptr;   // recorded on the main stream when the pass is complete
 };
 // workspace and stream of one MSM: the five MSMs of a proof are independent once their scalars are sorted, and the
@@ -177,6 +178,8 @@ struct zkhip_ctx {
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
     int ntt_skew_us = 0;      // start skew of a transform pass's first round of workgroups (kernels_ntt.cuh NttSkew; ZKHIP_NTT_SKEW_US)
     u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
+    int sort_two_level = 1;   // the placement pass of the sort in two levels (coarse bins of 256 buckets, then tiles: kernels_msm.cuh 1b); 0: round 5's
+                              // one-level k_msm_place (ZKHIP_SORT_TWO_LEVEL)
     int sort_kh_log = 15;     // log2 of the counters of one sort workgroup's LDS histogram (ZKHIP_SORT_KH_LOG: development knob — a smaller
                               // histogram leaves LDS to the kernels beside it and reads the digits once more per halving)
     int tenants = 1;          // contexts of one zkhip_multi that share this context's device (their keys are sized for a share of its memory)
@@ -554,7 +557,7 @@ static inline MsmShape with_inf(MsmShape sh, bool many) { sh.skip_inf = many; re
 static inline u64 msm_table_budget(const zkhip_ctx* ctx, u64 z_n, u64 h_n, u64 N, int W, u32 K) {
     size_t free_b = 0, total_b = 0;
     dev_mem_info(&free_b, &total_b);
-    const u64 per_slot = (2 * z_n + h_n) * (u64)W * 8 + 4 * N * 32 + (z_n + 2) * 64 + 6 * ((u64)K + (1u << 19)) * 288 + ((u64)1 << 29);
+    const u64 per_slot = (2 * z_n + h_n) * (u64)W * 16 + 4 * N * 32 + (z_n + 2) * 64 + 6 * ((u64)K + (1u << 19)) * 288 + ((u64)1 << 29);
     const u64 later = (u64)std::max(1, ctx->nslots) * per_slot + ((u64)1 << 30);
     const u64 budget = (u64)((ctx->tenants > 1 ? 0.5 : 0.6) * (double)free_b) / (u64)std::max(1, ctx->tenants);
     return budget > later ? budget - later : 0;
@@ -601,8 +604,26 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, halves), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
               ptr<u32>(so.cnt), keep);
     scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
-    ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, halves), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
-              level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted), keep);
+    if (ctx->sort_two_level && sh.K >= (1u << MSM_COARSE_BITS) && sh.K <= (1u << 16)) {
+        const u32 nbins = (u32)(nk >> MSM_COARSE_BITS);
+        const u64 total_max = sh.n * (u64)sh.W;
+        so.pairs.ensure(std::max<u64>(total_max, 1) * 8);
+        so.ccur.ensure((size_t)nbins * 4);
+        so.tile_off.ensure(((size_t)nbins + 1) * 4);
+        dev_memset(so.ccur.p, 0, (size_t)nbins * 4, s);
+        // ~1024 workgroups of the coarse pass (1 KiB of LDS each: they share CUs with anything), chunks of at least 4096 scalars
+        const u64 c_chunks = std::max<u64>(1, std::min<u64>((1024 + sh.W - 1) / sh.W, (sh.n + 4095) / 4096));
+        const u64 c_chunk = (sh.n + c_chunks - 1) / c_chunks;
+        ZK_LAUNCH(k_msm_part_coarse, dim3((unsigned)c_chunks, sh.W), dim3(256), 0, s, wm, sh.n, sh.c, sh.W, c_chunk, sh.sets, level_stride, ptr<u32>(so.off),
+                  ptr<u32>(so.ccur), (unsigned long long*)so.pairs.p, keep);
+        ZK_LAUNCH(k_msm_tile_offsets, dim3(1), dim3(MSM_TILE_SCAN_THREADS), 0, s, ptr<u32>(so.off), nbins, ptr<u32>(so.tile_off));
+        const u64 max_tiles = total_max / MSM_FINE_TILE + nbins;
+        ZK_LAUNCH(k_msm_part_fine, dim3((unsigned)max_tiles), dim3(256), 0, s, (const unsigned long long*)so.pairs.p, ptr<u32>(so.off), ptr<u32>(so.tile_off), nbins,
+                  ptr<u32>(so.cursor), ptr<u32>(so.sorted));
+    } else {
+        ZK_LAUNCH(k_msm_place, dim3((unsigned)sort_chunks, sh.W, halves), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
+                  level_stride, ptr<u32>(so.off), ptr<u32>(so.cursor), ptr<u32>(so.sorted), keep);
+    }
     event_record(so.ready, s);
 }
 

@@ -299,6 +299,133 @@ static __global__ void __launch_bounds__(ZK_SORT_THREADS) k_msm_place(const u32*
     }
 }
 
+// ---- 1b. the same placement in TWO levels (round 6; k_msm_place above stays as the path for windows below 9 bits) ----
+// k_msm_place scatters 4-byte entries into runs of ~2 entries per (workgroup, bucket): 15.7 M stores, each to a line of its own —
+// 548 MB of write traffic for 63 MB of payload, 0.28-0.36 ms per sort, behind a 128 KiB histogram that lets no second workgroup
+// (and no accumulation workgroup with LDS of its own) share the CU.  Two levels:
+//   k_msm_part_coarse   a workgroup = one window of a chunk of scalars, as before, but it only separates the 256-key COARSE bins
+//                       (key >> 8; 1 KiB of counters): runs of ~60 entries per (workgroup, bin), written as 8-byte pairs
+//                       (key & 255, entry) into the bin's region of `pairs` — the region every bucket of the bin will occupy in
+//                       `sorted`, so the bucket offsets of the counting pass serve both levels;
+//   k_msm_tile_offsets  how many tiles of MSM_FINE_TILE pairs every coarse region is cut into (one small workgroup);
+//   k_msm_part_fine     a workgroup = one tile of one region: 256 counters, one global atomic per touched bucket, entries placed
+//                       into runs of ~8 per (tile, bucket) inside a 0.25 MB region of `sorted` that the L2 keeps whole.
+// Same result as k_msm_place up to the order of the entries inside a bucket, which no consumer depends on.
+static constexpr u32 MSM_COARSE_BITS = 8;                 // keys per coarse bin = 256 (a window narrower than 9 bits takes k_msm_place)
+static constexpr u32 MSM_FINE_TILE = 2048;                // pairs per workgroup of the fine pass (8 per work-item)
+static __global__ void __launch_bounds__(256) k_msm_part_coarse(const u32* __restrict__ dig, u64 n, int c, int W, u64 chunk, u32 sets, u64 idx_stride,
+                                                              const u32* __restrict__ off, u32* __restrict__ ccur, unsigned long long* __restrict__ pairs,
+                                                              const u32* __restrict__ keep) {
+    ZK_PRIO_HIGH();
+    __shared__ u32 hist[256];
+    const u32 K = 1u << (c - 1), nb = K >> MSM_COARSE_BITS;          // coarse bins of one bucket set (<= 256: K <= 2^16)
+    const int j = blockIdx.y;
+    const u32 set = (u32)j % sets;
+    const u32* __restrict__ dj = dig + (u64)j * n;
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const u64 i0 = (u64)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    for (u64 i = i0 + threadIdx.x; i < i1; i += (u64)MSM_SORT_ILP * blockDim.x) {
+        u32 d[MSM_SORT_ILP];
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            const u64 ii = i + (u64)q * blockDim.x;
+            d[q] = (ii < i1 && !msm_skipped(keep, ii)) ? dj[ii] : MSM_NO_DIGIT;
+        }
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q)
+            if (d[q] != MSM_NO_DIGIT) atomicAdd(&hist[(d[q] & 0x7fffffffu) >> MSM_COARSE_BITS], 1u);
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) {
+        const u32 have = hist[b], bin = set * nb + b;
+        hist[b] = have ? off[(u64)bin << MSM_COARSE_BITS] + atomicAdd(&ccur[bin], have) : 0;   // this workgroup's run inside the bin's region
+    }
+    __syncthreads();
+    const u32 level = (u32)((u64)((u32)j / sets) * idx_stride);
+    for (u64 i = i0 + threadIdx.x; i < i1; i += (u64)MSM_SORT_ILP * blockDim.x) {
+        u32 d[MSM_SORT_ILP];
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            const u64 ii = i + (u64)q * blockDim.x;
+            d[q] = (ii < i1 && !msm_skipped(keep, ii)) ? dj[ii] : MSM_NO_DIGIT;
+        }
+        ZK_UNROLL for (int q = 0; q < MSM_SORT_ILP; ++q) {
+            if (d[q] == MSM_NO_DIGIT) continue;
+            const u32 b = d[q] & 0x7fffffffu;
+            const u32 pos = atomicAdd(&hist[b >> MSM_COARSE_BITS], 1u);
+            const u32 entry = (level + (u32)(i + (u64)q * blockDim.x)) | (d[q] & 0x80000000u);
+            pairs[pos] = (unsigned long long)(b & 255u) << 32 | entry;
+        }
+    }
+}
+// tile_off[r] = tiles of the coarse regions before r (tile_off[nbins] = all of them); one workgroup, nbins <= a few thousand
+static constexpr int MSM_TILE_SCAN_THREADS = 256;
+static __global__ void k_msm_tile_offsets(const u32* __restrict__ off, u32 nbins, u32* __restrict__ tile_off) {
+    ZK_PRIO_HIGH();
+    __shared__ u32 sh[MSM_TILE_SCAN_THREADS];
+    __shared__ u32 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 b0 = 0; b0 < nbins; b0 += MSM_TILE_SCAN_THREADS) {
+        const u32 r = b0 + threadIdx.x;
+        u32 x = 0;
+        if (r < nbins) {
+            const u32 size = off[(u64)(r + 1) << MSM_COARSE_BITS] - off[(u64)r << MSM_COARSE_BITS];
+            x = (size + MSM_FINE_TILE - 1) / MSM_FINE_TILE;
+        }
+        sh[threadIdx.x] = x;
+        __syncthreads();
+        for (int d = 1; d < MSM_TILE_SCAN_THREADS; d <<= 1) {
+            const u32 t = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (r < nbins) tile_off[r] = carry + sh[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == MSM_TILE_SCAN_THREADS - 1) carry += sh[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_off[nbins] = carry;
+}
+static __global__ void __launch_bounds__(256) k_msm_part_fine(const unsigned long long* __restrict__ pairs, const u32* __restrict__ off, const u32* __restrict__ tile_off,
+                                                            u32 nbins, u32* __restrict__ cursor, u32* __restrict__ sorted) {
+    ZK_PRIO_HIGH();
+    __shared__ u32 hist[256];
+    const u32 t = blockIdx.x;
+    if (t >= tile_off[nbins]) return;                    // (uniform: the grid is an upper bound)
+    u32 lo = 0, hi = nbins;                              // the region of tile t: tile_off[lo] <= t < tile_off[hi]
+    while (hi - lo > 1) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (tile_off[mid] <= t) lo = mid; else hi = mid;
+    }
+    const u32 r = lo;
+    const u32 rbeg = off[(u64)r << MSM_COARSE_BITS], rend = off[(u64)(r + 1) << MSM_COARSE_BITS];
+    const u32 p0 = rbeg + (t - tile_off[r]) * MSM_FINE_TILE;
+    const u32 p1 = rend - p0 > MSM_FINE_TILE ? p0 + MSM_FINE_TILE : rend;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int PER = MSM_FINE_TILE / 256;
+    unsigned long long e[PER];
+    ZK_UNROLL for (int q = 0; q < PER; ++q) {
+        const u32 p = p0 + threadIdx.x + (u32)q * 256u;
+        e[q] = p < p1 ? pairs[p] : ~0ull;
+    }
+    ZK_UNROLL for (int q = 0; q < PER; ++q)
+        if (e[q] != ~0ull) atomicAdd(&hist[(u32)(e[q] >> 32) & 255u], 1u);
+    __syncthreads();
+    {
+        const u32 key = (r << MSM_COARSE_BITS) + threadIdx.x, have = hist[threadIdx.x];
+        hist[threadIdx.x] = have ? off[key] + atomicAdd(&cursor[key], have) : 0;
+    }
+    __syncthreads();
+    ZK_UNROLL for (int q = 0; q < PER; ++q) {
+        if (e[q] == ~0ull) continue;
+        const u32 b = (u32)(e[q] >> 32) & 255u;
+        const u32 pos = atomicAdd(&hist[b], 1u);
+        ZK_ASSERT_IDX(pos >= off[(r << MSM_COARSE_BITS) + b] && pos < off[(r << MSM_COARSE_BITS) + b + 1]);
+        sorted[pos] = (u32)e[q];
+    }
+}
+
 // ---- 2a. exclusive scan of the counters: one workgroup per chunk of SCAN_CHUNK counters ----
 static constexpr int SCAN_THREADS = 256;
 static constexpr int SCAN_PER_THREAD = 16;
