@@ -593,30 +593,39 @@ static inline void msm_prepare(zkhip_ctx* ctx, Stream s, MsmSort& so, const u32*
     const u64 sort_chunks = std::min(want_chunks, max_chunks);
     const u64 chunk = (sh.n + sort_chunks - 1) / sort_chunks;
     const size_t hist_bytes = (size_t)kh * 4;
-    if (!wm_of) ZK_LAUNCH(k_msm_digits, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, sh.c, sh.W, ptr<u32>(so.dig));
-    const u32* wm = wm_of ? ptr<u32>(wm_of->dig) : ptr<u32>(so.dig);
+    const bool two_level = ctx->sort_two_level && sh.K >= (1u << MSM_COARSE_BITS) && sh.K <= (1u << 16);
+    const u32 nbins = (u32)(nk >> MSM_COARSE_BITS);
     so.cnt.ensure(nk * 4);
     so.cursor.ensure(nk * 4);
-    dev_memset(so.cnt.p, 0, nk * 4, s);
-    dev_memset(so.cursor.p, 0, nk * 4, s);
+    if (two_level) {
+        so.ccur.ensure((size_t)nbins * 4);
+        so.tile_off.ensure(((size_t)nbins + 1) * 4);
+    }
+    // the counters of the passes below start from zero: cleared by the digit kernel on its way (a sort that borrows another's digits:
+    // by a launch of its own)
+    const MsmZero zero{{ptr<u32>(so.cnt), ptr<u32>(so.cursor), two_level ? ptr<u32>(so.ccur) : nullptr}, {(u32)nk, (u32)nk, two_level ? nbins : 0u}};
+    if (!wm_of) ZK_LAUNCH(k_msm_digits, dim3(blocks_for(sh.n, T)), dim3(T), 0, s, d_scalars, sh.n, sh.c, sh.W, ptr<u32>(so.dig), zero);
+    else ZK_LAUNCH(k_msm_zero, dim3(blocks_for(nk, T)), dim3(T), 0, s, zero);
+    const u32* wm = wm_of ? ptr<u32>(wm_of->dig) : ptr<u32>(so.dig);
     lds_opt_in(ctx, (const void*)k_msm_count);
     lds_opt_in(ctx, (const void*)k_msm_place);
     ZK_LAUNCH(k_msm_count, dim3((unsigned)sort_chunks, sh.W, halves), dim3(ZK_SORT_THREADS), hist_bytes, s, wm, sh.n, sh.c, sh.W, chunk, sh.sets, kh,
               ptr<u32>(so.cnt), keep);
-    scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
-    if (ctx->sort_two_level && sh.K >= (1u << MSM_COARSE_BITS) && sh.K <= (1u << 16)) {
-        const u32 nbins = (u32)(nk >> MSM_COARSE_BITS);
+    if (nk <= SCAN_ONE_MAX) {
+        so.off.ensure((nk + 1) * 4);
+        ZK_LAUNCH(k_scan_one, dim3(1), dim3(SCAN_ONE_THREADS), 0, s, ptr<u32>(so.cnt), ptr<u32>(so.off), (u32)nk, two_level ? ptr<u32>(so.tile_off) : (u32*)nullptr, nbins);
+    } else {
+        scan_u32(s, so.cnt, so.off, nk, so.chunk_sum, so.grand);
+        if (two_level) ZK_LAUNCH(k_msm_tile_offsets, dim3(1), dim3(MSM_TILE_SCAN_THREADS), 0, s, ptr<u32>(so.off), nbins, ptr<u32>(so.tile_off));
+    }
+    if (two_level) {
         const u64 total_max = sh.n * (u64)sh.W;
         so.pairs.ensure(std::max<u64>(total_max, 1) * 8);
-        so.ccur.ensure((size_t)nbins * 4);
-        so.tile_off.ensure(((size_t)nbins + 1) * 4);
-        dev_memset(so.ccur.p, 0, (size_t)nbins * 4, s);
         // ~1024 workgroups of the coarse pass (1 KiB of LDS each: they share CUs with anything), chunks of at least 4096 scalars
         const u64 c_chunks = std::max<u64>(1, std::min<u64>((1024 + sh.W - 1) / sh.W, (sh.n + 4095) / 4096));
         const u64 c_chunk = (sh.n + c_chunks - 1) / c_chunks;
         ZK_LAUNCH(k_msm_part_coarse, dim3((unsigned)c_chunks, sh.W), dim3(256), 0, s, wm, sh.n, sh.c, sh.W, c_chunk, sh.sets, level_stride, ptr<u32>(so.off),
                   ptr<u32>(so.ccur), (unsigned long long*)so.pairs.p, keep);
-        ZK_LAUNCH(k_msm_tile_offsets, dim3(1), dim3(MSM_TILE_SCAN_THREADS), 0, s, ptr<u32>(so.off), nbins, ptr<u32>(so.tile_off));
         const u64 max_tiles = total_max / MSM_FINE_TILE + nbins;
         ZK_LAUNCH(k_msm_part_fine, dim3((unsigned)max_tiles), dim3(256), 0, s, (const unsigned long long*)so.pairs.p, ptr<u32>(so.off), ptr<u32>(so.tile_off), nbins,
                   ptr<u32>(so.cursor), ptr<u32>(so.sorted));

@@ -64,8 +64,7 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     lds_opt_in(ctx, (const void*)k_msm_fold_final<F, FS>);
     lds_opt_in(ctx, (const void*)k_msm_fold_final_scan<F, FS>);
     const unsigned T = 256;
-    dev_memset(lane.heavy.p, 0, 4, s);
-    ZK_LAUNCH(k_msm_lane_keys, dim3(blocks_for(nlanes, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.lane_key));
+    ZK_LAUNCH(k_msm_lane_keys, dim3(blocks_for(nlanes, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.lane_key), ptr<u32>(lane.heavy));
     ZK_LAUNCH(k_msm_find_heavy, dim3(blocks_for(sh.nkeys, T)), dim3(T), 0, s, ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.heavy) + 1,
               ptr<u32>(lane.heavy));
     if (accum_after && !ctx->serial) stream_wait_event(s, accum_after);   // (the slicing above only needs the sort)

@@ -175,8 +175,19 @@ static constexpr u32 MSM_HEAVY = 16;  // a bucket spread over more slices than t
 // key = (j % sets) * K + bucket;  sorted entry = ((j / sets) * idx_stride + i) | sign << 31 (idx_stride = table level stride).
 // Signed digit of window j: bucket (|d| - 1) | sign << 31, or MSM_NO_DIGIT.  digit = raw + carry_in, minus 2^c (and a carry out)
 // when that exceeds K = 2^(c-1); zero digits are dropped (a scalar 0 costs nothing, a scalar 1 is one entry of bucket 0).
-static __global__ void k_msm_digits(const u32* __restrict__ scalars, u64 n, int c, int W, u32* __restrict__ dig) {
+// (It also zeroes the counters the passes behind it accumulate into — `za` / `zb` / `zc`, any of them may be null — instead of three
+// fill launches of their own: every launch of a sort that runs beside an accumulation waits for a place of its own, 35-300 us each
+// in a lone proof's trace, profiles/r6h_*gantt*.)
+struct MsmZero { u32* p[3]; u32 n[3]; };
+static __device__ __forceinline__ void msm_zero(const MsmZero& z) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x, stride = (u64)gridDim.x * blockDim.x;
+    ZK_UNROLL for (int k = 0; k < 3; ++k)
+        if (z.p[k]) for (u64 i = g; i < z.n[k]; i += stride) z.p[k][i] = 0;
+}
+static __global__ void k_msm_zero(MsmZero z) { ZK_PRIO_HIGH(); msm_zero(z); }
+static __global__ void k_msm_digits(const u32* __restrict__ scalars, u64 n, int c, int W, u32* __restrict__ dig, MsmZero zero) {
     ZK_PRIO_HIGH();
+    msm_zero(zero);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32* __restrict__ sw = scalars + i * 8;        // 8 canonical words (their 32 bytes stay in the cache across the windows)
@@ -426,6 +437,88 @@ static __global__ void __launch_bounds__(256) k_msm_part_fine(const unsigned lon
     }
 }
 
+// ---- 2. exclusive scan of the counters in ONE workgroup (nk <= SCAN_ONE_MAX: every resident key has 2^16 of them) ----
+// off[k] = counters before k, off[nk] = their sum; with `tile_off` (the two-level placement) also the tiles of every coarse bin —
+// one launch where round 5 ran three (k_scan_local / _chunks / _add below: kept for more counters than one workgroup takes) and
+// the two-level placement a fourth.  Tiles of 4096 counters: a work-item loads four consecutive ones (coalesced 16-byte loads), the
+// wavefront scans its 64 sums with lane shuffles, the 16 wavefronts' totals meet in LDS, a running carry links the tiles.
+static constexpr u32 SCAN_ONE_THREADS = 256, SCAN_ONE_PER = 16, SCAN_ONE_MAX = 1u << 17;
+// (256 work-items: one wavefront per SIMD and 20 registers — a workgroup that finds a place beside accumulation kernels; a first
+// version with 1024 work-items needed a whole CU to itself and waited 2.5 ms for one in a lone proof's trace)
+static __device__ __forceinline__ u32 wave_inclusive_scan(u32 v) {
+    const u32 lane = threadIdx.x & 63u;
+    ZK_UNROLL for (u32 d = 1; d < 64; d <<= 1) {
+        const u32 o = __shfl(v, (int)(lane >= d ? lane - d : lane));
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+static __global__ void __launch_bounds__(256) k_scan_one(const u32* __restrict__ cnt, u32* __restrict__ off, u32 nk, u32* __restrict__ tile_off, u32 nbins) {
+    ZK_PRIO_HIGH();
+    constexpr u32 NW = SCAN_ONE_THREADS / 64, TILE = SCAN_ONE_THREADS * SCAN_ONE_PER;
+    __shared__ u32 wsum[NW];
+    __shared__ u32 coarse[(SCAN_ONE_MAX >> MSM_COARSE_BITS) + 1];      // off at every 256th key
+    const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    u32 carry = 0;
+    for (u32 base = 0; base < nk; base += TILE) {
+        const u32 k = base + SCAN_ONE_PER * t;                         // this work-item's 16 consecutive counters
+        u32 v[SCAN_ONE_PER];
+        if (k + SCAN_ONE_PER <= nk) {
+            ZK_UNROLL for (u32 q = 0; q < SCAN_ONE_PER / 4; ++q) {
+                const uint4 x = *(const uint4*)(cnt + k + 4 * q);
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            }
+        } else {
+            ZK_UNROLL for (u32 i = 0; i < SCAN_ONE_PER; ++i) v[i] = k + i < nk ? cnt[k + i] : 0;
+        }
+        u32 mine = 0;
+        ZK_UNROLL for (u32 i = 0; i < SCAN_ONE_PER; ++i) mine += v[i];
+        const u32 incl = wave_inclusive_scan(mine);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u32 before = carry, all = 0;
+        ZK_UNROLL for (u32 w = 0; w < NW; ++w) {
+            const u32 x = wsum[w];
+            if (w < wave) before += x;
+            all += x;
+        }
+        u32 run = before + incl - mine;
+        ZK_UNROLL for (u32 i = 0; i < SCAN_ONE_PER; ++i) {
+            if (k + i < nk) {
+                off[k + i] = run;
+                if (tile_off && ((k + i) & ((1u << MSM_COARSE_BITS) - 1)) == 0) coarse[(k + i) >> MSM_COARSE_BITS] = run;
+            }
+            run += v[i];
+        }
+        carry += all;
+        __syncthreads();                                           // (wsum is rewritten by the next tile)
+    }
+    if (t == 0) {
+        off[nk] = carry;
+        if (tile_off) coarse[nbins] = carry;
+    }
+    if (!tile_off) return;
+    __syncthreads();
+    // tiles per coarse bin and their exclusive scan (nbins <= 512: two bins per work-item)
+    u32 tcarry = 0;
+    for (u32 b0 = 0; b0 < nbins; b0 += SCAN_ONE_THREADS) {
+        const u32 r = b0 + t;
+        const u32 x = r < nbins ? (coarse[r + 1] - coarse[r] + MSM_FINE_TILE - 1) / MSM_FINE_TILE : 0;
+        const u32 incl = wave_inclusive_scan(x);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u32 before = tcarry, all = 0;
+        ZK_UNROLL for (u32 w = 0; w < NW; ++w) {
+            const u32 y = wsum[w];
+            if (w < wave) before += y;
+            all += y;
+        }
+        if (r < nbins) tile_off[r] = before + incl - x;
+        tcarry += all;
+        __syncthreads();
+    }
+    if (t == 0) tile_off[nbins] = tcarry;
+}
 // ---- 2a. exclusive scan of the counters: one workgroup per chunk of SCAN_CHUNK counters ----
 static constexpr int SCAN_THREADS = 256;
 static constexpr int SCAN_PER_THREAD = 16;
@@ -499,9 +592,10 @@ static __device__ __forceinline__ u32 msm_slice_len(const u32* __restrict__ off,
     return P > cut.min_slice ? P : cut.min_slice;
 }
 // first key of every lane's slice (upper bound over the offsets)
-static __global__ void k_msm_lane_keys(const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32* __restrict__ lane_key) {
+static __global__ void k_msm_lane_keys(const u32* __restrict__ off, u32 nkeys, MsmCut cut, u32* __restrict__ lane_key, u32* __restrict__ heavy_count) {
     ZK_PRIO_HIGH();
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) *heavy_count = 0;            // (k_msm_find_heavy, the next launch of the stream, counts into it)
     if (g >= cut.nlanes) return;
     const u32 P = msm_slice_len(off, nkeys, cut);
     const u64 pos = (u64)g * P;
