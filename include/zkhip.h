@@ -148,6 +148,9 @@ int32_t zkhip_ctx_clock_probe(zkhip_ctx* ctx, uint32_t duration_us, double* ghz_
                                       * workgroups drift apart so that one's loads land under the other's butterflies (kernels_ntt.cuh NttSkew) */
 #define ZKHIP_TUNE_SORT_TWO_LEVEL 23   /* 1 (default): the placement pass of the MSMs' counting sort in two levels (coarse bins of 256 buckets, then
                                       * tiles: line-sized runs, 1 KiB of LDS per workgroup); 0: the one-level pass behind a 128 KiB histogram */
+#define ZKHIP_TUNE_FOLD_LINES 24       /* the row and the column sums of an MSM's bucket matrix in one launch, a workgroup per line (kernels_msm.cuh 5a'):
+                                      * 0 (default) never (two launches: rows, then columns over the stored bucket values), 1 always, 2 for launches over one table */
+#define ZKHIP_TUNE_FOLD_HG 25          /* shares a column of the bucket matrix is cut into by the two-launch fold's column pass (a power of two <= 256) */
 #define ZKHIP_TUNE_HEAVY_RUNS 20      /* 1 (default): the partials of a bucket spread over many slices (the ones of a witness of bits) are
                                       * first summed run by run by a kernel of their own; 0: by the one workgroup of the bucket's row      */
 #define ZKHIP_TUNE_NTT_MAX_SUBLOG 16 /* log2 of the longest sub-transform of an NTT pass (2..11; default 11): domains above 2^(2 x this)

@@ -36,11 +36,11 @@ def schedule_invariance(c2, logn=5, kinds=("dense", "sha")):
                     assert g == gwant, (kind, gate, fuse, waves)
             # the placement pass of the sort, one level (round 5) against two (round 6), and the lone-proof layouts: the same bytes
             for two_level, lone in ((0, 0), (1, 3), (0, 1)):
-                c2.tune("sort_two_level", two_level); c2.tune("lone_sched", lone)
+                c2.tune("sort_two_level", two_level); c2.tune("lone_sched", lone); c2.tune("fold_lines", two_level + lone % 2)
                 assert native.prove_g16(c2, pk, cs, z, *rs[0]) == want[0], (kind, two_level, lone)
                 proofs, _ = native.prove_g16_batch(c2, pk, cs, np.concatenate([z] * len(rs)), rs)
                 assert proofs == want, (kind, two_level, lone)
                 assert native.prove_gm17(c2, gpk, cs, z, 21, 22, 23) == gwant
         finally:
-            c2.tune("z_gate", 1); c2.tune("fuse_z", 1); c2.tune("msm_fused_waves", 0); c2.tune("sort_two_level", 1); c2.tune("lone_sched", 0)
+            c2.tune("z_gate", 1); c2.tune("fuse_z", 1); c2.tune("msm_fused_waves", 0); c2.tune("sort_two_level", 1); c2.tune("lone_sched", 0); c2.tune("fold_lines", 0)
         assert gwant == cpu.gm17_trapdoor(oc, cpu.gm17_toxic_bytes(gtox), z, 21, 23)

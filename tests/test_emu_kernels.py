@@ -117,6 +117,42 @@ def test_msm_fold_fallback(ctx):
         ctx.tune("fold_scan", 1)
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_msm_fold_meets_equal_and_opposite_sums(ctx, curve):
+    """The fold adds bucket SUMS, and two of them can be the same point or opposite ones: the same base under two digits (buckets of one
+    row and of one column: the line sums and the scan both pair them), a bucket whose slices hold equal partial sums, sums that cancel.
+    xyzz_add_from's doubling takes the addition's own tail with other inputs (ec.cuh); both fold layouts must agree with the oracle."""
+    rnd = random.Random(12)
+    G1, G2 = groups(curve)
+    P1, Q1 = (G1.amul(G1.gen, rnd.randrange(1, curve.r)) for _ in range(2))
+    P2, Q2 = (G2.amul(G2.gen, rnd.randrange(1, curve.r)) for _ in range(2))
+    try:
+        for c, ks in ((3, [1, 3, 2, 4]),            # K = 4: buckets 0 and 2 hold P (the tree's first level pairs them), 1 and 3 hold Q and -Q
+                      (3, [1, 2, 3, 4]),
+                      (5, [1, 1 + 4, 9, 9 + 4]),     # K = 16: a 4 x 4 ... (Lw = K: one row) neighbours at every tree distance
+                      (10, [1, 1 + 256, 2, 2 + 256]),   # K = 512, Lw = 256, H = 2: P in one COLUMN (rows 0 and 1), Q / -Q in the next
+                      (4, [5, 5, 5, 5, 5, 5, 5, 5])):   # one bucket, eight entries P Q P Q ...: slices of two hold equal partial sums
+            n = len(ks)
+            if n == 4:
+                p1, p2 = [P1, P1, Q1, G1.aneg(Q1)], [P2, P2, Q2, G2.aneg(Q2)]
+            else:
+                p1, p2 = [P1, Q1] * 4, [P2, Q2] * 4
+            b1 = np.frombuffer(b"".join(formats.ser_g1(curve, P) for P in p1), dtype=np.uint8)
+            b2 = np.frombuffer(b"".join(formats.ser_g2(curve, P) for P in p2), dtype=np.uint8)
+            want1, want2 = cpu.msm(curve.curve_id, 1, b1, le(ks)), cpu.msm(curve.curve_id, 2, b2, le(ks))
+            ctx.tune("msm_c", c)
+            for lines in (1, 0):
+                ctx.tune("fold_lines", lines)
+                for min_slice in (1, 2):
+                    ctx.tune("msm_min_slice", min_slice)
+                    assert ctx.msm(curve.curve_id, 1, b1, le(ks)) == want1, (c, ks, lines, min_slice)
+                    assert ctx.msm(curve.curve_id, 2, b2, le(ks)) == want2, (c, ks, lines, min_slice)
+    finally:
+        ctx.tune("msm_c", 0)
+        ctx.tune("fold_lines", 0)
+        ctx.tune("msm_min_slice", 8)
+
+
 def test_msm_skewed_scalars(ctx):
     """Hot buckets: many scalars equal to 1, many copies of one full-width value and of -1 (a bucket spread over more
     than MSM_HEAVY slices -> workgroup reduction), zeros; several cuts of the sorted list (number of slices, finest

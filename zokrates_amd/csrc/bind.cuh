@@ -28,36 +28,42 @@ namespace zk {
 // (The kernels below carry the fold kernels' waves-per-SIMD target — MsmTuning::COLD_WPE: the out-of-line routines they share with
 // them, xyzz_dbl first of all, are compiled once per translation unit for the LEAST demanding of their callers, and a caller without
 // a target gave them the whole register file: the fold kernels then missed theirs.)
-template <class F>
-ZK_HD_CALL void xyzz_add_acc_call(Xyzz<F>* a, const Xyzz<F>* b) {
-    xyzz_add_acc(*a, *b);
-}
 // -p, coordinates within the stored bounds again (Y < 3p)
 template <class F>
 ZK_HD Xyzz<F> xyzz_neg_u(const Xyzz<F>& p) {
     if (p.is_inf()) return p;
     return {p.x, fe_relax(fe_sub_k<4>(F::zero(), p.y)), p.zz, p.zzz};
 }
-// k * p for a canonical integer k of `nw` 32-bit words: two bits at a time against {p, 2p, 3p} (127 additions instead of the
-// ~254 slots a wavefront pays for a bit-by-bit ladder, whose lanes disagree at every bit).  Out of line, like every big cold routine.
+// k * p for a canonical integer k of `nw` 32-bit words (read where they lie: `k` may point into HBM): two bits at a time against
+// {p, 2p, 3p} (127 additions instead of the ~254 slots a wavefront pays for a bit-by-bit ladder, whose lanes disagree at every bit).
+// The running point stays in REGISTERS: the doublings are inlined and in place (ec.cuh xyzz_dbl_acc), the additions fetch the table
+// entry from the lane's scratch where they use it (xyzz_add_from); `p_mem`: the point, wherever the caller keeps it.  Round 5's form was a chain of
+// out-of-line calls on points in scratch (xyzz_dbl, xyzz_add_acc_call: every operand through memory twice per call, a 2 KB frame):
+// 42 ms per transform stage at 2^20 where the arithmetic alone is ~25.
 template <class F>
-ZK_HD_CALL Xyzz<F> xyzz_mul_words(const Xyzz<F> p, const u32* k, int nw) {
+ZK_HD Xyzz<F> xyzz_mul_words(const Xyzz<F>* p_mem, const u32* __restrict__ k, int nw) {
     Xyzz<F> r = Xyzz<F>::inf();
-    if (p.is_inf()) return r;
-    Xyzz<F> tab[3];
-    tab[0] = p;
-    tab[1] = xyzz_dbl(p);
-    tab[2] = tab[1];
-    xyzz_add_acc_call(&tab[2], &p);
+    if (p_mem->is_inf()) return r;
+    Xyzz<F> tab[3];                                              // p, 2p, 3p
+    {
+        Xyzz<F> t = *p_mem;
+        tab[0] = t;
+        xyzz_dbl_acc(t);
+        tab[1] = t;
+        xyzz_add_from(t, &tab[0]);
+        tab[2] = t;
+    }
     int top = nw * 16 - 1;                                       // highest non-zero two-bit digit
     while (top >= 0 && ((k[top >> 4] >> ((top & 15) * 2)) & 3u) == 0) --top;
     for (int i = top; i >= 0; --i) {
         if (i != top) {
-            r = xyzz_dbl(r);
-            r = xyzz_dbl(r);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+            for (int rep = 0; rep < 2; ++rep) xyzz_dbl_acc(r);
         }
         const u32 d = (k[i >> 4] >> ((i & 15) * 2)) & 3u;
-        if (d) xyzz_add_acc_call(&r, &tab[d - 1]);
+        if (d) xyzz_add_from(r, &tab[d - 1]);
     }
     return r;
 }
@@ -78,9 +84,10 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_bind_scale(cons
         u32 w[2 * AffPacked<F>::NW];
         aff_load_words<F>(tbl, p, w);
         const Aff<F> a = aff_unpack<F>(w);
-        u32 k[12];
-        for (int q = 0; q < nw; ++q) k[q] = blockIdx.y == 0 ? scal[nat * (u64)nw + q] : konst[q];
-        r = xyzz_mul_words<F>(Xyzz<F>::from_affine(a), k, nw);
+        // (the point itself is parked in its output slot: the first entry of the multiplication's table)
+        Xyzz<F>* const slot = out + (u64)blockIdx.y * n + nat;
+        *slot = Xyzz<F>::from_affine(a);
+        r = xyzz_mul_words<F>(slot, blockIdx.y == 0 ? scal + nat * (u64)nw : konst, nw);
     }
     out[(u64)blockIdx.y * n + nat] = r;
 }
@@ -95,20 +102,17 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_bind_fft_stage(
     Xyzz<F>* v = x + (u64)blockIdx.y * n;
     const u64 blk = t / q, pos = t - blk * q;
     const u64 i = blk * 2 * q + pos, j = i + q;
-    const Xyzz<F> a = v[i], b = v[j];
-    Xyzz<F> s = a;
-    xyzz_add_acc_call(&s, &b);
-    Xyzz<F> d = a;
-    const Xyzz<F> nb = xyzz_neg_u(b);
-    xyzz_add_acc_call(&d, &nb);
-    const u64 e = pos * (n / (2 * q));
-    if (e != 0) {
-        u32 k[12];
-        for (int w = 0; w < nw; ++w) k[w] = tw[e * (u64)nw + w];
-        d = xyzz_mul_words<F>(d, k, nw);
+    // the difference first, held while the sum is made and stored; then it goes to its own slot, where the multiplication reads it
+    Xyzz<F> d = v[i];
+    xyzz_add_from(d, &v[j], true);
+    {
+        Xyzz<F> s = v[i];
+        xyzz_add_from(s, &v[j]);
+        v[i] = s;
     }
-    v[i] = s;
     v[j] = d;
+    const u64 e = pos * (n / (2 * q));
+    if (e != 0) v[j] = xyzz_mul_words<F>(&v[j], tw + e * (u64)nw, nw);
 }
 
 template <class F>
@@ -138,15 +142,16 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_bind_cmul(const
                                                    const u32* __restrict__ minus_one, u64 nnz, Xyzz<F>* __restrict__ prod) {
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nnz) return;
-    const Xyzz<F> p = x[bind_bitrev(row[e], logn)];
-    u32 k[12];
+    const Xyzz<F>* const src = x + bind_bitrev(row[e], logn);
     bool is_one = true, is_m1 = true;
     for (int w = 0; w < nw; ++w) {
-        k[w] = val[e * (u64)nw + w];
-        is_one = is_one && k[w] == (w == 0 ? 1u : 0u);
-        is_m1 = is_m1 && k[w] == minus_one[w];
+        const u32 kw = val[e * (u64)nw + w];
+        is_one = is_one && kw == (w == 0 ? 1u : 0u);
+        is_m1 = is_m1 && kw == minus_one[w];
     }
-    prod[e] = is_one ? p : is_m1 ? xyzz_neg_u(p) : xyzz_mul_words<F>(p, k, nw);
+    if (is_one) prod[e] = *src;
+    else if (is_m1) prod[e] = xyzz_neg_u(*src);
+    else prod[e] = xyzz_mul_words<F>(src, val + e * (u64)nw, nw);
 }
 
 // The per-variable sums S_v = l[v] + sum of prod[cptr[v] .. cptr[v+1]) in three stages (round 5 ran ONE workgroup of 64 per variable
@@ -165,10 +170,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_bind_l_sum_shor
     u32 w[2 * AffPacked<F>::NW];
     aff_load_words<F>(l, v, w);
     Xyzz<F> s = Xyzz<F>::from_affine(aff_unpack<F>(w));
-    for (u64 i = b; i < e; ++i) {
-        const Xyzz<F> t = prod[i];
-        xyzz_add_acc_call(&s, &t);
-    }
+    for (u64 i = b; i < e; ++i) xyzz_add_from(s, &prod[i]);
     sum[v] = s;
 }
 template <class F>
@@ -178,16 +180,12 @@ __global__ void __launch_bounds__(64, MsmTuning<F>::COLD_WPE) k_bind_l_sum_long(
     const u64 v = cols[blockIdx.x];
     const u64 b = cptr[v], e = cptr[v + 1];
     Xyzz<F> s = Xyzz<F>::inf();
-    for (u64 i = b + threadIdx.x; i < e; i += 64) {
-        const Xyzz<F> t = prod[i];
-        xyzz_add_acc_call(&s, &t);
-    }
+    for (u64 i = b + threadIdx.x; i < e; i += 64) xyzz_add_from(s, &prod[i]);
     sh[threadIdx.x] = s;
     __syncthreads();
     for (unsigned st = 32; st > 0; st >>= 1) {
         if (threadIdx.x < st) {
-            const Xyzz<F> o = sh[threadIdx.x + st];
-            xyzz_add_acc_call(&s, &o);
+            xyzz_add_from(s, &sh[threadIdx.x + st]);
             sh[threadIdx.x] = s;
         }
         __syncthreads();
@@ -195,8 +193,8 @@ __global__ void __launch_bounds__(64, MsmTuning<F>::COLD_WPE) k_bind_l_sum_long(
     if (threadIdx.x == 0) {
         u32 w[2 * AffPacked<F>::NW];
         aff_load_words<F>(l, v, w);
-        const Xyzz<F> lv = Xyzz<F>::from_affine(aff_unpack<F>(w));
-        xyzz_add_acc_call(&s, &lv);
+        sh[1] = Xyzz<F>::from_affine(aff_unpack<F>(w));       // (slot 1 is free after the tree's last level)
+        xyzz_add_from(s, &sh[1]);
         sum[v] = s;
     }
 }

@@ -157,6 +157,10 @@ struct zkhip_ctx {
     int fold_hg = 32;         // shares a column of rows is cut into in k_msm_fold_cols (a power of two <= 256; ZKHIP_FOLD_HG): 128 rows = 4 serial additions +
                               // 5 tree levels instead of 16 + 3 at 8 (the fold is a chain of dependent additions: Poseidon BLS12-381 8.95 -> 7.85 ms single)
     bool fold_scan = true;    // scan form of the last fold step (else double-and-add)
+    int fold_lines = 0;       // rows and columns of the bucket matrix in one launch (k_msm_fold_lines): 0 never (the rows-then-columns pair), 1 always,
+                              // 2 for launches over ONE table.  Measured and left OFF (profiles/r6m_fold_layouts_ab.txt): twice the workgroups of the
+                              // row pass — over three tables (A, B1, L) they no longer fit the machine in one round (290 us against 178 + 108), over
+                              // one table the launch saved is all there is (210 against 119 + 98); 110-112 proofs/s against 115-116 (ZKHIP_FOLD_LINES)
     bool fuse_z = true;       // A, B1 and L of a proof (one sorted list) as ONE slicing / accumulation / fold launch each
     int msm_fused_waves = 0;  // accumulation waves per SIMD of that launch (0 = per point type)
     int msm_g1_waves = 0, msm_g2_waves = 0;   // slices per SIMD lane of a single-table G1 / G2 accumulation (0 = per point type)

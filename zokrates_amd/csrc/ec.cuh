@@ -291,6 +291,120 @@ ZK_HD void xyzz_add_acc(Xyzz<F>& a, const Xyzz<F>& b) {   // a += b, both XYZZ
     a.x = X3;
 }
 
+// a += *bp for the fold kernels, whose second operand always sits in memory (LDS or the partial sums in HBM): the same products as
+// xyzz_add_acc in an order that lets every coordinate of b be fetched where it is used and die at once, and every coordinate of a
+// be overwritten by what replaces it (X1 by U1, Y1 by S1, ZZ1 by ZZ1 ZZ2, ...): nine field elements alive at the widest point, and
+// the addition fits the accumulation kernels' register budgets (128 for G1, 256 for G2) without a spill.
+// The doubling is not a second formula but a second set of INPUTS to the same tail: dbl-2008-s-1 is add-2008-s with
+//     Pp := 2 Y,  U1 := X,  R := 3 X^2,  S1 := Y,  ZZ1 ZZ2 := ZZ,  ZZZ1 ZZZ2 := ZZZ     and X3 without its "- PPP" term,
+// so two equal bucket sums (practically never) reload b, take ONE out-of-line square and rejoin the common code.  Round 5's fold
+// kernels called an out-of-line doubling instead: its frame — the point in and out, everything alive across the call — was the
+// 0.65 KB (G1) to 2 KB (G2) of scratch per lane those kernels reserved on every queue they ran on, untouched by their hot path.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_MEM_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)   /* neither loads nor arithmetic move across it */
+#else
+#define ZK_MEM_ORDER() ((void)0)
+#endif
+template <class P> ZK_HD Fu<P> ec_sqr_cold(const Fu<P>& a) { return fu_mul(a, a); }
+template <class P> ZK_HD Fu2<P> ec_sqr_cold(const Fu2<P>& a) { return fu2_sqr_call(a); }
+template <class P> ZK_HD Fe<P> ec_sqr_cold(const Fe<P>& a) { return ec_sqr(a); }
+template <class P> ZK_HD Fe2<P> ec_sqr_cold(const Fe2<P>& a) { return ec_sqr(a); }
+// (neg: a -= *bp — b's Y is negated where it is fetched)
+template <class F>
+ZK_HD F xyzz_y_of(const Xyzz<F>* bp, bool neg) {
+    const F y = bp->y;
+    return neg ? fe_relax(fe_sub_k<4>(F::zero(), y)) : y;      // Y < 4p -> 4p - Y, relaxed: < 3p
+}
+template <class F>
+ZK_HD void xyzz_add_from(Xyzz<F>& a, const Xyzz<F>* bp, bool neg = false) {
+    F U1, S1, Pp, R;
+    {
+        const F bzz = bp->zz;
+        if (bzz.is_zero()) return;
+        if (a.is_inf()) { a = *bp; if (neg) a.y = xyzz_y_of(bp, true); return; }
+        U1 = ec_mul(a.x, bzz);                               // X1 dies here
+        ZK_MEM_ORDER();
+        Pp = fe_sub_k<2>(ec_mul(bp->x, a.zz), U1);           // < 4p
+        ZK_MEM_ORDER();
+        a.zz = ec_mul(a.zz, bzz);                            // ZZ1 ZZ2 (times PP below)
+    }
+    ZK_MEM_ORDER();
+    {
+        const F bzzz = bp->zzz;
+        S1 = ec_mul(a.y, bzzz);                              // Y1 dies here
+        ZK_MEM_ORDER();
+        R = fe_sub_k<2>(ec_mul(xyzz_y_of(bp, neg), a.zzz), S1);
+        ZK_MEM_ORDER();
+        a.zzz = ec_mul(a.zzz, bzzz);
+    }
+    ZK_MEM_ORDER();
+    bool dbl = false;
+    if (fe_is_zero_modp(Pp)) {
+        // equal x: opposite points, or the same one — then a + b = 2b, and b is still where it was
+        if (!fe_is_zero_modp(R)) { a = Xyzz<F>::inf(); return; }
+        {
+            const F bx = bp->x;
+            const F X2 = ec_sqr_cold(bx);                    // (nothing but addresses is alive across this call)
+            R = fe_add(fe_dbl(X2), X2);                      // M = 3 X^2 < 6p
+        }
+        ZK_MEM_ORDER();
+        S1 = xyzz_y_of(bp, neg);
+        Pp = fe_dbl(S1);                                     // U = 2 Y < 8p
+        if (fe_is_zero_modp(Pp)) { a = Xyzz<F>::inf(); return; }       // (a point of order two: on neither curve's r-torsion)
+        U1 = bp->x;
+        a.zz = bp->zz;
+        a.zzz = bp->zzz;
+        dbl = true;
+    }
+    const F PP = ec_sqr(Pp);                                 // V
+    ZK_MEM_ORDER();
+    a.zz = ec_mul(a.zz, PP);
+    ZK_MEM_ORDER();
+    const F PPP = ec_mul(Pp, PP);                            // W
+    ZK_MEM_ORDER();
+    a.zzz = ec_mul(a.zzz, PPP);
+    ZK_MEM_ORDER();
+    const F Q = ec_mul(U1, PP);                              // S
+    ZK_MEM_ORDER();
+    const F X3 = fe_relax(fe_sub_k<4>(fe_sub_k<2>(ec_sqr(R), fe_select(dbl, F::zero(), PPP)), fe_dbl(Q)));
+    ZK_MEM_ORDER();
+    const F t = ec_mul(R, fe_sub_k<4>(Q, X3));
+    ZK_MEM_ORDER();
+    a.y = fe_sub_k<2>(t, ec_mul(S1, PPP));
+    a.x = X3;
+}
+
+// a = 2a in place (dbl-2008-s-1), products in an order that overwrites every coordinate where it dies: the running point of a
+// register-resident double-and-add loop (bind.cuh) — at most a, M, U, V alive beside one product's columns
+template <class F>
+ZK_HD void xyzz_dbl_acc(Xyzz<F>& a) {
+    if (a.is_inf()) return;
+    const F U = fe_dbl(a.y);                                 // < 8p
+    if (fe_is_zero_modp(U)) { a = Xyzz<F>::inf(); return; }
+    F M;
+    {
+        const F X2 = ec_sqr(a.x);
+        M = fe_add(fe_dbl(X2), X2);                          // < 6p
+    }
+    ZK_MEM_ORDER();
+    const F V = ec_sqr(U);
+    ZK_MEM_ORDER();
+    a.zz = ec_mul(V, a.zz);
+    ZK_MEM_ORDER();
+    const F S = ec_mul(a.x, V);                              // X dies here
+    ZK_MEM_ORDER();
+    const F W = ec_mul(U, V);                                // U, V die here
+    ZK_MEM_ORDER();
+    a.zzz = ec_mul(W, a.zzz);
+    ZK_MEM_ORDER();
+    const F t = ec_mul(W, a.y);                              // Y, W die here
+    ZK_MEM_ORDER();
+    const F X3 = fe_relax(fe_sub_k<4>(ec_sqr(M), fe_dbl(S)));
+    ZK_MEM_ORDER();
+    a.y = fe_sub_k<2>(ec_mul(M, fe_sub_k<4>(S, X3)), t);
+    a.x = X3;
+}
+
 // out-of-line a += b for the cold kernels (fold, heavy-bucket reduction): one copy of the addition per point
 // type keeps their code small; the accumulator then lives in scratch memory, which is fine off the hot path.
 // It deliberately wraps the out-of-line xyzz_add (whose doubling case is a further call): a single large

@@ -87,16 +87,25 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
         ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(MSM_HEAVY_CHUNKS, nt), dim3(T), (size_t)T * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
                   ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy));
     }
-    ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.sets, nt), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
-              ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy), ctx->heavy_runs ? 1u : 0u, ptr<Xyzz<F>>(lane.bucket),
-              ptr<Xyzz<F>>(lane.rows));
-    // column sums of the K = H x Lw buckets of a set; work-item (lo, hg) adds RG / HG rows serially
-    auto fold_cols = [&](const Xyzz<F>* src, u64 set_stride, u64 msm_stride, u32 Lw, u32 H, u32 RG, Xyzz<F>* dst) {
-        const u32 HG = std::max<u32>(1, std::min<u32>((u32)ctx->fold_hg, RG)), CW = std::min<u32>(Lw, 256 / HG), NG = H / RG;
-        ZK_LAUNCH((k_msm_fold_cols<F>), dim3(Lw / CW, sh.sets * NG, nt), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, src, set_stride, msm_stride, Lw, H, RG, dst);
-    };
     FoldDigits digs{};
-    fold_cols(ptr<Xyzz<F>>(lane.bucket), sh.K, sh.nkeys, sh.Lw, sh.H, sh.H, ptr<Xyzz<F>>(lane.cols));
+    const u32 widest = std::max(sh.H, sh.Lw);
+    if ((ctx->fold_lines == 1 || (ctx->fold_lines == 2 && nt == 1)) && widest <= 256) {
+        // rows and columns of the bucket matrix in ONE launch (kernels_msm.cuh 5a')
+        const unsigned TL = std::max<u32>(64, widest);
+        lds_opt_in(ctx, (const void*)k_msm_fold_lines<F>);
+        ZK_LAUNCH((k_msm_fold_lines<F>), dim3(widest, sh.sets * 2, nt), dim3(TL), (size_t)TL * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
+                  ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, sh.H, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy), ctx->heavy_runs ? 1u : 0u,
+                  ptr<Xyzz<F>>(lane.rows), ptr<Xyzz<F>>(lane.cols));
+    } else {
+        ZK_LAUNCH((k_msm_fold_rows<F>), dim3(sh.H, sh.sets, nt), dim3(sh.Lw), (size_t)sh.Lw * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
+                  ptr<u32>(so.off), sh.nkeys, cut, sh.K, sh.Lw, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy), ctx->heavy_runs ? 1u : 0u, ptr<Xyzz<F>>(lane.bucket),
+                  ptr<Xyzz<F>>(lane.rows));
+        // column sums of the K = H x Lw buckets of a set; work-item (lo, hg) adds RG / HG rows serially
+        const u32 RG = sh.H;
+        const u32 HG = std::max<u32>(1, std::min<u32>((u32)ctx->fold_hg, RG)), CW = std::min<u32>(sh.Lw, 256 / HG), NG = sh.H / RG;
+        ZK_LAUNCH((k_msm_fold_cols<F>), dim3(sh.Lw / CW, sh.sets * NG, nt), dim3(CW, HG), (size_t)CW * HG * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.bucket), (u64)sh.K,
+                  (u64)sh.nkeys, sh.Lw, sh.H, RG, ptr<Xyzz<F>>(lane.cols));
+    }
     digs.d[0] = FoldDigit{lane.cols.p, sh.Lw, 1, 0};
     digs.d[1] = FoldDigit{lane.rows.p, sh.H, 0, (u32)ilog2_floor(sh.Lw)};
     // the scan form of the last fold step: one workgroup of <= 256 work-items per digit; the double-and-add form (two digits

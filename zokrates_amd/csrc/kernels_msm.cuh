@@ -825,19 +825,32 @@ __device__ __forceinline__ Xyzz<F> msm_bucket_sum(const Xyzz<F>* partial, const 
     const u32 g0 = b / P, g1 = (e - 1) / P;
     Xyzz<F> s = partial[(u64)key + g0];
     if (g1 - g0 + 1 <= MSM_HEAVY)
-        for (u32 g = g0 + 1; g <= g1; ++g) xyzz_add_acc(s, partial[(u64)key + g]);
+        for (u32 g = g0 + 1; g <= g1; ++g) xyzz_add_from(s, &partial[(u64)key + g]);
     return s;
 }
 
 // workgroup tree sum over sh[0 .. blockDim.x) (blockDim.x a power of two); result in sh[0]
+// (a level reads slots >= st and writes slots < st: one barrier per level)
 template <class F>
 __device__ __forceinline__ void block_tree_sum(Xyzz<F>* sh) {
     __syncthreads();
     for (unsigned st = blockDim.x >> 1; st > 0; st >>= 1) {
         if (threadIdx.x < st) {
             Xyzz<F> a = sh[threadIdx.x];
-            xyzz_add_acc(a, sh[threadIdx.x + st]);
+            xyzz_add_from(a, &sh[threadIdx.x + st]);
             sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+}
+// the same with the work-item's value `v` kept in registers from level to level (v of work-item 0 ends as the sum; sh[t] = v on entry)
+template <class F>
+__device__ __forceinline__ void block_tree_sum_reg(Xyzz<F>* sh, Xyzz<F>& v, unsigned width) {
+    __syncthreads();
+    for (unsigned st = width >> 1; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            xyzz_add_from(v, &sh[threadIdx.x + st]);
+            if (st > 1) sh[threadIdx.x] = v;
         }
         __syncthreads();
     }
@@ -898,7 +911,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_heavy_reduc
         if (b > r.g1 || r.len == 1) continue;    // (uniform over the workgroup)
         const u32 e = b + r.len - 1 < r.g1 ? b + r.len - 1 : r.g1;
         Xyzz<F> s = Xyzz<F>::inf();
-        for (u32 g = b + lo; g <= e; g += blockDim.x) xyzz_add_acc(s, partial[(u64)hk + g]);
+        for (u32 g = b + lo; g <= e; g += blockDim.x) xyzz_add_from(s, &partial[(u64)hk + g]);
         sh[lo] = s;
         block_tree_sum<F>(sh);
         if (lo == 0) partial[(u64)hk + b] = sh[0];
@@ -925,7 +938,7 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(X
         const HeavyRun r = msm_heavy_run(off, hk, P);
         const u32 g0 = r.g0, g1 = r.g1, step = heavy_runs ? r.len : 1;     // heavy_runs: k_msm_heavy_reduce left one sum per run
         Xyzz<F> s = Xyzz<F>::inf();
-        for (u64 g = g0 + (u64)lo * step; g <= g1; g += (u64)blockDim.x * step) xyzz_add_acc(s, partial[(u64)hk + g]);
+        for (u64 g = g0 + (u64)lo * step; g <= g1; g += (u64)blockDim.x * step) xyzz_add_from(s, &partial[(u64)hk + g]);
         sh[lo] = s;
         block_tree_sum<F>(sh);
         if (lo == 0) partial[(u64)hk + g0] = sh[0];
@@ -938,6 +951,56 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_rows(X
     sh[lo] = v;
     block_tree_sum<F>(sh);
     if (lo == 0) rows[(u64)j * gridDim.x + hi] = sh[0];
+}
+// 5a'. rows AND columns in one launch (H, Lw <= 256: every resident key).  The column sums do not need the row pass: a workgroup
+//     per LINE of the H x Lw bucket matrix — blockIdx.y = 2 set + dir; dir 0: row blockIdx.x, one work-item per lo; dir 1: column
+//     blockIdx.x, one work-item per hi — combines its buckets' partials and tree-sums them; the bucket values are computed twice
+//     (a few additions per bucket, against the ~240 that made it) and never stored.  One kernel and 3-5 + 8 dependent additions
+//     where round 5 ran two (rows, then columns over the stored bucket values: 8 serial + 5 tree levels more) — the fold is a chain
+//     of dependent additions at the end of every MSM, and at the end of a lone proof nothing hides it.
+//     Heavy buckets: the whole workgroup sums the bucket's partials (or the run heads k_msm_heavy_reduce left) and hands the total
+//     to the bucket's work-item through LDS — nothing is written back, the other direction's workgroup reads the same slots.
+template <class F>
+__global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_lines(const Xyzz<F>* __restrict__ partial, u64 partial_stride, const u32* __restrict__ off, u32 nkeys,
+                                                                                MsmCut cut, u32 K, u32 Lw, u32 H, const u32* __restrict__ heavy_list,
+                                                                                const u32* __restrict__ heavy_count, u32 heavy_runs, Xyzz<F>* __restrict__ rows,
+                                                                                Xyzz<F>* __restrict__ cols) {
+    ZK_PRIO_HIGH();
+    ZK_DYN_SMEM(smem);
+    Xyzz<F>* sh = (Xyzz<F>*)smem;
+    const u32 sets = gridDim.y >> 1, j = blockIdx.y >> 1, dir = blockIdx.y & 1u, line = blockIdx.x, t = threadIdx.x;
+    const u32 len = dir ? H : Lw, nlines = dir ? Lw : H;       // work-items of this line, lines of this direction
+    if (line >= nlines) return;                                // (uniform: the grid is max(H, Lw) wide)
+    partial += (u64)blockIdx.z * partial_stride;               // blockIdx.z: which MSM of the launch
+    const u32 P = msm_slice_len(off, nkeys, cut);
+    const u32 set0 = j * K;
+    const bool live = t < len;
+    const u32 key = set0 + (dir ? t * Lw + line : line * Lw + t);
+    Xyzz<F> v = Xyzz<F>::inf();
+    bool have = !live;
+    const u32 nh = *heavy_count;
+    for (u32 h = 0; h < nh; ++h) {
+        const u32 hk = heavy_list[h];
+        const u32 rel = hk - set0;                             // (unsigned: a key of another set wraps far beyond K)
+        if (rel >= K || (dir ? rel % Lw : rel / Lw) != line) continue;     // (uniform over the workgroup)
+        const HeavyRun r = msm_heavy_run(off, hk, P);
+        const u32 step = heavy_runs ? r.len : 1;               // heavy_runs: k_msm_heavy_reduce left one sum per run, at the run's first slot
+        Xyzz<F> s = Xyzz<F>::inf();
+        for (u64 g = r.g0 + (u64)t * step; g <= r.g1; g += (u64)blockDim.x * step) xyzz_add_from(s, &partial[(u64)hk + g]);
+        sh[t] = s;
+        block_tree_sum_reg<F>(sh, s, blockDim.x);
+        if (t == 0) sh[0] = s;
+        __syncthreads();
+        if (live && key == hk) { v = sh[0]; have = true; }
+        __syncthreads();
+    }
+    if (!have) {
+        ZK_ASSERT_IDX(key < nkeys && (u64)key + (off[key + 1] ? (off[key + 1] - 1) / P : 0) < partial_stride);
+        v = msm_bucket_sum<F>(partial, off, key, P);
+    }
+    sh[t] = v;
+    block_tree_sum_reg<F>(sh, v, blockDim.x);
+    if (t == 0) (dir ? cols : rows)[((u64)blockIdx.z * sets + j) * nlines + line] = v;
 }
 // 5b. column sums: work-item (lo, hg) adds its share of the rows serially, then the HG shares are tree-added.
 //     blockDim = (CW, HG); grid = (Lw / CW, sets * NG, MSMs of the launch).  The H rows of a set are cut into NG = H / RG groups
@@ -957,13 +1020,13 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_cols(c
     src += (u64)blockIdx.z * msm_stride + (u64)j * set_stride + (u64)g * RG * Lw;
     dst += (((u64)blockIdx.z * sets + j) * NG + g) * Lw;
     Xyzz<F> s = Xyzz<F>::inf();
-    for (u32 hi = hg; hi < RG; hi += HG) xyzz_add_acc(s, src[(u64)hi * Lw + lo]);
+    for (u32 hi = hg; hi < RG; hi += HG) xyzz_add_from(s, &src[(u64)hi * Lw + lo]);
     sh[hg * blockDim.x + threadIdx.x] = s;
     __syncthreads();
     for (unsigned st = HG >> 1; st > 0; st >>= 1) {
         if (hg < st) {
             Xyzz<F> a = sh[hg * blockDim.x + threadIdx.x];
-            xyzz_add_acc(a, sh[(hg + st) * blockDim.x + threadIdx.x]);
+            xyzz_add_from(a, &sh[(hg + st) * blockDim.x + threadIdx.x]);
             sh[hg * blockDim.x + threadIdx.x] = a;
         }
         __syncthreads();
@@ -1031,29 +1094,20 @@ __global__ void __launch_bounds__(256, MsmTuning<F>::COLD_WPE) k_msm_fold_final_
     if (live) v = src[t];
     sh[t] = v;
     __syncthreads();
-    for (u32 d = 1; d < seglen; d <<= 1) {              // suffix scan
+    for (u32 d = 1; d < seglen; d <<= 1) {              // suffix scan: a step reads (the partner's value, from LDS, inside the addition), then writes
         const bool has = live && t + d < seglen;
-        Xyzz<F> o = Xyzz<F>::inf();
-        if (has) o = sh[t + d];
+        if (has) xyzz_add_from(v, &sh[t + d]);
         __syncthreads();
-        if (has) {
-            xyzz_add_acc(v, o);
-            sh[t] = v;
-        }
+        if (has) sh[t] = v;
         __syncthreads();
     }
-    if (!dg.plus_one && t == 0) sh[0] = Xyzz<F>::inf(); // S_0 carries weight 0
-    __syncthreads();
-    for (u32 st = seglen >> 1; st > 0; st >>= 1) {      // tree sum
-        if (t < st) {
-            Xyzz<F> a = sh[t];
-            xyzz_add_acc(a, sh[t + st]);
-            sh[t] = a;
-        }
-        __syncthreads();
+    if (!dg.plus_one && t == 0) {                       // S_0 carries weight 0
+        v = Xyzz<F>::inf();
+        sh[0] = v;
     }
+    block_tree_sum_reg<F>(sh, v, seglen);
     if (t == 0) {
-        Xyzz<F> r = sh[0];
+        Xyzz<F> r = v;
         for (u32 q = 0; q < dg.dbl; ++q) r = xyzz_dbl_inl(r);
         window_sum[nd * j + blockIdx.z] = xyzz_to_sat<FS>(r);
     }
