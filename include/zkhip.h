@@ -150,6 +150,7 @@ int32_t zkhip_ctx_clock_probe(zkhip_ctx* ctx, uint32_t duration_us, double* ghz_
                                       * tiles: line-sized runs, 1 KiB of LDS per workgroup); 0: the one-level pass behind a 128 KiB histogram */
 #define ZKHIP_TUNE_FOLD_LINES 24       /* the row and the column sums of an MSM's bucket matrix in one launch, a workgroup per line (kernels_msm.cuh 5a'):
                                       * 0 (default) never (two launches: rows, then columns over the stored bucket values), 1 always, 2 for launches over one table */
+#define ZKHIP_TUNE_NTT_FUSE_FIRST 26   /* 1 (default): the first butterfly round of a transform pass on the elements as they are fetched; 0: through LDS like the others */
 #define ZKHIP_TUNE_FOLD_HG 25          /* shares a column of the bucket matrix is cut into by the two-launch fold's column pass (a power of two <= 256) */
 #define ZKHIP_TUNE_HEAVY_RUNS 20      /* 1 (default): the partials of a bucket spread over many slices (the ones of a witness of bits) are
                                       * first summed run by run by a kernel of their own; 0: by the one workgroup of the bucket's row      */

@@ -52,7 +52,10 @@ def test_ntt(ctx, curve, single_max):
         for logn in ((0, 1, 2, 5, 7, 10) if single_max == 10 else (2, 3, 5, 6, 7, 9)):     # even / odd sub-lengths, N1 != N2
             a = le([rnd.randrange(curve.r) for _ in range(1 << logn)])
             for d in ("fft", "ifft", "coset_fft", "coset_ifft"):
-                assert c2.ntt(curve.curve_id, a, d).tobytes() == cpu.ntt(curve.curve_id, a, d).tobytes(), (logn, d)
+                want = cpu.ntt(curve.curve_id, a, d).tobytes()
+                for fuse in (1, 0):      # the first round of a pass on the way in (sub-transforms of 16 points and more) / through LDS
+                    c2.tune("ntt_fuse_first", fuse)
+                    assert c2.ntt(curve.curve_id, a, d).tobytes() == want, (logn, d, fuse)
     finally:
         c2.close()
 

@@ -180,6 +180,7 @@ struct zkhip_ctx {
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_max_sublog = 11;  // largest sub-transform of a pass (2^11 elements staged per sequence); domains above twice this take three passes
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
+    int ntt_fuse_first = 1;   // the first butterfly round of a pass done on the elements as they are fetched (kernels_ntt.cuh ntt_first_round; ZKHIP_NTT_FUSE_FIRST=0: every round through LDS)
     int ntt_skew_us = 0;      // start skew of a transform pass's first round of workgroups (kernels_ntt.cuh NttSkew; ZKHIP_NTT_SKEW_US)
     u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
     int sort_two_level = 1;   // the placement pass of the sort in two levels (coarse bins of 256 buckets, then tiles: kernels_msm.cuh 1b); 0: round 5's
@@ -437,7 +438,7 @@ static void ntt_cols(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool 
                      int canon = 0, const typename C::Fr* minus = nullptr) {
     typedef typename C::Fr Fr;
     ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3((unsigned)(pl->Nb / pl->C_cols), nvec), dim3(pl->threads_cols), pl->smem_cols, ctx->ws, data, vec_stride,
-              pl->log1, (u32)pl->Nb, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon, minus, (u64)0, ~(u64)0, ntt_skew(ctx, pl->smem_cols));
+              pl->log1, (u32)pl->Nb, pl->C_cols, ptr<u32>(pl->plan1[inverse ? 1 : 0]), pl->plen1, post, canon, minus, (u64)0, ~(u64)0, ntt_skew(ctx, pl->smem_cols), ctx->ntt_fuse_first);
 }
 // three passes only — the pass over N2: columns of the N2 x N3 matrix of every outer index (grid.z).  `post_mask`: Nb - 1 for
 // the per-block twiddles, all ones for a table as long as the vector.
@@ -445,7 +446,7 @@ template <class C>
 static void ntt_mid(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool inverse, const typename C::Fr* post, u64 post_mask, int nvec, u64 vec_stride) {
     typedef typename C::Fr Fr;
     ZK_LAUNCH((k_ntt_cols<typename Fr::Params>), dim3(pl->N3 / pl->C_mid, nvec, pl->N1), dim3(pl->threads_mid), pl->smem_mid, ctx->ws, data, vec_stride,
-              pl->log2, pl->N3, pl->C_mid, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, 0, (const Fr*)nullptr, pl->Nb, post_mask, ntt_skew(ctx, pl->smem_mid));
+              pl->log2, pl->N3, pl->C_mid, ptr<u32>(pl->plan2[inverse ? 1 : 0]), pl->plen2, post, 0, (const Fr*)nullptr, pl->Nb, post_mask, ntt_skew(ctx, pl->smem_mid), ctx->ntt_fuse_first);
 }
 // the pass over the last factor: contiguous sequences
 template <class C>
@@ -456,7 +457,7 @@ static void ntt_rows(zkhip_ctx* ctx, NttPlan<C>* pl, typename C::Fr* data, bool 
     const int lg = three ? pl->log3 : pl->log2;
     ZK_LAUNCH((k_ntt_rows<typename Fr::Params>), dim3((unsigned)((pl->N >> lg) / pl->R_rows), nvec), dim3(pl->threads_rows), pl->smem_rows, ctx->ws, data, vec_stride,
               lg, pl->R_rows, ptr<u32>((three ? pl->plan3 : pl->plan2)[inverse ? 1 : 0]), three ? pl->plen3 : pl->plen2, post, canon, minus, post_mask,
-              ntt_skew(ctx, pl->smem_rows));
+              ntt_skew(ctx, pl->smem_rows), ctx->ntt_fuse_first);
 }
 // natural order in -> sigma order out
 template <class C>

@@ -317,22 +317,34 @@ __device__ __forceinline__ Fu<P> ntt_plan_get(const u32* __restrict__ plan, u32 
     return r;
 }
 
+// The product of the passes: one operand a twiddle / element-wise factor straight from its table (TIGHT, limbs < 2^B), the other
+// TIGHT or a lazily added / subtracted pair (limbs < 2^(B+2)) — the operand shapes the loose quotient digits of fieldu.cuh are
+// sized for (fu_mul_loose: eight masks fewer per product; UConst::LOOSE_OK checked at compile time, the columns in the
+// ZK_CHECK_OVERFLOW builds).
+#ifndef ZK_NTT_LOOSE
+#define ZK_NTT_LOOSE 1
+#endif
+template <class P>
+__device__ __forceinline__ Fu<P> fu_mul_ntt(const Fu<P>& a, const Fu<P>& b) {
+    return ZK_NTT_LOOSE ? fu_mul_loose(a, b) : fu_mul_inl(a, b);
+}
 // In-place DIF over `nseq` sequences of n = 2^logn points; the result is left in bit-reversed index order.
 // Radix-4 butterflies = two radix-2 stages each:
 //   (a, b, c, d) at i, i+q, i+2q, i+3q (q = L/4)  ->  a+b+c+d | (a-b+c-d) w^2pos | (a-c + w4(b-d)) w^pos | (a-c - w4(b-d)) w^3pos
 // Value bounds (fieldu.cuh): inputs < 2p; sums/differences < 12p; products < 2p; the untwiddled output is brought back
 // below 2p by fe_relax.  The last round of an even-length transform has trivial twiddles and leaves values < 12p, which
 // the store path of the passes accepts.
+// (first_done: the round of length n has been done on the way in — ntt_first_round below — and the data in LDS is its output)
 template <class P>
-__device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn, int nseq, const u32* __restrict__ plan, u32 plen) {
+__device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn, int nseq, const u32* __restrict__ plan, u32 plen, bool first_done = false) {
     typedef Fu<P> U;
     const int n = 1 << logn;
     const int T = blockDim.x;
     if (logn >= 2) {
         const int per_seq = n >> 2, nbf = nseq * per_seq;
-        u32 off = 0;
-        int logq = logn - 2;                      // log2 of q = L / 4 (every length is a power of two: shifts, no divisions)
-        for (int L = n; L >= 4; L >>= 2, logq -= 2) {
+        u32 off = first_done ? 3u * (u32)(n >> 2) : 0u;
+        int logq = first_done ? logn - 4 : logn - 2;                      // log2 of q = L / 4 (every length is a power of two: shifts, no divisions)
+        for (int L = first_done ? n >> 2 : n; L >= 4; L >>= 2, logq -= 2) {
             const int q = L >> 2;
             for (int b = threadIdx.x; b < nbf; b += T) {
                 const int seq = b >> (logn - 2), bb = b & (per_seq - 1);
@@ -344,7 +356,7 @@ __device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn,
                 {
                     const U bq = lds_get_u<P>(lds, PL, s1), d = lds_get_u<P>(lds, PL, s3);
                     t2 = fe_add(bq, d);
-                    t3 = fu_mul_inl(fe_sub_k_lazy<4>(bq, d), ntt_plan_get<P>(plan, plen, plen - 1));   // * w4 (a difference that is
+                    t3 = fu_mul_ntt<P>(fe_sub_k_lazy<4>(bq, d), ntt_plan_get<P>(plan, plen, plen - 1));   // * w4 (a difference that is
                                                                                   // multiplied at once skips its carry round: fieldu.cuh)
                 }
                 U t0, t1;
@@ -355,9 +367,9 @@ __device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn,
                 }
                 lds_put_u<P>(lds, PL, s0, fe_relax(fe_add(t0, t2)));
                 if (L > 4) {
-                    lds_put_u<P>(lds, PL, s1, fu_mul_inl(fe_sub_k_lazy<8>(t0, t2), ntt_plan_get<P>(plan, plen, off + q + pos)));
-                    lds_put_u<P>(lds, PL, s2, fu_mul_inl(fe_add_lazy(t1, t3), ntt_plan_get<P>(plan, plen, off + pos)));
-                    lds_put_u<P>(lds, PL, s3, fu_mul_inl(fe_sub_k_lazy<4>(t1, t3), ntt_plan_get<P>(plan, plen, off + 2 * q + pos)));
+                    lds_put_u<P>(lds, PL, s1, fu_mul_ntt<P>(fe_sub_k_lazy<8>(t0, t2), ntt_plan_get<P>(plan, plen, off + q + pos)));
+                    lds_put_u<P>(lds, PL, s2, fu_mul_ntt<P>(fe_add_lazy(t1, t3), ntt_plan_get<P>(plan, plen, off + pos)));
+                    lds_put_u<P>(lds, PL, s3, fu_mul_ntt<P>(fe_sub_k_lazy<4>(t1, t3), ntt_plan_get<P>(plan, plen, off + 2 * q + pos)));
                 } else {
                     lds_put_u<P>(lds, PL, s1, fe_sub_k<8>(t0, t2));
                     lds_put_u<P>(lds, PL, s2, fe_add(t1, t3));
@@ -379,6 +391,26 @@ __device__ __forceinline__ void lds_ntt_dif4(u32* lds, int PL, int SS, int logn,
         }
         __syncthreads();
     }
+}
+// The FIRST radix-4 round of a sub-transform (length n, q = n / 4), done on the four elements a work-item has just fetched —
+// positions pos, pos + q, pos + 2q, pos + 3q of sequence `seq` are exactly what a pass's load phase hands one work-item when the
+// workgroup has a quarter as many work-items as the tile has elements — and written to LDS as that round's output: the tile skips
+// one trip through LDS (nine stores and nine loads per element) and one barrier of the pass's seven.  Needs n >= 16 (a twiddled
+// round); same arithmetic and bounds as the round in lds_ntt_dif4.
+template <class P>
+__device__ __forceinline__ void ntt_first_round(u32* lds, int PL, int base, int logn, int pos, const Fu<P>& a, const Fu<P>& bq, const Fu<P>& c, const Fu<P>& d,
+                                                const u32* __restrict__ plan, u32 plen) {
+    typedef Fu<P> U;
+    const int q = 1 << (logn - 2);
+    const int s0 = base + ntt_slot(pos), s1 = base + ntt_slot(pos + q), s2 = base + ntt_slot(pos + 2 * q), s3 = base + ntt_slot(pos + 3 * q);
+    const U t2 = fe_add(bq, d);
+    const U t3 = fu_mul_ntt<P>(fe_sub_k_lazy<4>(bq, d), ntt_plan_get<P>(plan, plen, plen - 1));
+    const U t0 = fe_add(a, c);
+    const U t1 = fe_sub_k<4>(a, c);
+    lds_put_u<P>(lds, PL, s0, fe_relax(fe_add(t0, t2)));
+    lds_put_u<P>(lds, PL, s1, fu_mul_ntt<P>(fe_sub_k_lazy<8>(t0, t2), ntt_plan_get<P>(plan, plen, (u32)(q + pos))));
+    lds_put_u<P>(lds, PL, s2, fu_mul_ntt<P>(fe_add_lazy(t1, t3), ntt_plan_get<P>(plan, plen, (u32)pos)));
+    lds_put_u<P>(lds, PL, s3, fu_mul_ntt<P>(fe_sub_k_lazy<4>(t1, t3), ntt_plan_get<P>(plan, plen, (u32)(2 * q + pos))));
 }
 static __device__ __forceinline__ int bitrev_n(int x, int logn) { return logn ? (int)(__brev((unsigned)x) >> (32 - logn)) : 0; }
 
@@ -405,7 +437,7 @@ __device__ __forceinline__ void ntt_store_with(uint4* __restrict__ data, size_t 
                                                const uint4* __restrict__ minus, size_t pg) {
     if (have_post) {
         const u32 w[8] = {plo.x, plo.y, plo.z, plo.w, phi.x, phi.y, phi.z, phi.w};
-        x = fu_mul_inl(x, fu_unpack<P>(w));
+        x = fu_mul_ntt<P>(x, fu_unpack<P>(w));
     } else {
         x = fe_relax(x);
     }
@@ -497,7 +529,7 @@ static __device__ __forceinline__ void ntt_start_skew(NttSkew sk) {
 template <class P>
 __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n1, u32 n2, int C, const u32* __restrict__ plan,
                                                      u32 plen, const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr,
-                                                     u64 batch_stride = 0, u64 post_mask = ~(u64)0, NttSkew skew = NttSkew{0, 0}) {
+                                                     u64 batch_stride = 0, u64 post_mask = ~(u64)0, NttSkew skew = NttSkew{0, 0}, int fuse_first = 1) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     static_assert(P::N == 8, "Fr is 8 x 32-bit words");
@@ -513,6 +545,9 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __re
     const u32 c0 = tile * C;
     const int total = C * n1;
     const int logC = 31 - __clz(C);                 // (C is a power of two)
+    // a quarter as many work-items as elements: what a work-item fetches — rows k, k + n1/4, k + 2 n1/4, k + 3 n1/4 of one column — is
+    // one butterfly of the first round, which is then done on the way in (ntt_first_round)
+    const bool fused = fuse_first && total == NTT_BATCH * (int)blockDim.x && log_n1 >= 4;
     for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
         uint4 lo[NTT_BATCH] = {}, hi[NTT_BATCH] = {};
         ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
@@ -523,13 +558,18 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __re
                 hi[q] = data[2 * g + 1];
             }
         }
-        ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
-            const int e = e0 + q * blockDim.x;
-            if (e < total) lds_put_u<P>(lds, PL, (e & (C - 1)) * SS + ntt_slot(e >> logC), ntt_unpack_words<P>(lo[q], hi[q]));
+        if (fused) {
+            ntt_first_round<P>(lds, PL, (e0 & (C - 1)) * SS, log_n1, e0 >> logC, ntt_unpack_words<P>(lo[0], hi[0]), ntt_unpack_words<P>(lo[1], hi[1]),
+                               ntt_unpack_words<P>(lo[2], hi[2]), ntt_unpack_words<P>(lo[3], hi[3]), plan, plen);
+        } else {
+            ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+                const int e = e0 + q * blockDim.x;
+                if (e < total) lds_put_u<P>(lds, PL, (e & (C - 1)) * SS + ntt_slot(e >> logC), ntt_unpack_words<P>(lo[q], hi[q]));
+            }
         }
     }
     __syncthreads();
-    lds_ntt_dif4<P>(lds, PL, SS, log_n1, C, plan, plen);
+    lds_ntt_dif4<P>(lds, PL, SS, log_n1, C, plan, plen, fused);
     for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
         uint4 plo[NTT_BATCH] = {}, phi[NTT_BATCH] = {};
         if (post) {
@@ -558,7 +598,7 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_cols(Fe<P>* __re
 template <class P>
 __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_rows(Fe<P>* __restrict__ data_, u64 vec_stride, int log_n2, int R, const u32* __restrict__ plan, u32 plen,
                                                      const Fe<P>* __restrict__ post_, int canon, const Fe<P>* __restrict__ minus_ = nullptr,
-                                                     u64 post_mask = ~(u64)0, NttSkew skew = NttSkew{0, 0}) {
+                                                     u64 post_mask = ~(u64)0, NttSkew skew = NttSkew{0, 0}, int fuse_first = 1) {
     ZK_PRIO_HIGH();
     ZK_DYN_SMEM(smem);
     ntt_start_skew(skew);
@@ -571,22 +611,37 @@ __global__ void __launch_bounds__(512, ZK_NTT_WGS_PER_CU) k_ntt_rows(Fe<P>* __re
     const int SS = n2 + (n2 >> 5) + 1, PL = R * SS;
     const size_t base = (size_t)tile * R * n2;
     const int total = R * n2;
-    for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
-        uint4 lo[NTT_BATCH] = {}, hi[NTT_BATCH] = {};
+    // (as in the cols pass: with a quarter as many work-items as elements, work-item t fetches positions pos + k n2/4 of row t / (n2/4)
+    // — one butterfly of the first round — and does it on the way in)
+    const bool fused = fuse_first && total == NTT_BATCH * (int)blockDim.x && log_n2 >= 4;
+    if (fused) {
+        const int seq = (int)threadIdx.x >> (log_n2 - 2), pos = (int)threadIdx.x & ((n2 >> 2) - 1);
+        uint4 lo[NTT_BATCH], hi[NTT_BATCH];
         ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
-            const int e = e0 + q * blockDim.x;
-            if (e < total) {
-                lo[q] = data[2 * (base + e)];
-                hi[q] = data[2 * (base + e) + 1];
-            }
+            const size_t g = base + (size_t)seq * n2 + pos + (size_t)q * (n2 >> 2);
+            lo[q] = data[2 * g];
+            hi[q] = data[2 * g + 1];
         }
-        ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
-            const int e = e0 + q * blockDim.x;
-            if (e < total) lds_put_u<P>(lds, PL, (e >> log_n2) * SS + ntt_slot(e & (n2 - 1)), ntt_unpack_words<P>(lo[q], hi[q]));
+        ntt_first_round<P>(lds, PL, seq * SS, log_n2, pos, ntt_unpack_words<P>(lo[0], hi[0]), ntt_unpack_words<P>(lo[1], hi[1]), ntt_unpack_words<P>(lo[2], hi[2]),
+                           ntt_unpack_words<P>(lo[3], hi[3]), plan, plen);
+    } else {
+        for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
+            uint4 lo[NTT_BATCH] = {}, hi[NTT_BATCH] = {};
+            ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+                const int e = e0 + q * blockDim.x;
+                if (e < total) {
+                    lo[q] = data[2 * (base + e)];
+                    hi[q] = data[2 * (base + e) + 1];
+                }
+            }
+            ZK_UNROLL for (int q = 0; q < NTT_BATCH; ++q) {
+                const int e = e0 + q * blockDim.x;
+                if (e < total) lds_put_u<P>(lds, PL, (e >> log_n2) * SS + ntt_slot(e & (n2 - 1)), ntt_unpack_words<P>(lo[q], hi[q]));
+            }
         }
     }
     __syncthreads();
-    lds_ntt_dif4<P>(lds, PL, SS, log_n2, R, plan, plen);
+    lds_ntt_dif4<P>(lds, PL, SS, log_n2, R, plan, plen, fused);
     for (int e0 = threadIdx.x; e0 < total; e0 += NTT_BATCH * blockDim.x) {
         uint4 plo[NTT_BATCH] = {}, phi[NTT_BATCH] = {};
         if (post) {

@@ -152,6 +152,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->sort_kh_log = env_int("ZKHIP_SORT_KH_LOG", 8, 15, 15);
         ctx->sort_two_level = env_int("ZKHIP_SORT_TWO_LEVEL", 0, 1, 1);
         ctx->fold_lines = env_int("ZKHIP_FOLD_LINES", 0, 2, 0);
+        ctx->ntt_fuse_first = env_int("ZKHIP_NTT_FUSE_FIRST", 0, 1, 1);
         // every (slot, lane) has a stream of its own: with one stream per lane shared by the slots, the accumulation of
         // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
         // fold workgroup holding the machine 16 % of the time).  Slot 0 — the one single proofs and the primitives use — is
@@ -249,6 +250,7 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_NTT_SKEW_US: in(0, 200); ctx->ntt_skew_us = value; break;
             case ZKHIP_TUNE_SORT_TWO_LEVEL: in(0, 1); ctx->sort_two_level = value; break;
             case ZKHIP_TUNE_FOLD_LINES: in(0, 2); ctx->fold_lines = value; break;
+            case ZKHIP_TUNE_NTT_FUSE_FIRST: in(0, 1); ctx->ntt_fuse_first = value; break;
             case ZKHIP_TUNE_FOLD_HG: in(1, 256); ctx->fold_hg = 1 << ilog2_floor((u64)value); break;
             case ZKHIP_TUNE_FUSE_Z: in(0, 1); ctx->fuse_z = value != 0; break;
             case ZKHIP_TUNE_MSM_FUSED_WAVES: in(0, 8); ctx->msm_fused_waves = value; break;
