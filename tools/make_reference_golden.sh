@@ -11,7 +11,7 @@
 # usage: tools/make_reference_golden.sh <path to the zokrates binary> [<stdlib path>] [<output directory>]
 #   e.g. (in a checkout of the reference)  cargo build --release -p zokrates_cli
 #        tools/make_reference_golden.sh target/release/zokrates zokrates_stdlib/stdlib
-# Cases: Groth16 on bn128 and bls12_381, GM17 on bn128; a program with outputs (`~out_i` become instance variables:
+# Cases: Groth16 on bn128 and bls12_381, GM17 on bn128 and bls12_381; a program with outputs (`~out_i` become instance variables:
 # zokrates_ark/src/lib.rs:52-69), one whose variables are first seen out of order in the constraints (the allocation order of
 # generate_constraints), one with a public and a private argument mixed, and the SHA-256 example of BASELINE.json configs[0].
 set -euo pipefail
@@ -73,6 +73,20 @@ def main(field p, private field s) -> field {
         acc = acc * acc + s;
     }
     return acc;
+}
+ZOK
+
+# GM17 a second time, on the other curve.  Cases 4 and 6 are THE test of a property of this repository's restatement that only
+# ark-gm17 0.3.0's create_proof can confirm: of its three draws (d1, d2, r) the proof depends on d1 and r only
+# through r + d1, and not on d2 at all.
+case_ chain_bls12_381_gm17 bls12_381 gm17 "golden vector 6" 4 17 <<'ZOK'
+def main(private field a, field b) -> field {
+    field mut t = a + b;
+    for u32 i in 0..4 {
+        t = t * t * a + b;
+    }
+    assert(t != a);
+    return t;
 }
 ZOK
 
