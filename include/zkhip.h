@@ -142,14 +142,19 @@ int32_t zkhip_ctx_clock_probe(zkhip_ctx* ctx, uint32_t duration_us, double* ghz_
                                       * of them are (real circuits: every variable that does not occur in B), 1 = always, 2 = never       */
 #define ZKHIP_TUNE_LONE_SCHED 21      /* how a LONE proof (the single-proof entry points) is laid out on the device, bits: 1 = its G2 accumulation
                                       * takes one workgroup per CU at raised wave priority, so that the short kernels of the witness map and the
-                                      * sorts find room beside it; 2 = its G1 lanes over the assignment also wait for the sort of h.  Batches are
-                                      * untouched; no setting changes a result. */
+                                      * sorts find room beside it; 2 = its G1 lanes over the assignment also wait for the sort of h; 4 = its witness
+                                      * map waits for the sort of the assignment.  Batches are untouched; no setting changes a result. */
 #define ZKHIP_TUNE_NTT_SKEW_US 22     /* start skew (microseconds, 0 = off) of the first round of workgroups of every transform pass: co-resident
                                       * workgroups drift apart so that one's loads land under the other's butterflies (kernels_ntt.cuh NttSkew) */
 #define ZKHIP_TUNE_SORT_TWO_LEVEL 23   /* 1 (default): the placement pass of the MSMs' counting sort in two levels (coarse bins of 256 buckets, then
                                       * tiles: line-sized runs, 1 KiB of LDS per workgroup); 0: the one-level pass behind a 128 KiB histogram */
 #define ZKHIP_TUNE_FOLD_LINES 24       /* the row and the column sums of an MSM's bucket matrix in one launch, a workgroup per line (kernels_msm.cuh 5a'):
                                       * 0 (default) never (two launches: rows, then columns over the stored bucket values), 1 always, 2 for launches over one table */
+#define ZKHIP_TUNE_PIPE_PLAN 28        /* 1: every stream of the context made at its first proof and placed on the chip's four dispatchers by plan — each accumulation
+                                         lane type on one of its own, the fold chains on the fourth (core.cuh make_pipe_streams; 16 streams: ask zkhip_init for 16
+                                         queues).  For accumulation-bound provers (dense circuits of 2^20 constraints and more: +1-3 % proofs/s); thin circuits
+                                         run 5-15 % slower under it.  0 (default): streams made as they are first used.  Chosen before the first proof */
+#define ZKHIP_TUNE_FOLD_HOP 27         /* the fold chain of an MSM on a second stream of its lane: 0 never, 1 every lane, 2 the G2 lane only */
 #define ZKHIP_TUNE_NTT_FUSE_FIRST 26   /* 1 (default): the first butterfly round of a transform pass on the elements as they are fetched; 0: through LDS like the others */
 #define ZKHIP_TUNE_FOLD_HG 25          /* shares a column of the bucket matrix is cut into by the two-launch fold's column pass (a power of two <= 256) */
 #define ZKHIP_TUNE_HEAVY_RUNS 20      /* 1 (default): the partials of a bucket spread over many slices (the ones of a witness of bits) are

@@ -13,12 +13,15 @@ use std::os::raw::c_char;
 pub const ZKHIP_CURVE_BN128: i32 = 0;
 pub const ZKHIP_CURVE_BLS12_381: i32 = 1;
 
+pub const ZKHIP_TUNE_PIPE_PLAN: i32 = 28;
+
 extern "C" {
     /// process-wide, before the first context: ask the HIP runtime for `hw_queues` hardware queues (the library never sets
     /// GPU_MAX_HW_QUEUES on its own; 8 for a resident prover, 16 if it is the only context of its process, 0 = leave it)
     pub fn zkhip_init(hw_queues: i32) -> i32;
     pub fn zkhip_ctx_create(device: i32, out: *mut *mut zkhip_ctx) -> i32;
     pub fn zkhip_ctx_free(ctx: *mut zkhip_ctx);
+    pub fn zkhip_ctx_tune(ctx: *mut zkhip_ctx, which: i32, value: i32) -> i32;
     pub fn zkhip_last_error(ctx: *const zkhip_ctx) -> *const c_char;
     pub fn zkhip_pk_load_g16(ctx: *mut zkhip_ctx, curve: i32, bytes: *const u8, len: usize, out: *mut *mut zkhip_pk) -> i32;
     pub fn zkhip_pk_load_gm17(ctx: *mut zkhip_ctx, curve: i32, bytes: *const u8, len: usize, out: *mut *mut zkhip_pk) -> i32;

@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
         const std::string entropy = argv[4];
         const Scheme scheme = std::string(argv[5]) == "gm17" ? Scheme::GM17 : Scheme::G16;
         Hip hip(0);
+        hip.separate_dispatchers();                           // (a stream plan is placement only: the same bytes on any layout)
         Program prog(out.data(), out.size());
         Key key = hip.load_proving_key(scheme, prog.curve(), pkb.data(), pkb.size());
         System sys = hip.load_system(prog);

@@ -13,7 +13,7 @@ from oracle.fields import BN254, BLS12_381
 from zokrates_amd import native
 
 from emu_util import emu_library
-from schedule_checks import schedule_invariance
+from schedule_checks import schedule_invariance, stream_plan_invariance
 
 CURVES = [BN254, BLS12_381]
 
@@ -431,6 +431,10 @@ def test_b_family_on_a_list_of_its_own(mode):
 
 def test_schedule_does_not_change_proofs(ctx):
     schedule_invariance(ctx, logn=5, kinds=("dense",))
+
+
+def test_stream_plan_does_not_change_proofs():
+    stream_plan_invariance(lambda: native.Context(0, emu_library()), logn=5)
 
 
 def test_two_pass_prove(ctx):

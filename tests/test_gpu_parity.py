@@ -194,6 +194,12 @@ def test_schedule_does_not_change_proofs(ctx):
     schedule_invariance(ctx, logn=12)
 
 
+def test_stream_plan_does_not_change_proofs():
+    """The resident prover's stream plan (ZKHIP_TUNE_PIPE_PLAN) on the device: a context of its own (the plan is fixed at the first proof)."""
+    from schedule_checks import stream_plan_invariance
+    stream_plan_invariance(lambda: native.Context(0), logn=12)
+
+
 def test_pairing_accepts_device_proof(ctx):
     """O3: the verification equation of zokrates_proof_systems/src/scheme/groth16.rs:156-172 accepts the
     device proof and rejects a mutated one (to_token.rs:68-71)."""

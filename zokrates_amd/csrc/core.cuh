@@ -108,6 +108,13 @@ struct MsmLane {
     bool high_priority = false;
     DBuf lane_key, heavy, partial, bucket, rows, cols;
     Event done = nullptr;
+    Stream fold_stream = 0;   // a second stream for the lane's fold chain (zkhip_ctx::fold_hop; made on first use: lane_fold_stream)
+    bool fold_made = false;
+    bool fold_owned = true;   // (false: one stream per lane TYPE, shared by the slots and owned by the context — make_pipe_streams)
+    Event acc_done = nullptr; // ... which waits for this event behind the lane's accumulation
+    bool lone_launch = false; // THIS launch of the lane belongs to a lone proof: its fold hops only to the lane's lone fold stream, if the plan made one
+    Stream lone_fold_stream = 0;   // ("gl" / "zl" / "hl" of the stream plan: slot 0's lanes)
+    bool lone_fold_made = false;
     bool share_cu = false;    // THIS launch of the lane: one accumulation workgroup per CU (LDS padding) at raised wave priority — a lone proof's
                               // G2 lane (zkhip_ctx::lone_sched); reset by msm_run_tables
 };
@@ -127,6 +134,8 @@ struct ProofSlot {
     Event half_ready = nullptr;                           // a member of a multi-GPU proof: its half of the witness map (a or b on the coset) is in va
     int half = -1;                                        // which half this proof's head computed (-1: the whole witness map)
     bool lone = false;                                    // (enqueue_head -> enqueue_tail)
+    Stream fold_slot = 0;                                 // one stream for the fold chains of this slot's three lanes ("f" of the stream plan)
+    bool fold_slot_made = false;
     bool ready = false;        // streams and events exist (slot_init)
     // the proof currently in flight in this slot
     bool busy = false;
@@ -180,6 +189,17 @@ struct zkhip_ctx {
     int ntt_single_max = 10;  // largest domain handled by one LDS-resident pass
     int ntt_max_sublog = 11;  // largest sub-transform of a pass (2^11 elements staged per sequence); domains above twice this take three passes
     int ntt_cols = 2;         // adjacent columns per workgroup of the cols pass (64-byte rows in HBM at 2)
+    int fold_hop = 0;         // the fold chain of a lane on a stream (hardware queue) of its own behind the accumulation: 0 never, 1 every lane,
+                              // 2 the G2 lane only (ZKHIP_FOLD_HOP).  A dispatch with workgroups still to place holds its queue's pipe; a fold
+                              // that shares the pipe of a later accumulation waits for that accumulation's last round.
+    int stream_skew = 0;      // streams made and left idle before a slot's lanes make theirs (ZKHIP_STREAM_SKEW): shifts which hardware queue a lane gets
+    std::vector<Stream> skew_streams;
+    std::string pipe_plan;    // which dispatcher ("pipe") each stream of a resident prover sits on (ZKHIP_PIPES; make_pipe_streams below)
+    bool pipes_made = false;
+    Stream ntt_lone_stream = 0;              // the witness map of a LONE proof ("n" of the plan), where the plan gives it a pipe of its own choosing
+    bool ntt_lone_made = false;
+    Stream fold_shared[3] = {0, 0, 0};       // the fold streams of the lanes Z, G, H when the plan gives one per type
+    bool fold_shared_made[3] = {false, false, false};
     int ntt_fuse_first = 1;   // the first butterfly round of a pass done on the elements as they are fetched (kernels_ntt.cuh ntt_first_round; ZKHIP_NTT_FUSE_FIRST=0: every round through LDS)
     int ntt_skew_us = 0;      // start skew of a transform pass's first round of workgroups (kernels_ntt.cuh NttSkew; ZKHIP_NTT_SKEW_US)
     u32 sort_wgs = 256;       // workgroups of a counting-sort pass (chunks x windows): fewer = longer runs per (workgroup, bucket)
@@ -199,15 +219,103 @@ struct zkhip_ctx {
     // process would leave the second GPU of a process at the 64 KiB default)
     std::unordered_set<const void*> lds_opted;
 };
+// ---- streams by dispatcher.  The hardware queues of a process are dealt round-robin to the chip's four compute dispatchers
+// ("pipes") in the order they are made, whatever their priority, and a dispatch that still has workgroups to place holds its
+// pipe: a kernel that arrives on another queue of that pipe waits until the whole of it is placed — 0.3 ms behind a 0.6 ms
+// kernel of four rounds, 3 ms behind an accumulation — while a kernel on another pipe gets the first place that comes free
+// (tools/pipe_probe.hip, profiles/r6s_pipe_probe.txt).  A proof's fold chains, transforms and sorts are short kernels that
+// arrive while accumulations are being placed; which pipe their streams share with which accumulation used to be an accident
+// of the order of first use.  The plan names the pipe (0..3, relative to one another) of every stream of a resident prover:
+//   M main (staging, z sort)  N witness map + h sort  O copy-out  |  per slot: Z, G, H the lanes of A/B1/L, B2 and H;
+//   z, g, h a second stream of that lane TYPE for its fold chain (absent: the fold stays behind its accumulation);
+//   f one stream per slot for the fold chains of its three lanes; gl / zl / hl a fold stream of slot 0's lane used by LONE proofs only
+// e.g. "M=3,N=3,O=3,G=0,Z=1,H=2,g=3,z=3,h=3"; a name followed by a slot number ("G1=2") overrides that slot.  All streams of
+// the plan are made in one go, in pipe order (idle streams fill the gaps), the first time a proof is enqueued.
+// the plan of an accumulation-bound prover (ZKHIP_TUNE_PIPE_PLAN = 1): sixteen streams, four per pipe, no idle one — every accumulation
+// lane type on a pipe of its own with one short chain that never meets it (the copy-out beside G2, the z sort beside A/B1/L, the witness
+// map beside H), the fold chains (a stream per lane type) and the lone proofs' witness map on the fourth.  Dense 2^20 BN254: +1-3 %
+// proofs/s, a lone proof 0.25-0.4 ms sooner; stdlib SHA-256 / Poseidon on BLS12-381 / GM17: 5-15 % SLOWER than streams in order of first
+// use (their accumulations are short, and one stream per fold type couples consecutive proofs) — opt-in (profiles/r6t_*, r6w_*).
+#define ZK_PIPE_PLAN_RESIDENT "M=1,N=2,n=3,O=0,G=0,Z=1,H=2,g=3,z=3,h=3"
+struct PipeWant { Stream* target; bool* made; bool high; int cls; bool done; };
+static inline void make_pipe_streams(zkhip_ctx* ctx) {
+    if (ctx->pipes_made || ctx->pipe_plan.empty() || ctx->serial) return;
+    ctx->pipes_made = true;
+    auto find = [&](const std::string& key) -> int {       // "key=d" in the plan, -1 if absent
+        size_t pos = 0;
+        const std::string& pl = ctx->pipe_plan;
+        while (pos < pl.size()) {
+            size_t end = pl.find(',', pos);
+            if (end == std::string::npos) end = pl.size();
+            const std::string tok = pl.substr(pos, end - pos);
+            const size_t eq = tok.find('=');
+            if (eq != std::string::npos && tok.substr(0, eq) == key && eq + 1 < tok.size() && tok[eq + 1] >= '0' && tok[eq + 1] <= '3') return tok[eq + 1] - '0';
+            pos = end + 1;
+        }
+        return -1;
+    };
+    std::vector<PipeWant> want;
+    static bool dummy_made;
+    int c;
+    if ((c = find("M")) >= 0) { stream_sync(ctx->stream); stream_destroy(ctx->stream); ctx->stream = 0; want.push_back({&ctx->stream, &dummy_made, true, c, false}); }
+    if ((c = find("N")) >= 0 && !ctx->ntt_made) want.push_back({&ctx->ntt_stream, &ctx->ntt_made, true, c, false});
+    if ((c = find("n")) >= 0) want.push_back({&ctx->ntt_lone_stream, &ctx->ntt_lone_made, true, c, false});
+    if ((c = find("O")) >= 0 && !ctx->out_made) want.push_back({&ctx->out_stream, &ctx->out_made, false, c, false});
+    static const char names[3] = {'Z', 'G', 'H'};
+    static const int lane_of[3] = {0, 3, 4};
+    for (int t = 0; t < 3; ++t) {       // a fold stream per lane type ("g=3"), unless the plan names slots ("g0=3")
+        const std::string low(1, (char)(names[t] + 32));
+        if ((c = find(low)) >= 0 && find(low + "0") < 0) want.push_back({&ctx->fold_shared[t], &ctx->fold_shared_made[t], true, c, false});
+    }
+    for (int k = 0; k < std::min(ctx->nslots, ZK_NSLOTS); ++k)
+        for (int t = 0; t < 3; ++t) {
+            MsmLane& lane = ctx->slots[k].lanes[lane_of[t]];
+            const std::string up(1, names[t]), low(1, (char)(names[t] + 32)), num = std::to_string(k);
+            c = find(up + num); if (c < 0) c = find(up);
+            if (c >= 0 && !lane.made) want.push_back({&lane.stream, &lane.made, t == 1 && ctx->g2_first, c, false});
+            c = find(low + num);
+            if (c >= 0 && !lane.fold_made) want.push_back({&lane.fold_stream, &lane.fold_made, true, c, false});
+        }
+    for (int t = 0; t < 3; ++t) {       // slot 0's lanes in a LONE proof: "gl=3" — the fold of that lane hops to a stream of its own
+        MsmLane& lane = ctx->slots[0].lanes[lane_of[t]];
+        if ((c = find(std::string(1, (char)(names[t] + 32)) + "l")) >= 0 && !lane.lone_fold_made) want.push_back({&lane.lone_fold_stream, &lane.lone_fold_made, true, c, false});
+    }
+    for (int k = 0; k < std::min(ctx->nslots, ZK_NSLOTS); ++k) {
+        c = find("f" + std::to_string(k)); if (c < 0) c = find("f");
+        if (c >= 0 && !ctx->slots[k].fold_slot_made) want.push_back({&ctx->slots[k].fold_slot, &ctx->slots[k].fold_slot_made, true, c, false});
+    }
+    size_t left = want.size();
+    for (int t = 0; left; ++t) {
+        PipeWant* pick = nullptr;
+        for (auto& w : want) if (!w.done && w.cls == (t & 3)) { pick = &w; break; }
+        if (pick) { *pick->target = pick->high ? stream_create_high_priority() : stream_create(); *pick->made = true; pick->done = true; --left; }
+        else ctx->skew_streams.push_back(stream_create_low_priority());      // (an idle queue of a priority nothing else uses)
+    }
+    for (int k = 0; k < ZK_NSLOTS; ++k)
+        if (ctx->slots[k].fold_slot_made)
+            for (int t = 0; t < 3; ++t) {
+                MsmLane& lane = ctx->slots[k].lanes[lane_of[t]];
+                if (!lane.fold_made) { lane.fold_stream = ctx->slots[k].fold_slot; lane.fold_made = true; lane.fold_owned = false; }
+            }
+    for (int t = 0; t < 3; ++t)
+        if (ctx->fold_shared_made[t])
+            for (int k = 0; k < ZK_NSLOTS; ++k) {
+                MsmLane& lane = ctx->slots[k].lanes[lane_of[t]];
+                if (!lane.fold_made) { lane.fold_stream = ctx->fold_shared[t]; lane.fold_made = true; lane.fold_owned = false; }
+            }
+    ctx->ws = ctx->stream;
+}
 // streams and events of one proof slot, made the first time the slot is used
 static inline void slot_init(zkhip_ctx* ctx, ProofSlot& sl) {
     if (sl.ready) return;
+    while ((int)ctx->skew_streams.size() < ctx->stream_skew) ctx->skew_streams.push_back(stream_create());
     for (auto& so : sl.sorts) so.ready = event_create();
     for (int k = 0; k < ZK_NLANES; ++k) {
         // lane 3 is the G2 MSM: the longest accumulation AND the longest fold tail of a proof; at high priority its
         // workgroups are dispatched first, it finishes early and its tail hides under the G1 accumulations
         sl.lanes[k].high_priority = k == 3 && ctx->g2_first;       // (the stream itself is made when a launch first needs it: lane_stream)
         sl.lanes[k].done = event_create();
+        sl.lanes[k].acc_done = event_create();
         sl.acc_b[k] = event_create();
         sl.acc_e[k] = event_create();
     }
@@ -223,9 +331,18 @@ static inline Stream lane_stream(MsmLane& lane) {
     if (!lane.made) { lane.stream = lane.high_priority ? stream_create_high_priority() : stream_create(); lane.made = true; }
     return lane.stream;
 }
+static inline Stream lane_fold_stream(MsmLane& lane) {
+    if (!lane.fold_made) { lane.fold_stream = stream_create_high_priority(); lane.fold_made = true; }
+    return lane.fold_stream;
+}
 static inline Stream ctx_out_stream(zkhip_ctx* ctx) {
     if (!ctx->out_made) { ctx->out_stream = stream_create(); ctx->out_made = true; }
     return ctx->out_stream;
+}
+static inline Stream ctx_ntt_stream(zkhip_ctx* ctx);
+// the stream of a proof's witness map: the context's, or — a lone proof under a plan that names one — the lone proofs' own
+static inline Stream slot_ntt_stream(zkhip_ctx* ctx, const ProofSlot& sl) {
+    return (sl.lone && ctx->ntt_lone_made) ? ctx->ntt_lone_stream : ctx_ntt_stream(ctx);
 }
 static inline Stream ctx_ntt_stream(zkhip_ctx* ctx) {
     if (!ctx->ntt_made) { ctx->ntt_stream = stream_create_high_priority(); ctx->ntt_made = true; }
@@ -1490,6 +1607,7 @@ struct Prover {
         require(pk->m == cs->l + cs->w && pk->w == cs->w && pk->N == cs->N, ZKHIP_ERR_BAD_ARG,
                 "proving key does not match the constraint system (m, w or domain size)");
         require(!sl.busy, ZKHIP_ERR_DEVICE, "internal: proof slot still in flight");
+        make_pipe_streams(ctx);     // (a resident prover's first proof: every stream of the plan, in pipe order)
         slot_init(ctx, sl);
         const u64 m = pk->m, N = pk->N;
         const bool bound = pk->bound_uid != 0 && pk->bound_uid == cs->uid;   // (zkhip_pk_bind_r1cs; a shard: its ranges of H' / L')
@@ -1547,13 +1665,17 @@ struct Prover {
             if (pk->thin_mask) msm_prepare(ctx, st, sl.sorts[2], (const u32*)d_scalars + pk->z_lo * 8, shz, pk->z_n, ptr<u32>(pk->thin_keep), &sl.sorts[0]);
             if (gate < 2) {
                 sl.lanes[3].share_cu = (lone_sched & 1) != 0;
+                sl.lanes[3].lone_launch = lone;
                 msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], nullptr, hs2);   // longest first
             }
         }
 
         // ---- K1-K4 and the h-sort, on the NTT stream: the main stream is free for the next proof's staging and z-sort
-        Stream wn = ctx->serial ? st : ctx_ntt_stream(ctx);
+        Stream wn = ctx->serial ? st : slot_ntt_stream(ctx, sl);
         stream_wait_event(wn, sl.ev[0]);
+        // (lone_sched bit 4: a lone proof's witness map waits for the sort of the assignment — the sort's kernels have the machine to
+        // themselves and the G2 accumulation starts that much sooner; the witness map then runs beside it)
+        if ((lone_sched & 4) && pk->z_n) stream_wait_event(wn, sl.sorts[0].ready);
         event_record(sl.ev[1], wn);
         ctx->ws = wn;
         witness_map(ctx, cs, pl, bound, half);
@@ -1567,7 +1689,7 @@ struct Prover {
         NttPlan<C>* pl = get_plan<C>(ctx, pk->logN);
         ctx->cur = &sl;
         Stream st = ctx->stream;
-        Stream wn = ctx->serial ? st : ctx_ntt_stream(ctx);
+        Stream wn = ctx->serial ? st : slot_ntt_stream(ctx, sl);
         const MsmShape shz = msm_shape(ctx, pk->z_n, Fr::Params::BITS, true, pk->c_z, pk->s_z);
         const MsmShape shh = msm_shape(ctx, pk->h_n, Fr::Params::BITS, true, pk->c_h, pk->s_h);
         const int Wmax = (int)std::max(shz.nsums(), shh.nsums());
@@ -1593,8 +1715,10 @@ struct Prover {
         if (h_sort_first) msm_prepare(ctx, wn, sl.sorts[1], h_scalars + pk->h_lo * 8, shh, pk->h_n);
         if (pk->z_n) {
             const Event h_ready = !gate ? nullptr : h_sort_first ? sl.sorts[1].ready : sl.ev[2];
-            if (gate >= 2)
+            if (gate >= 2) {
+                sl.lanes[3].lone_launch = lone;
                 msm_run<Fq2>(ctx, sl.lanes[3], sort_b, pk->b2_ext.p, with_inf(shz, inf_b2), ptr<Xyzz<Fq2>>(sl.ws2), sl.acc_b[4], sl.acc_e[4], h_ready, hs2);
+            }
             // A G2 accumulation at one wave per SIMD (BLS12-381: the wave takes the SIMD's whole register file) shares no SIMD with a
             // G1 wave: G1 workgroups that arrive while some of its workgroups are still waiting for a place take the places, and the
             // G2 lane — the longest chain of such a proof — finishes that much later.  The witness map used to be the head start; a
@@ -1609,6 +1733,7 @@ struct Prover {
                 event_record(sl.g1_go, st);
                 g1_after = sl.g1_go;
             }
+            if (lone) sl.lanes[0].lone_launch = sl.lanes[1].lone_launch = sl.lanes[2].lone_launch = true;
             run_z_g1(ctx, sl, pk, shz, ws1, Wmax, g1_after, bound, hs1);
         } else {
             empty_msm(ctx, sl, ws1, 3 * Wmax, ptr<Xyzz<Fq2>>(sl.ws2), Wmax, 0, 4);
@@ -1618,6 +1743,7 @@ struct Prover {
         if (pk->h_n) {
             if (!h_sort_first) msm_prepare(ctx, wn, sl.sorts[1], h_scalars + pk->h_lo * 8, shh, pk->h_n);
             // (a bound key: U in natural order against H' — the same MSM machinery, other bases)
+            if (lone) sl.lanes[4].lone_launch = true;
             msm_run<Fq>(ctx, sl.lanes[4], sl.sorts[1], bound ? pk->h_bound.p : pk->h_sigma.p, with_inf(shh, bound ? pk->inf_many_bound[1] : pk->inf_many[4]),
                         ws1 + 3 * Wmax, sl.acc_b[3], sl.acc_e[3], nullptr, hs1 + 3 * Wmax);
         } else {

@@ -348,6 +348,13 @@ inline Stream stream_create_high_priority() {
     ZK_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
     return s;
 }
+inline Stream stream_create_low_priority() {
+    int lo = 0, hi = 0;
+    ZK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    Stream s;
+    ZK_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo));
+    return s;
+}
 inline void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
 inline void stream_sync(Stream s) { ZK_HIP_CHECK(hipStreamSynchronize(s)); }
 inline void dev_sync_all() { (void)hipDeviceSynchronize(); }
@@ -449,6 +456,7 @@ inline void dev_copy_between(void* d, int, const void* s_, int, size_t n, Stream
 inline void dev_memset(void* d, int v, size_t n, Stream) { memset(d, v, n); }
 inline Stream stream_create() { return 0; }
 inline Stream stream_create_high_priority() { return 0; }
+inline Stream stream_create_low_priority() { return 0; }
 inline void stream_destroy(Stream) {}
 inline void stream_sync(Stream) {}
 inline void dev_sync_all() {}

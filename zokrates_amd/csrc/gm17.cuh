@@ -184,6 +184,7 @@ struct Gm17 {
                         const uint8_t* d1, const uint8_t* r) {
         check_match(pk, cs);
         require(!sl.busy, ZKHIP_ERR_DEVICE, "internal: proof slot still in flight");
+        make_pipe_streams(ctx);
         slot_init(ctx, sl);
         const u64 m = cs->l + cs->w, n = cs->n, l = cs->l, M = pk->m, D = pk->N;
         Fr dd = fe_from_bytes_canon<Fr>(d1), rr = fe_from_bytes_canon<Fr>(r);

@@ -51,6 +51,8 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     const u32 nlanes = (u32)std::max<u64>(1, std::min<u64>(machine, (sh.n * (u64)sh.W + ctx->msm_min_slice - 1) / ctx->msm_min_slice));
     const bool share = lane.share_cu && !ctx->serial;
     lane.share_cu = false;
+    const bool lone_launch = lane.lone_launch;
+    lane.lone_launch = false;
     const MsmCut cut{nlanes, ctx->msm_min_slice, (u32)std::min<u64>(sh.n * (u64)sh.levels, 0x7fffffffu), share ? 1u : 0u};
     const u64 partial_stride = (u64)sh.nkeys + nlanes;
     lane.heavy.ensure(((size_t)sh.nkeys + 1) * 4);            // [0] = count, [1..] = keys
@@ -82,6 +84,13 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
                   ptr<u32>(lane.lane_key), ptr<Xyzz<F>>(lane.partial), partial_stride, sh.nkeys, cut);
     }
     if (ev_end) event_record(ev_end, s);
+    // the fold chain on another stream (hardware queue) than the accumulation: a lone proof's — only where the stream plan made the lane
+    // a lone fold stream (the hop is an event on the proof's critical path); a batch's — the lane's fold stream of the plan, or zkhip_ctx::fold_hop
+    if (!ctx->serial && (lone_launch ? lane.lone_fold_made : (lane.fold_made || ctx->fold_hop == 1 || (ctx->fold_hop == 2 && MsmTuning<F>::IS_EXT)))) {
+        event_record(lane.acc_done, s);
+        s = lone_launch ? lane.lone_fold_stream : lane_fold_stream(lane);
+        stream_wait_event(s, lane.acc_done);
+    }
     if (ctx->heavy_runs) {
         lds_opt_in(ctx, (const void*)k_msm_heavy_reduce<F>);
         ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(MSM_HEAVY_CHUNKS, nt), dim3(T), (size_t)T * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,

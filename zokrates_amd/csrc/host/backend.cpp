@@ -215,6 +215,11 @@ void Hip::one_shot() {
     check(zkhip_ctx_tune(ctx_, ZKHIP_TUNE_MSM_SETS, 64));
     check(zkhip_ctx_tune(ctx_, ZKHIP_TUNE_SERIAL, 1));
 }
+// A long-lived prover of LARGE DENSE circuits (accumulation-bound: 2^20 constraints and more): all sixteen streams of the context made
+// in one go at its first proof, every accumulation lane type on a hardware dispatcher of its own and the fold chains on the fourth
+// (core.cuh make_pipe_streams).  Measured per workload (profiles/r6t_*, r6w_*): +1-3 % proofs/s and a lone proof 0.25-0.4 ms sooner
+// there, 5-15 % slower on thin circuits (SHA-256, Poseidon on BLS12-381, GM17) — so it is a request, never a default.
+void Hip::separate_dispatchers() { check(zkhip_ctx_tune(ctx_, ZKHIP_TUNE_PIPE_PLAN, 1)); }
 void Hip::check(int32_t rc) const {
     if (rc != ZKHIP_OK) throw Error(rc, zkhip_last_error(ctx_));
 }

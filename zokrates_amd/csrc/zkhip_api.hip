@@ -139,7 +139,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->nslots = env_int("ZKHIP_SLOTS", 1, ZK_NSLOTS, 3);
         ctx->z_gate = env_int("ZKHIP_Z_GATE", 0, 2, 1);
         ctx->g2_head_start = env_int("ZKHIP_G2_HEAD_START", 0, 2, 1);
-        ctx->lone_sched = env_int("ZKHIP_LONE_SCHED", 0, 3, 0);
+        ctx->lone_sched = env_int("ZKHIP_LONE_SCHED", 0, 7, 0);
         ctx->split_min_log = env_int("ZKHIP_SPLIT_MIN_LOG", 0, 40, 18);
         ctx->ntt_skew_us = env_int("ZKHIP_NTT_SKEW_US", 0, 200, 0);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
@@ -153,6 +153,9 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->sort_two_level = env_int("ZKHIP_SORT_TWO_LEVEL", 0, 1, 1);
         ctx->fold_lines = env_int("ZKHIP_FOLD_LINES", 0, 2, 0);
         ctx->ntt_fuse_first = env_int("ZKHIP_NTT_FUSE_FIRST", 0, 1, 1);
+        ctx->fold_hop = env_int("ZKHIP_FOLD_HOP", 0, 2, 0);
+        ctx->stream_skew = env_int("ZKHIP_STREAM_SKEW", 0, 32, 0);
+        if (const char* e = getenv("ZKHIP_PIPES")) ctx->pipe_plan = (e[0] == '-' || e[0] == '0') ? "" : (e[0] == '1' && !e[1]) ? ZK_PIPE_PLAN_RESIDENT : e;
         // every (slot, lane) has a stream of its own: with one stream per lane shared by the slots, the accumulation of
         // proof i+1 queued behind the latency-bound fold tail of proof i on the same lane (a kernel trace showed a lone
         // fold workgroup holding the machine 16 % of the time).  Slot 0 — the one single proofs and the primitives use — is
@@ -185,13 +188,20 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
     dev_sync_all();
     staging_drain();          // (the device's staging ring may still track transfers recorded on this context's streams)
     for (auto& sl : ctx->slots) {
+        // (streams first, whether or not the slot was ever used: a stream plan makes the streams of every slot at the first proof)
+        for (int k = 0; k < ZK_NLANES; ++k) {
+            if (sl.lanes[k].made) stream_destroy(sl.lanes[k].stream);
+            if (sl.lanes[k].fold_made && sl.lanes[k].fold_owned) stream_destroy(sl.lanes[k].fold_stream);
+            if (sl.lanes[k].lone_fold_made) stream_destroy(sl.lanes[k].lone_fold_stream);
+        }
+        if (sl.fold_slot_made) stream_destroy(sl.fold_slot);
         if (!sl.ready) continue;
         for (auto& so : sl.sorts) event_destroy(so.ready);
         for (int k = 0; k < ZK_NLANES; ++k) {
             event_destroy(sl.lanes[k].done);
+            event_destroy(sl.lanes[k].acc_done);
             event_destroy(sl.acc_b[k]);
             event_destroy(sl.acc_e[k]);
-            if (sl.lanes[k].made) stream_destroy(sl.lanes[k].stream);
         }
         for (auto& e : sl.ev) event_destroy(e);
         event_destroy(sl.ntt_b);
@@ -199,6 +209,9 @@ void zkhip_ctx_free(zkhip_ctx* ctx) {
         event_destroy(sl.g1_go);
         host_free_pinned(sl.h_ws);
     }
+    for (Stream q : ctx->skew_streams) stream_destroy(q);
+    for (int t = 0; t < 3; ++t) if (ctx->fold_shared_made[t]) stream_destroy(ctx->fold_shared[t]);
+    if (ctx->ntt_lone_made) stream_destroy(ctx->ntt_lone_stream);
     if (ctx->out_made) stream_destroy(ctx->out_stream);
     if (ctx->ntt_made) stream_destroy(ctx->ntt_stream);
     stream_destroy(ctx->stream);
@@ -246,11 +259,17 @@ int32_t zkhip_ctx_tune(zkhip_ctx* ctx, int32_t which, int32_t value) {
             case ZKHIP_TUNE_NTT_MAX_SUBLOG: in(2, NTT_MAX_SUBLOG); dev_sync_all(); ctx->ntt_max_sublog = value; ctx->plans.clear(); break;
             case ZKHIP_TUNE_SLOTS: in(1, ZK_NSLOTS); dev_sync_all(); ctx->nslots = value; break;
             case ZKHIP_TUNE_Z_GATE: in(0, 2); ctx->z_gate = value; break;
-            case ZKHIP_TUNE_LONE_SCHED: in(0, 3); ctx->lone_sched = value; break;
+            case ZKHIP_TUNE_LONE_SCHED: in(0, 7); ctx->lone_sched = value; break;
             case ZKHIP_TUNE_NTT_SKEW_US: in(0, 200); ctx->ntt_skew_us = value; break;
             case ZKHIP_TUNE_SORT_TWO_LEVEL: in(0, 1); ctx->sort_two_level = value; break;
             case ZKHIP_TUNE_FOLD_LINES: in(0, 2); ctx->fold_lines = value; break;
             case ZKHIP_TUNE_NTT_FUSE_FIRST: in(0, 1); ctx->ntt_fuse_first = value; break;
+            case ZKHIP_TUNE_FOLD_HOP: in(0, 2); ctx->fold_hop = value; break;
+            case ZKHIP_TUNE_PIPE_PLAN:
+                in(0, 1);
+                require(!ctx->pipes_made, ZKHIP_ERR_BAD_ARG, "the streams of this context exist already: the plan is chosen before its first proof");
+                if (!getenv("ZKHIP_PIPES")) ctx->pipe_plan = value ? ZK_PIPE_PLAN_RESIDENT : "";
+                break;
             case ZKHIP_TUNE_FOLD_HG: in(1, 256); ctx->fold_hg = 1 << ilog2_floor((u64)value); break;
             case ZKHIP_TUNE_FUSE_Z: in(0, 1); ctx->fuse_z = value != 0; break;
             case ZKHIP_TUNE_MSM_FUSED_WAVES: in(0, 8); ctx->msm_fused_waves = value; break;

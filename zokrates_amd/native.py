@@ -201,7 +201,7 @@ class Context:
         self._check(self.lib.L.zkhip_describe(self.h, buf, 256))
         return buf.value.decode()
 
-    TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7, "ntt_cols": 8, "slots": 9, "z_gate": 10, "fuse_z": 11, "msm_fused_waves": 12, "stream_jitter": 13, "ntt_max_sublog": 16, "msm_sets": 17, "skip_inf": 18, "b_sort": 19, "heavy_runs": 20, "lone_sched": 21, "ntt_skew_us": 22, "sort_two_level": 23, "fold_lines": 24, "fold_hg": 25, "ntt_fuse_first": 26}
+    TUNABLES = {"msm_c": 1, "msm_waves": 2, "msm_lanes": 3, "msm_min_slice": 4, "fold_scan": 5, "serial": 6, "ntt_single_max_log": 7, "ntt_cols": 8, "slots": 9, "z_gate": 10, "fuse_z": 11, "msm_fused_waves": 12, "stream_jitter": 13, "ntt_max_sublog": 16, "msm_sets": 17, "skip_inf": 18, "b_sort": 19, "heavy_runs": 20, "lone_sched": 21, "ntt_skew_us": 22, "sort_two_level": 23, "fold_lines": 24, "fold_hg": 25, "ntt_fuse_first": 26, "fold_hop": 27, "pipe_plan": 28}
 
     def clock_probe(self, duration_us=2000):
         """`zkhip_ctx_clock_probe`: the shader clock (GHz) the device runs at over the next `duration_us` microseconds — one wavefront
