@@ -34,8 +34,8 @@ for ctr in ${SKIP_PMC:+} $([ -z "${SKIP_PMC:-}" ] && echo FETCH_SIZE WRITE_SIZE)
   db=$(find "$out/prof_pmc_$ctr" -name "*.db" | head -1)
   [ -n "$db" ] && python "$root/tools/pmc_stats.py" "$db" "$out/${tag}_pmc_$ctr.md" > /dev/null
 done
-f=$(find "$out/prof_pmc_FETCH_SIZE" -name "*.db" | head -1); w=$(find "$out/prof_pmc_WRITE_SIZE" -name "*.db" | head -1)
-[ -n "$f" ] && [ -n "$w" ] && python "$root/tools/pmc_traffic.py" "$f" "$w" "$out/pmc_traffic.json" \
+f=$(find "$out/prof_pmc_FETCH_SIZE" -name "*.db" 2>/dev/null | head -1); w=$(find "$out/prof_pmc_WRITE_SIZE" -name "*.db" 2>/dev/null | head -1)
+[ -z "${SKIP_PMC:-}" ] && [ -n "$f" ] && [ -n "$w" ] && python "$root/tools/pmc_traffic.py" "$f" "$w" "$out/pmc_traffic.json" \
   "rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate runs), ZKHIP_SERIAL=1 python bench.py --bind 0 --steps 4 --warmup 1 --cpu-seconds 0 --serial-proofs 0; profiles/${tag}_pmc_FETCH_SIZE.md, ${tag}_pmc_WRITE_SIZE.md" > /dev/null
 unset ZKHIP_SERIAL
 # 5. GM17
