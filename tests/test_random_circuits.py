@@ -141,7 +141,7 @@ def _rows_of_every_length(curve, rnd, lengths, l=3):
 
 
 def _check_row_lengths(ctx, curve):
-    lengths = [0, 1, 2, 31, 32, 33, 34, 63, 64, 65, 127, 128, 129, 300, 1000, 32, 33, 1, 0, 64, 500, 33]
+    lengths = [0, 1, 2, 31, 32, 33, 34, 63, 64, 65, 127, 128, 129, 300, 1000, 32, 33, 1, 0, 64, 500, 33, 511, 512, 513, 1100, 2]
     cs, z = _rows_of_every_length(curve, random.Random(77 + curve.curve_id), lengths)
     mats = [csr(cs.A), csr(cs.B), csr(cs.C)]
     zb = le(z)
@@ -161,8 +161,8 @@ def _check_row_lengths(ctx, curve):
 
 @pytest.mark.parametrize("curve", [BN254, BLS12_381], ids=lambda c: c.name)
 def test_rows_around_the_long_row_boundary_on_emulator(curve):
-    """k_matvec leaves rows of more than 32 terms to k_matvec_long (a wavefront per row): every length around the boundary, in
-    every matrix, next to empty and one-term rows."""
+    """k_matvec leaves rows of more than 32 terms to k_matvec_long (a wavefront per row) and rows of more than 512 to k_matvec_huge (a
+    workgroup per row): every length around both boundaries, in every matrix, next to empty and one-term rows."""
     from emu_util import emu_library
     ctx = native.Context(0, emu_library())
     try:

@@ -906,8 +906,8 @@ struct zkhip_r1cs {
     DBuf rp[3], col[3], val[3];
     u64 nnz[3];
     u64 nnz_short[3];     // without the rows of more than MATVEC_LONG terms (what the lanes-per-row choice of k_matvec is made from)
-    DBuf long_rows;       // those rows, matrix << 32 | row (k_matvec_long)
-    u64 n_long = 0;
+    DBuf long_rows;       // those rows, matrix << 32 | row (k_matvec_long); the first n_huge of them have more than MATVEC_HUGE terms (k_matvec_huge)
+    u64 n_long = 0, n_huge = 0;
     u64 fp[2] = {0, 0};   // PkLoader::r1cs_fingerprint, computed when first asked for
     bool fp_made = false;
 };
@@ -1510,9 +1510,12 @@ struct Prover {
         for (int k = 0; k < 3; ++k) g[k] = (k >= mat0 && k < mat0 + nmat) ? matvec_group(cs->nnz_short[k], cs->n) : 1;
         ZK_LAUNCH((k_matvec<Fr>), dim3(blocks_for(N, 256 / gmax_rows(g)), nmat), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c, n,
                   l, N, g[0], g[1], g[2], cs->l + cs->w, mat0);
-        if (cs->n_long)
-            ZK_LAUNCH((k_matvec_long<Fr>), dim3(blocks_for(cs->n_long, 4)), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c,
-                      ptr<u64>(cs->long_rows), cs->n_long, cs->l + cs->w);
+        if (cs->n_huge)
+            ZK_LAUNCH((k_matvec_huge<Fr>), dim3((unsigned)cs->n_huge), dim3(MATVEC_HUGE_THREADS), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c,
+                      ptr<u64>(cs->long_rows), cs->l + cs->w);
+        if (cs->n_long > cs->n_huge)
+            ZK_LAUNCH((k_matvec_long<Fr>), dim3(blocks_for(cs->n_long - cs->n_huge, 4)), dim3(256), 0, ctx->ws, csr(cs, 0), csr(cs, 1), csr(cs, 2), zmont, a, b, c,
+                      ptr<u64>(cs->long_rows) + cs->n_huge, cs->n_long - cs->n_huge, cs->l + cs->w);
     }
     static unsigned gmax_rows(const int g[3]) { return (unsigned)std::max(g[0], std::max(g[1], g[2])); }
 
@@ -2275,7 +2278,8 @@ struct Prover {
 
     static void r1cs_load(zkhip_ctx* ctx, zkhip_r1cs* cs, const u64* const rp[3], const u32* const col[3], const uint8_t* const val[3]) {
         Stream s = ctx->stream;
-        std::vector<u64> long_rows;
+        std::vector<u64> long_rows, huge_rows;
+        const u64 huge_min = env_int("ZKHIP_MATVEC_HUGE", 0, 1, 1) ? (u64)MATVEC_HUGE : ~(u64)0;     // (0: every long row to k_matvec_long, for A/B runs)
         for (int k = 0; k < 3; ++k) {
             const u64 nnz = rp[k][cs->n];
             require(rp[k][0] == 0, ZKHIP_ERR_BAD_ARG, "rowptr[0] must be 0");
@@ -2283,7 +2287,7 @@ struct Prover {
             cs->nnz_short[k] = nnz;
             for (u64 i = 0; i < cs->n; ++i)
                 if (rp[k][i + 1] - rp[k][i] > MATVEC_LONG) {
-                    long_rows.push_back((u64)k << 32 | i);
+                    (rp[k][i + 1] - rp[k][i] > huge_min ? huge_rows : long_rows).push_back((u64)k << 32 | i);
                     cs->nnz_short[k] -= rp[k][i + 1] - rp[k][i];
                 }
             for (u64 q = 0; q < nnz; ++q) require(col[k][q] < cs->l + cs->w, ZKHIP_ERR_BAD_ARG, "column index out of range");
@@ -2298,6 +2302,8 @@ struct Prover {
                 ZK_LAUNCH((k_to_mont<Fr>), dim3(blocks_for(nnz, 256)), dim3(256), 0, s, ptr<Fr>(cs->val[k]), ptr<Fr>(cs->val[k]), nnz);
             }
         }
+        cs->n_huge = huge_rows.size();
+        long_rows.insert(long_rows.begin(), huge_rows.begin(), huge_rows.end());     // the huge rows first
         cs->n_long = long_rows.size();
         if (cs->n_long) {
             cs->long_rows.ensure(cs->n_long * 8);

@@ -248,6 +248,37 @@ __global__ void __launch_bounds__(256) k_matvec_long(CsrDev A, CsrDev B, CsrDev 
     }
     if (live && lane == 0) (which == 0 ? oa : which == 1 ? ob : oc)[i] = acc;
 }
+// one WORKGROUP of 512 work-items per row of more than MATVEC_HUGE terms.  The stdlib SHA-256 circuit has rows of 7 041 terms; a wavefront
+// walks one in 110 dependent rounds of (gather, product, sum) — 0.54 ms, and the witness map of a 4 ms proof waits for it
+// (profiles/r7a_*: `k_matvec_long` 544 us) — a workgroup in 14.
+static constexpr u32 MATVEC_HUGE = 512, MATVEC_HUGE_THREADS = 512;
+template <class F>
+__global__ void __launch_bounds__(MATVEC_HUGE_THREADS) k_matvec_huge(CsrDev A, CsrDev B, CsrDev C, const F* __restrict__ z, F* __restrict__ oa, F* __restrict__ ob,
+                                                                     F* __restrict__ oc, const u64* __restrict__ rows, u64 m_vars) {
+    ZK_PRIO_HIGH();
+    __shared__ F sh[MATVEC_HUGE_THREADS];
+    const u64 r = rows[blockIdx.x];
+    const int which = (int)(r >> 32);
+    const u64 i = r & 0xffffffffu;
+    const CsrDev M = which == 0 ? A : which == 1 ? B : C;
+    const F* val = (const F*)M.val;
+    F acc = F::zero();
+    const u64 e = M.rowptr[i + 1];
+    for (u64 k = M.rowptr[i] + threadIdx.x; k < e; k += MATVEC_HUGE_THREADS) {
+        ZK_ASSERT_IDX(M.col[k] < m_vars);
+        acc = fe_add(acc, fe_mul(val[k], z[M.col[k]]));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 st = MATVEC_HUGE_THREADS >> 1; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            acc = fe_add(acc, sh[threadIdx.x + st]);
+            sh[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) (which == 0 ? oa : which == 1 ? ob : oc)[i] = acc;
+}
 // lanes per row for a matrix with `nnz` entries in `n` rows: the largest power of two <= half the average row length
 static inline int matvec_group(u64 nnz, u64 n) {
     const u64 avg = n ? nnz / n : 0;
