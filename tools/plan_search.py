@@ -37,11 +37,15 @@ def evaluate(plan):
     return {w: run(plan, w) for w in WORKLOADS}
 
 
+LONE_WEIGHT = float(os.environ.get("PLAN_LONE_WEIGHT", "0"))      # > 0: the lone proof's latency counts as well (geometric mean of base / plan, to this power)
+
+
 def score(res, base):
-    s = 1.0
+    s, l = 1.0, 1.0
     for w in WORKLOADS:
         s *= (res[w][0] / base[w][0]) if base[w][0] else 1.0
-    return s ** (1.0 / len(WORKLOADS))
+        l *= (base[w][1] / res[w][1]) if res[w][1] and base[w][1] else 1.0
+    return s ** (1.0 / len(WORKLOADS)) * (l ** (1.0 / len(WORKLOADS))) ** LONE_WEIGHT
 
 
 def sizes(p):
@@ -73,8 +77,12 @@ def main():
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t_end = time.time() + 60 * minutes
     base = evaluate(None)
+    b2 = evaluate(None)      # two baselines, averaged: one run's noise (2 %) would tilt every score of the search
+    base = {w: ((base[w][0] + b2[w][0]) / 2, (base[w][1] + b2[w][1]) / 2) for w in WORKLOADS}
     print(json.dumps({"plan": "-", "res": base}), flush=True)
     cur = dict(REPLICA)
+    if os.environ.get("PLAN_START"):
+        cur = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ["PLAN_START"].split(",")}
     cur_res = evaluate(cur)
     cur_s = score(cur_res, base)
     print(json.dumps({"plan": plan_string(cur), "score": round(cur_s, 4), "res": cur_res}), flush=True)
