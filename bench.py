@@ -328,11 +328,11 @@ def main():
                          "transforms per proof instead of six, no C mat-vec, same proof bytes — checked here against an unbound proof; the line "
                          "also times one region with the key unbound again).  0 = the key as loaded; 2 = bound, without the unbound region")
     ap.add_argument("--pipe-plan", type=int, default=-1,
-                    help="the stream plan of accumulation-bound provers (ZKHIP_TUNE_PIPE_PLAN: the context's sixteen streams made at its first proof, "
-                         "every accumulation lane type on a hardware dispatcher of its own, the fold chains on the fourth).  Measured per workload "
-                         "(profiles/r6t_*, r6w_*): +1-3 %% proofs/s and a lone proof 0.25-0.4 ms sooner on the dense 2^20+ BN254 circuits, 5-15 %% "
-                         "SLOWER on the thin ones (stdlib SHA-256, the Poseidon chain on BLS12-381, GM17).  -1 (default) = on for the dense Groth16 "
-                         "workload at a domain of 2^20 and more, off otherwise and whenever --members puts more contexts into the process; 0 / 1 = off / on")
+                    help="the stream plan of resident provers (ZKHIP_TUNE_PIPE_PLAN: the context's sixteen streams made at its first proof, each on a "
+                         "chosen one of the GPU's four dispatchers; the layout comes from a local search over four workloads, tools/plan_search.py).  "
+                         "Against streams in order of first use (profiles/r7g_*, r7h_*: the last two lines of the search are the plan and no plan measured back to back): dense 2^20 level in batches and a lone proof 0.25-0.3 ms "
+                         "sooner, stdlib SHA-256 +8-9 %%, the Poseidon chain on BLS12-381 +3 %%, GM17 level.  -1 (default) and 1 = on, except where --members "
+                         "puts more contexts into the process; 0 = off")
     ap.add_argument("--oracle", default="auto", choices=["auto", "algorithmic", "trapdoor", "none"],
                     help="what the device proof is held to: `algorithmic` = the cpu_baseline leg's proof (the C++ restatement of ark's prover, "
                          "needs --cpu-seconds > 0), `trapdoor` = the closed form from the setup's toxic waste (oracle/c, independent of every "
@@ -397,8 +397,8 @@ def main():
     pci = native.default_library().device_pci_bus_id(device)
     placement = numa_placement(pci, pin=ranks.world > 1)      # N > 1: every rank's host threads on the NUMA node of its GPU
     ctx = native.Context(device)
-    dense_big = args.kind == "dense" and args.scheme == "g16" and args.curve in ("bn128", "bn254") and args.log_domain >= 20
-    stream_plan = (args.pipe_plan == 1 or (args.pipe_plan == -1 and dense_big)) and not args.members and os.environ.get("ZKHIP_PIPES", "1") not in ("0", "-")
+    # (every resident single-GPU prover of this script asks for the plan: round 7's is level or better on all four workloads)
+    stream_plan = args.pipe_plan != 0 and not args.members and os.environ.get("ZKHIP_PIPES", "1") not in ("0", "-")
     if stream_plan:
         ctx.tune("pipe_plan", 1)
     mark("context_created")
@@ -677,10 +677,11 @@ def main():
                          "source": "zkhip_ctx_clock_probe on a second context of the same device, 2 ms readings back to back (shader cycles / wall clock of one sleeping wavefront)"},
         "per_rank": per_rank,
         "bound_key": bound,
-        "stream_plan": {"on": stream_plan, "plan": os.environ.get("ZKHIP_PIPES") or ("M=1,N=2,n=3,O=0,G=0,Z=1,H=2,g=3,z=3,h=3" if stream_plan else None),
+        "stream_plan": {"on": stream_plan, "plan": os.environ.get("ZKHIP_PIPES") or ("M=2,N=3,O=1,n=3,G0=0,Z0=1,H0=0,G1=3,Z1=1,H1=0,G2=3,Z2=2,H2=1" if stream_plan else None),
                         "note": "the prover's streams placed on the GPU's four dispatchers (zkhip_ctx_tune PIPE_PLAN, core.cuh make_pipe_streams): same "
-                                "kernels, same proofs; A/B against streams made in order of first use in profiles/r6t_*.txt, per workload in r6w_*.txt: +1-3 % proofs/s and a lone "
-                                "proof 0.25-0.4 ms sooner on this workload, slower on the thin ones — which is why the configs legs run without it"},
+                                "kernels, same proofs; the plan comes from a local search scored on four workloads, batches and lone proofs (tools/plan_search.py, "
+                                "profiles/r7f_*, r7h_*); against streams made in order of first use (profiles/r7g_*, r7h_*): the dense circuit level in batches and a lone "
+                                "proof 0.25-0.3 ms sooner, stdlib SHA-256 +8-9 %, Poseidon / BLS12-381 +3 %, GM17 level — every leg of this line asks for it"},
     }
     # ---- optional legs (latency mode): a watchdog guarantees that the throughput line is printed even if one of them hangs
     # (a collective after an asymmetric failure; the in-library path on hardware this container cannot test)

@@ -150,10 +150,11 @@ int32_t zkhip_ctx_clock_probe(zkhip_ctx* ctx, uint32_t duration_us, double* ghz_
                                       * tiles: line-sized runs, 1 KiB of LDS per workgroup); 0: the one-level pass behind a 128 KiB histogram */
 #define ZKHIP_TUNE_FOLD_LINES 24       /* the row and the column sums of an MSM's bucket matrix in one launch, a workgroup per line (kernels_msm.cuh 5a'):
                                       * 0 (default) never (two launches: rows, then columns over the stored bucket values), 1 always, 2 for launches over one table */
-#define ZKHIP_TUNE_PIPE_PLAN 28        /* 1: every stream of the context made at its first proof and placed on the chip's four dispatchers by plan — each accumulation
-                                         lane type on one of its own, the fold chains on the fourth (core.cuh make_pipe_streams; 16 streams: ask zkhip_init for 16
-                                         queues).  For accumulation-bound provers (dense circuits of 2^20 constraints and more: +1-3 % proofs/s); thin circuits
-                                         run 5-15 % slower under it.  0 (default): streams made as they are first used.  Chosen before the first proof */
+#define ZKHIP_TUNE_PIPE_PLAN 28        /* 1: every stream of the context made at its first proof and placed on the chip's four dispatchers by plan (core.cuh
+                                         make_pipe_streams, ZK_PIPE_PLAN_RESIDENT: a layout found by a local search over four workloads, tools/plan_search.py;
+                                         16 streams: ask zkhip_init for 16 queues).  For long-lived provers: level or better than streams in order of first use on
+                                         every measured workload (stdlib SHA-256 +8-9 % proofs/s, a lone dense 2^20 proof 0.3 ms sooner); a one-proof process
+                                         pays 0.15 s for the streams.  0 (default): streams made as they are first used.  Chosen before the first proof */
 #define ZKHIP_TUNE_FOLD_HOP 27         /* the fold chain of an MSM on a second stream of its lane: 0 never, 1 every lane, 2 the G2 lane only */
 #define ZKHIP_TUNE_NTT_FUSE_FIRST 26   /* 1 (default): the first butterfly round of a transform pass on the elements as they are fetched; 0: through LDS like the others */
 #define ZKHIP_TUNE_FOLD_HG 25          /* shares a column of the bucket matrix is cut into by the two-launch fold's column pass (a power of two <= 256) */

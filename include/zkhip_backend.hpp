@@ -177,9 +177,9 @@ class Hip {
     // them costs ten times what they save a single proof (0.15 s of kernels at 2^20 against ~5 ms of proof time) — and the MSMs
     // fold one bucket set per window instead (ZKHIP_TUNE_MSM_SETS).  A resident prover keeps the default.
     void one_shot();
-    // A long-lived prover of large dense circuits (2^20 constraints and more), before its first proof: the context's streams made in
-    // one go and placed on the GPU's four dispatchers by plan (ZKHIP_TUNE_PIPE_PLAN; sixteen streams: call init(16) first, and keep the
-    // process below ~22 hardware queues in all).  +1-3 % proofs/s there, slower on thin circuits: measure before asking.
+    // A long-lived prover, before its first proof: the context's streams made in one go and placed on the GPU's four dispatchers by
+    // plan (ZKHIP_TUNE_PIPE_PLAN; sixteen streams: call init(16) first, and keep the process below ~22 hardware queues in all).  Level
+    // or better than streams in order of first use on every measured workload; not for one-proof processes (0.15 s).
     void separate_dispatchers();
     Hip(const Hip&) = delete;
     Hip& operator=(const Hip&) = delete;

@@ -178,8 +178,8 @@ impl Resident {
         }
         me
     }
-    /// For provers of large dense circuits (2^20 constraints and more), before the first proof: the context's streams placed on the GPU's
-    /// four dispatchers by plan (`ZKHIP_TUNE_PIPE_PLAN`; +1-3 % proofs/s there, slower on thin circuits: DESIGN.md §3.7).
+    /// For long-lived provers, before the first proof: the context's streams placed on the GPU's four dispatchers by plan
+    /// (`ZKHIP_TUNE_PIPE_PLAN`; level or better than streams in order of first use on every measured workload: DESIGN.md §3.7).
     pub fn separate_dispatchers(&self) { check(self.ctx, unsafe { ffi::zkhip_ctx_tune(self.ctx, ffi::ZKHIP_TUNE_PIPE_PLAN, 1) }) }
     /// one Groth16 proof over the resident pair: `z` the assignment in ark order (Flat::build's), r and s drawn by the caller as ark draws them
     pub fn prove(&self, z: &[u8], r: &[u8], s: &[u8]) -> Vec<u8> {

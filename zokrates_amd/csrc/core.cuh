@@ -231,12 +231,15 @@ struct zkhip_ctx {
 //   f one stream per slot for the fold chains of its three lanes; gl / zl / hl a fold stream of slot 0's lane used by LONE proofs only
 // e.g. "M=3,N=3,O=3,G=0,Z=1,H=2,g=3,z=3,h=3"; a name followed by a slot number ("G1=2") overrides that slot.  All streams of
 // the plan are made in one go, in pipe order (idle streams fill the gaps), the first time a proof is enqueued.
-// the plan of an accumulation-bound prover (ZKHIP_TUNE_PIPE_PLAN = 1): sixteen streams, four per pipe, no idle one — every accumulation
-// lane type on a pipe of its own with one short chain that never meets it (the copy-out beside G2, the z sort beside A/B1/L, the witness
-// map beside H), the fold chains (a stream per lane type) and the lone proofs' witness map on the fourth.  Dense 2^20 BN254: +1-3 %
-// proofs/s, a lone proof 0.25-0.4 ms sooner; stdlib SHA-256 / Poseidon on BLS12-381 / GM17: 5-15 % SLOWER than streams in order of first
-// use (their accumulations are short, and one stream per fold type couples consecutive proofs) — opt-in (profiles/r6t_*, r6w_*).
-#define ZK_PIPE_PLAN_RESIDENT "M=1,N=2,n=3,O=0,G=0,Z=1,H=2,g=3,z=3,h=3"
+// the plan of a resident prover (ZKHIP_TUNE_PIPE_PLAN = 1): found by a local search over the pipe of every stream, scored on four workloads at
+// once — dense 2^20 BN254, stdlib SHA-256 2^20, the Poseidon chain on BLS12-381 2^18, GM17 2^20 — batches AND lone proofs (tools/plan_search.py,
+// profiles/r7f_*, r7h_*, validated in r7g and at the end of r7h).  What its good layouts share: the witness-map stream N (and a lone proof's, n) on a pipe that
+// holds no A/B1/L lane and no H lane, only G2 lanes of later slots; slot 0's three lanes — the ones a lone proof uses — never three on one pipe.
+// Against streams in order of first use: dense level in batches and a lone proof 0.25-0.3 ms sooner, stdlib SHA-256 +8-9 % proofs/s, Poseidon
+// +3 %, GM17 level; no workload slower.  (Round 6's first plan — one pipe per lane TYPE, fold streams per type: "M=1,N=2,n=3,O=0,G=0,Z=1,H=2,
+// g=3,z=3,h=3" — gave the dense circuit the same and cost the thin ones 5-15 %: profiles/r6t_*, r6w_*.)  Still a request, not a default: the
+// sixteen streams cost a one-proof process 0.15 s.
+#define ZK_PIPE_PLAN_RESIDENT "M=2,N=3,O=1,n=3,G0=0,Z0=1,H0=0,G1=3,Z1=1,H1=0,G2=3,Z2=2,H2=1"
 struct PipeWant { Stream* target; bool* made; bool high; int cls; bool done; };
 static inline void make_pipe_streams(zkhip_ctx* ctx) {
     if (ctx->pipes_made || ctx->pipe_plan.empty() || ctx->serial) return;

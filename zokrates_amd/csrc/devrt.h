@@ -182,6 +182,16 @@ inline int& copy_mode() {
     static int mode = getenv("ZKHIP_COPY_MODE") ? atoi(getenv("ZKHIP_COPY_MODE")) : 2;   // 0: raw async (the runtime pins), 1: hipMemcpy, 2: staged
     return mode;
 }
+// host threads that fill the ring for one transfer of two chunks and more (ZKHIP_COPY_THREADS, 1 .. 8; read once)
+inline unsigned staging_copy_threads() {
+    static const unsigned t = [] {
+        const char* e = getenv("ZKHIP_COPY_THREADS");
+        const int v = e ? atoi(e) : 4;
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (unsigned)std::max(1, std::min(std::min(8, v), hw ? (int)hw : 1));
+    }();
+    return t;
+}
 struct StagingRing {
     static constexpr size_t CHUNK = (size_t)8 << 20;
     static constexpr int SLOTS = 4;
@@ -242,6 +252,67 @@ inline void dev_h2d(void* d, const void* h, size_t n, Stream s) {
     StagingRing& r = staging_ring();
     std::lock_guard<std::mutex> lock(r.mu);
     r.init();
+    const size_t nchunks = (n + StagingRing::CHUNK - 1) / StagingRing::CHUNK;
+    const unsigned T = nchunks >= 2 ? staging_copy_threads() : 1;
+    if (T > 1) {
+        // One thread copies ~15 GB/s into the ring: the 32 MiB assignment of a 2^20 proof that comes from host memory spent 2.2 ms
+        // there with the DMA engine mostly idle.  A few helpers, started ONCE per transfer (starting them per chunk cost more than
+        // it gained: profiles/r7g_*), each copy their share of every chunk; the calling thread copies share 0 and issues the DMA.
+        struct Shared {
+            std::atomic<long> go{-1}, done{0};
+            std::atomic<bool> abort{false};
+            unsigned T = 1;               // threads that copy (the caller included): set before the first `go`
+            std::vector<char*> slot;
+        } sh;
+        sh.slot.assign(nchunks, nullptr);
+        auto share = [n](size_t c, unsigned t, unsigned T_, size_t& lo, size_t& hi) {
+            const size_t len = std::min(StagingRing::CHUNK, n - c * StagingRing::CHUNK);
+            lo = len * t / T_ / 64 * 64;
+            hi = t + 1 == T_ ? len : len * (t + 1) / T_ / 64 * 64;
+        };
+        struct Release {      // (an exception of the issuing thread must not leave the helpers waiting)
+            Shared& sh;
+            ~Release() { sh.abort.store(true, std::memory_order_release); }
+        };
+        HostThreads th;       // (joined after `release` has run: declared first, destroyed last)
+        Release release{sh};
+        for (unsigned t = 1; t < T; ++t) {
+            try {
+                const unsigned me = (unsigned)th.th.size() + 1;
+                th.th.emplace_back([&sh, &share, h, nchunks, me] {
+                    for (size_t c = 0; c < nchunks; ++c) {
+                        while (sh.go.load(std::memory_order_acquire) < (long)c) {
+                            if (sh.abort.load(std::memory_order_acquire)) return;
+                            std::this_thread::yield();
+                        }
+                        size_t lo, hi;
+                        share(c, me, sh.T, lo, hi);
+                        memcpy(sh.slot[c] + lo, (const char*)h + c * StagingRing::CHUNK + lo, hi - lo);
+                        sh.done.fetch_add(1, std::memory_order_release);
+                    }
+                });
+            } catch (const std::system_error&) {      // (no thread to be had: the others share the work)
+                break;
+            }
+        }
+        const long helpers = (long)th.th.size();
+        sh.T = (unsigned)helpers + 1;
+        for (size_t c = 0; c < nchunks; ++c) {
+            const size_t off = c * StagingRing::CHUNK, len = std::min(StagingRing::CHUNK, n - off);
+            const int i = r.acquire();
+            sh.slot[c] = (char*)r.buf[i];
+            sh.go.store((long)c, std::memory_order_release);
+            size_t lo, hi;
+            share(c, 0, sh.T, lo, hi);
+            memcpy(sh.slot[c] + lo, (const char*)h + off + lo, hi - lo);
+            while (sh.done.load(std::memory_order_acquire) < (long)(c + 1) * helpers) std::this_thread::yield();
+            jitter_before(s);
+            ZK_HIP_CHECK(hipMemcpyAsync((char*)d + off, r.buf[i], len, hipMemcpyHostToDevice, s));
+            ZK_HIP_CHECK(hipEventRecord(r.ev[i], s));
+            r.used[i] = true;
+        }
+        return;
+    }
     for (size_t off = 0; off < n; off += StagingRing::CHUNK) {
         const size_t len = std::min(StagingRing::CHUNK, n - off);
         const int i = r.acquire();
