@@ -939,7 +939,17 @@ def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
             paths["cache_native"] = os.path.join(d, "cache_native")
             run("native_from_proving_key", [], native_exe)
             run("native_first_run_with_key_cache", ["--key-cache", paths["cache_native"]], native_exe)
-            run("native_from_key_image", ["--key-cache", paths["cache_native"]], native_exe)
+            # (the figure a `generate-proof` user sees: three processes, the one with the median wall clock reported and all three listed —
+            # HIP start alone moves between 0.11 and 0.27 s from one process to the next on one box: profiles/r7k_bench_driver_command.json)
+            runs = []
+            for _ in range(3):
+                run("native_from_key_image", ["--key-cache", paths["cache_native"]], native_exe)
+                if "process_wall_ms" not in res["native_from_key_image"] or "error" in res["native_from_key_image"]:
+                    break
+                runs.append(res["native_from_key_image"])
+            if runs:
+                runs.sort(key=lambda r: r["process_wall_ms"])
+                res["native_from_key_image"] = dict(runs[len(runs) // 2], process_wall_ms_runs=[round(r["process_wall_ms"], 1) for r in runs])
             res["file_bytes"]["key_image"] = sum(os.path.getsize(os.path.join(paths["cache_native"], f)) for f in os.listdir(paths["cache_native"]))
             ing = res["native_from_proving_key"].get("parse_program_ms")
         if os.environ.get("ZKHIP_BENCH_CLI_ALL") or not have_native:

@@ -222,12 +222,20 @@ def test_gpu_gm17_config5_full_size(gpu_ctx):
     pk = native.ProvingKey(gpu_ctx, 0, raw, scheme="gm17")
     assert pk.hlen - 1 == 1 << 21 and pk.m == 1 + 2 + circ.w + circ.n
     vk = gm17.vk_from_pk_bytes(curve, raw)
-    del raw
     z = circ.assignment(0x5EED0001)
     x = int.from_bytes(z[32:64].tobytes(), "little")
     d1, d2, r_ = 0x123456789abcdef0123456789, 0xfedcba9876543210, 0x1111222233334444555566667777
     p1 = native.prove_gm17(gpu_ctx, pk, cs, z, d1, d2, r_)
     assert p1[-3:] == b"\0\0\0"
+    from oracle import cpu
+    # the oracle at this size: the closed form from the toxic waste (no transform, no MSM) and — ZKHIP_TEST_FULL_O2=0 skips it — the
+    # C++ restatement of ark-gm17's create_proof over the key bytes the device made (four transforms on the doubled domain, five MSMs)
+    oc = cpu.Circuit.from_csr(0, circ.n, circ.l, circ.w, circ.mats())
+    tb = b"".join(int(v).to_bytes(32, "little") for v in (tox[0], tox[1], tox[2], tox[4]))
+    assert cpu.gm17_trapdoor(oc, tb, z, d1, r_) == p1
+    if os.environ.get("ZKHIP_TEST_FULL_O2", "1") != "0":
+        assert cpu.gm17_prove(oc, cpu.Gm17ProvingKey.parse(0, raw), z, d1, d2, r_)[0] == p1
+    del raw, oc
     assert gm17.verify(curve, vk, formats.proof_from_raw(curve, p1), [x])
     assert not gm17.verify(curve, vk, formats.proof_from_raw(curve, p1), [(x + 1) % curve.r])
     assert native.prove_gm17(gpu_ctx, pk, cs, z, d1 + 77, 5, r_ - 77) == p1

@@ -280,6 +280,12 @@ def test_full_size_properties(ctx):
     r_, s_ = 0xDEADBEEF12345678, 0xCAFEBABE87654321
     want = cpu.trapdoor(oc, tb, z, r_, s_)
     assert native.prove_g16(ctx, pk, cs, z, r_, s_) == want
+    # (1a) and the ALGORITHMIC oracle at this size (O2: the C++ restatement of ark's create_proof over the key bytes the device made —
+    # seven transforms and five Pippenger MSMs on all host threads, seconds at 2^20): the suite itself holds the device to it, not
+    # only bench.py's cpu_baseline leg
+    if lg <= int(os.environ.get("ZKHIP_TEST_FULL_O2_MAX_LOG", "20")):
+        want2, _ = cpu.prove(oc, cpu.ProvingKey.parse(0, raw.tobytes()), z, r_, s_)
+        assert want2 == want
     # (1b) the same with the key bound to the system (two 2^20-point transforms over G1 at bind time, H' and L' in the MSMs)
     pk.bind(cs)
     assert native.prove_g16(ctx, pk, cs, z, r_, s_) == want
