@@ -460,9 +460,11 @@ static __global__ void __launch_bounds__(256) k_scan_one(const u32* __restrict__
     __shared__ u32 coarse[(SCAN_ONE_MAX >> MSM_COARSE_BITS) + 1];      // off at every 256th key
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     u32 carry = 0;
-    for (u32 base = 0; base < nk; base += TILE) {
+    // (the tiles are a chain — carry, two barriers — but their LOADS are not: a work-item fetches the next tile's counters before it
+    // scans this one's, so that a tile costs its scan and not a trip to memory as well; 16 tiles at 2^16 counters: 44 -> ~15 us alone,
+    // and this kernel is on the path of every sort — the head of a lone proof, where nothing else can start before it)
+    auto fetch = [&](u32 base, u32 (&v)[SCAN_ONE_PER]) {
         const u32 k = base + SCAN_ONE_PER * t;                         // this work-item's 16 consecutive counters
-        u32 v[SCAN_ONE_PER];
         if (k + SCAN_ONE_PER <= nk) {
             ZK_UNROLL for (u32 q = 0; q < SCAN_ONE_PER / 4; ++q) {
                 const uint4 x = *(const uint4*)(cnt + k + 4 * q);
@@ -471,6 +473,14 @@ static __global__ void __launch_bounds__(256) k_scan_one(const u32* __restrict__
         } else {
             ZK_UNROLL for (u32 i = 0; i < SCAN_ONE_PER; ++i) v[i] = k + i < nk ? cnt[k + i] : 0;
         }
+    };
+    u32 nx[SCAN_ONE_PER];
+    fetch(0, nx);
+    for (u32 base = 0; base < nk; base += TILE) {
+        const u32 k = base + SCAN_ONE_PER * t;
+        u32 v[SCAN_ONE_PER];
+        ZK_UNROLL for (u32 i = 0; i < SCAN_ONE_PER; ++i) v[i] = nx[i];
+        if (base + TILE < nk) fetch(base + TILE, nx);
         u32 mine = 0;
         ZK_UNROLL for (u32 i = 0; i < SCAN_ONE_PER; ++i) mine += v[i];
         const u32 incl = wave_inclusive_scan(mine);
@@ -483,12 +493,22 @@ static __global__ void __launch_bounds__(256) k_scan_one(const u32* __restrict__
             all += x;
         }
         u32 run = before + incl - mine;
-        ZK_UNROLL for (u32 i = 0; i < SCAN_ONE_PER; ++i) {
-            if (k + i < nk) {
-                off[k + i] = run;
-                if (tile_off && ((k + i) & ((1u << MSM_COARSE_BITS) - 1)) == 0) coarse[(k + i) >> MSM_COARSE_BITS] = run;
+        static_assert((1u << MSM_COARSE_BITS) % SCAN_ONE_PER == 0, "a coarse bin starts at a work-item's first counter");
+        if (tile_off && k < nk && (k & ((1u << MSM_COARSE_BITS) - 1)) == 0) coarse[k >> MSM_COARSE_BITS] = run;
+        if (k + SCAN_ONE_PER <= nk) {                                  // (whole: four 16-byte stores)
+            ZK_UNROLL for (u32 q = 0; q < SCAN_ONE_PER / 4; ++q) {
+                uint4 o;
+                o.x = run; run += v[4 * q];
+                o.y = run; run += v[4 * q + 1];
+                o.z = run; run += v[4 * q + 2];
+                o.w = run; run += v[4 * q + 3];
+                *(uint4*)(off + k + 4 * q) = o;
             }
-            run += v[i];
+        } else {
+            ZK_UNROLL for (u32 i = 0; i < SCAN_ONE_PER; ++i) {
+                if (k + i < nk) off[k + i] = run;
+                run += v[i];
+            }
         }
         carry += all;
         __syncthreads();                                           // (wsum is rewritten by the next tile)
