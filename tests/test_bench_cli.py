@@ -88,6 +88,7 @@ def test_two_ranks_real_bench_script(scheme, port):
     assert len(lines0) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # ONE line, from rank 0
     d = json.loads(lines0[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["identical_to_oracle"] is True and "closed-form" in d["oracle"], d.get("oracle")     # N > 1: rank 0 holds its proof to the closed form
     assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1000.0)) < 1e-6 * d["value"]          # whole-job aggregate over both ranks
     s = d["sharded_single_proof"]
     assert s.get("identical_to_unsharded") is True and s["ranks"] == 2, s
