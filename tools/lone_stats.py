@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Lone proofs of one workload in ONE process: min / quartiles / median of `count` isolated proofs over a bound key (a lone proof's latency moves by
++-0.4 ms from proof to proof: bench.py's min-of-three cannot carry an A/B).  Settings come from the environment (ZKHIP_*), so an A/B is one process
+per setting, alternating.  usage: lone_stats.py <dense|poseidon> [count]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zokrates_amd import native, synth  # noqa: E402
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "dense"
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+native.default_library().init(16)
+ctx = native.Context(0)
+if os.environ.get("ZKHIP_PIPES", "1") not in ("0", "-"):
+    ctx.tune("pipe_plan", 1)
+if kind == "poseidon":
+    from zokrates_amd import poseidon
+    curve_id, circ = 1, poseidon.chain(1, 1024)
+else:
+    curve_id, circ = 0, synth.circuit(0, 20)
+cs = native.ConstraintSystem(ctx, curve_id, circ.n, circ.l, circ.w, circ.mats())
+pk = native.ProvingKey(ctx, curve_id, native.setup_g16(ctx, cs, synth.toxic_waste(curve_id)))
+zas = [native.Assignment(ctx, cs, circ.assignment(7 + i)) for i in range(4)]
+pk.bind(cs)
+ref = native.prove_g16_resident(ctx, pk, cs, zas[0], 11, 13)
+lone = []
+for i in range(count + 2):
+    p, tm = native.prove_g16_resident(ctx, pk, cs, zas[0], 11, 13, want_timings=True)
+    assert p == ref
+    if i >= 2:
+        lone.append(tm["total_ms"])
+lone.sort()
+q = lambda f: round(lone[min(len(lone) - 1, int(f * len(lone)))], 3)
+print(json.dumps({"kind": kind, "env": {k: v for k, v in os.environ.items() if k.startswith("ZKHIP_") and k != "ZKHIP_BENCH_CHILD"}, "count": len(lone),
+                  "min": q(0), "p25": q(0.25), "median": q(0.5), "p75": q(0.75), "max": q(1.0)}), flush=True)

@@ -163,6 +163,11 @@ struct zkhip_ctx {
     u32 msm_lanes = 0;        // slices of the sorted list (0 = one per resident work-item)
     u32 msm_min_slice = 8;    // finest cut of the sorted list
     bool heavy_runs = true;   // k_msm_heavy_reduce before the fold (ZKHIP_MSM_HEAVY_RUNS=0: the row's workgroup sums a heavy bucket alone)
+    int heavy_threads = 64;   // work-items per workgroup of k_msm_heavy_reduce (64 / 128 / 256; ZKHIP_HEAVY_THREADS).  The kernel is launched whether or not
+                              // a heavy bucket exists (the list is on the device) and must find a place before it can return: one wave and 9 / 18 KB of
+                              // LDS (G1 / G2) instead of four and 36 / 73 is a place found sooner beside the accumulations, and a run of a heavy bucket is
+                              // 8 serial additions + 6 tree levels instead of 2 + 8.  Lone dense proofs: median 9.61 against 9.78 ms over three processes
+                              // of 40 each, the stdlib SHA-256 circuit (which HAS heavy buckets) and the others level (profiles/r7s_*, r7q_*)
     int fold_hg = 32;         // shares a column of rows is cut into in k_msm_fold_cols (a power of two <= 256; ZKHIP_FOLD_HG): 128 rows = 4 serial additions +
                               // 5 tree levels instead of 16 + 3 at 8 (the fold is a chain of dependent additions: Poseidon BLS12-381 8.95 -> 7.85 ms single)
     bool fold_scan = true;    // scan form of the last fold step (else double-and-add)

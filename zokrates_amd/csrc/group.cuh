@@ -95,7 +95,8 @@ void msm_run_tables(zkhip_ctx* ctx, MsmLane& lane, const MsmSort& so, const void
     }
     if (ctx->heavy_runs) {
         lds_opt_in(ctx, (const void*)k_msm_heavy_reduce<F>);
-        ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(MSM_HEAVY_CHUNKS, nt), dim3(T), (size_t)T * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
+        const unsigned TH = (unsigned)ctx->heavy_threads;
+        ZK_LAUNCH((k_msm_heavy_reduce<F>), dim3(MSM_HEAVY_CHUNKS, nt), dim3(TH), (size_t)TH * sizeof(Xyzz<F>), s, ptr<Xyzz<F>>(lane.partial), partial_stride,
                   ptr<u32>(so.off), sh.nkeys, cut, ptr<u32>(lane.heavy) + 1, ptr<u32>(lane.heavy));
     }
     FoldDigits digs{};

@@ -144,6 +144,7 @@ int32_t zkhip_ctx_create(int32_t device, zkhip_ctx** out) {
         ctx->ntt_skew_us = env_int("ZKHIP_NTT_SKEW_US", 0, 200, 0);
         ctx->fuse_z = env_int("ZKHIP_FUSE_Z", 0, 1, 1) != 0;
         ctx->heavy_runs = env_int("ZKHIP_MSM_HEAVY_RUNS", 0, 1, 1) != 0;
+        { const int ht = env_int("ZKHIP_HEAVY_THREADS", 64, 256, 64); ctx->heavy_threads = ht >= 256 ? 256 : ht >= 128 ? 128 : 64; }
         { const int hg = env_int("ZKHIP_FOLD_HG", 1, 256, 32); ctx->fold_hg = 1 << ilog2_floor((u64)hg); }
         ctx->msm_fused_waves = env_int("ZKHIP_MSM_FUSED_WAVES", 1, 8, 0);
         ctx->msm_g1_waves = env_int("ZKHIP_MSM_G1_WAVES", 1, 16, 0);
