@@ -13,6 +13,7 @@ from zokrates_amd import native, synth  # noqa: E402
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 bound = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+native.default_library().init(int(os.environ.get("HWQ", "16")))      # (as bench.py: a process with one resident prover)
 ctx = native.Context(0)
 circ = synth.circuit(0, lg)
 cs = native.ConstraintSystem(ctx, 0, circ.n, circ.l, circ.w, circ.mats())
