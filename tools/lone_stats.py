@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Lone proofs of one workload in ONE process: min / quartiles / median of `count` isolated proofs over a bound key (a lone proof's latency moves by
 +-0.4 ms from proof to proof: bench.py's min-of-three cannot carry an A/B).  Settings come from the environment (ZKHIP_*), so an A/B is one process
-per setting, alternating.  usage: lone_stats.py <dense|poseidon> [count]"""
+per setting, alternating.  usage: lone_stats.py <dense|poseidon|sha256> [count]"""
 import json
 import os
 import sys
@@ -18,6 +18,10 @@ if os.environ.get("ZKHIP_PIPES", "1") not in ("0", "-"):
 if kind == "poseidon":
     from zokrates_amd import poseidon
     curve_id, circ = 1, poseidon.chain(1, 1024)
+elif kind == "sha256":
+    from zokrates_amd import sha256_circuit as sha
+    curve_id = 0
+    circ = sha.circuit(0, max(1, (1 << 20) // (len(sha.template()[0]) + 7)))
 else:
     curve_id, circ = 0, synth.circuit(0, 20)
 cs = native.ConstraintSystem(ctx, curve_id, circ.n, circ.l, circ.w, circ.mats())
