@@ -462,22 +462,28 @@ def main():
                 pass
         mark("key_bound")
     single = []
+    # the samplers of the timed regions are MADE here, before the warm-up (the clock probe is a second context: tens of milliseconds to create), and only
+    # started after it: with them made in between, the chip sat idle for ~30 ms after the warm-up and the first region — the one `value` is — ran 1-2 %
+    # behind the two that follow it back to back (114.4 against 116.6 / 117.1 proofs/s in profiles/r7k_*, the same pattern in every line of the round)
+    # (after the context's first proof, though: the stream plan's queues are dealt to the dispatchers in creation order, and the probe's context must not
+    # make its own before them — with the key bound a proof has run already, without (--bind 0) the isolated warm-up proof below is the first)
+    if args.warmup:
+        _, tm1 = prove_one(resident[0], rs(0))
+        single.append(tm1["total_ms"])
+    sampler = LoadSampler(pci)
+    idle_reading = sampler.read_once()
+    clock = ClockProbe(device)            # a second context's one-wave probe: the shader clock the proving kernels actually run at
     if args.warmup:
         # The W warm-up steps run the way the timed steps do — through the pipelined batch call — so that the timed region starts
         # on a chip in the state it will be measured in (clocks and power ramp over the first tens of milliseconds of load: with
         # W isolated proofs as warm-up the first of three identical regions was 1-2.5 % slower than the third,
         # profiles/r5c_bench_driver_command.json).  Every proof slot the library can keep in flight (ZK_NSLOTS = 4) allocates its
-        # workspaces the first time it is used, so never fewer than 4 proofs; one isolated proof first (its latency is reported).
-        _, tm1 = prove_one(resident[0], rs(0))
-        single.append(tm1["total_ms"])
+        # workspaces the first time it is used, so never fewer than 4 proofs; one isolated proof first (above; its latency is reported).
         nwarm = max(args.warmup, 4)
         prove_many([resident[i % nw] for i in range(nwarm)], [rs(100 + i) for i in range(nwarm)])
     steps = [args.warmup + i for i in range(args.steps)]
     mark("warmup_done")
-    sampler = LoadSampler(pci)
-    idle_reading = sampler.read_once()
     sampler.start()
-    clock = ClockProbe(device)            # a second context's one-wave probe: the shader clock the proving kernels actually run at
     clock.start()
     barrier_sync()
     t_begin = time.perf_counter()
