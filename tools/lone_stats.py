@@ -29,6 +29,13 @@ pk = native.ProvingKey(ctx, curve_id, native.setup_g16(ctx, cs, synth.toxic_wast
 zas = [native.Assignment(ctx, cs, circ.assignment(7 + i)) for i in range(4)]
 pk.bind(cs)
 ref = native.prove_g16_resident(ctx, pk, cs, zas[0], 11, 13)
+# PRE_BATCH=n: a pipelined batch of n proofs first (the state bench.py's lone proofs find the chip in: straight after its timed regions); PAUSE_S: idle after it
+import time
+if int(os.environ.get("PRE_BATCH", "0")):
+    nb = int(os.environ["PRE_BATCH"])
+    for _ in range(3):
+        native.prove_g16_resident_batch(ctx, pk, cs, [zas[i % 4] for i in range(nb)], [(100 + i, 7) for i in range(nb)])
+    time.sleep(float(os.environ.get("PAUSE_S", "0")))
 lone = []
 for i in range(count + 2):
     p, tm = native.prove_g16_resident(ctx, pk, cs, zas[0], 11, 13, want_timings=True)
@@ -37,5 +44,5 @@ for i in range(count + 2):
         lone.append(tm["total_ms"])
 lone.sort()
 q = lambda f: round(lone[min(len(lone) - 1, int(f * len(lone)))], 3)
-print(json.dumps({"kind": kind, "env": {k: v for k, v in os.environ.items() if k.startswith("ZKHIP_") and k != "ZKHIP_BENCH_CHILD"}, "count": len(lone),
+print(json.dumps({"kind": kind, "env": {k: v for k, v in os.environ.items() if k.startswith("ZKHIP_") and k != "ZKHIP_BENCH_CHILD"}, "pre_batch": os.environ.get("PRE_BATCH"), "pause_s": os.environ.get("PAUSE_S"), "count": len(lone),
                   "min": q(0), "p25": q(0.25), "median": q(0.5), "p75": q(0.75), "max": q(1.0)}), flush=True)
