@@ -812,17 +812,18 @@ def trapdoor_proof(circ, curve_id, z, rnd, gm17):
 
 
 CONFIG_LEGS = [
-    # (key, BASELINE.json config, bench.py arguments)
-    ("gm17_2e20", "configs[4]: GM17 on the 2^20-constraint BN254 circuit", ["--scheme", "gm17"]),
-    ("poseidon_chain_bls12_381_2e18", "configs[3]: stdlib Poseidon hash chain (depth 1024), BLS12-381", ["--curve", "bls12_381", "--log-domain", "18", "--kind", "poseidon"]),
-    ("sha256_stdlib_2e20", "configs[0] at the size of configs[1]: stdlib sha256/512bitPacked.zok side by side up to a 2^20 domain", ["--kind", "sha256", "--log-domain", "20"]),
-    ("dense_2e22_and_8_members", "configs[2]: 2^22 constraints, one GPU whole and as 8 members of one proof", ["--log-domain", "22", "--members", "8"]),
+    # (key, BASELINE.json config, bench.py arguments, timed steps: the thin circuits' proofs take 3-5 ms, and a region of 16 of them is a tenth pipeline
+    #  fill and drain — the Poseidon leg read 180-184 proofs/s where 32-step regions read 195-201: 48 steps cost a quarter of a second)
+    ("gm17_2e20", "configs[4]: GM17 on the 2^20-constraint BN254 circuit", ["--scheme", "gm17"], 16),
+    ("poseidon_chain_bls12_381_2e18", "configs[3]: stdlib Poseidon hash chain (depth 1024), BLS12-381", ["--curve", "bls12_381", "--log-domain", "18", "--kind", "poseidon"], 48),
+    ("sha256_stdlib_2e20", "configs[0] at the size of configs[1]: stdlib sha256/512bitPacked.zok side by side up to a 2^20 domain", ["--kind", "sha256", "--log-domain", "20"], 48),
+    ("dense_2e22_and_8_members", "configs[2]: 2^22 constraints, one GPU whole and as 8 members of one proof", ["--log-domain", "22", "--members", "8"], 16),
 ]
 
 
 def config_legs(args, budget_s=None):
     """BASELINE.json's other configurations as short runs of THIS script (a process each: a leg that dies or stalls costs its own entry,
-    not the line): 16 timed steps after 4 warm-up steps, the key bound as a resident prover would, the device proof — single, batched,
+    not the line): 16 or 48 timed steps (CONFIG_LEGS) after 4 warm-up steps, the key bound as a resident prover would, the device proof — single, batched,
     bound — held to the oracle's closed form.  Compact records; `wall_s` is the leg's whole process."""
     import subprocess
     budget_s = budget_s or float(os.environ.get("ZKHIP_BENCH_CONFIGS_BUDGET_S", "95"))
@@ -831,15 +832,15 @@ def config_legs(args, budget_s=None):
     legs = CONFIG_LEGS
     if os.environ.get("ZKHIP_BENCH_TEST_LEGS"):      # tests/test_bench_cli.py: the same four legs at toy size (the emulator build)
         legs = [(k, w, {"gm17_2e20": ["--scheme", "gm17", "--log-domain", "5"], "poseidon_chain_bls12_381_2e18": ["--curve", "bls12_381", "--log-domain", "8", "--kind", "poseidon"],
-                        "sha256_stdlib_2e20": ["--kind", "sha", "--log-domain", "6"], "dense_2e22_and_8_members": ["--log-domain", "6", "--members", "2"]}[k])
-                for k, w, _ in CONFIG_LEGS]
+                        "sha256_stdlib_2e20": ["--kind", "sha", "--log-domain", "6"], "dense_2e22_and_8_members": ["--log-domain", "6", "--members", "2"]}[k]
+                , 16) for k, w, _, _ in CONFIG_LEGS]
         budget_s = 1200
-    for key, what, extra in legs:
+    for key, what, extra, leg_steps in legs:
         left = budget_s - (time.time() - t_all)
         if left < 15:
             res[key] = {"config": what, "skipped": "time budget of the configs block (%.0f s) spent" % budget_s}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "16", "--warmup", "4", "--witnesses", "2", "--cpu-seconds", "0", "--e2e", "0",
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(leg_steps), "--warmup", "4", "--witnesses", "2", "--cpu-seconds", "0", "--e2e", "0",
                "--serial-proofs", "0", "--repeats", "2", "--oracle", "trapdoor", "--configs", "0"] + extra
         env = dict(os.environ, ZKHIP_BENCH_CHILD="1", ZKHIP_BENCH_LEG="1", ZKHIP_BENCH_STAGES="")
         env.pop("ZKHIP_BENCH_STAGES")
@@ -853,6 +854,7 @@ def config_legs(args, budget_s=None):
             else:
                 d = json.loads(lines[-1])
                 rec.update({"proofs_per_s": d["value"], "ms_per_step": d["ms_per_step"], "single_proof_ms": d["single_proof_ms"],
+                            "single_proof_median_ms": (d.get("single_proof_ms_stats") or {}).get("median"),
                             "identical_to_oracle": d.get("identical_to_oracle"), "oracle": d.get("oracle"),
                             "key_bound": d["bound_key"].get("bound"), "bind_ms": d["bound_key"].get("bind_ms"),
                             "proofs_per_s_unbound": d.get("value_unbound"), "single_proof_unbound_ms": d.get("single_proof_unbound_ms"),
