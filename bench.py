@@ -787,8 +787,8 @@ def main():
     want_configs = args.configs == 1 or (args.configs == -1 and default_workload and world == 1 and not os.environ.get("ZKHIP_BENCH_LEG"))
     if rank == 0 and want_configs:
         del resident[:]                      # this process's share of the device: the legs are processes of their own
-        for obj in (pk, cs):
-            try:
+        for obj in (pk, cs, ctx):            # (the context too: its sixteen idle hardware queues beside a leg's own cost the leg 5-8 % — legs read
+            try:                             # 177-185 / 295-306 / 81-83 proofs/s where the same commands alone read 195-201 / 314-330 / 86-87: r7q, r8f)
                 obj.close()
             except Exception:
                 pass
