@@ -42,6 +42,70 @@ import time
 T_PROCESS_START = time.time()
 
 
+CONFIG_LEGS = [
+    # (key, BASELINE.json config, bench.py arguments, timed steps: the thin circuits' proofs take 3-5 ms, and a region of 16 of them is a tenth pipeline
+    #  fill and drain — the Poseidon leg read 180-184 proofs/s where 32-step regions read 195-201: 48 steps cost a quarter of a second)
+    ("gm17_2e20", "configs[4]: GM17 on the 2^20-constraint BN254 circuit", ["--scheme", "gm17"], 16),
+    ("poseidon_chain_bls12_381_2e18", "configs[3]: stdlib Poseidon hash chain (depth 1024), BLS12-381", ["--curve", "bls12_381", "--log-domain", "18", "--kind", "poseidon"], 48),
+    ("sha256_stdlib_2e20", "configs[0] at the size of configs[1]: stdlib sha256/512bitPacked.zok side by side up to a 2^20 domain", ["--kind", "sha256", "--log-domain", "20"], 48),
+    ("dense_2e22_and_8_members", "configs[2]: 2^22 constraints, one GPU whole and as 8 members of one proof", ["--log-domain", "22", "--members", "8"], 16),
+]
+
+
+def config_legs(args, budget_s=None):
+    """BASELINE.json's other configurations as short runs of THIS script (a process each: a leg that dies or stalls costs its own entry,
+    not the line): 16 or 48 timed steps (CONFIG_LEGS) after 4 warm-up steps, the key bound as a resident prover would, the device proof — single, batched,
+    bound — held to the oracle's closed form.  Compact records; `wall_s` is the leg's whole process."""
+    import subprocess
+    budget_s = budget_s or float(os.environ.get("ZKHIP_BENCH_CONFIGS_BUDGET_S", "95"))
+    t_all = time.time()
+    res = {}
+    legs = CONFIG_LEGS
+    if os.environ.get("ZKHIP_BENCH_TEST_LEGS"):      # tests/test_bench_cli.py: the same four legs at toy size (the emulator build)
+        legs = [(k, w, {"gm17_2e20": ["--scheme", "gm17", "--log-domain", "5"], "poseidon_chain_bls12_381_2e18": ["--curve", "bls12_381", "--log-domain", "8", "--kind", "poseidon"],
+                        "sha256_stdlib_2e20": ["--kind", "sha", "--log-domain", "6"], "dense_2e22_and_8_members": ["--log-domain", "6", "--members", "2"]}[k]
+                , 16) for k, w, _, _ in CONFIG_LEGS]
+        budget_s = 1200
+    for key, what, extra, leg_steps in legs:
+        left = budget_s - (time.time() - t_all)
+        if left < 15:
+            res[key] = {"config": what, "skipped": "time budget of the configs block (%.0f s) spent" % budget_s}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(leg_steps), "--warmup", "4", "--witnesses", "2", "--cpu-seconds", "0", "--e2e", "0",
+               "--serial-proofs", "0", "--repeats", "2", "--oracle", "trapdoor", "--configs", "0"] + extra
+        env = dict(os.environ, ZKHIP_BENCH_CHILD="1", ZKHIP_BENCH_LEG="1", ZKHIP_BENCH_STAGES="")
+        env.pop("ZKHIP_BENCH_STAGES")
+        t0 = time.time()
+        rec = {"config": what}
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=left if os.environ.get("ZKHIP_BENCH_TEST_LEGS") else min(left, 75.0))
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not lines:
+                rec["error"] = "exit status %d: %s" % (p.returncode, (p.stderr or "")[-300:])
+            else:
+                d = json.loads(lines[-1])
+                rec.update({"proofs_per_s": d["value"], "ms_per_step": d["ms_per_step"], "single_proof_ms": d["single_proof_ms"],
+                            "single_proof_median_ms": (d.get("single_proof_ms_stats") or {}).get("median"),
+                            "identical_to_oracle": d.get("identical_to_oracle"), "oracle": d.get("oracle"),
+                            "key_bound": d["bound_key"].get("bound"), "bind_ms": d["bound_key"].get("bind_ms"),
+                            "proofs_per_s_unbound": d.get("value_unbound"), "single_proof_unbound_ms": d.get("single_proof_unbound_ms"),
+                            "steps": d["steps"], "constraints": d["config"]["constraints"], "domain": d["config"]["domain"], "curve": d["config"]["curve"]})
+                mm = d.get("multi_single_proof")
+                if mm:
+                    rec["members"] = {k: mm.get(k) for k in ("members", "distinct_gpus", "ms", "ms_unbound", "identical_to_unsharded", "identical_to_oracle", "key_bound",
+                                                               "bind_ms", "kernel_ntt_ms", "error") if k in mm}
+        except subprocess.TimeoutExpired:
+            rec["error"] = "timed out"
+        except Exception as e:
+            rec["error"] = repr(e)[:200]
+        rec["wall_s"] = round(time.time() - t0, 1)
+        res[key] = rec
+    return res
+
+
+CONFIGS_DEFERRED = "deferred to the supervising process"
+
+
 def supervise():
     """N = 1 runs measure in a CHILD process and the parent — which never loads the HIP runtime — relays its line.  A GPU
     memory fault does not raise an error, it aborts the process that owns the queue (round 2's driver run ended that way,
@@ -75,6 +139,12 @@ def supervise():
         if proc.returncode == 0 and json_lines:
             doc = json.loads(json_lines[-1])
             doc["attempts"] = attempts + [rec]
+            if doc.get("configs") == CONFIGS_DEFERRED:
+                # BASELINE.json's other configurations run from HERE, after the measuring process has gone: as its children — beside a process that
+                # still holds the device, even with its context closed — the legs read 3-5 % below the same commands run alone (GM17 81.3 against
+                # 85.4 proofs/s, the Poseidon chain 188 against 192: profiles/r8h_*).  This process never loads the HIP runtime.
+                del doc["configs"]
+                doc["configs"] = config_legs(None)      # LAST key of the line on purpose: it survives a reader that keeps the tail
             print(json.dumps(doc), flush=True)
             return 0
         rec["stderr_tail"] = other[-800:]
@@ -785,7 +855,9 @@ def main():
         out["box_probe"] = box_probe()
         out["rocm_smi"] = rocm_smi()
     want_configs = args.configs == 1 or (args.configs == -1 and default_workload and world == 1 and not os.environ.get("ZKHIP_BENCH_LEG"))
-    if rank == 0 and want_configs:
+    if rank == 0 and want_configs and os.environ.get("ZKHIP_BENCH_ATTEMPT") is not None:
+        out["configs"] = CONFIGS_DEFERRED    # (a supervised run: the parent runs the legs once this process has released the device)
+    elif rank == 0 and want_configs:
         del resident[:]                      # this process's share of the device: the legs are processes of their own
         for obj in (pk, cs, ctx):            # (the context too: its sixteen idle hardware queues beside a leg's own cost the leg 5-8 % — legs read
             try:                             # 177-185 / 295-306 / 81-83 proofs/s where the same commands alone read 195-201 / 314-330 / 86-87: r7q, r8f)
@@ -809,67 +881,6 @@ def trapdoor_proof(circ, curve_id, z, rnd, gm17):
         return cpu.gm17_trapdoor(oc, tb, z, rnd[0], rnd[2])
     tb = b"".join(int(v).to_bytes(32, "little") for v in tox)
     return cpu.trapdoor(oc, tb, z, rnd[0], rnd[1])
-
-
-CONFIG_LEGS = [
-    # (key, BASELINE.json config, bench.py arguments, timed steps: the thin circuits' proofs take 3-5 ms, and a region of 16 of them is a tenth pipeline
-    #  fill and drain — the Poseidon leg read 180-184 proofs/s where 32-step regions read 195-201: 48 steps cost a quarter of a second)
-    ("gm17_2e20", "configs[4]: GM17 on the 2^20-constraint BN254 circuit", ["--scheme", "gm17"], 16),
-    ("poseidon_chain_bls12_381_2e18", "configs[3]: stdlib Poseidon hash chain (depth 1024), BLS12-381", ["--curve", "bls12_381", "--log-domain", "18", "--kind", "poseidon"], 48),
-    ("sha256_stdlib_2e20", "configs[0] at the size of configs[1]: stdlib sha256/512bitPacked.zok side by side up to a 2^20 domain", ["--kind", "sha256", "--log-domain", "20"], 48),
-    ("dense_2e22_and_8_members", "configs[2]: 2^22 constraints, one GPU whole and as 8 members of one proof", ["--log-domain", "22", "--members", "8"], 16),
-]
-
-
-def config_legs(args, budget_s=None):
-    """BASELINE.json's other configurations as short runs of THIS script (a process each: a leg that dies or stalls costs its own entry,
-    not the line): 16 or 48 timed steps (CONFIG_LEGS) after 4 warm-up steps, the key bound as a resident prover would, the device proof — single, batched,
-    bound — held to the oracle's closed form.  Compact records; `wall_s` is the leg's whole process."""
-    import subprocess
-    budget_s = budget_s or float(os.environ.get("ZKHIP_BENCH_CONFIGS_BUDGET_S", "95"))
-    t_all = time.time()
-    res = {}
-    legs = CONFIG_LEGS
-    if os.environ.get("ZKHIP_BENCH_TEST_LEGS"):      # tests/test_bench_cli.py: the same four legs at toy size (the emulator build)
-        legs = [(k, w, {"gm17_2e20": ["--scheme", "gm17", "--log-domain", "5"], "poseidon_chain_bls12_381_2e18": ["--curve", "bls12_381", "--log-domain", "8", "--kind", "poseidon"],
-                        "sha256_stdlib_2e20": ["--kind", "sha", "--log-domain", "6"], "dense_2e22_and_8_members": ["--log-domain", "6", "--members", "2"]}[k]
-                , 16) for k, w, _, _ in CONFIG_LEGS]
-        budget_s = 1200
-    for key, what, extra, leg_steps in legs:
-        left = budget_s - (time.time() - t_all)
-        if left < 15:
-            res[key] = {"config": what, "skipped": "time budget of the configs block (%.0f s) spent" % budget_s}
-            continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(leg_steps), "--warmup", "4", "--witnesses", "2", "--cpu-seconds", "0", "--e2e", "0",
-               "--serial-proofs", "0", "--repeats", "2", "--oracle", "trapdoor", "--configs", "0"] + extra
-        env = dict(os.environ, ZKHIP_BENCH_CHILD="1", ZKHIP_BENCH_LEG="1", ZKHIP_BENCH_STAGES="")
-        env.pop("ZKHIP_BENCH_STAGES")
-        t0 = time.time()
-        rec = {"config": what}
-        try:
-            p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=left if os.environ.get("ZKHIP_BENCH_TEST_LEGS") else min(left, 75.0))
-            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-            if p.returncode != 0 or not lines:
-                rec["error"] = "exit status %d: %s" % (p.returncode, (p.stderr or "")[-300:])
-            else:
-                d = json.loads(lines[-1])
-                rec.update({"proofs_per_s": d["value"], "ms_per_step": d["ms_per_step"], "single_proof_ms": d["single_proof_ms"],
-                            "single_proof_median_ms": (d.get("single_proof_ms_stats") or {}).get("median"),
-                            "identical_to_oracle": d.get("identical_to_oracle"), "oracle": d.get("oracle"),
-                            "key_bound": d["bound_key"].get("bound"), "bind_ms": d["bound_key"].get("bind_ms"),
-                            "proofs_per_s_unbound": d.get("value_unbound"), "single_proof_unbound_ms": d.get("single_proof_unbound_ms"),
-                            "steps": d["steps"], "constraints": d["config"]["constraints"], "domain": d["config"]["domain"], "curve": d["config"]["curve"]})
-                mm = d.get("multi_single_proof")
-                if mm:
-                    rec["members"] = {k: mm.get(k) for k in ("members", "distinct_gpus", "ms", "ms_unbound", "identical_to_unsharded", "identical_to_oracle", "key_bound",
-                                                               "bind_ms", "kernel_ntt_ms", "error") if k in mm}
-        except subprocess.TimeoutExpired:
-            rec["error"] = "timed out"
-        except Exception as e:
-            rec["error"] = repr(e)[:200]
-        rec["wall_s"] = round(time.time() - t0, 1)
-        res[key] = rec
-    return res
 
 
 def cli_end_to_end(circ, curve_id, pk_bytes, z, scheme, ctx, pk, cs):
