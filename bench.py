@@ -1147,15 +1147,15 @@ def gather_per_rank(ranks, device, pci, placement, steps, elapsed_local):
 
 class LoadSampler:
     """Clocks, power and temperatures of the rank's GPU WHILE the timed regions run: a host thread reads the amdgpu hwmon files of
-    the device (found through its PCI address) every few milliseconds.  The prover's calls release the GIL, so the thread runs
+    the device (found through its PCI address) every 25 ms.  The prover's calls release the GIL, so the thread runs
     beside them; a read is a few tens of microseconds of host time.  rocm-smi after the run only ever showed an idle chip."""
     FILES = (("power_w", ("power1_average", "power1_input"), 1e-6), ("sclk_mhz", ("freq1_input",), 1e-6), ("mclk_mhz", ("freq2_input",), 1e-6),
              ("temp_edge_c", ("temp1_input",), 1e-3), ("temp_junction_c", ("temp2_input",), 1e-3), ("temp_mem_c", ("temp3_input",), 1e-3))
 
-    def __init__(self, pci, period_s=0.004):
+    def __init__(self, pci, period_s=0.025):      # (every 4 ms, as until session r8k, the reads themselves cost the first region ~1 %: profiles/r8k_*)
         import glob
         import threading
-        self.period = period_s
+        self.period = float(os.environ.get("ZKHIP_BENCH_SAMPLER_PERIOD_S", period_s))      # (experiment hook; <= 0: no sampling)
         self.paths = {}
         self.samples = []
         self._stop = threading.Event()
@@ -1184,7 +1184,7 @@ class LoadSampler:
 
     def start(self):
         import threading
-        if not self.paths:
+        if not self.paths or self.period <= 0:
             return
 
         def loop():
